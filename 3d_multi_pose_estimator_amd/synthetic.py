@@ -1,0 +1,247 @@
+"""Deterministic synthetic inputs and weights.
+
+No dataset or checkpoint of the reference is reachable offline, so both the parity
+fixtures and the benchmark use
+
+  * frames in the reference's JSON wire format (panoptic_conversor/
+    get_joints_from_panoptic_model_multi.py:231-236,281,287): per camera
+    ``[json-string of skeleton list, timestamp, 'no_image', bodies_3D]``, skeleton =
+    ``{joint_id_str: [joint_id, x, y, valid, prob]}``; 2D points are produced by
+    projecting random 3D skeletons with the Panoptic lens model (the published
+    k1,k2,p1,p2,k3 model, same as OpenCV's; reference panutils.py:14-26) so that
+    undistort + DLT recovers the 3D ground truth;
+  * GAT / MLP weights from a counter-based integer hash (splitmix64), so the values
+    are identical on every machine and torch version (no torch.manual_seed).
+
+Everything here is host-side numpy; nothing is on the timed path.
+"""
+import json
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def hash_uniform(seed, stream, n):
+    """n doubles in [0,1): u[i] = top 53 bits of splitmix64(mix(seed, stream) + i)."""
+    with np.errstate(over='ignore'):
+        base = _splitmix64(np.uint64(seed) * np.uint64(0x100000001B3) + np.uint64(stream))
+        idx = np.arange(n, dtype=np.uint64)
+        z = _splitmix64(_splitmix64(base + idx))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def hash_symmetric(seed, stream, shape, bound):
+    """float32 array uniform in [-bound, bound)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = hash_uniform(seed, stream, n)
+    return ((u * 2.0 - 1.0) * bound).astype(np.float32).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------------------
+
+GAT_HIDDEN = [40, 40, 40, 30]        # reference train_skeleton_matching.py:40-57 (deployed arch)
+GAT_HEADS = [10, 10, 8, 5]
+GAT_ALPHA = 0.15
+GAT_LAYERS = 5
+MLP_WIDTHS = [3072, 3072, 2048, 2048, 1024, 1024, 1024, 1024]   # reference utils/mlp.py:8-28
+MLP_SLOPE = 0.1
+
+
+def gat_layer_dims(num_feats, hidden=None, heads=None, n_classes=1):
+    """[(in_dim, num_heads, out_dim)] per layer, as GAT2.__init__ builds them
+    (reference gat2.py:91-135)."""
+    hidden = GAT_HIDDEN if hidden is None else hidden
+    heads = GAT_HEADS if heads is None else heads
+    dims = [(num_feats, heads[0], hidden[0])]
+    for l in range(1, len(hidden)):
+        dims.append((hidden[l - 1] * heads[l - 1], heads[l], hidden[l]))
+    dims.append((hidden[-1] * heads[-1], 1, n_classes))
+    return dims
+
+
+def gat_state_dict(seed, num_feats, hidden=None, heads=None, logit_gain=1.0, logit_shift=0.0):
+    """Deterministic GAT2 weights under the reference's state-dict names
+    (``layers.{l}.{attn_l,attn_r,fc1.weight,fc1.bias,fc2.weight,fc2.bias}``).
+
+    Scale follows xavier(gain=1.414) variance (reference gat2.py:35-38) but with a
+    uniform distribution.  `logit_gain` multiplies the last layer's fc2 so that the
+    sigmoid outputs spread over (0,1) instead of sitting in a narrow band (needed to
+    keep sorted-score gaps far above fp32 reordering noise in the parity tests);
+    `logit_shift` is added to the last layer's fc2 bias before the gain (centres the logits).
+    """
+    sd = {}
+    dims = gat_layer_dims(num_feats, hidden, heads)
+    for l, (din, nh, dout) in enumerate(dims):
+        s = 1000 * (l + 1)
+        std1 = 1.414 * np.sqrt(2.0 / (din + din))
+        std2 = 1.414 * np.sqrt(2.0 / (din + nh * dout))
+        stda = 1.414 * np.sqrt(2.0 / (dout + nh))
+        g2 = logit_gain if l == len(dims) - 1 else 1.0
+        sd['layers.%d.attn_l' % l] = hash_symmetric(seed, s + 1, (nh, dout, 1), np.sqrt(3.0) * stda)
+        sd['layers.%d.attn_r' % l] = hash_symmetric(seed, s + 2, (nh, dout, 1), np.sqrt(3.0) * stda)
+        sd['layers.%d.fc1.weight' % l] = hash_symmetric(seed, s + 3, (din, din), np.sqrt(3.0) * std1)
+        sd['layers.%d.fc1.bias' % l] = hash_symmetric(seed, s + 4, (din,), 1.0 / np.sqrt(din))
+        sd['layers.%d.fc2.weight' % l] = hash_symmetric(seed, s + 5, (nh * dout, din), np.sqrt(3.0) * std2 * g2)
+        b2 = hash_symmetric(seed, s + 6, (nh * dout,), 1.0 / np.sqrt(din))
+        if l == len(dims) - 1:
+            b2 = ((b2.astype(np.float64) + logit_shift) * g2).astype(np.float32)
+        sd['layers.%d.fc2.bias' % l] = b2
+    return sd
+
+
+def gat_params(num_feats, hidden=None, heads=None):
+    """Contents of ``skeleton_matching.prms`` (reference train_skeleton_matching.py:231-246)
+    minus the pickled activation modules (given here by slope / name)."""
+    return {'gnn_layers': GAT_LAYERS, 'num_feats': num_feats, 'n_classes': 1,
+            'num_hidden': list(GAT_HIDDEN if hidden is None else hidden),
+            'heads': list(GAT_HEADS if heads is None else heads),
+            'nonlinearity': 0.01, 'final_activation': 'sigmoid',
+            'in_drop': 0.0, 'attn_drop': 0.0, 'alpha': GAT_ALPHA, 'residual': False}
+
+
+def mlp_layer_dims(in_dim, out_dim=54):
+    w = [in_dim] + MLP_WIDTHS + [out_dim]
+    return [(w[i], w[i + 1]) for i in range(len(w) - 1)]
+
+
+def mlp_state_dict(seed, in_dim, out_dim=54, out_scale=0.3):
+    """Deterministic PoseEstimatorMLP weights, names ``layers.{1,3,..,17}.{weight,bias}``
+    (reference utils/mlp.py:8-28).  He-style scale for LeakyReLU(0.1) keeps activations
+    O(1) through the 9 layers so that the fp32 parity check is a real one."""
+    sd = {}
+    dims = mlp_layer_dims(in_dim, out_dim)
+    for i, (din, dout) in enumerate(dims):
+        key = 2 * i + 1
+        last = i == len(dims) - 1
+        std = np.sqrt(2.0 / ((1.0 + MLP_SLOPE ** 2) * din))
+        if last:
+            std = out_scale / np.sqrt(din)
+        sd['layers.%d.weight' % key] = hash_symmetric(seed, 50000 + 10 * i, (dout, din), np.sqrt(3.0) * std)
+        sd['layers.%d.bias' % key] = hash_symmetric(seed, 50001 + 10 * i, (dout,), 0.05 if not last else 0.2)
+    return sd
+
+
+# --------------------------------------------------------------------------------------
+# frames
+# --------------------------------------------------------------------------------------
+
+def project_panoptic(X, K, T_d, dist):
+    """Project 3xN world points (metres) with the k1,k2,p1,p2,k3 lens model.
+    Returns (2xN pixel coords, depth)."""
+    xc = T_d[:3, :3] @ X + T_d[:3, 3:4]
+    z = xc[2]
+    x = xc[0] / z
+    y = xc[1] / z
+    r = x * x + y * y
+    k1, k2, p1, p2, k3 = dist
+    radial = 1 + k1 * r + k2 * r * r + k3 * r * r * r
+    xd = x * radial + 2 * p1 * x * y + p2 * (r + 2 * x * x)
+    yd = y * radial + 2 * p2 * x * y + p1 * (r + 2 * y * y)
+    u = K[0, 0] * xd + K[0, 1] * yd + K[0, 2]
+    v = K[1, 0] * xd + K[1, 1] * yd + K[1, 2]
+    return np.stack([u, v]), z
+
+
+class FrameSpec:
+    """Knobs of the generator; defaults = clean Panoptic-shaped frame."""
+
+    def __init__(self, persons=4, cameras=None, noise_px=0.0, joint_drop=0.0,
+                 permute=True, add_id_key=False, spurious=0, empty_cameras=(),
+                 float_conf=True):
+        self.persons = persons
+        self.cameras = cameras            # list of camera names present (dict order); None = all
+        self.noise_px = noise_px
+        self.joint_drop = joint_drop
+        self.permute = permute
+        self.add_id_key = add_id_key
+        self.spurious = spurious
+        self.empty_cameras = tuple(empty_cameras)
+        self.float_conf = float_conf
+
+
+def _normal(u1, u2):
+    return np.sqrt(-2.0 * np.log(np.maximum(u1, 1e-300))) * np.cos(2.0 * np.pi * u2)
+
+
+def make_frame(calib, frame_index, spec=None, seed=1234):
+    """One frame dict in wire format plus its ground truth.
+
+    Returns (frame, gt) with gt = {'persons': [P x J x 3 world metres],
+    'owner': {cam: [person id per skeleton in list order]}}.
+    """
+    spec = spec or FrameSpec()
+    params = calib.params
+    J = len(params.joint_list)
+    W, H = params.image_width, params.image_height
+    P = spec.persons
+    st = int(frame_index) * 64
+    u = hash_uniform(seed, st + 0, P * 3)
+    root = np.stack([u[0::3] * 2.4 - 1.2, -(0.8 + 0.4 * u[1::3]), u[2::3] * 2.4 - 1.2], axis=1)   # P x 3
+    g = _normal(hash_uniform(seed, st + 1, P * J * 3), hash_uniform(seed, st + 2, P * J * 3)).reshape(P, J, 3)
+    pts = root[:, None, :] + 0.25 * g                                                             # P x J x 3
+    cams = list(spec.cameras) if spec.cameras is not None else list(params.camera_names)
+    frame = {}
+    owner = {}
+    for ci, cam in enumerate(cams):
+        k = calib.index(cam)
+        skeletons = []
+        own = []
+        if cam not in spec.empty_cameras:
+            cst = st + 8 + 4 * k
+            drop_u = hash_uniform(seed, cst + 0, P * J).reshape(P, J)
+            conf_u = hash_uniform(seed, cst + 1, P * J * 2).reshape(P, J, 2)
+            nz = _normal(hash_uniform(seed, cst + 2, P * J * 2), hash_uniform(seed, cst + 3, P * J * 2)).reshape(P, J, 2)
+            for p in range(P):
+                uv, z = project_panoptic(pts[p].T, calib.K32[k].astype(np.float64), calib.T_d[k], calib.dist[k])
+                sk = {}
+                for j in range(J):
+                    x = float(uv[0, j] + spec.noise_px * nz[p, j, 0])
+                    y = float(uv[1, j] + spec.noise_px * nz[p, j, 1])
+                    if z[j] <= 0.1 or x < 0 or x >= W or y < 0 or y >= H:
+                        continue
+                    if drop_u[p, j] < spec.joint_drop:
+                        continue
+                    if spec.float_conf:
+                        valid = float(np.float32(0.55 + 0.45 * conf_u[p, j, 0]))
+                        prob = float(np.float32(0.30 + 0.70 * conf_u[p, j, 1]))
+                    else:
+                        valid, prob = 1, 1
+                    sk[str(j)] = [j, x, y, valid, prob]
+                if spec.add_id_key and sk:
+                    sk['ID'] = p
+                skeletons.append(sk)
+                own.append(p)
+            for s in range(spec.spurious):
+                su = hash_uniform(seed, cst + 100 + s, J * 2).reshape(J, 2)
+                sk = {str(j): [j, float(su[j, 0] * W), float(su[j, 1] * H), 1, 1] for j in range(0, J, 2)}
+                skeletons.append(sk)
+                own.append(-1 - s)
+            if spec.permute and len(skeletons) > 1:
+                order = np.argsort(hash_uniform(seed, st + 40 + k, len(skeletons)), kind='stable')
+                skeletons = [skeletons[i] for i in order]
+                own = [own[i] for i in order]
+        gt_cm = [{('-1' if j == 2 else str(j)): [float(c) * 100.0 for c in pts[p, j]] for j in range(J)}
+                 for p in range(P)]
+        frame[cam] = [json.dumps(skeletons), float(frame_index), 'no_image', gt_cm]
+        owner[cam] = own
+    return frame, {'persons': pts, 'owner': owner}
+
+
+def make_frames(calib, n, spec=None, seed=1234, start=0):
+    frames, gts = [], []
+    for i in range(start, start + n):
+        f, g = make_frame(calib, i, spec, seed)
+        frames.append(f)
+        gts.append(g)
+    return frames, gts

@@ -1,0 +1,261 @@
+"""TEST INFRASTRUCTURE (build container only): produce tests/golden/*.npz + *.json by
+running the reference's own hot-path files (via oracle/refenv.py) on deterministic
+synthetic frames and weights.  The fixtures are data: inputs and the reference's
+outputs at every stage boundary of SURVEY.md §8(a).  Run:
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+The reference tree never travels to the GPU box; the fixtures do.
+"""
+import contextlib
+import importlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+import refenv  # noqa: E402
+
+GAT_SEED = 7
+MLP_SEED = 11
+LOGIT_GAIN = 25.0
+LOGIT_SHIFT = 0.698
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = refenv.load()
+    import torch
+    pkg = '3d_multi_pose_estimator_amd'
+    syn = importlib.import_module(pkg + '.synthetic')
+    cal = importlib.import_module(pkg + '.calibration')
+    par = importlib.import_module(pkg + '.parameters')
+    rparams = ref['parameters'].parameters
+    # our schema must agree with the reference's module field by field
+    for f in rparams._fields:
+        assert getattr(rparams, f) == getattr(par.parameters, f), f
+    calib = cal.Calibration(par.parameters)
+    gg = ref['graph_generator']
+    nf = len(gg.HumanGraphFromView.get_all_features('3'))
+
+    # calibration globals of the reference (a2)
+    np.savez_compressed(
+        os.path.join(OUT, 'calibration_panoptic.npz'),
+        T_d=np.stack([t.numpy() for t in gg.camera_d_transforms]),
+        T_i32=np.stack([t.numpy() for t in gg.camera_i_transforms]),
+        K32=np.stack([t.cpu().numpy() for t in gg.camera_matrices]),
+        Kinv32=np.stack([t.numpy() for t in gg.inverse_camera_matrices]),
+        centre32=np.stack([t.numpy() for t in gg.all_cameras_from_root]),
+        dist=np.stack([ref['pose_estimator_dataset_from_json'].distortion_coefficients[c] for c in rparams.camera_names]),
+        P=np.stack([ref['pose_estimator_dataset_from_json'].projection_matrices[c] for c in rparams.camera_names]),
+        features=np.array(gg.HumanGraphFromView.get_all_features('3')),
+    )
+
+    gat_sd = syn.gat_state_dict(GAT_SEED, nf, logit_gain=LOGIT_GAIN, logit_shift=LOGIT_SHIFT)
+    model = ref['gat2'].GAT2(None, syn.GAT_LAYERS, nf, 1, syn.GAT_HIDDEN, syn.GAT_HEADS, torch.nn.LeakyReLU(),
+                             torch.nn.Sigmoid(), 0., 0., syn.GAT_ALPHA, False, bias=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in gat_sd.items()})
+    in_dim = len(rparams.cameras) * len(rparams.joint_list) * rparams.numbers_per_joint
+    mlp_sd = syn.mlp_state_dict(MLP_SEED, in_dim)
+    with quiet():
+        mlp = ref['mlp'].PoseEstimatorMLP(input_dimensions=in_dim, output_dimensions=54)
+    mlp.load_state_dict({k: torch.from_numpy(v) for k, v in mlp_sd.items()})
+
+    F = syn.FrameSpec
+    cases = [
+        ('c1_2view_1person', F(persons=1, cameras=['trackera', 'trackerb']), [0, 1]),
+        ('c2_5x4_clean', F(persons=4), [0, 1, 2]),
+        ('c2_5x4_messy', F(persons=4, noise_px=2.0, joint_drop=0.3, add_id_key=True, spurious=1,
+                           empty_cameras=('trackerc',), float_conf=False), [3, 4]),
+        ('c2_5x4_reordered', F(persons=4, cameras=['trackerd', 'trackera', 'trackere', 'trackerb', 'trackerc'],
+                               joint_drop=0.15), [5]),
+        ('c2_3x2', F(persons=2, cameras=['trackerb', 'trackerd', 'trackere']), [6]),
+        ('c4_5x10', F(persons=10, noise_px=1.0), [7]),
+    ]
+    meta = {'gat_seed': GAT_SEED, 'mlp_seed': MLP_SEED, 'logit_gain': LOGIT_GAIN, 'logit_shift': LOGIT_SHIFT,
+            'num_feats': nf, 'mlp_in': in_dim, 'cases': {}}
+    for name, spec, idxs in cases:
+        frames_json = []
+        arrays = {}
+        for n, fi in enumerate(idxs):
+            frame, gt = syn.make_frame(calib, fi, spec)
+            frames_json.append(frame)
+            # ---- callers' pre-processing (metrics_from_model.py:182-191)
+            pi = {}
+            for cam in frame:
+                data = json.loads(frame[cam][0])
+                if data:
+                    pi[cam] = [json.dumps(data), frame[cam][1]]
+            with quiet():
+                sc = gg.MergedMultipleHumansDataset(pi, mode='test', limit=10000, debug=True, alt='3', verbose=False)
+            assert len(sc.graphs) == 1
+            g = sc.graphs[0]
+            feats = g.ndata['h']
+            src, dst = [x.numpy() for x in g.edges()]
+            idx = torch.squeeze(sc.data['edge_nodes_indices'][0], 1)
+            nodes_camera = sc.data['nodes_camera'][0]
+            model.g = g
+            for layer in model.layers:
+                layer.g = g
+            # per-layer activations (what GAT2.forward computes, gat2.py:137-149)
+            h = feats.float()
+            inter = []
+            for l in range(model.num_layers - 1):
+                h = model.activation(model.layers[l](h).flatten(1))
+                inter.append(h.numpy().copy())
+            outputs = torch.squeeze(model(feats.float(), g))
+            final_output = ref['skeleton_matching_utils'].get_person_proposal_from_network_output(
+                outputs, g, idx, nodes_camera, sc.jsons_for_head, 0.5)
+            nz = torch.nonzero(feats)
+            p = 'f%d_' % n
+            arrays[p + 'N'] = np.int64(g.number_of_nodes())
+            arrays[p + 'src'] = src
+            arrays[p + 'dst'] = dst
+            arrays[p + 'feat_rc'] = nz.numpy().astype(np.int32)
+            arrays[p + 'feat_v'] = feats[nz[:, 0], nz[:, 1]].numpy()
+            arrays[p + 'edge_nodes_indices'] = idx.numpy()
+            arrays[p + 'nodes_camera'] = np.array(nodes_camera)
+            arrays[p + 'skeleton_index'] = np.array([sc.skeleton_index[i] for i in range(len(sc.skeleton_index))], np.int32)
+            arrays[p + 'scores'] = outputs.numpy()
+            for l, a in enumerate(inter):
+                arrays[p + 'act%d_head' % l] = a[:4]                       # first heads
+                arrays[p + 'act%d_en' % l] = a[int(idx[0]):int(idx[0]) + 4]  # first edge-nodes
+            persons = np.array([[(-1 if fo[c] is None else fo[c]) for c in rparams.used_cameras_skeleton_matching]
+                                for fo in final_output], np.int32).reshape(-1, len(rparams.used_cameras_skeleton_matching))
+            arrays[p + 'persons'] = persons
+            # ---- 3D stage A (metrics_from_model.py:243-294)
+            rows = []
+            for person in final_output:
+                raw_input = {}
+                for camera in rparams.used_cameras:
+                    if person[camera] is not None:
+                        raw_input[camera] = [json.dumps([sc.jsons_for_head[person[camera]]])]
+                with quiet():
+                    ds = ref['pose_estimator_dataset_from_json'].PoseEstimatorDataset(
+                        raw_input, rparams.cameras, rparams.joint_list, save=False)
+                assert len(ds) == 1
+                rows.append(ds[0][0].numpy())
+            if rows:
+                x = torch.from_numpy(np.stack(rows))
+                out = mlp(x)
+                arrays[p + 'mlp_in'] = np.stack(rows)
+                arrays[p + 'mlp_out'] = out.numpy()
+                arrays[p + 'poses'] = np.stack([(out[i] * 10.).numpy().reshape(-1, 3) for i in range(out.shape[0])])
+            # ---- 3D stage B (metrics_from_triangulation.py:234-272)
+            pe = ref['pose_estimator_dataset_from_json']
+            tri = np.zeros((len(final_output), len(rparams.joint_list), 3))
+            tri_valid = np.zeros((len(final_output), len(rparams.joint_list)), np.int8)
+            cam_matrix = {c: ref['pose_estimator_utils'].camera_matrix(i).cpu().numpy() for i, c in enumerate(rparams.camera_names)}
+            for pi_, person in enumerate(final_output):
+                points_2D = {}
+                for cam_idx in rparams.cameras:
+                    camera = rparams.camera_names[cam_idx]
+                    if person[camera] is not None:
+                        for j, pos in sc.jsons_for_head[person[camera]].items():
+                            if j == 'ID':
+                                continue      # an "ID" entry would make the reference raise here; fixtures avoid it
+                            points_2D.setdefault(j, {})[camera] = np.array([pos[1], pos[2]])
+                r3 = ref['pose_estimator_utils'].triangulate(points_2D, cam_matrix, pe.distortion_coefficients,
+                                                              pe.projection_matrices, rparams.axes_3D['Y'][0])
+                for j in rparams.joint_list:
+                    if str(j) in r3:
+                        tri_valid[pi_, j] = 1
+                        if j in rparams.used_joints:
+                            tri[pi_, j] = [r3[str(j)][0][0], r3[str(j)][1][0], r3[str(j)][2][0]]
+            arrays[p + 'tri'] = tri
+            arrays[p + 'tri_valid'] = tri_valid
+            arrays[p + 'gt'] = gt['persons']
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+        with open(os.path.join(OUT, name + '.frames.json'), 'w') as fh:
+            json.dump(frames_json, fh)
+        meta['cases'][name] = {'frames': len(idxs)}
+        print(name, 'ok', {k: v.shape for k, v in arrays.items() if k.startswith('f0_') and hasattr(v, 'shape')})
+
+    gen_cluster_cases(ref, meta)
+    with open(os.path.join(OUT, 'meta.json'), 'w') as fh:
+        json.dump(meta, fh, indent=1)
+
+
+class _G:
+    """Duck-typed stand-in for the graph argument of get_person_proposal_from_network_output
+    (it only calls .edges(), skeleton_matching_utils.py:26)."""
+
+    def __init__(self, src, dst):
+        import torch
+        self._s, self._d = torch.tensor(src), torch.tensor(dst)
+
+    def edges(self):
+        return self._s, self._d
+
+
+def gen_cluster_cases(ref, meta):
+    """Clustering-only known answers: random and adversarial score vectors through the
+    reference's get_person_proposal_from_network_output (real file, real networkx)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle_np as onp
+    rparams = ref['parameters'].parameters
+    cams = list(rparams.used_cameras_skeleton_matching)
+    rng = np.random.default_rng(2024)
+    fn = ref['skeleton_matching_utils'].get_person_proposal_from_network_output
+    cases = []
+    for ci in range(400):
+        ncam = int(rng.integers(2, 6))
+        order = list(rng.permutation(5)[:ncam])
+        counts = [int(rng.integers(1, 5 if ci % 4 else 11)) for _ in order]
+        slots = []
+        hid = 0
+        for c, n in zip(order, counts):
+            slots.append((cams[c], list(range(hid, hid + n))))
+            hid += n
+        N, src, dst, pairs = onp.topology(slots)
+        H = hid
+        M = N - H
+        if M == 0:
+            continue
+        head_cam = [cams.index(s[0]) for s in slots for _ in s[1]]
+        kind = ci % 5
+        if kind == 0:      # uniform scores
+            sc = rng.uniform(0, 1, M)
+        elif kind == 1:    # trained-like: true pairs high, others low, with noise and some errors
+            owner = [int(rng.integers(0, max(counts))) for _ in range(H)]
+            sc = np.array([(0.9 if owner[a] == owner[b] else 0.1) for a, b in pairs]) + rng.normal(0, 0.25, M)
+            sc = np.clip(sc, 0, 1)
+        elif kind == 2:    # heavy ties (saturated sigmoid)
+            sc = rng.choice([1.0, 1.0, 0.99999994, 0.75, 0.5, 0.4999], M)
+        elif kind == 3:    # everything matches (merge-quirk territory)
+            sc = 0.5 + 0.5 * rng.uniform(0, 1, M) ** 0.3
+        else:              # coarse grid -> many ties among mid scores
+            sc = np.round(rng.uniform(0.3, 1.0, M), 1)
+        sc32 = sc.astype(np.float32)
+        outputs = torch.zeros(N)
+        outputs[H:] = torch.from_numpy(sc32)
+        nodes_camera = [s[0] for s in slots for _ in s[1]] + [''] * M
+        res = fn(outputs, _G(src.tolist(), dst.tolist()), torch.arange(H, N), nodes_camera, None, 0.5)
+        persons = np.array([[(-1 if r[c] is None else r[c]) for c in cams] for r in res], np.int32).reshape(-1, len(cams))
+        cases.append({'slot_cam': [cams.index(s[0]) for s in slots], 'slot_n': counts,
+                      'scores': sc32, 'persons': persons})
+    arrays = {}
+    for i, c in enumerate(cases):
+        arrays['c%d_slot_cam' % i] = np.array(c['slot_cam'], np.int32)
+        arrays['c%d_slot_n' % i] = np.array(c['slot_n'], np.int32)
+        arrays['c%d_scores' % i] = c['scores']
+        arrays['c%d_persons' % i] = c['persons']
+    np.savez_compressed(os.path.join(OUT, 'cluster_cases.npz'), n=np.int64(len(cases)), **arrays)
+    meta['cluster_cases'] = len(cases)
+    print('cluster cases', len(cases))
+
+
+if __name__ == '__main__':
+    main()

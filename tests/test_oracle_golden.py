@@ -1,0 +1,115 @@
+"""CPU: the oracle restatement (oracle/oracle_np.py) against the fixtures produced by the
+reference's own files (oracle/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import CASES, load_case, oracle, pkg
+
+
+def test_calibration_matches_reference_globals(calib):
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'calibration_panoptic.npz'))
+    assert np.array_equal(g['T_d'].astype(np.float64), calib.T_d.astype(np.float32).astype(np.float64))
+    assert np.array_equal(g['T_i32'], calib.T_i32)
+    assert np.array_equal(g['K32'], calib.K32)
+    assert np.array_equal(g['Kinv32'], calib.Kinv32)
+    assert np.array_equal(g['centre32'], calib.centre32)
+    assert np.array_equal(g['dist'], calib.dist)
+    assert np.array_equal(g['P'], calib.P)
+    assert len(g['features']) == 2 + 5 * 18 * 10
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_graph_and_gat(name, calib, gat_weights):
+    onp = oracle()
+    arr, frames = load_case(name)
+    sd, prm = gat_weights
+    for n, frame in enumerate(frames):
+        p = 'f%d_' % n
+        g = onp.build_graph(onp.processed_input(frame), calib)
+        assert g['N'] == int(arr[p + 'N'])
+        assert np.array_equal(g['src'], arr[p + 'src'])
+        assert np.array_equal(g['dst'], arr[p + 'dst'])
+        assert np.array_equal(g['edge_nodes_indices'], arr[p + 'edge_nodes_indices'])
+        assert list(arr[p + 'nodes_camera']) == g['nodes_camera']
+        assert [g['skeleton_index'][i] for i in range(g['H'])] == list(arr[p + 'skeleton_index'])
+        dense = torch.zeros_like(g['feats'])
+        rc = arr[p + 'feat_rc']
+        dense[rc[:, 0], rc[:, 1]] = torch.from_numpy(arr[p + 'feat_v'])
+        assert torch.equal(dense, g['feats'])            # bit-exact feature rows
+        scores, inter = onp.gat_forward(sd, prm, g['feats'], g['src'], g['dst'], keep=True)
+        # same torch CPU kernels on the same machine -> equal to a few ulp at most
+        np.testing.assert_allclose(scores.numpy(), arr[p + 'scores'], rtol=2e-5, atol=1e-7)
+        H = g['H']
+        for l, a in enumerate(inter):
+            np.testing.assert_allclose(a[:4].numpy(), arr[p + 'act%d_head' % l], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(a[H:H + 4].numpy(), arr[p + 'act%d_en' % l], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_cluster_on_golden_scores(name, calib):
+    onp = oracle()
+    arr, frames = load_case(name)
+    sm = list(calib.params.used_cameras_skeleton_matching)
+    for n, frame in enumerate(frames):
+        p = 'f%d_' % n
+        g = onp.build_graph(onp.processed_input(frame), calib)
+        head_cam = [sm.index(c) for c in g['nodes_camera'][:g['H']]]
+        persons = onp.cluster(arr[p + 'scores'][g['H']:], g['pairs'], g['H'], head_cam, len(sm))
+        assert np.array_equal(np.array(persons, np.int32).reshape(-1, len(sm)), arr[p + 'persons'])
+
+
+def test_cluster_known_answers(calib):
+    import os
+    from conftest import GOLDEN
+    onp = oracle()
+    arr = np.load(os.path.join(GOLDEN, 'cluster_cases.npz'))
+    sm = list(calib.params.used_cameras_skeleton_matching)
+    nonempty = 0
+    for i in range(int(arr['n'])):
+        slot_cam, slot_n = arr['c%d_slot_cam' % i], arr['c%d_slot_n' % i]
+        slots, hid = [], 0
+        for c, k in zip(slot_cam, slot_n):
+            slots.append((sm[c], list(range(hid, hid + k))))
+            hid += k
+        N, src, dst, pairs = onp.topology(slots)
+        head_cam = [int(c) for c, k in zip(slot_cam, slot_n) for _ in range(k)]
+        persons = onp.cluster(arr['c%d_scores' % i], pairs, hid, head_cam, len(sm))
+        want = arr['c%d_persons' % i]
+        assert np.array_equal(np.array(persons, np.int32).reshape(-1, len(sm)), want), i
+        nonempty += len(want) > 0
+    assert nonempty > 300
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_stage3d(name, calib, mlp_weights):
+    onp = oracle()
+    arr, frames = load_case(name)
+    sm = list(calib.params.used_cameras_skeleton_matching)
+    for n, frame in enumerate(frames):
+        p = 'f%d_' % n
+        persons = arr[p + 'persons']
+        if len(persons) == 0:
+            continue
+        g = onp.build_graph(onp.processed_input(frame), calib)
+        rows = []
+        for person in persons:
+            sk = onp.person_skeletons(list(person), g['jsons_for_head'], sm)
+            row, kept = onp.mlp_input_row(sk, calib)
+            assert kept
+            rows.append(row)
+            tri = onp.triangulate_person({c: {k: v for k, v in s.items() if k != 'ID'} for c, s in sk.items()}, calib)
+            k = len(rows) - 1
+            for j in range(18):
+                assert (j in tri) == bool(arr[p + 'tri_valid'][k, j])
+                if j in tri:
+                    np.testing.assert_allclose(tri[j], arr[p + 'tri'][k, j], rtol=0, atol=1e-9)
+        x = torch.stack(rows)
+        # f64 DLT through our SVD restatement vs numpy's in the shim: same LAPACK -> tiny diff
+        np.testing.assert_allclose(x.numpy(), arr[p + 'mlp_in'], rtol=0, atol=2e-7)
+        out = onp.mlp_forward(mlp_weights, torch.from_numpy(arr[p + 'mlp_in']))
+        np.testing.assert_allclose(out.numpy(), arr[p + 'mlp_out'], rtol=1e-5, atol=1e-6)
+        poses = np.stack([onp.decode_pose(out[i], 18) for i in range(out.shape[0])])
+        np.testing.assert_allclose(poses, arr[p + 'poses'], rtol=1e-5, atol=1e-5)
