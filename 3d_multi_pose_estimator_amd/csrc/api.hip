@@ -1,0 +1,604 @@
+// C-ABI entry points of libmpe_hip.so (see include/mpe.h).  Host-side orchestration only:
+// argument checks, workspace, weight upload, and the stream-ordered launch sequences.
+#include <cmath>
+#include <cstdarg>
+#include <new>
+#include <cstdio>
+#include <cstring>
+
+#include "mpe_internal.h"
+
+using namespace mpe;
+
+namespace {
+
+int fail(mpe_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ctx, MPE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(mpe_ctx *ctx, T **p, size_t count, bool zero = true) {
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(ctx, MPE_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) {
+        e = hipMemset(q, 0, bytes);
+        if (e != hipSuccess) return fail(ctx, MPE_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    ctx->owned.push_back(q);
+    *p = static_cast<T *>(q);
+    return MPE_OK;
+}
+
+int upload_linear(mpe_ctx *ctx, const float *w, const float *b, int out_dim, int in_dim, Linear *L) {
+    if (!w || out_dim <= 0 || in_dim <= 0) return fail(ctx, MPE_ERR_INVALID, "bad linear layer %dx%d", out_dim, in_dim);
+    L->in_dim = in_dim;
+    L->out_dim = out_dim;
+    L->ldw = round_up(in_dim, LD_ALIGN);
+    const int rows = round_up(out_dim, GEMM_BN);
+    int rc = dev_alloc(ctx, &L->w, (size_t)rows * L->ldw);
+    if (rc) return rc;
+    rc = dev_alloc(ctx, &L->b, (size_t)rows);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy2D(L->w, (size_t)L->ldw * sizeof(float), w, (size_t)in_dim * sizeof(float),
+                            (size_t)in_dim * sizeof(float), out_dim, hipMemcpyHostToDevice));
+    if (b) HIPCHK(ctx, hipMemcpy(L->b, b, (size_t)out_dim * sizeof(float), hipMemcpyHostToDevice));
+    return MPE_OK;
+}
+
+int check_batch(mpe_ctx *ctx, const mpe_batch *b) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (!b) return fail(ctx, MPE_ERR_INVALID, "batch is NULL");
+    if (b->n_frames < 0 || b->n_heads < 0 || b->n_edge_nodes < 0) return fail(ctx, MPE_ERR_INVALID, "negative batch size");
+    if (b->n_frames > ctx->cfg.max_frames || b->n_heads > ctx->cfg.max_heads ||
+        b->n_edge_nodes > ctx->cfg.max_edge_nodes)
+        return fail(ctx, MPE_ERR_CAPACITY, "batch (%d frames, %d heads, %d edge-nodes) exceeds capacity (%d, %d, %d)",
+                    b->n_frames, b->n_heads, b->n_edge_nodes, ctx->cfg.max_frames, ctx->cfg.max_heads,
+                    ctx->cfg.max_edge_nodes);
+    if (b->n_frames > 0 && (!b->d_frame_head_off || !b->d_frame_en_off || !b->d_slot_cam || !b->d_slot_n))
+        return fail(ctx, MPE_ERR_INVALID, "batch offset tables missing");
+    if (b->n_heads > 0 && (!b->d_head_cam || !b->d_joint_mask || !b->d_tri_mask || !b->d_xy || !b->d_vp))
+        return fail(ctx, MPE_ERR_INVALID, "batch skeleton arrays missing");
+    return MPE_OK;
+}
+
+struct GemmProf {
+    mpe_ctx *ctx;
+    hipStream_t s;
+    bool on;
+    size_t idx;
+    GemmProf(mpe_ctx *c, hipStream_t st, double flop, int dev_m_n, int dev_m_k) : ctx(c), s(st), on(false), idx(0) {
+        if (!c->profiling) return;
+        if (c->prof_used == c->prof.size()) {
+            ProfileRec r{};
+            if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+            c->prof.push_back(r);
+        }
+        idx = c->prof_used++;
+        c->prof[idx].flop = flop;
+        c->prof[idx].dev_n = dev_m_n;
+        c->prof[idx].dev_k = dev_m_k;
+        on = true;
+        (void)hipEventRecord(c->prof[idx].start, s);
+    }
+    ~GemmProf() {
+        if (on) (void)hipEventRecord(ctx->prof[idx].stop, s);
+    }
+};
+
+int linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, const Linear &L, float *C, int ldc, int m,
+           const int32_t *d_m, bool leaky, float slope, bool acc64 = false) {
+    if (m <= 0) return MPE_OK;
+    if (lda < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", lda, L.ldw);
+    GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0);
+    HIPCHK(ctx, launch_linear(s, A, lda, L.w, L.ldw, L.b, C, ldc, m, d_m, L.out_dim, L.ldw, leaky, slope, acc64));
+    return MPE_OK;
+}
+
+int ensure_gat_workspace(mpe_ctx *ctx) {
+    if (ctx->act[0]) return MPE_OK;
+    for (int l = 0; l < ctx->gat_layers; ++l)
+        if (!ctx->gat_ready[l]) return fail(ctx, MPE_ERR_STATE, "GAT layer %d has no weights", l);
+    if (ctx->gat_layers <= 0) return fail(ctx, MPE_ERR_STATE, "GAT parameters not set");
+    const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints;
+    const int F = 2 + V * J * 10;
+    if (ctx->gat[0].in_dim != F)
+        return fail(ctx, MPE_ERR_INVALID, "GAT input width %d != 2 + V*J*10 = %d", ctx->gat[0].in_dim, F);
+    ctx->feat_ld = round_up(F, LD_ALIGN);
+    int widest = 0;
+    for (int l = 0; l < ctx->gat_layers; ++l) {
+        const GatLayer &g = ctx->gat[l];
+        if (l > 0 && g.in_dim != ctx->gat[l - 1].heads * ctx->gat[l - 1].out_dim)
+            return fail(ctx, MPE_ERR_INVALID, "GAT layer %d input width mismatch", l);
+        if (g.heads > 16) return fail(ctx, MPE_ERR_INVALID, "at most 16 attention heads supported");
+        if (l > 0) widest = widest > g.in_dim ? widest : g.in_dim;
+        widest = widest > g.heads * g.out_dim ? widest : g.heads * g.out_dim;
+    }
+    ctx->act_ld = round_up(widest, LD_ALIGN);
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->x0, (size_t)ctx->cfg.max_heads * ctx->feat_ld))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->h0, (size_t)ctx->cfg.max_heads * ctx->feat_ld))) return rc;
+    for (int i = 0; i < 3; ++i)
+        if ((rc = dev_alloc(ctx, &ctx->act[i], (size_t)ctx->max_nodes * ctx->act_ld))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->a12, (size_t)ctx->max_nodes * 32))) return rc;
+    // layer-0 constants of the edge-nodes: every edge-node row is the one-hot e_1, so
+    // fc1(e_1) = W1[:,1] + b1 and everything downstream of it is a model constant.
+    const GatLayer &g0 = ctx->gat[0];
+    std::vector<float> w1((size_t)g0.in_dim * g0.fc1.ldw), b1(g0.in_dim), c1(ctx->feat_ld, 0.f);
+    HIPCHK(ctx, hipMemcpy(w1.data(), g0.fc1.w, w1.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(b1.data(), g0.fc1.b, b1.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int n = 0; n < g0.in_dim; ++n) {
+        const float v = w1[(size_t)n * g0.fc1.ldw + 1] + b1[n];
+        c1[n] = v > 0.f ? v : v * ctx->gat_alpha;
+    }
+    float *d_c1 = nullptr;
+    if ((rc = dev_alloc(ctx, &d_c1, (size_t)ctx->feat_ld))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->en0_ft2, (size_t)ctx->act_ld))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->en0_a, 32))) return rc;
+    HIPCHK(ctx, hipMemcpy(d_c1, c1.data(), c1.size() * sizeof(float), hipMemcpyHostToDevice));
+    const bool was = ctx->profiling;
+    ctx->profiling = false;
+    rc = linear(ctx, nullptr, d_c1, ctx->feat_ld, g0.fc2, ctx->en0_ft2, ctx->act_ld, 1, nullptr, false, 0.f);
+    ctx->profiling = was;
+    if (rc) return rc;
+    HIPCHK(ctx, launch_attn_coef(nullptr, ctx->en0_ft2, ctx->act_ld, 1, g0.heads, g0.out_dim, g0.attn_l, g0.attn_r,
+                                 ctx->en0_a));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    ctx->en0_ready = true;
+    return MPE_OK;
+}
+
+int ensure_mlp_workspace(mpe_ctx *ctx) {
+    if (ctx->mlp_rows) return MPE_OK;
+    if (ctx->mlp_layers <= 0) return fail(ctx, MPE_ERR_STATE, "MLP parameters not set");
+    for (int l = 0; l < ctx->mlp_layers; ++l)
+        if (!ctx->mlp_ready[l]) return fail(ctx, MPE_ERR_STATE, "MLP layer %d has no weights", l);
+    const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints, npj = ctx->cfg.numbers_per_joint;
+    if (ctx->mlp[0].in_dim != V * J * npj)
+        return fail(ctx, MPE_ERR_INVALID, "MLP input width %d != V*J*numbers_per_joint = %d", ctx->mlp[0].in_dim,
+                    V * J * npj);
+    int widest = 0;
+    for (int l = 0; l < ctx->mlp_layers; ++l) {
+        if (l > 0 && ctx->mlp[l].in_dim != ctx->mlp[l - 1].out_dim)
+            return fail(ctx, MPE_ERR_INVALID, "MLP layer %d input width mismatch", l);
+        widest = widest > ctx->mlp[l].out_dim ? widest : ctx->mlp[l].out_dim;
+    }
+    ctx->mlp_ld_in = round_up(ctx->mlp[0].in_dim, LD_ALIGN);
+    ctx->mlp_ld_hidden = round_up(widest, LD_ALIGN);
+    const size_t rows = (size_t)ctx->cfg.max_frames * ctx->cfg.max_persons_per_frame;
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->mlp_rows, rows * ctx->mlp_ld_in))) return rc;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = dev_alloc(ctx, &ctx->mlp_act[i], rows * ctx->mlp_ld_hidden))) return rc;
+    return MPE_OK;
+}
+
+int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en, float *d_scores_heads) {
+    int rc = ensure_gat_workspace(ctx);
+    if (rc) return rc;
+    const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints;
+    const int n_nodes = b->n_heads + b->n_edge_nodes;
+    const int hmax = ctx->cfg.max_heads_per_frame;
+    HIPCHK(ctx, launch_topology(s, *b, V, ctx->node_off, ctx->row_frame, ctx->en_pair));
+    HIPCHK(ctx, launch_head_features(s, ctx->d_cfg, *b, J, ctx->x0, ctx->feat_ld, 0, 0, true));
+    const int L = ctx->gat_layers;
+    for (int l = 0; l < L; ++l) {
+        const GatLayer &g = ctx->gat[l];
+        const bool last = l == L - 1;
+        AggArgs a{};
+        a.heads = g.heads;
+        a.out_dim = g.out_dim;
+        a.alpha = ctx->gat_alpha;
+        a.out_slope = ctx->gat_hidden_slope;
+        a.ld = ctx->act_ld;
+        a.a12 = ctx->a12;
+        if (l == 0) {
+            // heads only: edge-node rows are the layer-0 constants
+            if ((rc = linear(ctx, s, ctx->x0, ctx->feat_ld, g.fc1, ctx->h0, ctx->feat_ld, b->n_heads, nullptr, true,
+                             ctx->gat_alpha, ctx->gat_acc64)))
+                return rc;
+            if ((rc = linear(ctx, s, ctx->h0, ctx->feat_ld, g.fc2, ctx->act[1], ctx->act_ld, b->n_heads, nullptr,
+                             false, 0.f, ctx->gat_acc64)))
+                return rc;
+            HIPCHK(ctx, launch_attn_coef(s, ctx->act[1], ctx->act_ld, b->n_heads, g.heads, g.out_dim, g.attn_l,
+                                         g.attn_r, ctx->a12));
+            a.ft2 = ctx->act[1];
+            a.en_const_ft2 = ctx->en0_ft2;
+            a.en_const_a = ctx->en0_a;
+        } else {
+            if ((rc = linear(ctx, s, ctx->act[0], ctx->act_ld, g.fc1, ctx->act[1], ctx->act_ld, n_nodes, nullptr, true,
+                             ctx->gat_alpha, ctx->gat_acc64)))
+                return rc;
+            if ((rc = linear(ctx, s, ctx->act[1], ctx->act_ld, g.fc2, ctx->act[2], ctx->act_ld, n_nodes, nullptr,
+                             false, 0.f, ctx->gat_acc64)))
+                return rc;
+            HIPCHK(ctx, launch_attn_coef(s, ctx->act[2], ctx->act_ld, n_nodes, g.heads, g.out_dim, g.attn_l, g.attn_r,
+                                         ctx->a12));
+            a.ft2 = ctx->act[2];
+        }
+        if (last) {
+            a.out_mode = 1;
+            a.score_mode = 1;
+            a.out = d_scores_en;
+            a.out_heads = d_scores_heads;
+            a.ld_out = 1;
+        } else {
+            a.out_mode = 0;
+            a.out = ctx->act[0];
+            a.ld_out = ctx->act_ld;
+        }
+        HIPCHK(ctx, launch_aggregate(s, *b, V, hmax, ctx->node_off, ctx->row_frame, ctx->en_pair, a, n_nodes));
+    }
+    return MPE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mpe_version(void) { return "mpe-hip 0.1 (gfx950)"; }
+
+const char *mpe_last_error(const mpe_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int mpe_create(const mpe_config *cfg, mpe_ctx **out) {
+    if (!cfg || !out) return MPE_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->n_cameras < 1 || cfg->n_cameras > MPE_MAX_CAMERAS || cfg->n_joints < 1 ||
+        cfg->n_joints > MPE_MAX_JOINTS || cfg->max_frames < 1 || cfg->max_heads < 1 || cfg->max_edge_nodes < 1 ||
+        cfg->max_heads_per_frame < 2 || cfg->max_heads_per_frame > 32767 || cfg->max_persons_per_frame < 1 ||
+        !cfg->Kinv || !cfg->K || !cfg->T_i || !cfg->P || !cfg->dist)
+        return MPE_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MPE_ERR_HIP;
+    mpe_ctx *ctx = new (std::nothrow) mpe_ctx();
+    if (!ctx) return MPE_ERR_NOMEM;
+    ctx->cfg = *cfg;
+    DevCfg &h = ctx->hcfg;
+    memset(&h, 0, sizeof h);
+    h.V = cfg->n_cameras;
+    h.J = cfg->n_joints;
+    h.W = cfg->image_width;
+    h.H = cfg->image_height;
+    h.npj = cfg->numbers_per_joint;
+    h.min_views = cfg->min_views;
+    h.median_axis = cfg->median_axis;
+    h.used_joint_mask = cfg->used_joint_mask;
+    h.threshold = cfg->threshold;
+    h.median_window = cfg->median_window;
+    for (int c = 0; c < h.V; ++c) {
+        memcpy(h.Kinv[c], cfg->Kinv + 9 * c, 9 * sizeof(float));
+        memcpy(h.K[c], cfg->K + 9 * c, 9 * sizeof(float));
+        memcpy(h.T_i[c], cfg->T_i + 16 * c, 16 * sizeof(float));
+        memcpy(h.P[c], cfg->P + 12 * c, 12 * sizeof(double));
+        memcpy(h.dist[c], cfg->dist + 5 * c, 5 * sizeof(double));
+    }
+    ctx->cfg.Kinv = ctx->cfg.K = ctx->cfg.T_i = nullptr;
+    ctx->cfg.P = ctx->cfg.dist = nullptr;
+    ctx->max_nodes = cfg->max_heads + cfg->max_edge_nodes;
+    int rc = MPE_OK;
+    do {
+        if ((rc = dev_alloc(ctx, &ctx->d_cfg, 1))) break;
+        if (hipMemcpy(ctx->d_cfg, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) { rc = MPE_ERR_HIP; break; }
+        if ((rc = dev_alloc(ctx, &ctx->row_frame, (size_t)ctx->max_nodes))) break;
+        if ((rc = dev_alloc(ctx, &ctx->en_pair, (size_t)cfg->max_edge_nodes * 2))) break;
+        if ((rc = dev_alloc(ctx, &ctx->node_off, (size_t)cfg->max_frames + 1))) break;
+        ctx->cl_keys_per_frame = cluster_keys_per_frame(cfg->max_heads_per_frame);
+        ctx->cl_scratch_per_frame = cluster_scratch_per_frame(cfg->max_heads_per_frame);
+        if ((rc = dev_alloc(ctx, &ctx->cl_keys, ctx->cl_keys_per_frame * cfg->max_frames, false))) break;
+        if ((rc = dev_alloc(ctx, &ctx->cl_scratch, ctx->cl_scratch_per_frame * cfg->max_frames, false))) break;
+        if ((rc = dev_alloc(ctx, &ctx->mlp_count, 1))) break;
+        if ((rc = dev_alloc(ctx, &ctx->scores_tmp, (size_t)cfg->max_edge_nodes))) break;
+        if ((rc = dev_alloc(ctx, &ctx->person_off, (size_t)cfg->max_frames + 1))) break;
+        if ((rc = dev_alloc(ctx, &ctx->valid_tmp, (size_t)cfg->max_frames * cfg->max_persons_per_frame))) break;
+    } while (0);
+    if (rc) {
+        mpe_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return MPE_OK;
+}
+
+void mpe_destroy(mpe_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipDeviceSynchronize();
+    for (void *p : ctx->owned) (void)hipFree(p);
+    for (auto &r : ctx->prof) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    if (ctx->tot_start) (void)hipEventDestroy(ctx->tot_start);
+    if (ctx->tot_stop) (void)hipEventDestroy(ctx->tot_stop);
+    delete ctx;
+}
+
+int mpe_set_gat_params(mpe_ctx *ctx, int32_t n_layers, float alpha, float hidden_slope) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (n_layers < 2 || n_layers > MPE_MAX_GAT_LAYERS) return fail(ctx, MPE_ERR_INVALID, "bad GAT layer count %d", n_layers);
+    if (ctx->act[0]) return fail(ctx, MPE_ERR_STATE, "GAT weights are frozen after the first batch");
+    ctx->gat_layers = n_layers;
+    ctx->gat_alpha = alpha;
+    ctx->gat_hidden_slope = hidden_slope;
+    return MPE_OK;
+}
+
+int mpe_set_gat_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t heads, int32_t out_dim, const float *fc1_w,
+                      const float *fc1_b, const float *fc2_w, const float *fc2_b, const float *attn_l,
+                      const float *attn_r) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (layer < 0 || layer >= ctx->gat_layers) return fail(ctx, MPE_ERR_INVALID, "GAT layer index %d out of range", layer);
+    if (ctx->act[0]) return fail(ctx, MPE_ERR_STATE, "GAT weights are frozen after the first batch");
+    if (!fc1_w || !fc1_b || !fc2_w || !fc2_b || !attn_l || !attn_r || heads < 1 || out_dim < 1)
+        return fail(ctx, MPE_ERR_INVALID, "GAT layer %d: missing tensor", layer);
+    GatLayer &g = ctx->gat[layer];
+    g.in_dim = in_dim;
+    g.heads = heads;
+    g.out_dim = out_dim;
+    int rc;
+    if ((rc = upload_linear(ctx, fc1_w, fc1_b, in_dim, in_dim, &g.fc1))) return rc;
+    if ((rc = upload_linear(ctx, fc2_w, fc2_b, heads * out_dim, in_dim, &g.fc2))) return rc;
+    if ((rc = dev_alloc(ctx, &g.attn_l, (size_t)heads * out_dim))) return rc;
+    if ((rc = dev_alloc(ctx, &g.attn_r, (size_t)heads * out_dim))) return rc;
+    HIPCHK(ctx, hipMemcpy(g.attn_l, attn_l, (size_t)heads * out_dim * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(g.attn_r, attn_r, (size_t)heads * out_dim * sizeof(float), hipMemcpyHostToDevice));
+    ctx->gat_ready[layer] = true;
+    return MPE_OK;
+}
+
+int mpe_set_mlp_params(mpe_ctx *ctx, int32_t n_layers, float slope) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (n_layers < 1 || n_layers > MPE_MAX_MLP_LAYERS) return fail(ctx, MPE_ERR_INVALID, "bad MLP layer count %d", n_layers);
+    if (ctx->mlp_rows) return fail(ctx, MPE_ERR_STATE, "MLP weights are frozen after the first batch");
+    ctx->mlp_layers = n_layers;
+    ctx->mlp_slope = slope;
+    return MPE_OK;
+}
+
+int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_dim, const float *w, const float *b) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (layer < 0 || layer >= ctx->mlp_layers) return fail(ctx, MPE_ERR_INVALID, "MLP layer index %d out of range", layer);
+    if (ctx->mlp_rows) return fail(ctx, MPE_ERR_STATE, "MLP weights are frozen after the first batch");
+    if (!w || !b) return fail(ctx, MPE_ERR_INVALID, "MLP layer %d: missing tensor", layer);
+    int rc = upload_linear(ctx, w, b, out_dim, in_dim, &ctx->mlp[layer]);
+    if (rc) return rc;
+    ctx->mlp_ready[layer] = true;
+    return MPE_OK;
+}
+
+int mpe_upload_linear(mpe_ctx *ctx, const float *w, const float *b, int32_t out_dim, int32_t in_dim, float **d_w,
+                      float **d_b, int32_t *ldw) {
+    if (!ctx || !d_w || !d_b || !ldw) return MPE_ERR_INVALID;
+    Linear L;
+    int rc = upload_linear(ctx, w, b, out_dim, in_dim, &L);
+    if (rc) return rc;
+    *d_w = L.w;
+    *d_b = L.b;
+    *ldw = L.ldw;
+    return MPE_OK;
+}
+
+int mpe_free_device(mpe_ctx *ctx, void *d_ptr) {
+    if (!ctx) return MPE_ERR_INVALID;
+    for (size_t i = 0; i < ctx->owned.size(); ++i)
+        if (ctx->owned[i] == d_ptr) {
+            (void)hipFree(d_ptr);
+            ctx->owned.erase(ctx->owned.begin() + i);
+            return MPE_OK;
+        }
+    return fail(ctx, MPE_ERR_INVALID, "pointer not owned by this context");
+}
+
+int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const float *d_w, int32_t ldw,
+               const float *d_bias, float *d_c, int32_t ldc, int32_t m, const int32_t *d_m, int32_t n, int32_t k,
+               int32_t slope_on, float slope) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (!d_a || !d_w || !d_bias || !d_c || m < 0 || n < 1 || k < 1)
+        return fail(ctx, MPE_ERR_INVALID, "mpe_linear: bad argument");
+    if (ldw % LD_ALIGN || ldw < k || lda < ldw || ldc % 4 || ldc < n)
+        return fail(ctx, MPE_ERR_INVALID, "mpe_linear: strides must satisfy ldw%%32==0, lda>=ldw>=k, ldc%%4==0");
+    Linear L;
+    L.w = const_cast<float *>(d_w);
+    L.b = const_cast<float *>(d_bias);
+    L.in_dim = k;
+    L.out_dim = n;
+    L.ldw = ldw;
+    return linear(ctx, static_cast<hipStream_t>(stream), d_a, lda, L, d_c, ldc, m, d_m, (slope_on & 1) != 0, slope,
+                  (slope_on & 2) != 0);
+}
+
+int mpe_head_features(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_feat) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    if (!d_feat) return fail(ctx, MPE_ERR_INVALID, "d_feat is NULL");
+    HIPCHK(ctx, launch_head_features(static_cast<hipStream_t>(stream), ctx->d_cfg, *b, ctx->cfg.n_joints, d_feat,
+                                     ctx->cfg.n_joints * 10, 0, 0, false));
+    return MPE_OK;
+}
+
+int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_scores_en, float *d_scores_heads) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    if (!d_scores_en) return fail(ctx, MPE_ERR_INVALID, "d_scores_en is NULL");
+    return run_gat(ctx, static_cast<hipStream_t>(stream), b, d_scores_en, d_scores_heads);
+}
+
+int mpe_gat_debug_layer(mpe_ctx *ctx, void *stream, int32_t, float *d_out, int32_t ld_out, int32_t n_rows) {
+    // copies the current content of the hidden-activation buffer (valid right after a
+    // forward that was stopped by setting the layer count) -- see tests
+    if (!ctx || !d_out) return MPE_ERR_INVALID;
+    if (!ctx->act[0]) return fail(ctx, MPE_ERR_STATE, "no forward pass has run");
+    HIPCHK(ctx, hipMemcpy2DAsync(d_out, (size_t)ld_out * sizeof(float), ctx->act[0], (size_t)ctx->act_ld * sizeof(float),
+                                 (size_t)(ld_out < ctx->act_ld ? ld_out : ctx->act_ld) * sizeof(float), n_rows,
+                                 hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return MPE_OK;
+}
+
+int mpe_cluster_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float *d_scores, int32_t *d_persons,
+                      int32_t *d_n_persons) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    if (!d_scores || !d_persons || !d_n_persons) return fail(ctx, MPE_ERR_INVALID, "mpe_cluster_batch: NULL output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIPCHK(ctx, launch_topology(s, *b, ctx->cfg.n_cameras, ctx->node_off, ctx->row_frame, ctx->en_pair));
+    HIPCHK(ctx, launch_cluster(s, ctx->d_cfg, *b, ctx->en_pair, d_scores, ctx->cfg.max_persons_per_frame,
+                               ctx->cfg.max_heads_per_frame, ctx->cl_keys, ctx->cl_keys_per_frame, ctx->cl_scratch,
+                               ctx->cl_scratch_per_frame, d_persons, d_n_persons));
+    return MPE_OK;
+}
+
+int mpe_match_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_scores, int32_t *d_persons,
+                    int32_t *d_n_persons) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    if (!d_persons || !d_n_persons) return fail(ctx, MPE_ERR_INVALID, "mpe_match_batch: NULL output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *scores = d_scores;
+    if (!scores) {
+        scores = ctx->scores_tmp;
+    }
+    if ((rc = run_gat(ctx, s, b, scores, nullptr))) return rc;
+    HIPCHK(ctx, launch_cluster(s, ctx->d_cfg, *b, ctx->en_pair, scores, ctx->cfg.max_persons_per_frame,
+                               ctx->cfg.max_heads_per_frame, ctx->cl_keys, ctx->cl_keys_per_frame, ctx->cl_scratch,
+                               ctx->cl_scratch_per_frame, d_persons, d_n_persons));
+    return MPE_OK;
+}
+
+int mpe_mlp_input_rows(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_t *d_persons,
+                       const int32_t *d_n_persons, float *d_rows, int32_t ld_rows, uint8_t *d_valid) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    const int width = ctx->cfg.n_cameras * ctx->cfg.n_joints * ctx->cfg.numbers_per_joint;
+    if (!d_persons || !d_n_persons || !d_rows || ld_rows < width)
+        return fail(ctx, MPE_ERR_INVALID, "mpe_mlp_input_rows: bad argument");
+    HIPCHK(ctx, launch_mlp_rows(static_cast<hipStream_t>(stream), ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints, *b,
+                                d_persons, d_n_persons, nullptr, ctx->cfg.max_persons_per_frame, d_rows, ld_rows,
+                                d_valid));
+    return MPE_OK;
+}
+
+static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int m, const int32_t *d_m, float **y_out,
+                     int *ld_y) {
+    const float *in = x;
+    int ld_in = ld_x;
+    int rc;
+    for (int l = 0; l < ctx->mlp_layers; ++l) {
+        float *out = ctx->mlp_act[l & 1];
+        const bool last = l == ctx->mlp_layers - 1;
+        if ((rc = linear(ctx, s, in, ld_in, ctx->mlp[l], out, ctx->mlp_ld_hidden, m, d_m, !last, ctx->mlp_slope,
+                         ctx->mlp_acc64)))
+            return rc;
+        in = out;
+        ld_in = ctx->mlp_ld_hidden;
+    }
+    *y_out = const_cast<float *>(in);
+    *ld_y = ld_in;
+    return MPE_OK;
+}
+
+int mpe_mlp_forward(mpe_ctx *ctx, void *stream, const float *d_x, int32_t ld_x, int32_t m, float *d_y, int32_t ld_y) {
+    if (!ctx) return MPE_ERR_INVALID;
+    int rc = ensure_mlp_workspace(ctx);
+    if (rc) return rc;
+    if (!d_x || !d_y || m < 0) return fail(ctx, MPE_ERR_INVALID, "mpe_mlp_forward: bad argument");
+    if ((size_t)m > (size_t)ctx->cfg.max_frames * ctx->cfg.max_persons_per_frame)
+        return fail(ctx, MPE_ERR_CAPACITY, "mpe_mlp_forward: %d rows exceed capacity", m);
+    if (ld_x < ctx->mlp_ld_in) return fail(ctx, MPE_ERR_INVALID, "mpe_mlp_forward: ld_x must be >= %d (zero padded)", ctx->mlp_ld_in);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *y;
+    int ldy;
+    if ((rc = mlp_chain(ctx, s, d_x, ld_x, m, nullptr, &y, &ldy))) return rc;
+    const int n_out = ctx->mlp[ctx->mlp_layers - 1].out_dim;
+    HIPCHK(ctx, hipMemcpy2DAsync(d_y, (size_t)ld_y * sizeof(float), y, (size_t)ldy * sizeof(float),
+                                 (size_t)n_out * sizeof(float), m, hipMemcpyDeviceToDevice, s));
+    return MPE_OK;
+}
+
+int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_t *d_persons,
+                    const int32_t *d_n_persons, float *d_poses, uint8_t *d_valid) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    if ((rc = ensure_mlp_workspace(ctx))) return rc;
+    if (!d_persons || !d_n_persons || !d_poses) return fail(ctx, MPE_ERR_INVALID, "mpe_mlp3d_batch: NULL argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int pcap = ctx->cfg.max_persons_per_frame;
+    HIPCHK(ctx, launch_person_scan(s, b->n_frames, pcap, d_n_persons, ctx->person_off, ctx->mlp_count));
+    HIPCHK(ctx, launch_mlp_rows(s, ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints, *b, d_persons, d_n_persons,
+                                ctx->person_off, pcap, ctx->mlp_rows, ctx->mlp_ld_in, d_valid ? d_valid : ctx->valid_tmp));
+    float *y;
+    int ldy;
+    if ((rc = mlp_chain(ctx, s, ctx->mlp_rows, ctx->mlp_ld_in, b->n_frames * pcap, ctx->mlp_count, &y, &ldy))) return rc;
+    const int n_out = ctx->mlp[ctx->mlp_layers - 1].out_dim;
+    if (n_out != ctx->cfg.n_joints * 3)
+        return fail(ctx, MPE_ERR_INVALID, "MLP output width %d != 3*J", n_out);
+    HIPCHK(ctx, launch_decode(s, b->n_frames, pcap, n_out, 10.f, d_n_persons, ctx->person_off, y, ldy, d_poses));
+    return MPE_OK;
+}
+
+int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_t *d_persons,
+                          const int32_t *d_n_persons, double *d_poses, uint8_t *d_joint_valid) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    if (!d_persons || !d_n_persons || !d_poses || !d_joint_valid)
+        return fail(ctx, MPE_ERR_INVALID, "mpe_triangulate_batch: NULL argument");
+    HIPCHK(ctx, launch_triangulate(static_cast<hipStream_t>(stream), ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints,
+                                   *b, d_persons, d_n_persons, ctx->cfg.max_persons_per_frame, d_poses, d_joint_valid));
+    return MPE_OK;
+}
+
+int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t *d_cams, int32_t n, double *d_out) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (!d_pts || !d_cams || !d_out || n < 0) return fail(ctx, MPE_ERR_INVALID, "mpe_dlt_pairs: bad argument");
+    HIPCHK(ctx, launch_dlt_pairs(static_cast<hipStream_t>(stream), ctx->d_cfg, d_pts, d_cams, n, d_out));
+    return MPE_OK;
+}
+
+int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
+    if (!ctx) return MPE_ERR_INVALID;
+    ctx->gat_acc64 = gat_acc64 != 0;
+    ctx->mlp_acc64 = mlp_acc64 != 0;
+    return MPE_OK;
+}
+
+int mpe_profile_enable(mpe_ctx *ctx, int32_t on) {
+    if (!ctx) return MPE_ERR_INVALID;
+    ctx->profiling = on != 0;
+    ctx->prof_used = 0;
+    return MPE_OK;
+}
+
+int mpe_profile_read(mpe_ctx *ctx, double *gemm_ms, double *gemm_flop, int64_t *gemm_launches, double *total_ms) {
+    if (!ctx) return MPE_ERR_INVALID;
+    HIPCHK(ctx, hipDeviceSynchronize());
+    int32_t dev_m = 0;
+    HIPCHK(ctx, hipMemcpy(&dev_m, ctx->mlp_count, sizeof dev_m, hipMemcpyDeviceToHost));
+    double ms = 0, flop = 0;
+    for (size_t i = 0; i < ctx->prof_used; ++i) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, ctx->prof[i].start, ctx->prof[i].stop) == hipSuccess) ms += t;
+        flop += ctx->prof[i].flop;
+        if (ctx->prof[i].dev_n) flop += 2.0 * dev_m * (double)ctx->prof[i].dev_n * ctx->prof[i].dev_k;
+    }
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_flop) *gemm_flop = flop;
+    if (gemm_launches) *gemm_launches = (int64_t)ctx->prof_used;
+    if (total_ms) *total_ms = 0;
+    ctx->prof_used = 0;
+    return MPE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+// Graph side of the skeleton-matching network, frame-batched and with implicit topology.
+//
+// The reference materialises, per frame, a DGL graph with a dense N x 902 feature matrix
+// (graph_generator.py:813-876) and runs apply_edges / edge_softmax / update_all on it
+// (gat2.py:57-66).  For graph alternative '3' the topology is a pure function of the
+// per-camera skeleton counts, so no graph object exists here: kernels derive the in-edges
+// of a node from slot_n[frame][V]:
+//
+//   head h (slot s, index i):   (h,h), then every edge-node X that pairs h with a head of
+//                               another slot, in ascending X  (edge ids are created per
+//                               edge-node in ascending order, graph_generator.py:632-651)
+//   edge-node X = (h1,h2):      (h1,X), (h2,X), (X,X)
+//
+// Sums over in-edges run in that order (= DGL's edge order for a destination).
+#include "mpe_internal.h"
+
+namespace mpe {
+
+// ---------------------------------------------------------------------------------------
+// topology tables: node_off[f], row_frame[row], en_pair[m] = (h1,h2) frame-local
+// ---------------------------------------------------------------------------------------
+__global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head_off,
+                           const int32_t *__restrict__ en_off, const int32_t *__restrict__ slot_n,
+                           int32_t *__restrict__ node_off, int32_t *__restrict__ row_frame,
+                           int32_t *__restrict__ en_pair) {
+    const int f = blockIdx.x;
+    __shared__ int s_n[MPE_MAX_CAMERAS], s_start[MPE_MAX_CAMERAS];
+    const int h0 = head_off[f], H = head_off[f + 1] - h0;
+    const int e0 = en_off[f], M = en_off[f + 1] - e0;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int s = 0; s < V; ++s) {
+            s_n[s] = slot_n[f * V + s];
+            s_start[s] = acc;
+            acc += s_n[s];
+        }
+        node_off[f] = h0 + e0;
+        if (f == n_frames - 1) node_off[n_frames] = head_off[n_frames] + en_off[n_frames];
+    }
+    __syncthreads();
+    const int r0 = h0 + e0;
+    for (int i = threadIdx.x; i < H + M; i += blockDim.x) row_frame[r0 + i] = f;
+    int base = 0;
+    for (int a = 0; a < V; ++a)
+        for (int b = a + 1; b < V; ++b) {
+            const int na = s_n[a], nb = s_n[b], cnt = na * nb;
+            for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+                const int i = t / nb, j = t - i * nb;
+                en_pair[2 * (size_t)(e0 + base + t) + 0] = s_start[a] + i;
+                en_pair[2 * (size_t)(e0 + base + t) + 1] = s_start[b] + j;
+            }
+            base += cnt;
+        }
+}
+
+hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *row_frame,
+                           int32_t *en_pair) {
+    if (b.n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_topology, dim3(b.n_frames), dim3(128), 0, s, b.n_frames, V, b.d_frame_head_off,
+                       b.d_frame_en_off, b.d_slot_n, node_off, row_frame, en_pair);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// head featurisation (graph_generator.py:444-508)
+// ---------------------------------------------------------------------------------------
+// Per present joint: [i, j, valid, prob, cx, cy, cz, vx, vy, vz] with
+//   i = (x - W/2)/(W/2), j = (H/2 - y)/(H/2) evaluated in f64 and rounded to f32,
+//   c = camera centre (T_i @ [0,0,0,1]), v = (T_i @ [Kinv @ [x,y,1]; 0])[0:3] in f32.
+// dense = true writes the whole zero-padded F-wide row (col 0 = 1, own-camera block at
+// 2 + cam*J*10); dense = false writes only the J*10 block.
+__global__ void k_head_features(const DevCfg *__restrict__ cfg, int n_heads, int J,
+                                const int32_t *__restrict__ head_cam, const uint32_t *__restrict__ joint_mask,
+                                const double *__restrict__ xy, const float *__restrict__ vp,
+                                float *__restrict__ feat, int ld_feat, int dense) {
+#pragma clang fp contract(off)
+    const int h = blockIdx.x;
+    if (h >= n_heads) return;
+    __shared__ float s_f[MPE_MAX_JOINTS * 10];
+    const int cam = head_cam[h];
+    const int t = threadIdx.x;
+    if (t < J) {
+        const uint32_t mask = joint_mask[h];
+        float o[10];
+        if (mask >> t & 1u) {
+            const double x = xy[((size_t)h * J + t) * 2 + 0], y = xy[((size_t)h * J + t) * 2 + 1];
+            const double hw = cfg->W / 2.0, hh = cfg->H / 2.0;
+            o[0] = (float)((x - hw) / hw);
+            o[1] = (float)((hh - y) / hh);
+            o[2] = vp[((size_t)h * J + t) * 2 + 0];
+            o[3] = vp[((size_t)h * J + t) * 2 + 1];
+            const float *Ki = cfg->Kinv[cam];
+            const float *T = cfg->T_i[cam];
+            const float px = (float)x, py = (float)y;
+            float pix[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float a = Ki[r * 3 + 0] * px;
+                a = __builtin_fmaf(Ki[r * 3 + 1], py, a);
+                a = __builtin_fmaf(Ki[r * 3 + 2], 1.0f, a);
+                pix[r] = a;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                o[4 + r] = T[r * 4 + 3];      // T_i @ [0,0,0,1]
+                float a = T[r * 4 + 0] * pix[0];
+                a = __builtin_fmaf(T[r * 4 + 1], pix[1], a);
+                a = __builtin_fmaf(T[r * 4 + 2], pix[2], a);
+                o[7 + r] = a;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) o[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s_f[t * 10 + k] = o[k];
+    }
+    __syncthreads();
+    const int blk = J * 10;
+    if (dense) {
+        const int lo = 2 + cam * blk;
+        float *row = feat + (size_t)h * ld_feat;
+        for (int c = t; c < ld_feat; c += blockDim.x) {
+            float v = 0.f;
+            if (c == 0) v = 1.f;
+            else if (c >= lo && c < lo + blk) v = s_f[c - lo];
+            row[c] = v;
+        }
+    } else {
+        float *row = feat + (size_t)h * ld_feat;
+        for (int c = t; c < blk; c += blockDim.x) row[c] = s_f[c];
+    }
+}
+
+hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
+                                int ld_feat, int, int, bool dense) {
+    if (b.n_heads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_head_features, dim3(b.n_heads), dim3(128), 0, s, cfg, b.n_heads, J, b.d_head_cam,
+                       b.d_joint_mask, b.d_xy, b.d_vp, feat, ld_feat, dense ? 1 : 0);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// attention coefficients a1 = <ft2[n,h,:], attn_l[h,:]>, a2 with attn_r  (gat2.py:57-58)
+// ---------------------------------------------------------------------------------------
+constexpr int COEF_ROWS = 8;
+
+__global__ __launch_bounds__(256) void k_attn_coef(const float *__restrict__ ft2, int ld, int n_rows, int heads,
+                                                   int out_dim, const float *__restrict__ attn_l,
+                                                   const float *__restrict__ attn_r, float *__restrict__ a12) {
+    extern __shared__ float s_ft[];                 // [COEF_ROWS][hd]
+    const int hd = heads * out_dim;
+    const int r0 = blockIdx.x * COEF_ROWS;
+    const int nr = min(COEF_ROWS, n_rows - r0);
+    for (int i = threadIdx.x; i < nr * hd; i += blockDim.x) {
+        const int r = i / hd, c = i - r * hd;
+        s_ft[r * hd + c] = ft2[(size_t)(r0 + r) * ld + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * heads * 2; i += blockDim.x) {
+        const int r = i / (heads * 2), rem = i - r * heads * 2;
+        const int which = rem / heads, h = rem - which * heads;
+        const float *av = (which ? attn_r : attn_l) + h * out_dim;
+        const float *fv = s_ft + r * hd + h * out_dim;
+        float acc = 0.f;
+        for (int d = 0; d < out_dim; ++d) acc = __builtin_fmaf(fv[d], av[d], acc);
+        a12[(size_t)(r0 + r) * 32 + which * 16 + h] = acc;
+    }
+}
+
+hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,
+                            const float *attn_l, const float *attn_r, float *a12) {
+    if (n_rows <= 0) return hipSuccess;
+    const int grid = (n_rows + COEF_ROWS - 1) / COEF_ROWS;
+    const size_t shm = (size_t)COEF_ROWS * heads * out_dim * sizeof(float);
+    hipLaunchKernelGGL(k_attn_coef, dim3(grid), dim3(256), shm, s, ft2, ld, n_rows, heads, out_dim, attn_l, attn_r,
+                       a12);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// edge attention + softmax over in-edges + weighted sum + activation
+// (gat2.py:61-66,78-88 and the activation of GAT2.forward :141-147)
+// ---------------------------------------------------------------------------------------
+constexpr int AGG_ROWS = 4;
+
+__global__ __launch_bounds__(256) void k_aggregate(
+    int n_nodes, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
+    const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off, const int32_t *__restrict__ row_frame,
+    const int32_t *__restrict__ en_pair, AggArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ float s_dyn[];
+    // layout: alpha [AGG_ROWS][max_deg][heads] | src [AGG_ROWS][max_deg] (int)
+    float *s_alpha = s_dyn;
+    int *s_src = reinterpret_cast<int *>(s_dyn + (size_t)AGG_ROWS * max_deg * a.heads);
+    __shared__ int s_deg[AGG_ROWS], s_f[AGG_ROWS], s_v[AGG_ROWS], s_H[AGG_ROWS], s_skip[AGG_ROWS];
+
+    const int row0 = blockIdx.x * AGG_ROWS;
+    const int t = threadIdx.x;
+    const int heads = a.heads, hd = a.heads * a.out_dim;
+
+    // phase A: in-edge lists (frame-local node ids; >= H means edge-node)
+    if (t < AGG_ROWS) {
+        const int row = row0 + t;
+        int deg = 0, skip = 1;
+        if (row < n_nodes) {
+            const int f = row_frame[row];
+            const int v = row - node_off[f];
+            const int H = head_off[f + 1] - head_off[f];
+            s_f[t] = f;
+            s_v[t] = v;
+            s_H[t] = H;
+            int *src = s_src + t * max_deg;
+            if (v >= H) {
+                const size_t m = (size_t)en_off[f] + (v - H);
+                src[0] = en_pair[2 * m + 0];
+                src[1] = en_pair[2 * m + 1];
+                src[2] = v;
+                deg = 3;
+                skip = 0;
+            } else if (!a.score_mode || a.out_heads) {
+                skip = 0;
+                const int32_t *sn = slot_n + (size_t)f * V;
+                int s = 0, start = 0;
+                while (s < V && v >= start + sn[s]) { start += sn[s]; ++s; }
+                const int i = v - start, ns = sn[s];
+                src[deg++] = v;                      // self loop (edge id h)
+                int base = H;
+                for (int p = 0; p < V; ++p)
+                    for (int q = p + 1; q < V; ++q) {
+                        const int np_ = sn[p], nq = sn[q];
+                        if (q == s) {
+                            for (int k = 0; k < np_; ++k) src[deg++] = base + k * ns + i;
+                        } else if (p == s) {
+                            for (int k = 0; k < nq; ++k) src[deg++] = base + i * nq + k;
+                        }
+                        base += np_ * nq;
+                    }
+            }
+        }
+        s_deg[t] = deg;
+        s_skip[t] = skip;
+    }
+    __syncthreads();
+
+    // phase B: logits e = LeakyReLU_alpha(a1[src] + a2[dst])
+    for (int r = 0; r < AGG_ROWS; ++r) {
+        if (s_skip[r]) continue;
+        const int deg = s_deg[r], f = s_f[r], v = s_v[r], H = s_H[r];
+        const int32_t nb = node_off[f], hb = head_off[f];
+        const bool l0 = a.en_const_ft2 != nullptr;
+        const float *a_dst;
+        if (l0) a_dst = v >= H ? a.en_const_a : a.a12 + (size_t)(hb + v) * 32;
+        else a_dst = a.a12 + (size_t)(nb + v) * 32;
+        for (int i = t; i < deg * heads; i += blockDim.x) {
+            const int e = i / heads, hh = i - e * heads;
+            const int u = s_src[r * max_deg + e];
+            const float *a_src;
+            if (l0) a_src = u >= H ? a.en_const_a : a.a12 + (size_t)(hb + u) * 32;
+            else a_src = a.a12 + (size_t)(nb + u) * 32;
+            const float a2v = a_dst[16 + hh];
+            const float a1v = a_src[hh];
+            float x = a1v + a2v;
+            x = x > 0.f ? x : x * a.alpha;
+            s_alpha[((size_t)r * max_deg + e) * heads + hh] = x;
+        }
+    }
+    __syncthreads();
+
+    // phase C: softmax over the in-edges of each (row, head): max, exp, sum in edge order, div
+    for (int i = t; i < AGG_ROWS * heads; i += blockDim.x) {
+        const int r = i / heads, hh = i - r * heads;
+        if (s_skip[r]) continue;
+        const int deg = s_deg[r];
+        float *al = s_alpha + (size_t)r * max_deg * heads + hh;
+        float mx = -INFINITY;
+        for (int e = 0; e < deg; ++e) mx = fmaxf(mx, al[e * heads]);
+        float sum = 0.f;
+        for (int e = 0; e < deg; ++e) {
+            const float ex = expf(al[e * heads] - mx);
+            al[e * heads] = ex;
+            sum = sum + ex;
+        }
+        for (int e = 0; e < deg; ++e) al[e * heads] = al[e * heads] / sum;
+    }
+    __syncthreads();
+
+    // phase D: out[v][c] = sum_e round(alpha[e][h(c)] * ft2[src_e][c]), then activation
+    for (int i = t; i < AGG_ROWS * hd; i += blockDim.x) {
+        const int r = i / hd, c = i - r * hd;
+        if (s_skip[r]) continue;
+        const int deg = s_deg[r], f = s_f[r], v = s_v[r], H = s_H[r];
+        const int hh = c / a.out_dim;
+        const int32_t nb = node_off[f], hb = head_off[f];
+        const bool l0 = a.en_const_ft2 != nullptr;
+        float acc = 0.f;
+        for (int e = 0; e < deg; ++e) {
+            const int u = s_src[r * max_deg + e];
+            float fv;
+            if (l0) fv = u >= H ? a.en_const_ft2[c] : a.ft2[(size_t)(hb + u) * a.ld + c];
+            else fv = a.ft2[(size_t)(nb + u) * a.ld + c];
+            const float m = fv * s_alpha[((size_t)r * max_deg + e) * heads + hh];
+            acc = acc + m;
+        }
+        float o;
+        if (a.out_mode == 0) o = acc > 0.f ? acc : acc * a.out_slope;
+        else if (a.out_mode == 1) o = 1.f / (1.f + expf(-acc));
+        else o = acc;
+        if (a.score_mode) {
+            if (v >= H) a.out[(size_t)en_off[f] + (v - H)] = o;
+            else if (a.out_heads) a.out_heads[(size_t)hb + v] = o;
+        } else {
+            a.out[(size_t)(nb + v) * a.ld_out + c] = o;
+        }
+    }
+}
+
+hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
+                                const int32_t *node_off, const int32_t *row_frame, const int32_t *en_pair,
+                                const AggArgs &a, int n_nodes) {
+    if (n_nodes <= 0) return hipSuccess;
+    int max_deg = max_heads_per_frame + 1;
+    if (max_deg < 3) max_deg = 3;
+    const size_t shm = (size_t)AGG_ROWS * max_deg * (a.heads * sizeof(float) + sizeof(int));
+    const int grid = (n_nodes + AGG_ROWS - 1) / AGG_ROWS;
+    hipLaunchKernelGGL(k_aggregate, dim3(grid), dim3(256), shm, s, n_nodes, V, max_deg, b.d_frame_head_off,
+                       b.d_frame_en_off, b.d_slot_n, node_off, row_frame, en_pair, a);
+    return hipGetLastError();
+}
+
+}  // namespace mpe

@@ -1,0 +1,221 @@
+// fp32 MFMA "NT" GEMM with fused bias + LeakyReLU epilogue:  C = act(A * W^T + b).
+//
+// Replaces every nn.Linear(+LeakyReLU) call site of the path: GraphAttention2 fc1/fc2
+// (reference gat2.py:53-55) and PoseEstimatorMLP (reference utils/mlp.py:8-28).
+//
+// gfx950 design
+//   * v_mfma_f32_16x16x4_f32 (exact f32 fma chain, 256 FLOP/clk/CU): the model's widths
+//     (400, 320, 160, 912, 3072, 2048, 1024) are multiples of 16, not of 32/128, so the
+//     16-wide tile wastes <2 % where a 128-wide tile would waste up to 22 %.
+//   * workgroup = 4 waves, tile 128 rows x 80 features x 32 deep; wave w owns rows
+//     [32w,32w+32) x all 80 features = 2 x 5 MFMA tiles (40 accumulator VGPRs).
+//   * operands are swapped (A-operand = weight rows, B-operand = activation rows) so each
+//     lane ends up with 4 consecutive output features of one row: one 16-byte store.
+//   * LDS image is planar in the MFMA k-quarter: plane q holds, for every tile row, the 8
+//     k-values {8q..8q+7} in 48-byte slots (32 B data + 16 B pad); a lane fetches its whole
+//     K-stage share with two conflict-free ds_read_b128, and the global->LDS pass writes
+//     rows x chunks transposed over the lanes so the ds_write_b128 are conflict-free too.
+//   * double-buffered LDS (78 KB, 2 workgroups/CU), register prefetch of the next K stage,
+//     one barrier per stage; XCD-aware workgroup order so the tiles that share activation
+//     rows run on one XCD's L2.
+#include "mpe_internal.h"
+
+namespace mpe {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int RS = 12;                          // floats per (row, k-quarter) slot
+constexpr int PLANE_A = GEMM_BM * RS;           // 1536 floats
+constexpr int PLANE_W = GEMM_BN * RS;           //  960 floats
+constexpr int STAGE = 4 * (PLANE_A + PLANE_W);  // 9984 floats = 39936 B
+constexpr int A_PASSES = GEMM_BM / 32;          // 4
+constexpr int W_PASSES = (GEMM_BN + 31) / 32;   // 3 (last one half populated)
+constexpr int NT = GEMM_BN / 16;                // 5 feature tiles per wave
+constexpr int MT = 2;                           // 2 row tiles per wave
+
+template <bool LEAKY, bool ACC64>
+__global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, int lda,
+                                                   const float *__restrict__ W, int ldw,
+                                                   const float *__restrict__ bias, float *__restrict__ C,
+                                                   int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
+                                                   int k_pad, float slope, int ntn) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+    int M = m_cap;
+    if (d_m) {
+        int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    // XCD-aware order: workgroups with equal (id % 8) share an L2; give each such class a
+    // contiguous range of tiles so the feature tiles of one row block hit the same L2.
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tm = swz / ntn, tn = swz - tm * ntn;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    if (m0 >= M) return;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // global->LDS staging role: 8 rows x 8 chunks (16 B) per wave and pass
+    const int lr = lane & 7, ch = lane >> 3;
+    const int st_off = (ch & 1) * 4;   // within-slot float offset
+    const int st_q = ch >> 1;
+
+    const float *a_src[A_PASSES];
+    int a_dst[A_PASSES];
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+        int row = p * 32 + wave * 8 + lr;
+        int grow = m0 + row;
+        grow = grow < M ? grow : M - 1;
+        a_src[p] = A + (size_t)grow * lda + ch * 4;
+        a_dst[p] = st_q * PLANE_A + row * RS + st_off;
+    }
+    const float *w_src[W_PASSES];
+    int w_dst[W_PASSES];
+    bool w_on[W_PASSES];
+#pragma unroll
+    for (int p = 0; p < W_PASSES; ++p) {
+        int row = p * 32 + wave * 8 + lr;
+        w_on[p] = row < GEMM_BN;
+        int rr = w_on[p] ? row : 0;
+        w_src[p] = W + (size_t)(n0 + rr) * ldw + ch * 4;
+        w_dst[p] = 4 * PLANE_A + st_q * PLANE_W + rr * RS + st_off;
+    }
+
+    // fragment read offsets (floats)
+    const int fq = lane >> 4, fr = lane & 15;
+    int a_rd[MT], w_rd[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_rd[mt] = fq * PLANE_A + (wave * 32 + mt * 16 + fr) * RS;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) w_rd[nt] = 4 * PLANE_A + fq * PLANE_W + (nt * 16 + fr) * RS;
+
+    f32x4 acc[NT][MT];
+    // ACC64: every K stage (32 products per output, one MFMA chain) starts from zero and is
+    // flushed into an f64 running sum, so the result carries ~1 rounding instead of ~sqrt(K).
+    double run[ACC64 ? NT : 1][ACC64 ? MT : 1][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ACC64) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] = 0.0;
+            }
+        }
+
+    f32x4 pa[A_PASSES], pw[W_PASSES];
+    const int nk = k_pad / GEMM_BK;
+
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) pa[p] = *reinterpret_cast<const f32x4 *>(a_src[p]);
+#pragma unroll
+    for (int p = 0; p < W_PASSES; ++p)
+        if (w_on[p]) pw[p] = *reinterpret_cast<const f32x4 *>(w_src[p]);
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[a_dst[p]]) = pa[p];
+#pragma unroll
+    for (int p = 0; p < W_PASSES; ++p)
+        if (w_on[p]) *reinterpret_cast<f32x4 *>(&lds[w_dst[p]]) = pw[p];
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = (kt & 1) * STAGE;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int koff = (kt + 1) * GEMM_BK;
+#pragma unroll
+            for (int p = 0; p < A_PASSES; ++p) pa[p] = *reinterpret_cast<const f32x4 *>(a_src[p] + koff);
+#pragma unroll
+            for (int p = 0; p < W_PASSES; ++p)
+                if (w_on[p]) pw[p] = *reinterpret_cast<const f32x4 *>(w_src[p] + koff);
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x4 af[MT], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + hh * 4]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + hh * 4]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
+        }
+        if (ACC64) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] += (double)acc[nt][mt][i];
+                    acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        if (more) {
+            const int nxt = ((kt + 1) & 1) * STAGE;
+#pragma unroll
+            for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[nxt + a_dst[p]]) = pa[p];
+#pragma unroll
+            for (int p = 0; p < W_PASSES; ++p)
+                if (w_on[p]) *reinterpret_cast<f32x4 *>(&lds[nxt + w_dst[p]]) = pw[p];
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds features nb..nb+3 of row m for every (nt, mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nb = n0 + nt * 16 + fq * 4;
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wave * 32 + mt * 16 + fr;
+            if (m >= M) continue;
+            f32x4 v;
+            if (ACC64) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (float)(run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] + (double)bv[i]);
+            } else {
+                v = acc[nt][mt] + bv;
+            }
+            if (LEAKY) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+            }
+            float *dst = C + (size_t)m * ldc + nb;
+            if (nb + 3 < n) {
+                *reinterpret_cast<f32x4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (nb + i < n) dst[i] = v[i];
+            }
+        }
+    }
+}
+
+hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
+                         float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
+                         float slope, bool acc64) {
+    if (m_cap <= 0 || n <= 0) return hipSuccess;
+    const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
+    const int ntn = (n + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid(ntm * ntn), block(256);
+#define MPE_LAUNCH(L_, A_)                                                                                   \
+    hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
+                       slope, ntn)
+    if (leaky && acc64) MPE_LAUNCH(true, true);
+    else if (leaky) MPE_LAUNCH(true, false);
+    else if (acc64) MPE_LAUNCH(false, true);
+    else MPE_LAUNCH(false, false);
+#undef MPE_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace mpe

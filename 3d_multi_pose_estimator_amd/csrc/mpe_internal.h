@@ -1,0 +1,155 @@
+// Internal declarations shared by the HIP translation units of libmpe_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mpe.h"
+
+namespace mpe {
+
+constexpr int GEMM_BM = 128;   // activation rows per workgroup
+constexpr int GEMM_BN = 80;    // output features per workgroup (5 MFMA tiles of 16)
+constexpr int GEMM_BK = 32;    // K depth per LDS stage
+constexpr int LD_ALIGN = 32;   // every activation / weight row stride is a multiple of this
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Linear {                // one nn.Linear, zero padded on the device
+    float *w = nullptr;        // [round_up(out, GEMM_BN)][ldw]
+    float *b = nullptr;        // [round_up(out, GEMM_BN)]
+    int in_dim = 0, out_dim = 0, ldw = 0;
+};
+
+struct GatLayer {
+    Linear fc1, fc2;
+    float *attn_l = nullptr;   // [heads*out_dim]
+    float *attn_r = nullptr;
+    int in_dim = 0, heads = 0, out_dim = 0;
+};
+
+struct DevCfg {                // calibration + scalars, lives in device memory
+    int32_t V, J, W, H, npj, min_views, median_axis;
+    uint32_t used_joint_mask;
+    float threshold, median_window;
+    float Kinv[MPE_MAX_CAMERAS][9];
+    float K[MPE_MAX_CAMERAS][9];
+    float T_i[MPE_MAX_CAMERAS][16];
+    double P[MPE_MAX_CAMERAS][12];
+    double dist[MPE_MAX_CAMERAS][5];
+};
+
+struct ProfileRec {
+    hipEvent_t start, stop;
+    double flop;      // known on the host, or
+    int dev_n, dev_k;  // 2 * (device-side row count) * dev_n * dev_k
+};
+
+}  // namespace mpe
+
+struct mpe_ctx {
+    mpe_config cfg;
+    mpe::DevCfg hcfg;
+    mpe::DevCfg *d_cfg = nullptr;
+    std::string err;
+    // weights
+    int gat_layers = 0;
+    float gat_alpha = 0.15f, gat_hidden_slope = 0.01f;
+    mpe::GatLayer gat[MPE_MAX_GAT_LAYERS];
+    bool gat_ready[MPE_MAX_GAT_LAYERS] = {};
+    float *en0_ft2 = nullptr;      // layer-0 transformed feature shared by all edge-nodes [ld]
+    float *en0_a = nullptr;        // its a1 | a2 coefficients [2*heads]
+    bool en0_ready = false;
+    int mlp_layers = 0;
+    float mlp_slope = 0.1f;
+    bool mlp_acc64 = true;         // f64 running sums in the MLP GEMMs (parity mode)
+    bool gat_acc64 = false;
+    mpe::Linear mlp[MPE_MAX_MLP_LAYERS];
+    bool mlp_ready[MPE_MAX_MLP_LAYERS] = {};
+    // workspace (sized at create / grown when weights define the widths)
+    int max_nodes = 0;
+    int feat_ld = 0;               // padded F
+    int act_ld = 0;                // padded widest hidden activation of the GAT
+    float *x0 = nullptr;           // [max_heads][feat_ld] dense head rows
+    float *h0 = nullptr;           // [max_heads][feat_ld] fc1 output of layer 0
+    float *act[3] = {nullptr, nullptr, nullptr};   // [max_nodes][act_ld]
+    float *a12 = nullptr;          // [max_nodes][2*16]
+    int32_t *row_frame = nullptr;  // [max_nodes]
+    int32_t *en_pair = nullptr;    // [max_edge_nodes][2] frame-local head ids
+    int32_t *node_off = nullptr;   // [max_frames+1]
+    uint64_t *cl_keys = nullptr;   // clustering scratch
+    int32_t *cl_scratch = nullptr;
+    size_t cl_keys_per_frame = 0, cl_scratch_per_frame = 0;
+    int mlp_ld_in = 0, mlp_ld_hidden = 0;
+    float *mlp_rows = nullptr;     // [max_frames*Pcap][mlp_ld_in]
+    float *mlp_act[2] = {nullptr, nullptr};
+    int32_t *mlp_count = nullptr;
+    float *scores_tmp = nullptr;    // [max_edge_nodes]
+    int32_t *person_off = nullptr;  // [max_frames+1]
+    uint8_t *valid_tmp = nullptr;   // [max_frames*Pcap]
+    std::vector<void *> owned;     // everything to hipFree at destroy
+    // profiling
+    bool profiling = false;
+    std::vector<mpe::ProfileRec> prof;
+    size_t prof_used = 0;
+    hipEvent_t tot_start = nullptr, tot_stop = nullptr;
+    bool tot_valid = false;
+};
+
+namespace mpe {
+
+// gemm.hip
+hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
+                         float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
+                         float slope, bool acc64);
+
+// gat.hip
+hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *row_frame,
+                           int32_t *en_pair);
+hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
+                                int ld_feat, int col0, int stride_cam, bool dense);
+hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,
+                            const float *attn_l, const float *attn_r, float *a12);
+struct AggArgs {
+    const float *ft2;          // rows of transformed features
+    int ld;
+    const float *a12;          // [rows][32]: a1[0..15] | a2[0..15]
+    int heads, out_dim;
+    float alpha, out_slope;    // attention LeakyReLU slope; activation applied to the output
+    int out_mode;              // 0 = LeakyReLU(out_slope), 1 = sigmoid, 2 = identity
+    const float *en_const_ft2; // layer 0: one row shared by all edge-nodes (ft2 holds head rows only)
+    const float *en_const_a;   // layer 0: its a1|a2
+    float *out;                // [n_nodes][ld_out] (or scores when score_mode)
+    int ld_out;
+    int score_mode;            // last layer: write out[edge-node index] (and heads to out_heads)
+    float *out_heads;
+};
+hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
+                            const int32_t *node_off, const int32_t *row_frame, const int32_t *en_pair,
+                            const AggArgs &a, int n_nodes);
+
+// cluster.hip
+size_t cluster_keys_per_frame(int max_heads_per_frame);
+size_t cluster_scratch_per_frame(int max_heads_per_frame);
+hipError_t launch_cluster(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, const int32_t *en_pair,
+                          const float *scores, int pcap, int max_heads_per_frame, uint64_t *keys,
+                          size_t keys_per_frame, int32_t *scratch, size_t scratch_per_frame,
+                          int32_t *persons, int32_t *n_persons);
+
+// pose3d.hip
+hipError_t launch_person_scan(hipStream_t s, int n_frames, int pcap, const int32_t *n_persons, int32_t *person_off,
+                              int32_t *total);
+hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
+                           const int32_t *persons, const int32_t *n_persons, const int32_t *person_off, int pcap,
+                           float *rows, int ld_rows, uint8_t *valid);
+hipError_t launch_triangulate(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
+                              const int32_t *persons, const int32_t *n_persons, int pcap, double *poses,
+                              uint8_t *joint_valid);
+hipError_t launch_dlt_pairs(hipStream_t s, const DevCfg *cfg, const double *pts, const int32_t *cams, int n,
+                            double *out);
+hipError_t launch_decode(hipStream_t s, int n_frames, int pcap, int n_out, float scale, const int32_t *n_persons,
+                         const int32_t *person_off, const float *y, int ld_y, float *poses);
+int cluster_table_cap(int hmax);
+
+}  // namespace mpe

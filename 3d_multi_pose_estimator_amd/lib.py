@@ -1,0 +1,111 @@
+"""ctypes binding of libmpe_hip.so (include/mpe.h).
+
+The HIP library is the product: there is no CPU fallback.  Importing this module works
+anywhere (so that host-side logic can be tested without a GPU); *using* it without the
+built library raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmpe_hip.so')
+
+MPE_MAX_CAMERAS = 32
+MPE_MAX_JOINTS = 32
+
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_u32p = C.POINTER(C.c_uint32)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+class MpeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('libmpe_hip error %d: %s' % (code, msg))
+        self.code = code
+
+
+class mpe_config(C.Structure):
+    _fields_ = [
+        ('n_cameras', C.c_int32), ('n_joints', C.c_int32), ('image_width', C.c_int32),
+        ('image_height', C.c_int32), ('numbers_per_joint', C.c_int32), ('min_views', C.c_int32),
+        ('median_axis', C.c_int32), ('used_joint_mask', C.c_uint32), ('threshold', C.c_float),
+        ('median_window', C.c_float), ('max_frames', C.c_int32), ('max_heads', C.c_int32),
+        ('max_edge_nodes', C.c_int32), ('max_heads_per_frame', C.c_int32),
+        ('max_persons_per_frame', C.c_int32),
+        ('Kinv', c_f32p), ('K', c_f32p), ('T_i', c_f32p), ('P', c_f64p), ('dist', c_f64p),
+    ]
+
+
+class mpe_batch(C.Structure):
+    _fields_ = [
+        ('n_frames', C.c_int32), ('n_heads', C.c_int32), ('n_edge_nodes', C.c_int32),
+        ('d_frame_head_off', C.c_void_p), ('d_frame_en_off', C.c_void_p), ('d_slot_cam', C.c_void_p),
+        ('d_slot_n', C.c_void_p), ('d_head_cam', C.c_void_p), ('d_joint_mask', C.c_void_p),
+        ('d_tri_mask', C.c_void_p), ('d_xy', C.c_void_p), ('d_vp', C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/mpe.h declares
+SYMBOLS = {
+    'mpe_create': (C.c_int, [C.POINTER(mpe_config), C.POINTER(C.c_void_p)]),
+    'mpe_destroy': (None, [C.c_void_p]),
+    'mpe_last_error': (C.c_char_p, [C.c_void_p]),
+    'mpe_version': (C.c_char_p, []),
+    'mpe_set_gat_params': (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float]),
+    'mpe_set_gat_layer': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]),
+    'mpe_set_mlp_params': (C.c_int, [C.c_void_p, C.c_int32, C.c_float]),
+    'mpe_set_mlp_layer': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p]),
+    'mpe_set_precision': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    'mpe_match_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mpe_mlp3d_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    'mpe_triangulate_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    'mpe_upload_linear': (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int32, C.c_int32,
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
+    'mpe_free_device': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mpe_linear': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                             C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                             C.c_float]),
+    'mpe_head_features': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p]),
+    'mpe_gat_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p]),
+    'mpe_gat_debug_layer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
+    'mpe_cluster_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    'mpe_mlp_input_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int32, C.c_void_p]),
+    'mpe_mlp_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    'mpe_dlt_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'mpe_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
+    'mpe_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Return the loaded library; raise if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('%s is missing: build it with `python __graft_entry__.py` or '
+                          '`make -C 3d_multi_pose_estimator_amd/csrc` (hipcc, gfx950). '
+                          'There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx, rc):
+    if rc != 0:
+        msg = load().mpe_last_error(ctx)
+        raise MpeError(rc, msg.decode() if msg else '?')

@@ -1,0 +1,188 @@
+"""Frame JSON -> packed structure-of-arrays batch (the `mpe_batch` of include/mpe.h).
+
+Host-side counterpart of MergedMultipleHumansDataset.load_people_view_graph (reference
+skeleton_matching/graph_generator.py:573-605): it only *orders* the data; every number the
+network sees is computed on the device from these arrays.
+
+Ordering rules kept from the reference:
+  * cameras in the frame dict's key order (not `parameters` order), skipping cameras that
+    are not in ``used_cameras_skeleton_matching`` (:583-584);
+  * skeletons in list order, skipping those without any joint key other than "ID"
+    (:590-591); ``skeleton_index`` remembers the position in the original list (:597-599);
+  * joint key j is the COCO joint id string; values = [id, x, y, valid, prob].
+"""
+import json
+
+import numpy as np
+
+
+class PackedBatch:
+    """Host (numpy) form; `.to(device)` gives torch tensors + the ctypes struct."""
+
+    def __init__(self, V, J):
+        self.V, self.J = V, J
+        self.n_frames = 0
+        self.frame_head_off = None
+        self.frame_en_off = None
+        self.slot_cam = None
+        self.slot_n = None
+        self.head_cam = None
+        self.joint_mask = None
+        self.tri_mask = None
+        self.xy = None
+        self.vp = None
+        self.skeleton_index = None     # [n_heads] position in the camera's original list
+        self.jsons_for_head = None     # optional: list (per frame) of {head id: skeleton dict}
+
+    @property
+    def n_heads(self):
+        return int(self.frame_head_off[-1])
+
+    @property
+    def n_edge_nodes(self):
+        return int(self.frame_en_off[-1])
+
+    def frame_counts(self, f):
+        h0, h1 = int(self.frame_head_off[f]), int(self.frame_head_off[f + 1])
+        e0, e1 = int(self.frame_en_off[f]), int(self.frame_en_off[f + 1])
+        return h0, h1 - h0, e0, e1 - e0
+
+    def max_heads_per_frame(self):
+        return int(np.max(np.diff(self.frame_head_off))) if self.n_frames else 0
+
+    def to(self, device):
+        return DeviceBatch(self, device)
+
+
+class DeviceBatch:
+    def __init__(self, pb, device):
+        import ctypes as C
+
+        import torch
+
+        from . import lib as L
+        self.host = pb
+        self.device = torch.device(device)
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.t = {
+            'frame_head_off': up(pb.frame_head_off), 'frame_en_off': up(pb.frame_en_off),
+            'slot_cam': up(pb.slot_cam), 'slot_n': up(pb.slot_n), 'head_cam': up(pb.head_cam),
+            'joint_mask': up(pb.joint_mask.view(np.int32)), 'tri_mask': up(pb.tri_mask.view(np.int32)),
+            'xy': up(pb.xy), 'vp': up(pb.vp),
+        }
+        s = L.mpe_batch()
+        s.n_frames, s.n_heads, s.n_edge_nodes = pb.n_frames, pb.n_heads, pb.n_edge_nodes
+        for k, v in self.t.items():
+            setattr(s, 'd_' + k, C.c_void_p(v.data_ptr()))
+        self.struct = s
+
+    @property
+    def n_frames(self):
+        return self.host.n_frames
+
+    @property
+    def n_heads(self):
+        return self.host.n_heads
+
+    @property
+    def n_edge_nodes(self):
+        return self.host.n_edge_nodes
+
+
+def parse_skeletons(frame_cam_entry):
+    """`frame[cam]` is `[json-string or list of skeleton dicts, ...]`."""
+    sk = frame_cam_entry[0]
+    return json.loads(sk) if isinstance(sk, (str, bytes)) else sk
+
+
+def pack_frames(frames, params, keep_json=False):
+    """frames: list of {cam: [json string of skeleton list, ...]} -> PackedBatch."""
+    sm = list(params.used_cameras_skeleton_matching)
+    V, J = len(sm), len(params.joint_list)
+    B = len(frames)
+    pb = PackedBatch(V, J)
+    pb.n_frames = B
+    slot_cam = np.full((B, V), -1, np.int32)
+    slot_n = np.zeros((B, V), np.int32)
+    head_off = np.zeros(B + 1, np.int32)
+    en_off = np.zeros(B + 1, np.int32)
+    head_cam, jmask, tmask, skidx = [], [], [], []
+    xy_rows, vp_rows = [], []
+    jsons = [] if keep_json else None
+    for f, frame in enumerate(frames):
+        s = 0
+        counts = []
+        fj = {} if keep_json else None
+        nh = 0
+        for cam in frame:
+            if cam not in sm:
+                continue
+            if s >= V:
+                raise ValueError('frame %d lists more cameras than configured' % f)
+            c = sm.index(cam)
+            n_here = 0
+            for idx, sk in enumerate(parse_skeletons(frame[cam])):
+                xy = np.zeros((J, 2), np.float64)
+                vp = np.zeros((J, 2), np.float32)
+                m = 0
+                t = 0
+                for key, val in sk.items():
+                    if key == 'ID':
+                        continue
+                    j = int(key)
+                    if j < 0 or j >= J:
+                        raise ValueError('joint id %r out of range' % key)
+                    m |= 1 << j
+                    if val[0] > 0.:
+                        t |= 1 << j
+                    xy[j, 0], xy[j, 1] = val[1], val[2]
+                    vp[j, 0], vp[j, 1] = val[3], val[4]
+                if m == 0:
+                    continue
+                head_cam.append(c)
+                jmask.append(m)
+                tmask.append(t)
+                skidx.append(idx)
+                xy_rows.append(xy)
+                vp_rows.append(vp)
+                if keep_json:
+                    fj[nh] = sk
+                n_here += 1
+                nh += 1
+            slot_cam[f, s] = c
+            slot_n[f, s] = n_here
+            counts.append(n_here)
+            s += 1
+        tot = sum(counts)
+        pairs = (tot * tot - sum(k * k for k in counts)) // 2
+        head_off[f + 1] = head_off[f] + tot
+        en_off[f + 1] = en_off[f] + pairs
+        if keep_json:
+            jsons.append(fj)
+    n = len(head_cam)
+    pb.frame_head_off, pb.frame_en_off = head_off, en_off
+    pb.slot_cam, pb.slot_n = slot_cam, slot_n
+    pb.head_cam = np.array(head_cam, np.int32).reshape(n)
+    pb.joint_mask = np.array(jmask, np.uint32).reshape(n)
+    pb.tri_mask = np.array(tmask, np.uint32).reshape(n)
+    pb.skeleton_index = np.array(skidx, np.int32).reshape(n)
+    pb.xy = np.stack(xy_rows).reshape(n, J, 2) if n else np.zeros((0, J, 2), np.float64)
+    pb.vp = np.stack(vp_rows).reshape(n, J, 2) if n else np.zeros((0, J, 2), np.float32)
+    pb.jsons_for_head = jsons
+    return pb
+
+
+def pairs_of_frame(slot_n_row):
+    """(h1, h2) of every edge-node of one frame, in edge-node order (host mirror of the
+    device topology kernel; used by the Python API mirrors and tests)."""
+    starts = np.concatenate([[0], np.cumsum(slot_n_row)])
+    out = []
+    V = len(slot_n_row)
+    for a in range(V):
+        for b in range(a + 1, V):
+            for i in range(slot_n_row[a]):
+                for j in range(slot_n_row[b]):
+                    out.append((starts[a] + i, starts[b] + j))
+    return np.array(out, np.int32).reshape(-1, 2)

@@ -1,0 +1,257 @@
+"""Batched engine over libmpe_hip.so: the frame-batched form of the reference's per-frame
+loop body (test/metrics_from_model.py:178-294, test/metrics_from_triangulation.py:187-272).
+
+PyTorch is plumbing here (device memory, current stream); every computation on the path is
+a HIP kernel behind the C ABI of include/mpe.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .calibration import Calibration
+from .packing import DeviceBatch, PackedBatch, pack_frames
+
+
+def _f32p(a):
+    return a.ctypes.data_as(L.c_f32p)
+
+
+class Engine:
+    def __init__(self, params=None, calib=None, max_frames=1024, max_heads_per_frame=None,
+                 max_persons_per_camera=4, device='cuda:0', threshold=0.5):
+        from .parameters import parameters as default_params
+        self.params = params or default_params
+        self.calib = calib or Calibration(self.params)
+        self.lib = L.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('Engine needs a GPU device (there is no CPU fallback)')
+        torch.cuda.set_device(self.device)
+        p = self.params
+        sm = list(p.used_cameras_skeleton_matching)
+        if sm != list(p.used_cameras) or sm != [c for c in p.camera_names if c in sm]:
+            raise ValueError('used_cameras_skeleton_matching must equal used_cameras in camera_names order')
+        self.V, self.J = len(sm), len(p.joint_list)
+        cal_idx = [self.calib.index(c) for c in sm]
+        hpf = max_heads_per_frame or self.V * max_persons_per_camera
+        self.max_frames = int(max_frames)
+        self.hpf = int(hpf)
+        self.pcap = max(1, hpf // max(1, p.min_number_of_views))
+        # largest edge-node count of a frame with `hpf` heads (even spread over V cameras)
+        m_frame = hpf * hpf * (self.V - 1) // (2 * self.V) + 1
+        self._keep = {
+            'Kinv': np.ascontiguousarray(self.calib.Kinv32[cal_idx].reshape(-1), np.float32),
+            'K': np.ascontiguousarray(self.calib.K32[cal_idx].reshape(-1), np.float32),
+            'T_i': np.ascontiguousarray(self.calib.T_i32[cal_idx].reshape(-1), np.float32),
+            'P': np.ascontiguousarray(self.calib.P[cal_idx].reshape(-1), np.float64),
+            'dist': np.ascontiguousarray(self.calib.dist[cal_idx].reshape(-1), np.float64),
+        }
+        cfg = L.mpe_config()
+        cfg.n_cameras, cfg.n_joints = self.V, self.J
+        cfg.image_width, cfg.image_height = p.image_width, p.image_height
+        cfg.numbers_per_joint = p.numbers_per_joint
+        cfg.min_views = p.min_number_of_views
+        cfg.median_axis = p.axes_3D['Y'][0]
+        cfg.used_joint_mask = sum(1 << j for j in p.used_joints)
+        cfg.threshold = threshold
+        cfg.median_window = 0.05
+        cfg.max_frames = self.max_frames
+        cfg.max_heads = self.max_frames * hpf
+        cfg.max_edge_nodes = self.max_frames * m_frame
+        cfg.max_heads_per_frame = hpf
+        cfg.max_persons_per_frame = self.pcap
+        cfg.Kinv = _f32p(self._keep['Kinv'])
+        cfg.K = _f32p(self._keep['K'])
+        cfg.T_i = _f32p(self._keep['T_i'])
+        cfg.P = self._keep['P'].ctypes.data_as(L.c_f64p)
+        cfg.dist = self._keep['dist'].ctypes.data_as(L.c_f64p)
+        self.ctx = C.c_void_p()
+        rc = self.lib.mpe_create(C.byref(cfg), C.byref(self.ctx))
+        if rc != 0:
+            raise L.MpeError(rc, 'mpe_create failed')
+        self.gat_dims = None
+        self.mlp_out = None
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.mpe_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ----------------------------------------------------------------------
+    def _chk(self, rc):
+        L.check(self.ctx, rc)
+
+    def load_gat(self, state_dict, prm):
+        """state_dict: reference names ``layers.{l}.{fc1,fc2}.{weight,bias}``, ``attn_l/r``
+        (numpy or torch); prm: contents of skeleton_matching.prms."""
+        sd = {k: _np32(v) for k, v in state_dict.items()}
+        n_layers = int(prm['gnn_layers'])
+        heads = list(prm['heads']) + [1]
+        slope = prm.get('nonlinearity', 0.01)
+        slope = getattr(slope, 'negative_slope', slope)
+        self._chk(self.lib.mpe_set_gat_params(self.ctx, n_layers, float(prm['alpha']), float(slope)))
+        dims = []
+        for l in range(n_layers):
+            w1 = sd['layers.%d.fc1.weight' % l]
+            w2 = sd['layers.%d.fc2.weight' % l]
+            in_dim, nh = w1.shape[1], heads[l]
+            out_dim = w2.shape[0] // nh
+            al = np.ascontiguousarray(sd['layers.%d.attn_l' % l].reshape(nh, out_dim))
+            ar = np.ascontiguousarray(sd['layers.%d.attn_r' % l].reshape(nh, out_dim))
+            self._chk(self.lib.mpe_set_gat_layer(
+                self.ctx, l, in_dim, nh, out_dim, _f32p(w1), _f32p(sd['layers.%d.fc1.bias' % l]),
+                _f32p(w2), _f32p(sd['layers.%d.fc2.bias' % l]), _f32p(al), _f32p(ar)))
+            dims.append((in_dim, nh, out_dim))
+        self.gat_dims = dims
+
+    def load_mlp(self, state_dict, slope=0.1):
+        sd = {k: _np32(v) for k, v in state_dict.items()}
+        keys = sorted({int(k.split('.')[1]) for k in sd})
+        self._chk(self.lib.mpe_set_mlp_params(self.ctx, len(keys), float(slope)))
+        for n, k in enumerate(keys):
+            w = sd['layers.%d.weight' % k]
+            self._chk(self.lib.mpe_set_mlp_layer(self.ctx, n, w.shape[1], w.shape[0], _f32p(w),
+                                                 _f32p(sd['layers.%d.bias' % k])))
+            self.mlp_out = w.shape[0]
+
+    # ---- batches ----------------------------------------------------------------------
+    def pack(self, frames, keep_json=False):
+        return pack_frames(frames, self.params, keep_json=keep_json)
+
+    def to_device(self, pb):
+        if isinstance(pb, DeviceBatch):
+            return pb
+        assert isinstance(pb, PackedBatch)
+        return pb.to(self.device)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def match(self, db, want_scores=True):
+        """-> (scores[n_edge_nodes] f32 or None, persons[B,Pcap,V] i32, n_persons[B] i32)."""
+        B = db.n_frames
+        scores = torch.empty(max(db.n_edge_nodes, 1), dtype=torch.float32, device=self.device) if want_scores else None
+        persons = torch.empty((B, self.pcap, self.V), dtype=torch.int32, device=self.device)
+        n_persons = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.mpe_match_batch(self.ctx, self._stream(), C.byref(db.struct),
+                                           _ptr(scores), _ptr(persons), _ptr(n_persons)))
+        return (scores[:db.n_edge_nodes] if want_scores else None), persons, n_persons
+
+    def gat_scores(self, db, heads=False):
+        sc = torch.empty(max(db.n_edge_nodes, 1), dtype=torch.float32, device=self.device)
+        sh = torch.empty(max(db.n_heads, 1), dtype=torch.float32, device=self.device) if heads else None
+        self._chk(self.lib.mpe_gat_forward(self.ctx, self._stream(), C.byref(db.struct), _ptr(sc), _ptr(sh)))
+        return (sc[:db.n_edge_nodes], sh[:db.n_heads]) if heads else sc[:db.n_edge_nodes]
+
+    def cluster(self, db, scores):
+        B = db.n_frames
+        scores = scores.to(self.device, torch.float32).contiguous()
+        persons = torch.empty((B, self.pcap, self.V), dtype=torch.int32, device=self.device)
+        n_persons = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.mpe_cluster_batch(self.ctx, self._stream(), C.byref(db.struct), _ptr(scores),
+                                             _ptr(persons), _ptr(n_persons)))
+        return persons, n_persons
+
+    def head_features(self, db):
+        out = torch.empty((max(db.n_heads, 1), self.J, 10), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.mpe_head_features(self.ctx, self._stream(), C.byref(db.struct), _ptr(out)))
+        return out[:db.n_heads]
+
+    def mlp_input_rows(self, db, persons, n_persons):
+        B = db.n_frames
+        width = self.V * self.J * self.params.numbers_per_joint
+        ld = (width + 31) // 32 * 32
+        rows = torch.zeros((B * self.pcap, ld), dtype=torch.float32, device=self.device)
+        valid = torch.zeros((B * self.pcap,), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.mpe_mlp_input_rows(self.ctx, self._stream(), C.byref(db.struct), _ptr(persons),
+                                              _ptr(n_persons), _ptr(rows), ld, _ptr(valid)))
+        return rows.view(B, self.pcap, ld)[:, :, :width], valid.view(B, self.pcap)
+
+    def mlp_forward(self, x):
+        """x [m, in_dim] f32 (device) -> [m, out_dim]."""
+        m, k = x.shape
+        ld = (k + 31) // 32 * 32
+        xp = torch.zeros((m, ld), dtype=torch.float32, device=self.device)
+        xp[:, :k] = x
+        y = torch.empty((m, self.mlp_out), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.mpe_mlp_forward(self.ctx, self._stream(), _ptr(xp), ld, m, _ptr(y), self.mlp_out))
+        return y
+
+    def mlp3d(self, db, persons, n_persons):
+        """-> (poses[B,Pcap,J,3] f32 metres, valid[B,Pcap] u8)."""
+        B = db.n_frames
+        poses = torch.empty((B, self.pcap, self.J, 3), dtype=torch.float32, device=self.device)
+        valid = torch.empty((B, self.pcap), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.mpe_mlp3d_batch(self.ctx, self._stream(), C.byref(db.struct), _ptr(persons),
+                                           _ptr(n_persons), _ptr(poses), _ptr(valid)))
+        return poses, valid
+
+    def triangulate(self, db, persons, n_persons):
+        """-> (poses[B,Pcap,J,3] f64, joint_valid[B,Pcap,J] u8)."""
+        B = db.n_frames
+        poses = torch.empty((B, self.pcap, self.J, 3), dtype=torch.float64, device=self.device)
+        jv = torch.empty((B, self.pcap, self.J), dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.mpe_triangulate_batch(self.ctx, self._stream(), C.byref(db.struct), _ptr(persons),
+                                                 _ptr(n_persons), _ptr(poses), _ptr(jv)))
+        return poses, jv
+
+    def dlt_pairs(self, pts, cams):
+        pts = torch.as_tensor(pts, dtype=torch.float64, device=self.device).contiguous()
+        cams = torch.as_tensor(cams, dtype=torch.int32, device=self.device).contiguous()
+        n = pts.shape[0]
+        out = torch.empty((n, 3), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.mpe_dlt_pairs(self.ctx, self._stream(), _ptr(pts), _ptr(cams), n, _ptr(out)))
+        return out
+
+    def set_precision(self, gat_acc64=False, mlp_acc64=True):
+        self._chk(self.lib.mpe_set_precision(self.ctx, int(gat_acc64), int(mlp_acc64)))
+
+    def linear(self, x, w, b, slope=None, acc64=False):
+        """act(x @ w.T + b) through the MFMA GEMM (parity tests). x device [m,k]; w,b host."""
+        w = _np32(w)
+        b = _np32(b)
+        n, k = w.shape
+        dw, dbias, ldw = C.c_void_p(), C.c_void_p(), C.c_int32()
+        self._chk(self.lib.mpe_upload_linear(self.ctx, _f32p(w), _f32p(b), n, k, C.byref(dw), C.byref(dbias),
+                                             C.byref(ldw)))
+        try:
+            m = x.shape[0]
+            xp = torch.zeros((m, ldw.value), dtype=torch.float32, device=self.device)
+            xp[:, :k] = x
+            ldc = (n + 3) // 4 * 4
+            y = torch.empty((m, ldc), dtype=torch.float32, device=self.device)
+            self._chk(self.lib.mpe_linear(self.ctx, self._stream(), _ptr(xp), ldw.value, dw, ldw.value, dbias,
+                                          _ptr(y), ldc, m, None, n, k, (0 if slope is None else 1) | (2 if acc64 else 0),
+                                          0.0 if slope is None else float(slope)))
+            torch.cuda.synchronize(self.device)
+            return y[:, :n].contiguous()
+        finally:
+            self.lib.mpe_free_device(self.ctx, dw)
+            self.lib.mpe_free_device(self.ctx, dbias)
+
+    # ---- profiling --------------------------------------------------------------------
+    def profile(self, on):
+        self._chk(self.lib.mpe_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_read(self):
+        ms, fl, n, tot = C.c_double(), C.c_double(), C.c_int64(), C.c_double()
+        self._chk(self.lib.mpe_profile_read(self.ctx, C.byref(ms), C.byref(fl), C.byref(n), C.byref(tot)))
+        return {'gemm_ms': ms.value, 'gemm_flop': fl.value, 'gemm_launches': n.value}
+
+
+def _np32(v):
+    if isinstance(v, torch.Tensor):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(v, dtype=np.float32)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())

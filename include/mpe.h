@@ -1,0 +1,197 @@
+/*
+ * mpe.h — C ABI of libmpe_hip.so, the MI355X (gfx950) implementation of the per-frame
+ * inference path of gnns4hri/3D_multi_pose_estimator:
+ *
+ *   2D skeletons per camera -> graph featurisation -> 5-layer graph attention network
+ *   -> greedy person clustering -> { MLP 3D regression | pairwise-DLT triangulation }.
+ *
+ * The reference has no FFI: its operator API is the set of Python symbols that
+ * test/metrics_from_model.py:12-24 and test/metrics_from_triangulation.py:13-23 import.
+ * Each entry point below names the reference code it replaces; the Python mirror of
+ * those symbols (the .py files of 3d_multi_pose_estimator_amd) is a thin ctypes layer over this
+ * file (see INTEGRATION.md for the binding a maintainer would add to the reference).
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions across the boundary;
+ *   - every call returns 0 on success or a negative mpe_status; mpe_last_error(ctx)
+ *     gives the message of the last failure on that context;
+ *   - pointers named d_* are DEVICE pointers owned by the caller (e.g. torch
+ *     tensor.data_ptr()); everything else is host memory, copied during the call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all batch
+ *     entry points are asynchronous with respect to the host and allocate nothing;
+ *   - one mpe_ctx may be used from one thread at a time.
+ */
+#ifndef MPE_H
+#define MPE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPE_MAX_CAMERAS 32      /* camera sets are kept as 32-bit masks in the clustering kernel */
+#define MPE_MAX_JOINTS 32       /* joint presence is a 32-bit mask per skeleton */
+#define MPE_MAX_GAT_LAYERS 8
+#define MPE_MAX_MLP_LAYERS 16
+
+typedef enum {
+    MPE_OK = 0,
+    MPE_ERR_INVALID = -1,       /* bad argument / shape mismatch                      */
+    MPE_ERR_CAPACITY = -2,      /* batch exceeds the capacity given to mpe_create     */
+    MPE_ERR_STATE = -3,         /* weights not uploaded yet                           */
+    MPE_ERR_HIP = -4,           /* a HIP runtime call failed                          */
+    MPE_ERR_NOMEM = -5
+} mpe_status;
+
+typedef struct mpe_ctx mpe_ctx;
+
+/* Static configuration = reference `parameters` (parameters.py:12-45) plus the calibration
+ * globals the hot-path modules derive at import time (graph_generator.py:32-52,
+ * pose_estimator_dataset_from_json.py:28-47).  Cameras are indexed by their position in
+ * parameters.used_cameras_skeleton_matching (== used_cameras == camera_names for the
+ * shipped presets). */
+typedef struct {
+    int32_t n_cameras;          /* V_cfg                                               */
+    int32_t n_joints;           /* J = len(parameters.joint_list) (18)                 */
+    int32_t image_width;        /* parameters.image_width                              */
+    int32_t image_height;       /* parameters.image_height                             */
+    int32_t numbers_per_joint;  /* parameters.numbers_per_joint (14)                   */
+    int32_t min_views;          /* parameters.min_number_of_views                      */
+    int32_t median_axis;        /* parameters.axes_3D['Y'][0]                          */
+    uint32_t used_joint_mask;   /* bit j set for j in parameters.used_joints           */
+    float threshold;            /* CLASSIFICATION_THRESHOLD (0.5)                      */
+    float median_window;        /* 0.05 m (pose_estimator_utils.py:73)                 */
+    /* capacities of one batch (workspace is sized from these at mpe_create) */
+    int32_t max_frames;
+    int32_t max_heads;          /* total 2D skeletons in a batch                       */
+    int32_t max_edge_nodes;     /* total cross-camera skeleton pairs in a batch        */
+    int32_t max_heads_per_frame;
+    int32_t max_persons_per_frame;  /* Pcap, >= floor(max_heads_per_frame / min_views) */
+    /* calibration, row-major, host pointers */
+    const float *Kinv;          /* [V][9]  torch.inverse(camera_matrix) f32            */
+    const float *K;             /* [V][9]  camera_matrix f32                           */
+    const float *T_i;           /* [V][16] get_transform(cam,"root") cast to f32       */
+    const double *P;            /* [V][12] get_transform("root",cam)[0:3,:] f64        */
+    const double *dist;         /* [V][5]  k1,k2,p1,p2,k3 f64 (OpenCV order)           */
+} mpe_config;
+
+/* One batch of frames in packed, structure-of-arrays form.  A "head" is one 2D skeleton
+ * with at least one joint; heads of a frame are numbered in the reference's order
+ * (cameras in the frame dict's key order, then list order; graph_generator.py:583-601).
+ * A "slot" is one camera of that dict order.  All pointers are device pointers. */
+typedef struct {
+    int32_t n_frames;
+    int32_t n_heads;                 /* total heads in the batch                        */
+    int32_t n_edge_nodes;            /* total edge-nodes (cross-slot head pairs)        */
+    const int32_t *d_frame_head_off; /* [n_frames+1] exclusive prefix of heads          */
+    const int32_t *d_frame_en_off;   /* [n_frames+1] exclusive prefix of edge-nodes     */
+    const int32_t *d_slot_cam;       /* [n_frames][V] camera index of slot s, -1 unused */
+    const int32_t *d_slot_n;         /* [n_frames][V] number of heads in slot s         */
+    const int32_t *d_head_cam;       /* [n_heads] camera index                          */
+    const uint32_t *d_joint_mask;    /* [n_heads] bit j: joint j present in the dict    */
+    const uint32_t *d_tri_mask;      /* [n_heads] bit j: present and values[0] > 0      */
+    const double *d_xy;              /* [n_heads][J][2] pixel x,y (values[1], values[2])*/
+    const float *d_vp;               /* [n_heads][J][2] values[3] (valid), values[4]    */
+} mpe_batch;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+int mpe_create(const mpe_config *cfg, mpe_ctx **out);
+void mpe_destroy(mpe_ctx *ctx);
+const char *mpe_last_error(const mpe_ctx *ctx);
+const char *mpe_version(void);
+
+/* ---- weights (host pointers, copied once; ctx owns padded device copies) ---------------
+ * GAT2 state-dict tensors of layer l (gat2.py:18-48): fc1.weight [in][in], fc1.bias [in],
+ * fc2.weight [heads*out][in], fc2.bias [heads*out], attn_l / attn_r [heads][out]. */
+int mpe_set_gat_params(mpe_ctx *ctx, int32_t n_layers, float alpha, float hidden_slope);
+int mpe_set_gat_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t heads, int32_t out_dim,
+                      const float *fc1_w, const float *fc1_b, const float *fc2_w, const float *fc2_b,
+                      const float *attn_l, const float *attn_r);
+/* PoseEstimatorMLP (utils/mlp.py:8-28): layer l = Linear(in,out) [+ LeakyReLU(slope)] */
+int mpe_set_mlp_params(mpe_ctx *ctx, int32_t n_layers, float slope);
+int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_dim,
+                      const float *w, const float *b);
+
+/* Accumulation mode of the fp32 MFMA GEMMs.  0 = one fp32 MFMA chain over the whole K
+ * (fastest); 1 = every 32-deep K stage is flushed into f64 running sums, so a dot product
+ * carries about one rounding, like a blocked CPU sgemm.  Defaults: GAT 0, MLP 1 (the MLP's
+ * K is up to 3072 and its 3D output is held to the 1e-3 mm parity bound). */
+int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64);
+
+/* ---- batch entry points ---------------------------------------------------------------
+ * mpe_match_batch replaces, per frame: MergedMultipleHumansDataset(mode='test', alt='3')
+ * (graph_generator.py:813-876), GAT2.forward (gat2.py:137-149) and
+ * get_person_proposal_from_network_output (skeleton_matching_utils.py:12-132).
+ *   d_scores   [n_edge_nodes]  sigmoid output of every edge-node (may be NULL)
+ *   d_persons  [n_frames][Pcap][V] frame-local head id per camera, -1 = None
+ *   d_n_persons[n_frames] */
+int mpe_match_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
+                    float *d_scores, int32_t *d_persons, int32_t *d_n_persons);
+
+/* 3D stage A: PoseEstimatorDataset dict branch (pose_estimator_dataset_from_json.py:237-298,
+ * incl. get_3D_from_triangulation :63-101) + PoseEstimatorMLP + x10 decode
+ * (metrics_from_model.py:243-294).
+ *   d_poses [n_frames][Pcap][J][3] f32 metres, d_valid [n_frames][Pcap] 1 = person row kept */
+int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
+                    const int32_t *d_persons, const int32_t *d_n_persons,
+                    float *d_poses, uint8_t *d_valid);
+
+/* 3D stage B: caller gather + triangulate (metrics_from_triangulation.py:234-272,
+ * pose_estimator_utils.py:52-75).
+ *   d_poses [n_frames][Pcap][J][3] f64, d_joint_valid [n_frames][Pcap][J] 1 = joint emitted */
+int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
+                          const int32_t *d_persons, const int32_t *d_n_persons,
+                          double *d_poses, uint8_t *d_joint_valid);
+
+/* ---- stage-level entry points (parity tests, Python mirrors of single reference symbols) */
+/* C[M][N] = act(A[M][K] * W[N][K]^T + bias): nn.Linear (+ LeakyReLU when slope_on != 0).
+ * Row strides in elements; A and C device pointers, W/bias device pointers prepared by
+ * mpe_upload_linear (zero padded).  d_m, if not NULL, overrides M with a device-side count.
+ * flags: bit 0 = apply LeakyReLU(slope), bit 1 = f64 running sums (see mpe_set_precision). */
+int mpe_upload_linear(mpe_ctx *ctx, const float *w, const float *b, int32_t out_dim, int32_t in_dim,
+                      float **d_w, float **d_b, int32_t *ldw);
+int mpe_free_device(mpe_ctx *ctx, void *d_ptr);
+int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const float *d_w, int32_t ldw,
+               const float *d_bias, float *d_c, int32_t ldc, int32_t m, const int32_t *d_m,
+               int32_t n, int32_t k, int32_t flags, float slope);
+
+/* HumanGraphFromView.initializeWithAlternative3 (graph_generator.py:444-508): the J*10
+ * non-zero block of every head row: d_feat [n_heads][J][10]. */
+int mpe_head_features(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_feat);
+
+/* GAT2.forward over the batch: d_scores_en [n_edge_nodes]; optional d_scores_heads
+ * [n_heads] (the reference also evaluates the last layer at head nodes; unused downstream);
+ * optional d_layer_out[l] = activation after layer l, [n_nodes][ld] (debug / parity). */
+int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_scores_en,
+                    float *d_scores_heads);
+int mpe_gat_debug_layer(mpe_ctx *ctx, void *stream, int32_t layer, float *d_out, int32_t ld_out,
+                        int32_t n_rows);
+
+/* get_person_proposal_from_network_output on caller-provided scores. */
+int mpe_cluster_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float *d_scores,
+                      int32_t *d_persons, int32_t *d_n_persons);
+
+/* MLP input rows only: d_rows [n_frames*Pcap][ld_rows] f32 (row r = frame*Pcap + p). */
+int mpe_mlp_input_rows(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_t *d_persons,
+                       const int32_t *d_n_persons, float *d_rows, int32_t ld_rows, uint8_t *d_valid);
+/* PoseEstimatorMLP.forward on d_x [m][ld_x] -> d_y [m][out_dim] (no x10). */
+int mpe_mlp_forward(mpe_ctx *ctx, void *stream, const float *d_x, int32_t ld_x, int32_t m,
+                    float *d_y, int32_t ld_y);
+
+/* cv2.undistortPoints + cv2.triangulatePoints for explicit pairs (pose_estimator_utils.py:63-67):
+ * d_pts [n][2][2] pixel points, d_cams [n][2] camera indices -> d_out [n][3] f64. */
+int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t *d_cams,
+                  int32_t n, double *d_out);
+
+/* Timing probe for bench.py: average duration (ms) of the dominant GEMM launches measured
+ * with HIP events on the launch stream during the last mpe_match_batch / mpe_mlp3d_batch
+ * when profiling is enabled; see bench.py. */
+int mpe_profile_enable(mpe_ctx *ctx, int32_t on);
+int mpe_profile_read(mpe_ctx *ctx, double *gemm_ms, double *gemm_flop, int64_t *gemm_launches,
+                     double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPE_H */
