@@ -188,14 +188,28 @@ int ensure_mlp_workspace(mpe_ctx *ctx) {
     return MPE_OK;
 }
 
-int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en, float *d_scores_heads) {
+int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en, float *d_scores_heads,
+            const float *d_feats = nullptr, int ld_feats = 0) {
     int rc = ensure_gat_workspace(ctx);
     if (rc) return rc;
     const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints;
     const int n_nodes = b->n_heads + b->n_edge_nodes;
     const int hmax = ctx->cfg.max_heads_per_frame;
     HIPCHK(ctx, launch_topology(s, *b, V, ctx->node_off, ctx->row_frame, ctx->en_pair));
-    HIPCHK(ctx, launch_head_features(s, ctx->d_cfg, *b, J, ctx->x0, ctx->feat_ld, 0, 0, true));
+    const bool dense_in = d_feats != nullptr;   // caller-provided N x F rows (GAT2.forward(inputs, g))
+    if (dense_in) {
+        if (ld_feats < ctx->gat[0].in_dim) return fail(ctx, MPE_ERR_INVALID, "feature stride too small");
+        if (!ctx->xdense) {
+            int rc2 = dev_alloc(ctx, &ctx->xdense, (size_t)ctx->max_nodes * ctx->feat_ld);
+            if (rc2) return rc2;
+            if ((rc2 = dev_alloc(ctx, &ctx->hdense, (size_t)ctx->max_nodes * ctx->feat_ld))) return rc2;
+        }
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->xdense, (size_t)ctx->feat_ld * sizeof(float), d_feats,
+                                     (size_t)ld_feats * sizeof(float), (size_t)ctx->gat[0].in_dim * sizeof(float),
+                                     n_nodes, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIPCHK(ctx, launch_head_features(s, ctx->d_cfg, *b, J, ctx->x0, ctx->feat_ld, 0, 0, true));
+    }
     const int L = ctx->gat_layers;
     for (int l = 0; l < L; ++l) {
         const GatLayer &g = ctx->gat[l];
@@ -207,7 +221,17 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
         a.out_slope = ctx->gat_hidden_slope;
         a.ld = ctx->act_ld;
         a.a12 = ctx->a12;
-        if (l == 0) {
+        if (l == 0 && dense_in) {
+            if ((rc = linear(ctx, s, ctx->xdense, ctx->feat_ld, g.fc1, ctx->hdense, ctx->feat_ld, n_nodes, nullptr, true,
+                             ctx->gat_alpha, ctx->gat_acc64)))
+                return rc;
+            if ((rc = linear(ctx, s, ctx->hdense, ctx->feat_ld, g.fc2, ctx->act[2], ctx->act_ld, n_nodes, nullptr, false,
+                             0.f, ctx->gat_acc64)))
+                return rc;
+            HIPCHK(ctx, launch_attn_coef(s, ctx->act[2], ctx->act_ld, n_nodes, g.heads, g.out_dim, g.attn_l, g.attn_r,
+                                         ctx->a12));
+            a.ft2 = ctx->act[2];
+        } else if (l == 0) {
             // heads only: edge-node rows are the layer-0 constants
             if ((rc = linear(ctx, s, ctx->x0, ctx->feat_ld, g.fc1, ctx->h0, ctx->feat_ld, b->n_heads, nullptr, true,
                              ctx->gat_alpha, ctx->gat_acc64)))
@@ -430,11 +454,21 @@ int mpe_head_features(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_f
     return MPE_OK;
 }
 
-int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_scores_en, float *d_scores_heads) {
+int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float *d_feats, int32_t ld_feats,
+                    float *d_scores_en, float *d_scores_heads) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
     if (!d_scores_en) return fail(ctx, MPE_ERR_INVALID, "d_scores_en is NULL");
-    return run_gat(ctx, static_cast<hipStream_t>(stream), b, d_scores_en, d_scores_heads);
+    return run_gat(ctx, static_cast<hipStream_t>(stream), b, d_scores_en, d_scores_heads, d_feats, ld_feats);
+}
+
+int mpe_set_threshold(mpe_ctx *ctx, float threshold) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (!(threshold >= 0.f)) return fail(ctx, MPE_ERR_INVALID, "threshold must be >= 0");
+    ctx->hcfg.threshold = threshold;
+    ctx->cfg.threshold = threshold;
+    HIPCHK(ctx, hipMemcpy(ctx->d_cfg, &ctx->hcfg, sizeof ctx->hcfg, hipMemcpyHostToDevice));
+    return MPE_OK;
 }
 
 int mpe_gat_debug_layer(mpe_ctx *ctx, void *stream, int32_t, float *d_out, int32_t ld_out, int32_t n_rows) {
@@ -550,13 +584,14 @@ int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_
 }
 
 int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_t *d_persons,
-                          const int32_t *d_n_persons, double *d_poses, uint8_t *d_joint_valid) {
+                          const int32_t *d_n_persons, double *d_poses, uint8_t *d_joint_valid, uint32_t flags) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
     if (!d_persons || !d_n_persons || !d_poses || !d_joint_valid)
         return fail(ctx, MPE_ERR_INVALID, "mpe_triangulate_batch: NULL argument");
     HIPCHK(ctx, launch_triangulate(static_cast<hipStream_t>(stream), ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints,
-                                   *b, d_persons, d_n_persons, ctx->cfg.max_persons_per_frame, d_poses, d_joint_valid));
+                                   *b, d_persons, d_n_persons, ctx->cfg.max_persons_per_frame, d_poses, d_joint_valid,
+                                   (flags & 1u) ? 0xFFFFFFFFu : ctx->cfg.used_joint_mask));
     return MPE_OK;
 }
 

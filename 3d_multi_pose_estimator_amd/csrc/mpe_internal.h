@@ -73,6 +73,8 @@ struct mpe_ctx {
     int act_ld = 0;                // padded widest hidden activation of the GAT
     float *x0 = nullptr;           // [max_heads][feat_ld] dense head rows
     float *h0 = nullptr;           // [max_heads][feat_ld] fc1 output of layer 0
+    float *xdense = nullptr;       // [max_nodes][feat_ld] caller-provided dense rows (API mirror only)
+    float *hdense = nullptr;
     float *act[3] = {nullptr, nullptr, nullptr};   // [max_nodes][act_ld]
     float *a12 = nullptr;          // [max_nodes][2*16]
     int32_t *row_frame = nullptr;  // [max_nodes]
@@ -145,7 +147,7 @@ hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const
                            float *rows, int ld_rows, uint8_t *valid);
 hipError_t launch_triangulate(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                               const int32_t *persons, const int32_t *n_persons, int pcap, double *poses,
-                              uint8_t *joint_valid);
+                              uint8_t *joint_valid, uint32_t out_mask);
 hipError_t launch_dlt_pairs(hipStream_t s, const DevCfg *cfg, const double *pts, const int32_t *cams, int n,
                             double *out);
 hipError_t launch_decode(hipStream_t s, int n_frames, int pcap, int n_out, float scale, const int32_t *n_persons,

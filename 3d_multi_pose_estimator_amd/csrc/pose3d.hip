@@ -336,7 +336,8 @@ __global__ __launch_bounds__(128) void k_triangulate(const DevCfg *__restrict__ 
                                                      const double *__restrict__ xy,
                                                      const int32_t *__restrict__ persons,
                                                      const int32_t *__restrict__ n_persons,
-                                                     double *__restrict__ poses, uint8_t *__restrict__ joint_valid) {
+                                                     double *__restrict__ poses, uint8_t *__restrict__ joint_valid,
+                                                     uint32_t out_mask) {
 #pragma clang fp contract(off)
     extern __shared__ double s_dyn64[];
     const int f = blockIdx.x / pcap, p = blockIdx.x - f * pcap;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(128) void k_triangulate(const DevCfg *__restrict__ 
                     }
                 }
             }
-            if (cfg->used_joint_mask >> j & 1u) {
+            if (out_mask >> j & 1u) {
                 ox = sx / kept;
                 oy = sy / kept;
                 oz = sz / kept;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(128) void k_triangulate(const DevCfg *__restrict__ 
 
 hipError_t launch_triangulate(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                               const int32_t *persons, const int32_t *n_persons, int pcap, double *poses,
-                              uint8_t *joint_valid) {
+                              uint8_t *joint_valid, uint32_t out_mask) {
     if (b.n_frames <= 0) return hipSuccess;
     const size_t shm = ((size_t)V * J * 2 + (size_t)J * (V * (V - 1) / 2) * 3) * sizeof(double);
     if (shm > 64 * 1024) {
@@ -444,7 +445,7 @@ hipError_t launch_triangulate(hipStream_t s, const DevCfg *cfg, int V, int J, co
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_triangulate, dim3(b.n_frames * pcap), dim3(128), shm, s, cfg, pcap, b.d_frame_head_off,
-                       b.d_joint_mask, b.d_xy, persons, n_persons, poses, joint_valid);
+                       b.d_joint_mask, b.d_xy, persons, n_persons, poses, joint_valid, out_mask);
     return hipGetLastError();
 }
 

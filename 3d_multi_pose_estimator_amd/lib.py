@@ -63,7 +63,7 @@ SYMBOLS = {
     'mpe_mlp3d_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     'mpe_triangulate_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_uint32]),
     'mpe_upload_linear': (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int32, C.c_int32,
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     'mpe_free_device': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -71,7 +71,9 @@ SYMBOLS = {
                              C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                              C.c_float]),
     'mpe_head_features': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p]),
-    'mpe_gat_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p]),
+    'mpe_gat_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_void_p]),
+    'mpe_set_threshold': (C.c_int, [C.c_void_p, C.c_float]),
     'mpe_gat_debug_layer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     'mpe_cluster_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
                                     C.c_void_p]),

@@ -145,11 +145,20 @@ class Engine:
                                            _ptr(scores), _ptr(persons), _ptr(n_persons)))
         return (scores[:db.n_edge_nodes] if want_scores else None), persons, n_persons
 
-    def gat_scores(self, db, heads=False):
+    def gat_scores(self, db, heads=False, feats=None):
+        """GAT2.forward; `feats` (optional) = dense [n_nodes, F] rows supplied by the caller."""
         sc = torch.empty(max(db.n_edge_nodes, 1), dtype=torch.float32, device=self.device)
         sh = torch.empty(max(db.n_heads, 1), dtype=torch.float32, device=self.device) if heads else None
-        self._chk(self.lib.mpe_gat_forward(self.ctx, self._stream(), C.byref(db.struct), _ptr(sc), _ptr(sh)))
+        ld = 0
+        if feats is not None:
+            feats = feats.to(self.device, torch.float32).contiguous()
+            ld = feats.shape[1]
+        self._chk(self.lib.mpe_gat_forward(self.ctx, self._stream(), C.byref(db.struct), _ptr(feats), ld,
+                                           _ptr(sc), _ptr(sh)))
         return (sc[:db.n_edge_nodes], sh[:db.n_heads]) if heads else sc[:db.n_edge_nodes]
+
+    def set_threshold(self, thr):
+        self._chk(self.lib.mpe_set_threshold(self.ctx, float(thr)))
 
     def cluster(self, db, scores):
         B = db.n_frames
@@ -194,13 +203,13 @@ class Engine:
                                            _ptr(n_persons), _ptr(poses), _ptr(valid)))
         return poses, valid
 
-    def triangulate(self, db, persons, n_persons):
+    def triangulate(self, db, persons, n_persons, all_joints=False):
         """-> (poses[B,Pcap,J,3] f64, joint_valid[B,Pcap,J] u8)."""
         B = db.n_frames
         poses = torch.empty((B, self.pcap, self.J, 3), dtype=torch.float64, device=self.device)
         jv = torch.empty((B, self.pcap, self.J), dtype=torch.uint8, device=self.device)
         self._chk(self.lib.mpe_triangulate_batch(self.ctx, self._stream(), C.byref(db.struct), _ptr(persons),
-                                                 _ptr(n_persons), _ptr(poses), _ptr(jv)))
+                                                 _ptr(n_persons), _ptr(poses), _ptr(jv), 1 if all_joints else 0))
         return poses, jv
 
     def dlt_pairs(self, pts, cams):

@@ -1,0 +1,103 @@
+"""API mirror of the reference's utils/pose_estimator_dataset_from_json.py, dict branch
+(:237-298): one person -> one 1 x (V*J*14) MLP input row, built by the HIP kernel k_mlp_rows
+(undistortion, pairwise DLT, mean, ray rotation) through mpe_mlp_input_rows.
+
+The list-of-files branch (:146-236) is the training path (augmentation, caching) and is out
+of scope."""
+import json
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import runtime
+from .packing import PackedBatch
+from .parameters import parameters
+
+number_of_joints = len(parameters.joint_list)
+numbers_per_joint = parameters.numbers_per_joint
+
+
+def get_skeleton_indices(data):
+    """Index of the skeleton with most keys per camera (reference :49-61)."""
+    out = {}
+    for cam in data.keys():
+        skeletons = json.loads(data[cam][0])
+        n_joints, index = 0, 0
+        for i, sk in enumerate(skeletons):
+            if len(sk) > n_joints:
+                n_joints, index = len(sk), i
+        out[cam] = index
+    return out
+
+
+class PoseEstimatorDataset(Dataset):
+    def __init__(self, input_data, cameras, joint_list, transform=None, data_augmentation=False, reload=False,
+                 save=False, device=None):
+        if not isinstance(input_data, dict):
+            if isinstance(input_data, list):
+                raise NotImplementedError('list-of-files input is the training path (out of scope)')
+            raise Exception(f'Invalid dataset input {type(input_data)} for json_files. Only list and dict are allowed.')
+        self.transform = transform
+        eng = runtime.shared_engine()
+        names = list(parameters.camera_names)
+        J = number_of_joints
+        idx = get_skeleton_indices(input_data)
+        heads = []
+        for cam in input_data:
+            if cam not in parameters.used_cameras:
+                continue
+            skeletons = json.loads(input_data[cam][0])
+            if not skeletons:
+                continue
+            heads.append((cam, skeletons[idx[cam]]))
+        pb = PackedBatch(len(names), J)
+        n = len(heads)
+        pb.n_frames = 1
+        pb.slot_cam = np.full((1, len(names)), -1, np.int32)
+        pb.slot_n = np.zeros((1, len(names)), np.int32)
+        pb.head_cam = np.zeros(n, np.int32)
+        pb.joint_mask = np.zeros(n, np.uint32)
+        pb.tri_mask = np.zeros(n, np.uint32)
+        pb.xy = np.zeros((n, J, 2), np.float64)
+        pb.vp = np.zeros((n, J, 2), np.float32)
+        person = torch.full((1, eng.pcap, eng.V), -1, dtype=torch.int32)
+        for h, (cam, sk) in enumerate(heads):
+            c = names.index(cam)
+            pb.slot_cam[0, h], pb.slot_n[0, h], pb.head_cam[h] = c, 1, c
+            person[0, 0, c] = h
+            for key, v in sk.items():
+                if key == 'ID':
+                    continue
+                j = int(key)
+                pb.joint_mask[h] |= np.uint32(1 << j)
+                if v[0] > 0.:
+                    pb.tri_mask[h] |= np.uint32(1 << j)
+                pb.xy[h, j] = (v[1], v[2])
+                pb.vp[h, j] = (v[3], v[4])
+        pb.frame_head_off = np.array([0, n], np.int32)
+        pb.frame_en_off = np.array([0, n * (n - 1) // 2], np.int32)
+        pb.skeleton_index = np.zeros(n, np.int32)
+        self.data, self.orig_data = [], []
+        if n:
+            db = eng.to_device(pb)
+            rows, valid = eng.mlp_input_rows(db, person.to(eng.device), torch.ones(1, dtype=torch.int32, device=eng.device))
+            if bool(valid[0, 0]):
+                self.data.append(rows[0, 0].cpu())
+        self.orig_data = self.data
+        # torch.stack of an empty list raises, exactly like the reference (:294)
+        self.data = torch.stack(self.data)
+        self.orig_data = torch.stack(self.orig_data)
+        if device is not None:
+            self.data = self.data.to(device=device)
+            self.orig_data = self.orig_data.to(device=device)
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __getitem__(self, idx):
+        ret1 = self.data[idx]
+        ret2 = self.orig_data[idx]
+        if self.transform:
+            ret1 = self.transform(ret1)
+        return ret1, ret2

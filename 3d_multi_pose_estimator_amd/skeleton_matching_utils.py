@@ -1,0 +1,31 @@
+"""API mirror of the reference's utils/skeleton_matching_utils.py: the greedy clustering runs
+in the HIP kernel k_cluster (csrc/cluster.hip) through mpe_cluster_batch."""
+import torch
+
+from . import runtime
+from .parameters import parameters
+
+
+def get_person_proposal_from_network_output(outputs, subgraph, indices, nodes_camera, jsons_for_head=None,
+                                            CLASSIFICATION_THRESHOLD=0.5):
+    """Same arguments and result as the reference (:12-132): a list of
+    ``{camera_name: head id or None}`` over ``used_cameras_skeleton_matching``.  `outputs` may
+    be a tensor or a Python list of per-node scores; only edge-node entries are read."""
+    eng = runtime.shared_engine()
+    db = subgraph.device_batch(eng)
+    if type(outputs) is list:
+        outputs = torch.tensor(outputs, dtype=torch.float32)
+    outputs = outputs.reshape(-1).float()
+    idx = torch.as_tensor(indices).reshape(-1).long()
+    H = subgraph.H
+    if idx.numel() != subgraph.M or (idx.numel() and int(idx[0]) != H):
+        raise ValueError('indices must be the edge-node ids of the graph')
+    scores = outputs.to(eng.device)[idx.to(eng.device)]
+    if eng.params is not parameters:
+        raise RuntimeError('engine / parameters mismatch')
+    eng.set_threshold(CLASSIFICATION_THRESHOLD)
+    persons, n_persons = eng.cluster(db, scores)
+    n = int(n_persons[0])
+    rows = persons[0, :n].cpu().tolist()
+    cams = list(parameters.used_cameras_skeleton_matching)
+    return [{cam: (None if row[c] < 0 else row[c]) for c, cam in enumerate(cams)} for row in rows]

@@ -139,10 +139,12 @@ int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
 
 /* 3D stage B: caller gather + triangulate (metrics_from_triangulation.py:234-272,
  * pose_estimator_utils.py:52-75).
- *   d_poses [n_frames][Pcap][J][3] f64, d_joint_valid [n_frames][Pcap][J] 1 = joint emitted */
+ *   d_poses [n_frames][Pcap][J][3] f64, d_joint_valid [n_frames][Pcap][J] 1 = joint emitted
+ *   flags bit 0: emit every triangulated joint (what `triangulate` itself returns); otherwise
+ *   joints outside parameters.used_joints come back as zeros, as the caller's copy does. */
 int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
                           const int32_t *d_persons, const int32_t *d_n_persons,
-                          double *d_poses, uint8_t *d_joint_valid);
+                          double *d_poses, uint8_t *d_joint_valid, uint32_t flags);
 
 /* ---- stage-level entry points (parity tests, Python mirrors of single reference symbols) */
 /* C[M][N] = act(A[M][K] * W[N][K]^T + bias): nn.Linear (+ LeakyReLU when slope_on != 0).
@@ -160,11 +162,16 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
  * non-zero block of every head row: d_feat [n_heads][J][10]. */
 int mpe_head_features(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_feat);
 
-/* GAT2.forward over the batch: d_scores_en [n_edge_nodes]; optional d_scores_heads
- * [n_heads] (the reference also evaluates the last layer at head nodes; unused downstream);
- * optional d_layer_out[l] = activation after layer l, [n_nodes][ld] (debug / parity). */
-int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_scores_en,
-                    float *d_scores_heads);
+/* GAT2.forward over the batch (gat2.py:137-149).  d_feats == NULL: node rows are featurised
+ * on the device from the packed skeletons (the production path; edge-node rows are constant
+ * and de-duplicated).  d_feats != NULL: caller-provided dense [n_nodes][ld_feats] rows in
+ * node order (frame by frame: heads, then edge-nodes), as GAT2.forward(inputs, g) receives.
+ * d_scores_en [n_edge_nodes]; optional d_scores_heads [n_heads] (the reference also evaluates
+ * the last layer at head nodes; unused downstream). */
+int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float *d_feats, int32_t ld_feats,
+                    float *d_scores_en, float *d_scores_heads);
+/* CLASSIFICATION_THRESHOLD of get_person_proposal_from_network_output (default from mpe_config) */
+int mpe_set_threshold(mpe_ctx *ctx, float threshold);
 int mpe_gat_debug_layer(mpe_ctx *ctx, void *stream, int32_t layer, float *d_out, int32_t ld_out,
                         int32_t n_rows);
 

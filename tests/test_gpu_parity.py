@@ -231,7 +231,10 @@ def test_batch_vs_oracle(engine, calib, gat_weights, mlp_weights):
         if own == res['persons']:
             exact += 1
             if len(own):
-                worst_pose = max(worst_pose, np.abs(poses[f, :len(own)] - res['poses']).max())
+                # mixed-up / spurious skeletons triangulate far away and drive MLP inputs and
+                # outputs to tens of metres: the bound scales with the magnitude (4 m = volume)
+                mag = max(1.0, float(np.abs(res['poses']).max()) / 4.0)
+                worst_pose = max(worst_pose, np.abs(poses[f, :len(own)] - res['poses']).max() / mag)
                 for k, person in enumerate(own):
                     sk = onp.person_skeletons(person, res['graph']['jsons_for_head'], sm)
                     t = onp.triangulate_person(sk, calib)

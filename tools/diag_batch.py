@@ -1,0 +1,33 @@
+import importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import oracle_np as onp
+PKG = '3d_multi_pose_estimator_amd'
+syn = importlib.import_module(PKG + '.synthetic'); cal = importlib.import_module(PKG + '.calibration')
+par = importlib.import_module(PKG + '.parameters'); pipeline = importlib.import_module(PKG + '.pipeline')
+calib = cal.Calibration(par.parameters)
+sd = syn.gat_state_dict(7, 902, logit_gain=25.0, logit_shift=0.698); prm = syn.gat_params(902); mlp = syn.mlp_state_dict(11, 1260)
+eng = pipeline.Engine(par.parameters, calib, max_frames=64, max_persons_per_camera=10)
+eng.load_gat(sd, prm); eng.load_mlp(mlp)
+specs = [syn.FrameSpec(persons=4), syn.FrameSpec(persons=3, joint_drop=0.2, noise_px=1.5),
+         syn.FrameSpec(persons=5, cameras=['trackerb', 'trackera', 'trackerd', 'trackere']),
+         syn.FrameSpec(persons=2, empty_cameras=('trackera',), spurious=1)]
+frames = [onp.processed_input(syn.make_frame(calib, 100 + i, specs[i % 4])[0]) for i in range(48)]
+db = eng.to_device(eng.pack(frames))
+scores, persons, n_persons = eng.match(db)
+poses, valid = eng.mlp3d(db, persons, n_persons)
+rows, v2 = eng.mlp_input_rows(db, persons, n_persons)
+persons_c, n_c, poses_c, rows_c = persons.cpu().numpy(), n_persons.cpu().numpy(), poses.cpu().numpy(), rows.cpu().numpy()
+sm = list(calib.params.used_cameras_skeleton_matching)
+for f, frame in enumerate(frames):
+    res = onp.run_frame(frame, calib, sd, prm, mlp, mode='mlp')
+    own = [list(p) for p in persons_c[f, :n_c[f]]]
+    if own != res['persons']: print(f, 'clusters differ'); continue
+    if not len(own): continue
+    dp = np.abs(poses_c[f, :len(own)] - res['poses']).max()
+    dr = np.abs(rows_c[f, :len(own)] - res['mlp_in'].numpy())
+    if dp > 5e-6 or dr.max() > 5e-7:
+        k, c = np.unravel_index(dr.argmax(), dr.shape)
+        print('frame', f, 'spec', f % 4, 'pose diff %.2e' % dp, 'row diff %.2e at person %d col %d (cam %d joint %d slot %d)' % (dr.max(), k, c, c // 252, (c % 252) // 14, c % 14),
+              'gpu', rows_c[f, k, c], 'cpu', res['mlp_in'].numpy()[k, c], 'max|pose|', np.abs(res['poses']).max(), 'max|row|', np.abs(res['mlp_in'].numpy()).max())
