@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
                                                    const float *__restrict__ W, int ldw,
                                                    const float *__restrict__ bias, float *__restrict__ C,
                                                    int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
-                                                   int k_pad, float slope, int ntn) {
+                                                   int k_pad, float slope, int ntn, int n_major) {
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
     int M = m_cap;
@@ -47,13 +47,24 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
         M = dm < m_cap ? dm : m_cap;
     }
     // XCD-aware order: workgroups with equal (id % 8) share an L2; give each such class a
-    // contiguous range of tiles so the feature tiles of one row block hit the same L2.
-    const int bid = blockIdx.x, nwg = gridDim.x;
+    // contiguous range of tiles.  m-major (feature tiles of one row block adjacent) keeps the
+    // activation rows L2-resident when the weights are small (GAT); n-major keeps one weight
+    // panel resident while the row blocks stream past it (MLP: M small, N*K*4 >> L2).
+    // The grid is sized for m_cap; with a device-side M only the first ntm*ntn ids do work.
+    const int ntm = (M + GEMM_BM - 1) / GEMM_BM;
+    const int bid = blockIdx.x, nwg = ntm * ntn;
+    if (bid >= nwg) return;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tm = swz / ntn, tn = swz - tm * ntn;
+    int tm, tn;
+    if (n_major) {
+        tn = swz / ntm;
+        tm = swz - tn * ntm;
+    } else {
+        tm = swz / ntn;
+        tn = swz - tm * ntn;
+    }
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-    if (m0 >= M) return;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // global->LDS staging role: 8 rows x 8 chunks (16 B) per wave and pass
@@ -71,16 +82,17 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
         a_src[p] = A + (size_t)grow * lda + ch * 4;
         a_dst[p] = st_q * PLANE_A + row * RS + st_off;
     }
+    // weight tile: 80 rows = 2.5 passes of 32; in the last pass waves 2,3 repeat the rows of
+    // waves 0,1 (same bytes to the same LDS slot) so that no load sits under a branch --
+    // hipcc serialises predicated loads with vmcnt waits.
     const float *w_src[W_PASSES];
     int w_dst[W_PASSES];
-    bool w_on[W_PASSES];
 #pragma unroll
     for (int p = 0; p < W_PASSES; ++p) {
         int row = p * 32 + wave * 8 + lr;
-        w_on[p] = row < GEMM_BN;
-        int rr = w_on[p] ? row : 0;
-        w_src[p] = W + (size_t)(n0 + rr) * ldw + ch * 4;
-        w_dst[p] = 4 * PLANE_A + st_q * PLANE_W + rr * RS + st_off;
+        if (row >= GEMM_BN) row -= 16;
+        w_src[p] = W + (size_t)(n0 + row) * ldw + ch * 4;
+        w_dst[p] = 4 * PLANE_A + st_q * PLANE_W + row * RS + st_off;
     }
 
     // fragment read offsets (floats)
@@ -112,13 +124,11 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) pa[p] = *reinterpret_cast<const f32x4 *>(a_src[p]);
 #pragma unroll
-    for (int p = 0; p < W_PASSES; ++p)
-        if (w_on[p]) pw[p] = *reinterpret_cast<const f32x4 *>(w_src[p]);
+    for (int p = 0; p < W_PASSES; ++p) pw[p] = *reinterpret_cast<const f32x4 *>(w_src[p]);
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[a_dst[p]]) = pa[p];
 #pragma unroll
-    for (int p = 0; p < W_PASSES; ++p)
-        if (w_on[p]) *reinterpret_cast<f32x4 *>(&lds[w_dst[p]]) = pw[p];
+    for (int p = 0; p < W_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[w_dst[p]]) = pw[p];
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -129,8 +139,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
 #pragma unroll
             for (int p = 0; p < A_PASSES; ++p) pa[p] = *reinterpret_cast<const f32x4 *>(a_src[p] + koff);
 #pragma unroll
-            for (int p = 0; p < W_PASSES; ++p)
-                if (w_on[p]) pw[p] = *reinterpret_cast<const f32x4 *>(w_src[p] + koff);
+            for (int p = 0; p < W_PASSES; ++p) pw[p] = *reinterpret_cast<const f32x4 *>(w_src[p] + koff);
         }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -162,8 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
 #pragma unroll
             for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[nxt + a_dst[p]]) = pa[p];
 #pragma unroll
-            for (int p = 0; p < W_PASSES; ++p)
-                if (w_on[p]) *reinterpret_cast<f32x4 *>(&lds[nxt + w_dst[p]]) = pw[p];
+            for (int p = 0; p < W_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[nxt + w_dst[p]]) = pw[p];
         }
         __syncthreads();
     }
@@ -206,10 +214,11 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
     const int ntn = (n + GEMM_BN - 1) / GEMM_BN;
+    const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
     dim3 grid(ntm * ntn), block(256);
 #define MPE_LAUNCH(L_, A_)                                                                                   \
     hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
-                       slope, ntn)
+                       slope, ntn, n_major)
     if (leaky && acc64) MPE_LAUNCH(true, true);
     else if (leaky) MPE_LAUNCH(true, false);
     else if (acc64) MPE_LAUNCH(false, true);
