@@ -11,30 +11,33 @@
 //     [32w,32w+32) x all 80 features = 2 x 5 MFMA tiles (40 accumulator VGPRs).
 //   * operands are swapped (A-operand = weight rows, B-operand = activation rows) so each
 //     lane ends up with 4 consecutive output features of one row: one 16-byte store.
-//   * LDS image is planar in the MFMA k-quarter: plane q holds, for every tile row, the 8
-//     k-values {8q..8q+7} in 48-byte slots (32 B data + 16 B pad); a lane fetches its whole
-//     K-stage share with two conflict-free ds_read_b128, and the global->LDS pass writes
-//     rows x chunks transposed over the lanes so the ds_write_b128 are conflict-free too.
-//   * double-buffered LDS (78 KB, 2 workgroups/CU), register prefetch of the next K stage,
-//     one barrier per stage; XCD-aware workgroup order so the tiles that share activation
-//     rows run on one XCD's L2.
+//   * LDS image is planar in the MFMA k-quarter and dense: plane q holds, for every tile
+//     row r, the 8 k-values {8q..8q+7} as two 16-byte halves stored at chunk 2r + (h ^ s(r)),
+//     s(r) = bit3(r) ^ bit2(r).  With that swizzle a lane fetches its K-stage share with two
+//     conflict-free ds_read_b128 (4 LDS cycles each) and the global->LDS pass (rows x chunks
+//     transposed over the lanes) writes conflict-free ds_write_b128 (8 cycles each).
+//   * double-buffered LDS (52 KB -> 3 workgroups/CU), register prefetch of the next K stage,
+//     one barrier per stage; XCD-aware workgroup order so the tiles that share operands run
+//     on one XCD's L2.
 #include "mpe_internal.h"
 
 namespace mpe {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int RS = 12;                          // floats per (row, k-quarter) slot
-constexpr int PLANE_A = GEMM_BM * RS;           // 1536 floats
-constexpr int PLANE_W = GEMM_BN * RS;           //  960 floats
-constexpr int STAGE = 4 * (PLANE_A + PLANE_W);  // 9984 floats = 39936 B
+constexpr int RS = 8;                           // floats per (row, k-quarter) slot (dense)
+constexpr int PLANE_A = GEMM_BM * RS;           // 1024 floats
+constexpr int PLANE_W = GEMM_BN * RS;           //  640 floats
+constexpr int STAGE = 4 * (PLANE_A + PLANE_W);  // 6656 floats = 26624 B
+
+__device__ __forceinline__ int lds_swz(int row) { return ((row >> 3) ^ (row >> 2)) & 1; }
 constexpr int A_PASSES = GEMM_BM / 32;          // 4
 constexpr int W_PASSES = (GEMM_BN + 31) / 32;   // 3 (last one half populated)
 constexpr int NT = GEMM_BN / 16;                // 5 feature tiles per wave
 constexpr int MT = 2;                           // 2 row tiles per wave
 
 template <bool LEAKY, bool ACC64>
-__global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, int lda,
+__global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__restrict__ A, int lda,
                                                    const float *__restrict__ W, int ldw,
                                                    const float *__restrict__ bias, float *__restrict__ C,
                                                    int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // global->LDS staging role: 8 rows x 8 chunks (16 B) per wave and pass
     const int lr = lane & 7, ch = lane >> 3;
-    const int st_off = (ch & 1) * 4;   // within-slot float offset
+    const int st_h = ch & 1;           // which 16-byte half of the slot
     const int st_q = ch >> 1;
 
     const float *a_src[A_PASSES];
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
         int grow = m0 + row;
         grow = grow < M ? grow : M - 1;
         a_src[p] = A + (size_t)grow * lda + ch * 4;
-        a_dst[p] = st_q * PLANE_A + row * RS + st_off;
+        a_dst[p] = st_q * PLANE_A + row * RS + ((st_h ^ lds_swz(row)) << 2);
     }
     // weight tile: 80 rows = 2.5 passes of 32; in the last pass waves 2,3 repeat the rows of
     // waves 0,1 (same bytes to the same LDS slot) so that no load sits under a branch --
@@ -92,11 +95,12 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
         int row = p * 32 + wave * 8 + lr;
         if (row >= GEMM_BN) row -= 16;
         w_src[p] = W + (size_t)(n0 + row) * ldw + ch * 4;
-        w_dst[p] = 4 * PLANE_A + st_q * PLANE_W + row * RS + st_off;
+        w_dst[p] = 4 * PLANE_A + st_q * PLANE_W + row * RS + ((st_h ^ lds_swz(row)) << 2);
     }
 
     // fragment read offsets (floats)
     const int fq = lane >> 4, fr = lane & 15;
+    const int fsw = lds_swz(fr);       // rows of every fragment tile differ from fr by multiples of 16
     int a_rd[MT], w_rd[NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a_rd[mt] = fq * PLANE_A + (wave * 32 + mt * 16 + fr) * RS;
@@ -145,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void k_linear(const float *__restrict__ A, 
         for (int hh = 0; hh < 2; ++hh) {
             f32x4 af[MT], wf[NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + hh * 4]);
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + ((hh ^ fsw) << 2)]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + hh * 4]);
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + ((hh ^ fsw) << 2)]);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll

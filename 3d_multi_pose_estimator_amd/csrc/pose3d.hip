@@ -58,7 +58,8 @@ __device__ inline void dlt_solve(const double *P1, const double *P2, double x1, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) Vm[k][j] = (k == j) ? 1.0 : 0.0;
     }
-    for (int sweep = 0; sweep < 30; ++sweep) {
+    // converged when every column pair is orthogonal to a few ulp: |<a_p,a_q>| <= 4e-16 |a_p||a_q|
+    for (int sweep = 0; sweep < 12; ++sweep) {
         bool rotated = false;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -71,7 +72,7 @@ __device__ inline void dlt_solve(const double *P1, const double *P2, double x1, 
                     be += A[i][q] * A[i][q];
                     ga += A[i][p] * A[i][q];
                 }
-                if (fabs(ga) <= 1e-17 * sqrt(al * be) || ga == 0.0) continue;
+                if (ga * ga <= 1.6e-31 * (al * be) || ga == 0.0) continue;
                 rotated = true;
                 const double zeta = (be - al) / (2.0 * ga);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
