@@ -195,7 +195,7 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
     const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints;
     const int n_nodes = b->n_heads + b->n_edge_nodes;
     const int hmax = ctx->cfg.max_heads_per_frame;
-    HIPCHK(ctx, launch_topology(s, *b, V, ctx->node_off, ctx->row_frame, ctx->en_pair));
+    HIPCHK(ctx, launch_topology(s, *b, V, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair));
     const bool dense_in = d_feats != nullptr;   // caller-provided N x F rows (GAT2.forward(inputs, g))
     if (dense_in) {
         if (ld_feats < ctx->gat[0].in_dim) return fail(ctx, MPE_ERR_INVALID, "feature stride too small");
@@ -266,7 +266,7 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
             a.out = ctx->act[0];
             a.ld_out = ctx->act_ld;
         }
-        HIPCHK(ctx, launch_aggregate(s, *b, V, hmax, ctx->node_off, ctx->row_frame, ctx->en_pair, a, n_nodes));
+        HIPCHK(ctx, launch_aggregate(s, *b, V, hmax, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair, a));
     }
     return MPE_OK;
 }
@@ -318,7 +318,8 @@ int mpe_create(const mpe_config *cfg, mpe_ctx **out) {
     do {
         if ((rc = dev_alloc(ctx, &ctx->d_cfg, 1))) break;
         if (hipMemcpy(ctx->d_cfg, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) { rc = MPE_ERR_HIP; break; }
-        if ((rc = dev_alloc(ctx, &ctx->row_frame, (size_t)ctx->max_nodes))) break;
+        if ((rc = dev_alloc(ctx, &ctx->head_frame, (size_t)cfg->max_heads))) break;
+        if ((rc = dev_alloc(ctx, &ctx->en_frame, (size_t)cfg->max_edge_nodes))) break;
         if ((rc = dev_alloc(ctx, &ctx->en_pair, (size_t)cfg->max_edge_nodes * 2))) break;
         if ((rc = dev_alloc(ctx, &ctx->node_off, (size_t)cfg->max_frames + 1))) break;
         ctx->cl_keys_per_frame = cluster_keys_per_frame(cfg->max_heads_per_frame);
@@ -488,7 +489,7 @@ int mpe_cluster_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const floa
     if (rc) return rc;
     if (!d_scores || !d_persons || !d_n_persons) return fail(ctx, MPE_ERR_INVALID, "mpe_cluster_batch: NULL output");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIPCHK(ctx, launch_topology(s, *b, ctx->cfg.n_cameras, ctx->node_off, ctx->row_frame, ctx->en_pair));
+    HIPCHK(ctx, launch_topology(s, *b, ctx->cfg.n_cameras, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair));
     HIPCHK(ctx, launch_cluster(s, ctx->d_cfg, *b, ctx->en_pair, d_scores, ctx->cfg.max_persons_per_frame,
                                ctx->cfg.max_heads_per_frame, ctx->cl_keys, ctx->cl_keys_per_frame, ctx->cl_scratch,
                                ctx->cl_scratch_per_frame, d_persons, d_n_persons));

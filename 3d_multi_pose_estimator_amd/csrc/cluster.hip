@@ -1,12 +1,11 @@
-// Greedy person clustering, one wavefront per frame (sequential integer logic; lane 0
-// replays the reference's algorithm, the other lanes help with the sort).
+// Greedy person clustering, one wavefront per frame.
 //
 // Restates get_person_proposal_from_network_output (reference
 // utils/skeleton_matching_utils.py:12-132) on the implicit topology, bit for bit:
 //   * a matching exists for edge-node X=(h1,h2) when score[X] > threshold (:49-55); which of
 //     the two heads is `a` follows CPython's iteration order of the 2-element set (:53);
-//   * stable sort by score, descending (:60) -> 64-bit keys (inverted score bits, creation
-//     index), so ties keep creation order;
+//   * stable sort by score, descending (:60) -> 64-bit keys (inverted score bits, edge-node
+//     index): matchings are created in edge-node order, so ties keep creation order;
 //   * camera-uniqueness tests and human-index bookkeeping (:61-108) with camera sets as
 //     32-bit masks, including the quirk that merging two humans drops the absorbed group's
 //     camera list (:97-102);
@@ -14,6 +13,11 @@
 //     _plain_bfs, whose result is a Python set: iteration order of that set decides which
 //     head wins when a component holds two heads of one camera, so CPython's set
 //     (open addressing, LINEAR_PROBES 9, PERTURB_SHIFT 5, growth x4) is emulated exactly.
+//
+// Work split inside the wave: all 64 lanes build the keys and run a bitonic sort in LDS;
+// lane 0 then replays the sequential greedy rules and the component walk on LDS-resident
+// state (a few hundred dependent steps of ~64-cycle LDS latency instead of HBM latency).
+// Frames whose edge-node count does not fit the LDS budget use the global-scratch variant.
 #include "mpe_internal.h"
 
 namespace mpe {
@@ -97,6 +101,133 @@ __device__ inline bool pair_first_is_h1(int h1, int h2) {
     return s1 < i;
 }
 
+constexpr uint64_t KEY_NONE = ~0ull;
+
+__device__ inline uint64_t make_key(float score, float thr, int m) {
+    // Python compares float(score) > threshold; NaN fails the test
+    if (!(score > thr)) return KEY_NONE;
+    return ((uint64_t)(0xFFFFFFFFu - __float_as_uint(score)) << 32) | (uint32_t)m;
+}
+
+// the sequential part, shared by both variants; every array lives in `W` (LDS or global)
+struct Work {
+    int32_t *seen, *order, *linked, *human, *cfh, *ea, *eb, *done, *lvl, *nxt, *tabA, *tabB;
+};
+
+__device__ inline Work carve(int32_t *base, int hmax, int table_cap) {
+    Work w;
+    w.seen = base;
+    w.order = w.seen + hmax;
+    w.linked = w.order + hmax;
+    w.human = w.linked + hmax;
+    w.cfh = w.human + hmax;
+    w.ea = w.cfh + hmax;
+    w.eb = w.ea + hmax;
+    w.done = w.eb + hmax;
+    w.lvl = w.done + hmax;
+    w.nxt = w.lvl + hmax;
+    w.tabA = w.nxt + hmax;
+    w.tabB = w.tabA + table_cap;
+    return w;
+}
+
+// greedy merge over the sorted keys + connected components; returns the number of persons
+template <typename PairFn>
+__device__ inline int greedy_and_components(const Work &w, const uint64_t *keys, int n_keys, PairFn pair_of, int H,
+                                            int M, const int32_t *cam, int V, int min_views, int pcap,
+                                            int32_t *out) {
+    for (int h = 0; h < H; ++h) {
+        w.seen[h] = 0;
+        w.human[h] = -1;
+        w.done[h] = 0;
+        w.linked[h] = (int32_t)(1u << cam[h]);
+    }
+    // G.add_node order = first appearance in the edge scan (h1 then h2 of every edge-node)
+    int n_nodes = 0;
+    for (int m = 0; m < M && n_nodes < H; ++m) {
+        int h1, h2;
+        pair_of(m, h1, h2);
+        if (!w.seen[h1]) { w.seen[h1] = 1; w.order[n_nodes++] = h1; }
+        if (!w.seen[h2]) { w.seen[h2] = 1; w.order[n_nodes++] = h2; }
+    }
+    int cur = 0, ne = 0;
+    for (int k = 0; k < n_keys; ++k) {
+        const uint64_t key = keys[k];
+        if (key == KEY_NONE) break;
+        int h1, h2;
+        pair_of((int)(key & 0xFFFFFFFFu), h1, h2);
+        const bool first1 = pair_first_is_h1(h1, h2);
+        const int a = first1 ? h1 : h2, b = first1 ? h2 : h1;
+        const uint32_t ba = 1u << cam[a], bb = 1u << cam[b];
+        if (((uint32_t)w.linked[b] & ba) || ((uint32_t)w.linked[a] & bb)) continue;
+        const int ha = w.human[a], hb = w.human[b];
+        if (ha >= 0 && ((uint32_t)w.cfh[ha] & bb)) continue;
+        if (hb >= 0 && ((uint32_t)w.cfh[hb] & ba)) continue;
+        if (ha < 0 && hb < 0) {
+            w.human[a] = cur;
+            w.human[b] = cur;
+            w.cfh[cur] = (int32_t)(ba | bb);
+            ++cur;
+        } else if (ha >= 0 && hb < 0) {
+            w.human[b] = ha;
+            w.cfh[ha] = (int32_t)((uint32_t)w.cfh[ha] | bb);
+        } else if (hb >= 0 && ha < 0) {
+            w.human[a] = hb;
+            w.cfh[hb] = (int32_t)((uint32_t)w.cfh[hb] | ba);
+        } else {
+            if ((uint32_t)w.cfh[hb] & (uint32_t)w.cfh[ha]) continue;
+            for (int n = 0; n < H; ++n)
+                if (w.human[n] == hb) w.human[n] = ha;
+            // the absorbed group's camera list is dropped, not merged (reference :97-102)
+        }
+        w.ea[ne] = a;
+        w.eb[ne] = b;
+        ++ne;
+        w.linked[a] = (int32_t)((uint32_t)w.linked[a] | bb);
+        w.linked[b] = (int32_t)((uint32_t)w.linked[b] | ba);
+    }
+    int np = 0;
+    for (int oi = 0; oi < n_nodes; ++oi) {
+        const int v = w.order[oi];
+        if (w.done[v]) continue;
+        PySet set{w.tabA, w.tabB, 7, 0};
+        pyset_init(set);
+        pyset_add(set, v);
+        int nl = 1;
+        w.lvl[0] = v;
+        bool full = set.fill == n_nodes;
+        int32_t *L = w.lvl, *N = w.nxt;
+        while (nl > 0 && !full) {
+            int nn = 0;
+            for (int li = 0; li < nl; ++li) {
+                const int x = L[li];
+                for (int e = 0; e < ne; ++e) {
+                    int wv = -1;
+                    if (w.ea[e] == x) wv = w.eb[e];
+                    else if (w.eb[e] == x) wv = w.ea[e];
+                    if (wv >= 0 && !pyset_contains(set, wv)) {
+                        pyset_add(set, wv);
+                        N[nn++] = wv;
+                    }
+                }
+                if (set.fill == n_nodes) { full = true; break; }
+            }
+            int32_t *t = L; L = N; N = t;
+            nl = nn;
+        }
+        const int cnt = set.fill;
+        int32_t *pout = (cnt >= min_views && np < pcap) ? out + (size_t)np * V : nullptr;
+        for (int i = 0; i <= set.mask; ++i) {
+            const int h = set.tab[i];
+            if (h < 0) continue;
+            w.done[h] = 1;
+            if (pout) pout[cam[h]] = h;
+        }
+        if (pout) ++np;
+    }
+    return np;
+}
+
 __device__ inline void sift_down(uint64_t *k, int start, int end) {
     int root = start;
     while (true) {
@@ -133,18 +264,85 @@ int cluster_table_cap(int hmax) {
 size_t cluster_keys_per_frame(int hmax) { return (size_t)hmax * hmax / 2 + 1; }
 
 size_t cluster_scratch_per_frame(int hmax) {
-    return (size_t)10 * hmax + 2 * (size_t)cluster_table_cap(hmax) + cluster_keys_per_frame(hmax);
+    return (size_t)10 * hmax + 2 * (size_t)cluster_table_cap(hmax);
 }
 
-__global__ __launch_bounds__(64) void k_cluster(const DevCfg *__restrict__ cfg, int n_frames,
-                                                const int32_t *__restrict__ head_off,
-                                                const int32_t *__restrict__ en_off,
-                                                const int32_t *__restrict__ head_cam,
-                                                const int32_t *__restrict__ en_pair, const float *__restrict__ scores,
-                                                int pcap, int hmax, int table_cap, uint64_t *__restrict__ keys_all,
-                                                size_t keys_per_frame, int32_t *__restrict__ scratch_all,
-                                                size_t scratch_per_frame, int32_t *__restrict__ persons,
-                                                int32_t *__restrict__ n_persons) {
+// ---- LDS variant: keys [n_pow2] u64 | pairs [n_pow2] u32 | work arrays ------------------
+__global__ __launch_bounds__(64) void k_cluster_lds(const DevCfg *__restrict__ cfg, int n_frames,
+                                                    const int32_t *__restrict__ head_off,
+                                                    const int32_t *__restrict__ en_off,
+                                                    const int32_t *__restrict__ head_cam,
+                                                    const int32_t *__restrict__ en_pair,
+                                                    const float *__restrict__ scores, int pcap, int hmax,
+                                                    int table_cap, int n_pow2, int32_t *__restrict__ persons,
+                                                    int32_t *__restrict__ n_persons) {
+    extern __shared__ uint64_t s_keys[];
+    const int f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int V = cfg->V;
+    const int lane = threadIdx.x;
+    const int h0 = head_off[f], H = head_off[f + 1] - h0;
+    const int e0 = en_off[f], M = en_off[f + 1] - e0;
+    int32_t *out = persons + (size_t)f * pcap * V;
+    for (int i = lane; i < pcap * V; i += 64) out[i] = -1;
+    if (M <= 0 || H > hmax || M > n_pow2) {
+        if (lane == 0) n_persons[f] = 0;
+        return;
+    }
+    uint32_t *s_pair = reinterpret_cast<uint32_t *>(s_keys + n_pow2);
+    int32_t *s_work = reinterpret_cast<int32_t *>(s_pair + n_pow2);
+    int32_t *s_cam = s_work + 10 * hmax + 2 * table_cap;
+    const float thr = cfg->threshold;
+    // smallest power of two covering this frame's edge-nodes
+    int n = 64;
+    while (n < M) n <<= 1;
+    for (int m = lane; m < n; m += 64) {
+        uint64_t key = KEY_NONE;
+        if (m < M) {
+            const int h1 = en_pair[2 * (size_t)(e0 + m)], h2 = en_pair[2 * (size_t)(e0 + m) + 1];
+            s_pair[m] = ((uint32_t)h1 << 16) | (uint32_t)h2;
+            key = make_key(scores[e0 + m], thr, m);
+        }
+        s_keys[m] = key;
+    }
+    for (int h = lane; h < H; h += 64) s_cam[h] = head_cam[h0 + h];
+    __syncthreads();
+    // bitonic sort, ascending (KEY_NONE sinks to the end)
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < n / 2; t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+                const int p = i | j;
+                const bool up = (i & k) == 0;
+                const uint64_t x = s_keys[i], y = s_keys[p];
+                if ((x > y) == up) {
+                    s_keys[i] = y;
+                    s_keys[p] = x;
+                }
+            }
+            __syncthreads();
+        }
+    if (lane != 0) return;
+    Work w = carve(s_work, hmax, table_cap);
+    auto pair_of = [&](int m, int &h1, int &h2) {
+        const uint32_t pr = s_pair[m];
+        h1 = (int)(pr >> 16);
+        h2 = (int)(pr & 0xFFFFu);
+    };
+    n_persons[f] = greedy_and_components(w, s_keys, n, pair_of, H, M, s_cam, V, cfg->min_views, pcap, out);
+}
+
+// ---- global-scratch variant (frames too large for LDS) ---------------------------------
+__global__ __launch_bounds__(64) void k_cluster_big(const DevCfg *__restrict__ cfg, int n_frames,
+                                                    const int32_t *__restrict__ head_off,
+                                                    const int32_t *__restrict__ en_off,
+                                                    const int32_t *__restrict__ head_cam,
+                                                    const int32_t *__restrict__ en_pair,
+                                                    const float *__restrict__ scores, int pcap, int hmax,
+                                                    int table_cap, uint64_t *__restrict__ keys_all,
+                                                    size_t keys_per_frame, int32_t *__restrict__ scratch_all,
+                                                    size_t scratch_per_frame, int32_t *__restrict__ persons,
+                                                    int32_t *__restrict__ n_persons) {
     const int f = blockIdx.x;
     if (f >= n_frames) return;
     const int V = cfg->V;
@@ -152,140 +350,56 @@ __global__ __launch_bounds__(64) void k_cluster(const DevCfg *__restrict__ cfg, 
     const int e0 = en_off[f], M = en_off[f + 1] - e0;
     int32_t *out = persons + (size_t)f * pcap * V;
     for (int i = threadIdx.x; i < pcap * V; i += blockDim.x) out[i] = -1;
-    if (threadIdx.x != 0) return;
     if (M <= 0 || H > hmax || (size_t)M > keys_per_frame) {
-        n_persons[f] = 0;
+        if (threadIdx.x == 0) n_persons[f] = 0;
         return;
     }
     uint64_t *keys = keys_all + (size_t)f * keys_per_frame;
-    int32_t *sc = scratch_all + (size_t)f * scratch_per_frame;
-    int32_t *seen = sc;
-    int32_t *order = seen + hmax;
-    int32_t *linked = order + hmax;
-    int32_t *human = linked + hmax;
-    int32_t *cfh = human + hmax;
-    int32_t *ea = cfh + hmax;
-    int32_t *eb = ea + hmax;
-    int32_t *done = eb + hmax;
-    int32_t *lvl = done + hmax;
-    int32_t *nxt = lvl + hmax;
-    int32_t *tabA = nxt + hmax;
-    int32_t *tabB = tabA + table_cap;
-    int32_t *ab = tabB + table_cap;
-    const int32_t *cam = head_cam + h0;
     const float thr = cfg->threshold;
-
-    for (int h = 0; h < H; ++h) {
-        seen[h] = 0;
-        human[h] = -1;
-        done[h] = 0;
-        linked[h] = (int32_t)(1u << cam[h]);
-    }
-    int n_nodes = 0, nm = 0;
-    for (int m = 0; m < M; ++m) {
-        const int h1 = en_pair[2 * (size_t)(e0 + m) + 0], h2 = en_pair[2 * (size_t)(e0 + m) + 1];
-        if (!seen[h1]) { seen[h1] = 1; order[n_nodes++] = h1; }
-        if (!seen[h2]) { seen[h2] = 1; order[n_nodes++] = h2; }
-        const float s = scores[e0 + m];
-        if (s > thr) {
-            const bool first1 = pair_first_is_h1(h1, h2);
-            const int a = first1 ? h1 : h2, b = first1 ? h2 : h1;
-            ab[nm] = (a << 16) | b;
-            keys[nm] = ((uint64_t)(0xFFFFFFFFu - __float_as_uint(s)) << 32) | (uint32_t)nm;
-            ++nm;
-        }
-    }
-    // heapsort ascending on (inverted score bits, creation index)
-    for (int start = nm / 2 - 1; start >= 0; --start) sift_down(keys, start, nm - 1);
-    for (int end = nm - 1; end > 0; --end) {
+    for (int m = threadIdx.x; m < M; m += blockDim.x) keys[m] = make_key(scores[e0 + m], thr, m);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    // heapsort ascending
+    for (int start = M / 2 - 1; start >= 0; --start) sift_down(keys, start, M - 1);
+    for (int end = M - 1; end > 0; --end) {
         const uint64_t t = keys[0];
         keys[0] = keys[end];
         keys[end] = t;
         sift_down(keys, 0, end - 1);
     }
-    int cur = 0, ne = 0;
-    for (int k = 0; k < nm; ++k) {
-        const int idx = (int)(keys[k] & 0xFFFFFFFFu);
-        const int a = ab[idx] >> 16, b = ab[idx] & 0xFFFF;
-        const uint32_t ba = 1u << cam[a], bb = 1u << cam[b];
-        if (((uint32_t)linked[b] & ba) || ((uint32_t)linked[a] & bb)) continue;
-        const int ha = human[a], hb = human[b];
-        if (ha >= 0 && ((uint32_t)cfh[ha] & bb)) continue;
-        if (hb >= 0 && ((uint32_t)cfh[hb] & ba)) continue;
-        if (ha < 0 && hb < 0) {
-            human[a] = cur;
-            human[b] = cur;
-            cfh[cur] = (int32_t)(ba | bb);
-            ++cur;
-        } else if (ha >= 0 && hb < 0) {
-            human[b] = ha;
-            cfh[ha] = (int32_t)((uint32_t)cfh[ha] | bb);
-        } else if (hb >= 0 && ha < 0) {
-            human[a] = hb;
-            cfh[hb] = (int32_t)((uint32_t)cfh[hb] | ba);
-        } else {
-            if ((uint32_t)cfh[hb] & (uint32_t)cfh[ha]) continue;
-            for (int n = 0; n < H; ++n)
-                if (human[n] == hb) human[n] = ha;
-            // the absorbed group's camera list is dropped, not merged (reference :97-102)
-        }
-        ea[ne] = a;
-        eb[ne] = b;
-        ++ne;
-        linked[a] = (int32_t)((uint32_t)linked[a] | bb);
-        linked[b] = (int32_t)((uint32_t)linked[b] | ba);
-    }
-    // connected components in node-insertion order
-    int np = 0;
-    const int min_views = cfg->min_views;
-    for (int oi = 0; oi < n_nodes; ++oi) {
-        const int v = order[oi];
-        if (done[v]) continue;
-        PySet set{tabA, tabB, 7, 0};
-        pyset_init(set);
-        pyset_add(set, v);
-        int nl = 1;
-        lvl[0] = v;
-        bool full = set.fill == n_nodes;
-        int32_t *L = lvl, *N = nxt;
-        while (nl > 0 && !full) {
-            int nn = 0;
-            for (int li = 0; li < nl; ++li) {
-                const int x = L[li];
-                for (int e = 0; e < ne; ++e) {
-                    int w = -1;
-                    if (ea[e] == x) w = eb[e];
-                    else if (eb[e] == x) w = ea[e];
-                    if (w >= 0 && !pyset_contains(set, w)) {
-                        pyset_add(set, w);
-                        N[nn++] = w;
-                    }
-                }
-                if (set.fill == n_nodes) { full = true; break; }
-            }
-            int32_t *t = L; L = N; N = t;
-            nl = nn;
-        }
-        const int cnt = set.fill;
-        int32_t *pout = (cnt >= min_views && np < pcap) ? out + (size_t)np * V : nullptr;
-        for (int i = 0; i <= set.mask; ++i) {
-            const int h = set.tab[i];
-            if (h < 0) continue;
-            done[h] = 1;
-            if (pout) pout[cam[h]] = h;
-        }
-        if (pout) ++np;
-    }
-    n_persons[f] = np;
+    Work w = carve(scratch_all + (size_t)f * scratch_per_frame, hmax, table_cap);
+    const int32_t *prs = en_pair + 2 * (size_t)e0;
+    auto pair_of = [&](int m, int &h1, int &h2) {
+        h1 = prs[2 * m];
+        h2 = prs[2 * m + 1];
+    };
+    n_persons[f] = greedy_and_components(w, keys, M, pair_of, H, M, head_cam + h0, V, cfg->min_views, pcap, out);
 }
 
 hipError_t launch_cluster(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, const int32_t *en_pair,
                           const float *scores, int pcap, int hmax, uint64_t *keys, size_t keys_per_frame,
                           int32_t *scratch, size_t scratch_per_frame, int32_t *persons, int32_t *n_persons) {
     if (b.n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_cluster, dim3(b.n_frames), dim3(64), 0, s, cfg, b.n_frames, b.d_frame_head_off,
-                       b.d_frame_en_off, b.d_head_cam, en_pair, scores, pcap, hmax, cluster_table_cap(hmax), keys,
-                       keys_per_frame, scratch, scratch_per_frame, persons, n_persons);
+    const int table_cap = cluster_table_cap(hmax);
+    size_t m_cap = keys_per_frame;
+    int n_pow2 = 64;
+    while ((size_t)n_pow2 < m_cap) n_pow2 <<= 1;
+    const size_t shm = (size_t)n_pow2 * (sizeof(uint64_t) + sizeof(uint32_t)) +
+                       ((size_t)10 * hmax + 2 * (size_t)table_cap + hmax) * sizeof(int32_t);
+    if (shm <= 96 * 1024) {
+        if (shm > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cluster_lds),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_cluster_lds, dim3(b.n_frames), dim3(64), shm, s, cfg, b.n_frames, b.d_frame_head_off,
+                           b.d_frame_en_off, b.d_head_cam, en_pair, scores, pcap, hmax, table_cap, n_pow2, persons,
+                           n_persons);
+    } else {
+        hipLaunchKernelGGL(k_cluster_big, dim3(b.n_frames), dim3(64), 0, s, cfg, b.n_frames, b.d_frame_head_off,
+                           b.d_frame_en_off, b.d_head_cam, en_pair, scores, pcap, hmax, table_cap, keys,
+                           keys_per_frame, scratch, scratch_per_frame, persons, n_persons);
+    }
     return hipGetLastError();
 }
 

@@ -17,12 +17,12 @@
 namespace mpe {
 
 // ---------------------------------------------------------------------------------------
-// topology tables: node_off[f], row_frame[row], en_pair[m] = (h1,h2) frame-local
+// topology tables: node_off[f], head_frame[h], en_frame[m], en_pair[m] = (h1,h2) frame-local
 // ---------------------------------------------------------------------------------------
 __global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head_off,
                            const int32_t *__restrict__ en_off, const int32_t *__restrict__ slot_n,
-                           int32_t *__restrict__ node_off, int32_t *__restrict__ row_frame,
-                           int32_t *__restrict__ en_pair) {
+                           int32_t *__restrict__ node_off, int32_t *__restrict__ head_frame,
+                           int32_t *__restrict__ en_frame, int32_t *__restrict__ en_pair) {
     const int f = blockIdx.x;
     __shared__ int s_n[MPE_MAX_CAMERAS], s_start[MPE_MAX_CAMERAS];
     const int h0 = head_off[f], H = head_off[f + 1] - h0;
@@ -38,8 +38,8 @@ __global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head
         if (f == n_frames - 1) node_off[n_frames] = head_off[n_frames] + en_off[n_frames];
     }
     __syncthreads();
-    const int r0 = h0 + e0;
-    for (int i = threadIdx.x; i < H + M; i += blockDim.x) row_frame[r0 + i] = f;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) head_frame[h0 + i] = f;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) en_frame[e0 + i] = f;
     int base = 0;
     for (int a = 0; a < V; ++a)
         for (int b = a + 1; b < V; ++b) {
@@ -53,11 +53,11 @@ __global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head
         }
 }
 
-hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *row_frame,
-                           int32_t *en_pair) {
+hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
+                           int32_t *en_frame, int32_t *en_pair) {
     if (b.n_frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_topology, dim3(b.n_frames), dim3(128), 0, s, b.n_frames, V, b.d_frame_head_off,
-                       b.d_frame_en_off, b.d_slot_n, node_off, row_frame, en_pair);
+                       b.d_frame_en_off, b.d_slot_n, node_off, head_frame, en_frame, en_pair);
     return hipGetLastError();
 }
 
@@ -181,86 +181,150 @@ hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows,
 // ---------------------------------------------------------------------------------------
 // edge attention + softmax over in-edges + weighted sum + activation
 // (gat2.py:61-66,78-88 and the activation of GAT2.forward :141-147)
+//
+// Two kernels: edge-node destinations (89 % of the rows at 5x4) have exactly three in-edges
+// (h1, h2, self), so every lane recomputes its head's 3-way softmax in registers and streams
+// its columns -- no LDS, no barrier.  Head destinations (in-degree 1 + heads of the other
+// cameras) use the general LDS path.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float agg_activate(float x, int mode, float slope) {
+    if (mode == 0) return x > 0.f ? x : x * slope;
+    if (mode == 1) return 1.f / (1.f + expf(-x));
+    return x;
+}
+
+constexpr int EN_ROWS = 16;     // edge-node rows per workgroup
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *__restrict__ head_off,
+                                                      const int32_t *__restrict__ en_off,
+                                                      const int32_t *__restrict__ node_off,
+                                                      const int32_t *__restrict__ en_frame,
+                                                      const int32_t *__restrict__ en_pair, AggArgs a) {
+#pragma clang fp contract(off)
+    typedef float vecf __attribute__((ext_vector_type(VEC)));
+    const int hd = a.heads * a.out_dim;
+    const int per_row = hd / VEC;
+    const int m0 = blockIdx.x * EN_ROWS;
+    const int rows = min(EN_ROWS, n_en - m0);
+    const bool l0 = a.en_const_ft2 != nullptr;
+    for (int i = threadIdx.x; i < rows * per_row; i += blockDim.x) {
+        const int r = i / per_row;
+        const int c = (i - r * per_row) * VEC;
+        const int m = m0 + r;
+        const int f = en_frame[m];
+        const int hb = head_off[f], H = head_off[f + 1] - hb;
+        const int nb = node_off[f];
+        const int v = H + (m - en_off[f]);
+        const int h1 = en_pair[2 * (size_t)m], h2 = en_pair[2 * (size_t)m + 1];
+        const int hh = c / a.out_dim;
+        const float *ra1, *ra2, *ra3;     // a1|a2 rows of h1, h2, self
+        const float *f1, *f2, *f3;        // feature rows
+        if (l0) {
+            ra1 = a.a12 + (size_t)(hb + h1) * 32;
+            ra2 = a.a12 + (size_t)(hb + h2) * 32;
+            ra3 = a.en_const_a;
+            f1 = a.ft2 + (size_t)(hb + h1) * a.ld;
+            f2 = a.ft2 + (size_t)(hb + h2) * a.ld;
+            f3 = a.en_const_ft2;
+        } else {
+            ra1 = a.a12 + (size_t)(nb + h1) * 32;
+            ra2 = a.a12 + (size_t)(nb + h2) * 32;
+            ra3 = a.a12 + (size_t)(nb + v) * 32;
+            f1 = a.ft2 + (size_t)(nb + h1) * a.ld;
+            f2 = a.ft2 + (size_t)(nb + h2) * a.ld;
+            f3 = a.ft2 + (size_t)(nb + v) * a.ld;
+        }
+        const vecf v1 = *reinterpret_cast<const vecf *>(f1 + c);
+        const vecf v2 = *reinterpret_cast<const vecf *>(f2 + c);
+        const vecf v3 = *reinterpret_cast<const vecf *>(f3 + c);
+        const float a2v = ra3[16 + hh];
+        float e1 = ra1[hh] + a2v, e2 = ra2[hh] + a2v, e3 = ra3[hh] + a2v;
+        e1 = e1 > 0.f ? e1 : e1 * a.alpha;
+        e2 = e2 > 0.f ? e2 : e2 * a.alpha;
+        e3 = e3 > 0.f ? e3 : e3 * a.alpha;
+        const float mx = fmaxf(fmaxf(e1, e2), e3);
+        const float x1 = expf(e1 - mx), x2 = expf(e2 - mx), x3 = expf(e3 - mx);
+        const float sum = (x1 + x2) + x3;
+        const float w1 = x1 / sum, w2 = x2 / sum, w3 = x3 / sum;
+        vecf o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float acc = v1[k] * w1;
+            acc = acc + v2[k] * w2;
+            acc = acc + v3[k] * w3;
+            o[k] = agg_activate(acc, a.out_mode, a.out_slope);
+        }
+        if (a.score_mode) a.out[m] = o[0];
+        else *reinterpret_cast<vecf *>(a.out + (size_t)(nb + v) * a.ld_out + c) = o;
+    }
+}
+
 constexpr int AGG_ROWS = 4;
 
-__global__ __launch_bounds__(256) void k_aggregate(
-    int n_nodes, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
-    const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off, const int32_t *__restrict__ row_frame,
-    const int32_t *__restrict__ en_pair, AggArgs a) {
+__global__ __launch_bounds__(256) void k_aggregate_heads(
+    int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
+    const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off,
+    const int32_t *__restrict__ head_frame, AggArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ float s_dyn[];
     // layout: alpha [AGG_ROWS][max_deg][heads] | src [AGG_ROWS][max_deg] (int)
     float *s_alpha = s_dyn;
     int *s_src = reinterpret_cast<int *>(s_dyn + (size_t)AGG_ROWS * max_deg * a.heads);
-    __shared__ int s_deg[AGG_ROWS], s_f[AGG_ROWS], s_v[AGG_ROWS], s_H[AGG_ROWS], s_skip[AGG_ROWS];
+    __shared__ int s_deg[AGG_ROWS], s_f[AGG_ROWS], s_v[AGG_ROWS], s_H[AGG_ROWS];
 
     const int row0 = blockIdx.x * AGG_ROWS;
     const int t = threadIdx.x;
     const int heads = a.heads, hd = a.heads * a.out_dim;
 
-    // phase A: in-edge lists (frame-local node ids; >= H means edge-node)
+    // phase A: in-edge list of head v: (v,v), then the adjacent edge-nodes in ascending id
     if (t < AGG_ROWS) {
-        const int row = row0 + t;
-        int deg = 0, skip = 1;
-        if (row < n_nodes) {
-            const int f = row_frame[row];
-            const int v = row - node_off[f];
+        const int gh = row0 + t;
+        int deg = 0;
+        if (gh < n_heads) {
+            const int f = head_frame[gh];
+            const int v = gh - head_off[f];
             const int H = head_off[f + 1] - head_off[f];
             s_f[t] = f;
             s_v[t] = v;
             s_H[t] = H;
             int *src = s_src + t * max_deg;
-            if (v >= H) {
-                const size_t m = (size_t)en_off[f] + (v - H);
-                src[0] = en_pair[2 * m + 0];
-                src[1] = en_pair[2 * m + 1];
-                src[2] = v;
-                deg = 3;
-                skip = 0;
-            } else if (!a.score_mode || a.out_heads) {
-                skip = 0;
-                const int32_t *sn = slot_n + (size_t)f * V;
-                int s = 0, start = 0;
-                while (s < V && v >= start + sn[s]) { start += sn[s]; ++s; }
-                const int i = v - start, ns = sn[s];
-                src[deg++] = v;                      // self loop (edge id h)
-                int base = H;
-                for (int p = 0; p < V; ++p)
-                    for (int q = p + 1; q < V; ++q) {
-                        const int np_ = sn[p], nq = sn[q];
-                        if (q == s) {
-                            for (int k = 0; k < np_; ++k) src[deg++] = base + k * ns + i;
-                        } else if (p == s) {
-                            for (int k = 0; k < nq; ++k) src[deg++] = base + i * nq + k;
-                        }
-                        base += np_ * nq;
+            const int32_t *sn = slot_n + (size_t)f * V;
+            int s = 0, start = 0;
+            while (s < V && v >= start + sn[s]) { start += sn[s]; ++s; }
+            const int i = v - start, ns = sn[s];
+            src[deg++] = v;
+            int base = H;
+            for (int p = 0; p < V; ++p)
+                for (int q = p + 1; q < V; ++q) {
+                    const int np_ = sn[p], nq = sn[q];
+                    if (q == s) {
+                        for (int k = 0; k < np_; ++k) src[deg++] = base + k * ns + i;
+                    } else if (p == s) {
+                        for (int k = 0; k < nq; ++k) src[deg++] = base + i * nq + k;
                     }
-            }
+                    base += np_ * nq;
+                }
         }
         s_deg[t] = deg;
-        s_skip[t] = skip;
     }
     __syncthreads();
 
     // phase B: logits e = LeakyReLU_alpha(a1[src] + a2[dst])
     for (int r = 0; r < AGG_ROWS; ++r) {
-        if (s_skip[r]) continue;
-        const int deg = s_deg[r], f = s_f[r], v = s_v[r], H = s_H[r];
+        const int deg = s_deg[r];
+        if (deg == 0) continue;
+        const int f = s_f[r], v = s_v[r], H = s_H[r];
         const int32_t nb = node_off[f], hb = head_off[f];
         const bool l0 = a.en_const_ft2 != nullptr;
-        const float *a_dst;
-        if (l0) a_dst = v >= H ? a.en_const_a : a.a12 + (size_t)(hb + v) * 32;
-        else a_dst = a.a12 + (size_t)(nb + v) * 32;
+        const float *a_dst = l0 ? a.a12 + (size_t)(hb + v) * 32 : a.a12 + (size_t)(nb + v) * 32;
         for (int i = t; i < deg * heads; i += blockDim.x) {
             const int e = i / heads, hh = i - e * heads;
             const int u = s_src[r * max_deg + e];
             const float *a_src;
             if (l0) a_src = u >= H ? a.en_const_a : a.a12 + (size_t)(hb + u) * 32;
             else a_src = a.a12 + (size_t)(nb + u) * 32;
-            const float a2v = a_dst[16 + hh];
-            const float a1v = a_src[hh];
-            float x = a1v + a2v;
+            float x = a_src[hh] + a_dst[16 + hh];
             x = x > 0.f ? x : x * a.alpha;
             s_alpha[((size_t)r * max_deg + e) * heads + hh] = x;
         }
@@ -270,8 +334,8 @@ __global__ __launch_bounds__(256) void k_aggregate(
     // phase C: softmax over the in-edges of each (row, head): max, exp, sum in edge order, div
     for (int i = t; i < AGG_ROWS * heads; i += blockDim.x) {
         const int r = i / heads, hh = i - r * heads;
-        if (s_skip[r]) continue;
         const int deg = s_deg[r];
+        if (deg == 0) continue;
         float *al = s_alpha + (size_t)r * max_deg * heads + hh;
         float mx = -INFINITY;
         for (int e = 0; e < deg; ++e) mx = fmaxf(mx, al[e * heads]);
@@ -288,8 +352,9 @@ __global__ __launch_bounds__(256) void k_aggregate(
     // phase D: out[v][c] = sum_e round(alpha[e][h(c)] * ft2[src_e][c]), then activation
     for (int i = t; i < AGG_ROWS * hd; i += blockDim.x) {
         const int r = i / hd, c = i - r * hd;
-        if (s_skip[r]) continue;
-        const int deg = s_deg[r], f = s_f[r], v = s_v[r], H = s_H[r];
+        const int deg = s_deg[r];
+        if (deg == 0) continue;
+        const int f = s_f[r], v = s_v[r], H = s_H[r];
         const int hh = c / a.out_dim;
         const int32_t nb = node_off[f], hb = head_off[f];
         const bool l0 = a.en_const_ft2 != nullptr;
@@ -302,29 +367,41 @@ __global__ __launch_bounds__(256) void k_aggregate(
             const float m = fv * s_alpha[((size_t)r * max_deg + e) * heads + hh];
             acc = acc + m;
         }
-        float o;
-        if (a.out_mode == 0) o = acc > 0.f ? acc : acc * a.out_slope;
-        else if (a.out_mode == 1) o = 1.f / (1.f + expf(-acc));
-        else o = acc;
-        if (a.score_mode) {
-            if (v >= H) a.out[(size_t)en_off[f] + (v - H)] = o;
-            else if (a.out_heads) a.out_heads[(size_t)hb + v] = o;
-        } else {
-            a.out[(size_t)(nb + v) * a.ld_out + c] = o;
-        }
+        const float o = agg_activate(acc, a.out_mode, a.out_slope);
+        if (a.score_mode) a.out_heads[(size_t)hb + v] = o;
+        else a.out[(size_t)(nb + v) * a.ld_out + c] = o;
     }
 }
 
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
-                                const int32_t *node_off, const int32_t *row_frame, const int32_t *en_pair,
-                                const AggArgs &a, int n_nodes) {
-    if (n_nodes <= 0) return hipSuccess;
-    int max_deg = max_heads_per_frame + 1;
-    if (max_deg < 3) max_deg = 3;
-    const size_t shm = (size_t)AGG_ROWS * max_deg * (a.heads * sizeof(float) + sizeof(int));
-    const int grid = (n_nodes + AGG_ROWS - 1) / AGG_ROWS;
-    hipLaunchKernelGGL(k_aggregate, dim3(grid), dim3(256), shm, s, n_nodes, V, max_deg, b.d_frame_head_off,
-                       b.d_frame_en_off, b.d_slot_n, node_off, row_frame, en_pair, a);
+                            const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
+                            const int32_t *en_pair, const AggArgs &a) {
+    const int hd = a.heads * a.out_dim;
+    if (b.n_edge_nodes > 0) {
+        int vec = 1;
+        if (!a.score_mode && a.ld % 4 == 0 && a.ld_out % 4 == 0) {
+            if (a.out_dim % 4 == 0) vec = 4;
+            else if (a.out_dim % 2 == 0) vec = 2;
+        }
+        const unsigned blocks = (unsigned)((b.n_edge_nodes + EN_ROWS - 1) / EN_ROWS);
+#define MPE_EN(V_)                                                                                      \
+    hipLaunchKernelGGL(k_aggregate_en<V_>, dim3(blocks), dim3(256), 0, s, b.n_edge_nodes, b.d_frame_head_off, \
+                       b.d_frame_en_off, node_off, en_frame, en_pair, a)
+        if (vec == 4) MPE_EN(4);
+        else if (vec == 2) MPE_EN(2);
+        else MPE_EN(1);
+#undef MPE_EN
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (b.n_heads > 0 && (!a.score_mode || a.out_heads)) {
+        int max_deg = max_heads_per_frame + 1;
+        if (max_deg < 3) max_deg = 3;
+        const size_t shm = (size_t)AGG_ROWS * max_deg * (a.heads * sizeof(float) + sizeof(int));
+        const int grid = (b.n_heads + AGG_ROWS - 1) / AGG_ROWS;
+        hipLaunchKernelGGL(k_aggregate_heads, dim3(grid), dim3(256), shm, s, b.n_heads, V, max_deg,
+                           b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a);
+    }
     return hipGetLastError();
 }
 

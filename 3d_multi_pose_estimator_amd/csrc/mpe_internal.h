@@ -77,7 +77,8 @@ struct mpe_ctx {
     float *hdense = nullptr;
     float *act[3] = {nullptr, nullptr, nullptr};   // [max_nodes][act_ld]
     float *a12 = nullptr;          // [max_nodes][2*16]
-    int32_t *row_frame = nullptr;  // [max_nodes]
+    int32_t *head_frame = nullptr; // [max_heads]
+    int32_t *en_frame = nullptr;   // [max_edge_nodes]
     int32_t *en_pair = nullptr;    // [max_edge_nodes][2] frame-local head ids
     int32_t *node_off = nullptr;   // [max_frames+1]
     uint64_t *cl_keys = nullptr;   // clustering scratch
@@ -107,8 +108,8 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
                          float slope, bool acc64);
 
 // gat.hip
-hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *row_frame,
-                           int32_t *en_pair);
+hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
+                           int32_t *en_frame, int32_t *en_pair);
 hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
                                 int ld_feat, int col0, int stride_cam, bool dense);
 hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,
@@ -128,8 +129,8 @@ struct AggArgs {
     float *out_heads;
 };
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
-                            const int32_t *node_off, const int32_t *row_frame, const int32_t *en_pair,
-                            const AggArgs &a, int n_nodes);
+                            const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
+                            const int32_t *en_pair, const AggArgs &a);
 
 // cluster.hip
 size_t cluster_keys_per_frame(int max_heads_per_frame);
