@@ -153,7 +153,7 @@ def main():
         out['roofline'] = {
             'kernel': 'mpe::k_linear (fp32 MFMA 16x16x4 GEMM + bias + LeakyReLU)', 'bound': 'mfma',
             'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+            'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(),
             'launches': prof['gemm_launches'], 'avg_launch_ms': prof['gemm_ms'] / max(1, prof['gemm_launches']),
             'flop_per_step': prof['gemm_flop'] / args.steps,
             'gemm_share_of_step': gemm_s / elapsed,
@@ -165,6 +165,19 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def pmc_traffic():
+    """Fabric bytes per k_linear launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+    2x FETCH correction); None when the file is absent.  PMC cannot be sampled from inside
+    the process, so this is the offline measurement, not a live one."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as fh:
+            return json.load(fh)['k_linear_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(args, frames, calib, gat_sd, prm, mlp_sd):
