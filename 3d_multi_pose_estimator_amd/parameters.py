@@ -79,7 +79,24 @@ def _arplab():
     )
 
 
-PRESETS = {'PANOPTIC': _panoptic, 'ARPLAB': _arplab}
+def ring_variant(n_cameras=23):
+    """Stress preset of BASELINE.json config 5: `n_cameras` cameras on a ring, intrinsics and
+    lens coefficients cycled from the five Panoptic cameras (not a reference preset; the
+    extrinsics come from synthetic.ring_transform_manager)."""
+    base = _panoptic()
+    names = ['ring%02d' % i for i in range(n_cameras)]
+
+    def cyc(v):
+        return [v[i % len(v)] for i in range(n_cameras)]
+    return base._replace(
+        cameras=list(range(n_cameras)), camera_names=list(names),
+        fx=cyc(base.fx), fy=cyc(base.fy), cx=cyc(base.cx), cy=cyc(base.cy),
+        kd0=cyc(base.kd0), kd1=cyc(base.kd1), kd2=cyc(base.kd2), p1=cyc(base.p1), p2=cyc(base.p2),
+        transformations_path='../tm_ring%d.pickle' % n_cameras,
+        used_cameras=list(names), used_cameras_skeleton_matching=list(names))
+
+
+PRESETS = {'PANOPTIC': _panoptic, 'ARPLAB': _arplab, 'RING23': lambda: ring_variant(23)}
 
 CONFIGURATION = 'PANOPTIC'            # values = {PANOPTIC, ARPLAB} (reference parameters.py:47)
 

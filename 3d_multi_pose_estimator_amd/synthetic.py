@@ -153,6 +153,30 @@ def project_panoptic(X, K, T_d, dist):
     return np.stack([u, v]), z
 
 
+def ring_transform_manager(params, radius=3.6):
+    """root->camera transforms for cameras on a ring around the capture volume, all looking
+    at the centre, heights alternating (world: y down, as in the Panoptic calibration)."""
+    from .calibration import TransformManager
+    tm = TransformManager()
+    n = len(params.camera_names)
+    for i, name in enumerate(params.camera_names):
+        ang = 2.0 * np.pi * i / n
+        height = -(1.6 + 0.9 * ((i * 7) % 5) / 4.0)
+        C = np.array([radius * np.cos(ang), height, radius * np.sin(ang)])
+        target = np.array([0.0, -1.0, 0.0])
+        z = target - C
+        z /= np.linalg.norm(z)
+        x = np.cross(np.array([0.0, 1.0, 0.0]), z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])              # world -> camera rotation
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = -R @ C
+        tm.add_transform('root', name, T)
+    return tm
+
+
 class FrameSpec:
     """Knobs of the generator; defaults = clean Panoptic-shaped frame."""
 

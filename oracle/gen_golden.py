@@ -27,31 +27,82 @@ GAT_SEED = 7
 MLP_SEED = 11
 LOGIT_GAIN = 25.0
 LOGIT_SHIFT = 0.698
+VARIANT_SHIFT = {'arplab': 0.698 + 0.2952, 'ring23': 0.698 - 0.1833}   # centre each variant's logits
 
 
 def quiet():
     return contextlib.redirect_stdout(io.StringIO())
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
-    ref = refenv.load()
+def write_variant_parameters(params, tm, workdir):
+    """A `parameters.py` with the reference's schema holding the variant's values (what a
+    user obtains by editing CONFIGURATION / the preset in the reference's own file), plus
+    the pickled TransformManager it points to."""
+    import pickle
+    sys.path.insert(0, os.path.join(ROOT, 'oracle', 'shims'))
+    from pytransform3d.transform_manager import TransformManager
+    os.makedirs(workdir, exist_ok=True)
+    tm_path = os.path.join(workdir, 'tm_variant.pickle')
+    t = TransformManager()
+    for k, v in tm.transforms.items():
+        t.add_transform(k[0], k[1], v)
+    with open(tm_path, 'wb') as fh:
+        pickle.dump(t, fh)
+    fields = params._replace(transformations_path=tm_path)._asdict()
+    with open(os.path.join(workdir, 'parameters.py'), 'w') as fh:
+        fh.write('from collections import namedtuple\n')
+        fh.write('TrackerParameters = namedtuple("TrackerParameters", %r)\n' % (list(fields.keys()),))
+        fh.write('parameters = TrackerParameters(**%r)\n' % (dict(fields),))
+    return fields['transformations_path']
+
+
+def check_arplab_against_reference(par):
+    """Our ARPLAB preset against the reference's file with its CONFIGURATION switch flipped
+    (evaluated in memory; the file itself is never modified or copied)."""
+    src = open(os.path.join(refenv.REF, 'parameters.py')).read()
+    ns = {}
+    exec(compile(src.replace("CONFIGURATION = 'PANOPTIC'", "CONFIGURATION = 'ARPLAB'"), 'parameters_arplab', 'exec'), ns)
+    theirs, ours = ns['parameters'], par.select('ARPLAB')
+    for f in theirs._fields:
+        assert getattr(theirs, f) == getattr(ours, f), f
+
+
+def main(variant='panoptic'):
+    global OUT
     import torch
     pkg = '3d_multi_pose_estimator_amd'
     syn = importlib.import_module(pkg + '.synthetic')
     cal = importlib.import_module(pkg + '.calibration')
     par = importlib.import_module(pkg + '.parameters')
+    if variant == 'panoptic':
+        our_params = par.parameters
+        ref = refenv.load()
+        calib = cal.Calibration(our_params)
+    else:
+        OUT = os.path.join(OUT, variant)
+        if variant == 'arplab':
+            check_arplab_against_reference(par)
+            our_params = par.select('ARPLAB')
+            tm = cal.load_transform_manager(os.path.join(refenv.REF, 'tm_arp.pickle'))
+        else:
+            our_params = par.select('RING23')
+            tm = syn.ring_transform_manager(our_params)
+        workdir = '/tmp/mpe_variant_' + variant
+        tm_path = write_variant_parameters(our_params, tm, workdir)
+        ref = refenv.load(parameters_dir=workdir)
+        our_params = our_params._replace(transformations_path=tm_path)
+        calib = cal.Calibration(our_params, tm)
+    os.makedirs(OUT, exist_ok=True)
     rparams = ref['parameters'].parameters
-    # our schema must agree with the reference's module field by field
+    # our schema must agree with the module the reference imported, field by field
     for f in rparams._fields:
-        assert getattr(rparams, f) == getattr(par.parameters, f), f
-    calib = cal.Calibration(par.parameters)
+        assert getattr(rparams, f) == getattr(our_params, f), f
     gg = ref['graph_generator']
     nf = len(gg.HumanGraphFromView.get_all_features('3'))
 
     # calibration globals of the reference (a2)
     np.savez_compressed(
-        os.path.join(OUT, 'calibration_panoptic.npz'),
+        os.path.join(OUT, 'calibration_%s.npz' % variant),
         T_d=np.stack([t.numpy() for t in gg.camera_d_transforms]),
         T_i32=np.stack([t.numpy() for t in gg.camera_i_transforms]),
         K32=np.stack([t.cpu().numpy() for t in gg.camera_matrices]),
@@ -62,7 +113,8 @@ def main():
         features=np.array(gg.HumanGraphFromView.get_all_features('3')),
     )
 
-    gat_sd = syn.gat_state_dict(GAT_SEED, nf, logit_gain=LOGIT_GAIN, logit_shift=LOGIT_SHIFT)
+    shift = VARIANT_SHIFT.get(variant, LOGIT_SHIFT)
+    gat_sd = syn.gat_state_dict(GAT_SEED, nf, logit_gain=LOGIT_GAIN, logit_shift=shift)
     model = ref['gat2'].GAT2(None, syn.GAT_LAYERS, nf, 1, syn.GAT_HIDDEN, syn.GAT_HEADS, torch.nn.LeakyReLU(),
                              torch.nn.Sigmoid(), 0., 0., syn.GAT_ALPHA, False, bias=True)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in gat_sd.items()})
@@ -73,7 +125,15 @@ def main():
     mlp.load_state_dict({k: torch.from_numpy(v) for k, v in mlp_sd.items()})
 
     F = syn.FrameSpec
-    cases = [
+    names = list(rparams.camera_names)
+    if variant == 'arplab':
+        cases = [('arp_6x3', F(persons=3, add_id_key=True, noise_px=1.0, float_conf=False), [0, 1]),
+                 ('arp_robot_pair', F(persons=2, cameras=['orinbot_r', 'orinbot_l']), [2])]
+    elif variant == 'ring23':
+        cases = [('ring23x3', F(persons=3, noise_px=0.5), [0]),
+                 ('ring23_sparse', F(persons=2, cameras=names[3::4], joint_drop=0.1), [1])]
+    else:
+      cases = [
         ('c1_2view_1person', F(persons=1, cameras=['trackera', 'trackerb']), [0, 1]),
         ('c2_5x4_clean', F(persons=4), [0, 1, 2]),
         ('c2_5x4_messy', F(persons=4, noise_px=2.0, joint_drop=0.3, add_id_key=True, spurious=1,
@@ -82,9 +142,9 @@ def main():
                                joint_drop=0.15), [5]),
         ('c2_3x2', F(persons=2, cameras=['trackerb', 'trackerd', 'trackere']), [6]),
         ('c4_5x10', F(persons=10, noise_px=1.0), [7]),
-    ]
-    meta = {'gat_seed': GAT_SEED, 'mlp_seed': MLP_SEED, 'logit_gain': LOGIT_GAIN, 'logit_shift': LOGIT_SHIFT,
-            'num_feats': nf, 'mlp_in': in_dim, 'cases': {}}
+      ]
+    meta = {'gat_seed': GAT_SEED, 'mlp_seed': MLP_SEED, 'logit_gain': LOGIT_GAIN, 'logit_shift': shift,
+            'num_feats': nf, 'mlp_in': in_dim, 'variant': variant, 'cases': {}}
     for name, spec, idxs in cases:
         frames_json = []
         arrays = {}
@@ -133,6 +193,7 @@ def main():
                 arrays[p + 'act%d_en' % l] = a[int(idx[0]):int(idx[0]) + 4]  # first edge-nodes
             persons = np.array([[(-1 if fo[c] is None else fo[c]) for c in rparams.used_cameras_skeleton_matching]
                                 for fo in final_output], np.int32).reshape(-1, len(rparams.used_cameras_skeleton_matching))
+            print(name, n, 'scores>0.5: %d of %d, persons %d' % (int((outputs[idx] > 0.5).sum()), len(idx), len(persons)))
             arrays[p + 'persons'] = persons
             # ---- 3D stage A (metrics_from_model.py:243-294)
             rows = []
@@ -156,6 +217,7 @@ def main():
             pe = ref['pose_estimator_dataset_from_json']
             tri = np.zeros((len(final_output), len(rparams.joint_list), 3))
             tri_valid = np.zeros((len(final_output), len(rparams.joint_list)), np.int8)
+            tri_all = np.zeros((len(final_output), len(rparams.joint_list), 3))
             cam_matrix = {c: ref['pose_estimator_utils'].camera_matrix(i).cpu().numpy() for i, c in enumerate(rparams.camera_names)}
             for pi_, person in enumerate(final_output):
                 points_2D = {}
@@ -171,10 +233,12 @@ def main():
                 for j in rparams.joint_list:
                     if str(j) in r3:
                         tri_valid[pi_, j] = 1
+                        tri_all[pi_, j] = [r3[str(j)][0][0], r3[str(j)][1][0], r3[str(j)][2][0]]
                         if j in rparams.used_joints:
                             tri[pi_, j] = [r3[str(j)][0][0], r3[str(j)][1][0], r3[str(j)][2][0]]
             arrays[p + 'tri'] = tri
             arrays[p + 'tri_valid'] = tri_valid
+            arrays[p + 'tri_all'] = tri_all
             arrays[p + 'gt'] = gt['persons']
         np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
         with open(os.path.join(OUT, name + '.frames.json'), 'w') as fh:
@@ -182,7 +246,8 @@ def main():
         meta['cases'][name] = {'frames': len(idxs)}
         print(name, 'ok', {k: v.shape for k, v in arrays.items() if k.startswith('f0_') and hasattr(v, 'shape')})
 
-    gen_cluster_cases(ref, meta)
+    if variant == 'panoptic':
+        gen_cluster_cases(ref, meta)
     with open(os.path.join(OUT, 'meta.json'), 'w') as fh:
         json.dump(meta, fh, indent=1)
 
@@ -258,4 +323,4 @@ def gen_cluster_cases(ref, meta):
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else 'panoptic')

@@ -26,35 +26,86 @@ def oracle():
     return importlib.import_module('oracle_np')
 
 
+VARIANT_CASES = {
+    'panoptic': ['c1_2view_1person', 'c2_5x4_clean', 'c2_5x4_messy', 'c2_5x4_reordered', 'c2_3x2', 'c4_5x10'],
+    'arplab': ['arp_6x3', 'arp_robot_pair'],
+    'ring23': ['ring23x3', 'ring23_sparse'],
+}
+CASES = VARIANT_CASES['panoptic']
+ALL_CASES = [(v, c) for v, cs in VARIANT_CASES.items() for c in cs]
+
+
+def golden_dir(variant='panoptic'):
+    return GOLDEN if variant == 'panoptic' else os.path.join(GOLDEN, variant)
+
+
+class Env:
+    """Parameters, calibration and deterministic weights of one fixture variant."""
+
+    def __init__(self, variant):
+        self.variant = variant
+        with open(os.path.join(golden_dir(variant), 'meta.json')) as fh:
+            self.meta = json.load(fh)
+        par, cal, syn = pkg('parameters'), pkg('calibration'), pkg('synthetic')
+        if variant == 'panoptic':
+            self.params = par.parameters
+            self.calib = cal.Calibration(self.params)
+        elif variant == 'arplab':
+            self.params = par.select('ARPLAB')
+            self.calib = cal.Calibration(self.params)          # package copy of tm_arp
+        else:
+            self.params = par.select('RING23')
+            self.calib = cal.Calibration(self.params, syn.ring_transform_manager(self.params))
+        self._gat = self._mlp = None
+
+    @property
+    def gat(self):
+        if self._gat is None:
+            syn = pkg('synthetic')
+            m = self.meta
+            self._gat = (syn.gat_state_dict(m['gat_seed'], m['num_feats'], logit_gain=m['logit_gain'],
+                                            logit_shift=m['logit_shift']), syn.gat_params(m['num_feats']))
+        return self._gat
+
+    @property
+    def mlp(self):
+        if self._mlp is None:
+            self._mlp = pkg('synthetic').mlp_state_dict(self.meta['mlp_seed'], self.meta['mlp_in'])
+        return self._mlp
+
+
+_envs = {}
+
+
+def env(variant='panoptic'):
+    if variant not in _envs:
+        _envs[variant] = Env(variant)
+    return _envs[variant]
+
+
 @pytest.fixture(scope='session')
 def meta():
-    with open(os.path.join(GOLDEN, 'meta.json')) as fh:
-        return json.load(fh)
+    return env().meta
 
 
 @pytest.fixture(scope='session')
 def calib():
-    return pkg('calibration').Calibration(pkg('parameters').parameters)
+    return env().calib
 
 
 @pytest.fixture(scope='session')
-def gat_weights(meta):
-    syn = pkg('synthetic')
-    sd = syn.gat_state_dict(meta['gat_seed'], meta['num_feats'], logit_gain=meta['logit_gain'],
-                            logit_shift=meta['logit_shift'])
-    return sd, syn.gat_params(meta['num_feats'])
+def gat_weights():
+    return env().gat
 
 
 @pytest.fixture(scope='session')
-def mlp_weights(meta):
-    return pkg('synthetic').mlp_state_dict(meta['mlp_seed'], meta['mlp_in'])
+def mlp_weights():
+    return env().mlp
 
 
-def load_case(name):
-    arr = np.load(os.path.join(GOLDEN, name + '.npz'))
-    with open(os.path.join(GOLDEN, name + '.frames.json')) as fh:
+def load_case(name, variant='panoptic'):
+    d = golden_dir(variant)
+    arr = np.load(os.path.join(d, name + '.npz'))
+    with open(os.path.join(d, name + '.frames.json')) as fh:
         frames = json.load(fh)
     return arr, frames
-
-
-CASES = ['c1_2view_1person', 'c2_5x4_clean', 'c2_5x4_messy', 'c2_5x4_reordered', 'c2_3x2', 'c4_5x10']

@@ -4,13 +4,14 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CASES, load_case, oracle, pkg
+from conftest import ALL_CASES, CASES, env, golden_dir, load_case, oracle, pkg
 
 
-def test_calibration_matches_reference_globals(calib):
+@pytest.mark.parametrize('variant', ['panoptic', 'arplab', 'ring23'])
+def test_calibration_matches_reference_globals(variant):
     import os
-    from conftest import GOLDEN
-    g = np.load(os.path.join(GOLDEN, 'calibration_panoptic.npz'))
+    calib = env(variant).calib
+    g = np.load(os.path.join(golden_dir(variant), 'calibration_%s.npz' % variant))
     assert np.array_equal(g['T_d'].astype(np.float64), calib.T_d.astype(np.float32).astype(np.float64))
     assert np.array_equal(g['T_i32'], calib.T_i32)
     assert np.array_equal(g['K32'], calib.K32)
@@ -18,14 +19,15 @@ def test_calibration_matches_reference_globals(calib):
     assert np.array_equal(g['centre32'], calib.centre32)
     assert np.array_equal(g['dist'], calib.dist)
     assert np.array_equal(g['P'], calib.P)
-    assert len(g['features']) == 2 + 5 * 18 * 10
+    assert len(g['features']) == 2 + calib.n_cameras * 18 * 10 == env(variant).meta['num_feats']
 
 
-@pytest.mark.parametrize('name', CASES)
-def test_graph_and_gat(name, calib, gat_weights):
+@pytest.mark.parametrize('variant,name', ALL_CASES)
+def test_graph_and_gat(variant, name):
     onp = oracle()
-    arr, frames = load_case(name)
-    sd, prm = gat_weights
+    calib = env(variant).calib
+    arr, frames = load_case(name, variant)
+    sd, prm = env(variant).gat
     for n, frame in enumerate(frames):
         p = 'f%d_' % n
         g = onp.build_graph(onp.processed_input(frame), calib)
@@ -38,7 +40,11 @@ def test_graph_and_gat(name, calib, gat_weights):
         dense = torch.zeros_like(g['feats'])
         rc = arr[p + 'feat_rc']
         dense[rc[:, 0], rc[:, 1]] = torch.from_numpy(arr[p + 'feat_v'])
-        assert torch.equal(dense, g['feats'])            # bit-exact feature rows
+        # feature rows: bit-exact except the ray columns (3-term fp32 dot products through
+        # MKL, whose rounding depends on operand alignment): those within 1 ulp
+        ray = ((torch.arange(dense.shape[1]) - 2) % 10 >= 7) & (torch.arange(dense.shape[1]) >= 2)
+        assert torch.equal(dense[:, ~ray], g['feats'][:, ~ray])
+        np.testing.assert_allclose(g['feats'][:, ray].numpy(), dense[:, ray].numpy(), rtol=0, atol=1.2e-7)
         scores, inter = onp.gat_forward(sd, prm, g['feats'], g['src'], g['dst'], keep=True)
         # same torch CPU kernels on the same machine -> equal to a few ulp at most
         np.testing.assert_allclose(scores.numpy(), arr[p + 'scores'], rtol=2e-5, atol=1e-7)
@@ -48,10 +54,11 @@ def test_graph_and_gat(name, calib, gat_weights):
             np.testing.assert_allclose(a[H:H + 4].numpy(), arr[p + 'act%d_en' % l], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize('name', CASES)
-def test_cluster_on_golden_scores(name, calib):
+@pytest.mark.parametrize('variant,name', ALL_CASES)
+def test_cluster_on_golden_scores(variant, name):
     onp = oracle()
-    arr, frames = load_case(name)
+    calib = env(variant).calib
+    arr, frames = load_case(name, variant)
     sm = list(calib.params.used_cameras_skeleton_matching)
     for n, frame in enumerate(frames):
         p = 'f%d_' % n
@@ -83,10 +90,12 @@ def test_cluster_known_answers(calib):
     assert nonempty > 300
 
 
-@pytest.mark.parametrize('name', CASES)
-def test_stage3d(name, calib, mlp_weights):
+@pytest.mark.parametrize('variant,name', ALL_CASES)
+def test_stage3d(variant, name):
     onp = oracle()
-    arr, frames = load_case(name)
+    calib = env(variant).calib
+    mlp_weights = env(variant).mlp
+    arr, frames = load_case(name, variant)
     sm = list(calib.params.used_cameras_skeleton_matching)
     for n, frame in enumerate(frames):
         p = 'f%d_' % n
