@@ -19,6 +19,8 @@
 //   * double-buffered LDS (52 KB -> 3 workgroups/CU), register prefetch of the next K stage,
 //     one barrier per stage; XCD-aware workgroup order so the tiles that share operands run
 //     on one XCD's L2.
+#include <cstdlib>
+
 #include "mpe_internal.h"
 
 namespace mpe {
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
                                                    const float *__restrict__ W, int ldw,
                                                    const float *__restrict__ bias, float *__restrict__ C,
                                                    int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
-                                                   int k_pad, float slope, int ntn, int n_major) {
+                                                   int k_pad, float slope, int ntn, int n_major, int tune) {
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
     int M = m_cap;
@@ -68,6 +70,11 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
         tn = swz - tm * ntn;
     }
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    if (tune & 1) {
+        // de-synchronise the workgroups that share a CU (they run the same program in lockstep)
+        const int ph = (bid >> 3) % 3;
+        for (int i = 0; i < ph * 4; ++i) __builtin_amdgcn_s_sleep(3);
+    }
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // global->LDS staging role: 8 rows x 8 chunks (16 B) per wave and pass
@@ -136,8 +143,8 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = (kt & 1) * STAGE;
-        const bool more = kt + 1 < nk;
+        const int cur = (tune & 4) ? 0 : (kt & 1) * STAGE;
+        const bool more = kt + 1 < nk && !(tune & 4);     // tune&4: ablation, MFMA + LDS reads only
         if (more) {
             const int koff = (kt + 1) * GEMM_BK;
 #pragma unroll
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
             for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + ((hh ^ fsw) << 2)]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + ((hh ^ fsw) << 2)]);
+            if (tune & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -159,6 +167,7 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
+            if (tune & 2) __builtin_amdgcn_s_setprio(0);
         }
         if (ACC64) {
 #pragma unroll
@@ -218,11 +227,12 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
     const int ntn = (n + GEMM_BN - 1) / GEMM_BN;
+    static const int tune = getenv("MPE_GEMM_TUNE") ? atoi(getenv("MPE_GEMM_TUNE")) : 0;
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
     dim3 grid(ntm * ntn), block(256);
 #define MPE_LAUNCH(L_, A_)                                                                                   \
     hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
-                       slope, ntn, n_major)
+                       slope, ntn, n_major, tune)
     if (leaky && acc64) MPE_LAUNCH(true, true);
     else if (leaky) MPE_LAUNCH(true, false);
     else if (acc64) MPE_LAUNCH(false, true);

@@ -40,6 +40,9 @@ def main():
     ap.add_argument('--mode', choices=['mlp', 'tri'], default='mlp')
     ap.add_argument('--cpu-sample', type=int, default=40, help='frames of the CPU baseline sample (0 = skip)')
     ap.add_argument('--fast-mlp', action='store_true', help='plain fp32 accumulation in the MLP GEMMs')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)')
+    ap.add_argument('--streams', type=int, default=1, choices=[1, 2],
+                    help='2 = software pipeline across steps: matching of batch i+1 overlaps the 3D stage of batch i')
     args = ap.parse_args()
 
     import numpy as np
@@ -53,10 +56,12 @@ def main():
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     n_gpus = world if distributed else 1
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
 
     syn = importlib.import_module(PKG + '.synthetic')
@@ -94,18 +99,40 @@ def main():
     torch.cuda.synchronize(device)
 
     gather_buf = None
+    s_match = torch.cuda.Stream(device) if args.streams == 2 else None
+    s_3d = torch.cuda.Stream(device) if args.streams == 2 else None
+    keep = []          # tensors produced on one stream and consumed on the other stay referenced
+
+    def stage3d(persons, n_persons):
+        if args.mode == 'mlp':
+            return eng.mlp3d(db, persons, n_persons)[0]
+        return eng.triangulate(db, persons, n_persons)[0]
 
     def step():
-        _, persons, n_persons = eng.match(db, want_scores=False)
-        if args.mode == 'mlp':
-            poses, _ = eng.mlp3d(db, persons, n_persons)
+        if args.streams == 2:
+            # the two stages use disjoint workspace, so matching of the next step may run
+            # while the 3D stage of this one is still in flight
+            with torch.cuda.stream(s_match):
+                _, persons, n_persons = eng.match(db, want_scores=False)
+                ev = torch.cuda.Event()
+                ev.record(s_match)
+            with torch.cuda.stream(s_3d):
+                s_3d.wait_event(ev)
+                poses = stage3d(persons, n_persons)
+            keep.append((persons, n_persons, poses))
+            if len(keep) > 4:
+                keep.pop(0)
+            if not distributed:
+                return poses, n_persons
+            torch.cuda.current_stream(device).wait_stream(s_3d)
         else:
-            poses, _ = eng.triangulate(db, persons, n_persons)
+            _, persons, n_persons = eng.match(db, want_scores=False)
+            poses = stage3d(persons, n_persons)
         if distributed:
             nonlocal gather_buf
             if gather_buf is None:
-                gather_buf = torch.empty((world,) + tuple(poses.shape), dtype=poses.dtype, device=device)
-                step.np_buf = torch.empty((world, B), dtype=torch.int32, device=device)
+                gather_buf = torch.empty((world * poses.shape[0],) + tuple(poses.shape[1:]), dtype=poses.dtype, device=device)
+                step.np_buf = torch.empty((world * B,), dtype=torch.int32, device=device)
             dist.all_gather_into_tensor(gather_buf, poses)
             dist.all_gather_into_tensor(step.np_buf, n_persons)
         return poses, n_persons
@@ -144,6 +171,7 @@ def main():
                                 % (args.persons, 'MLP 3D' if args.mode == 'mlp' else 'DLT triangulation', B)),
                    'frames_per_step_per_gpu': B, 'heads_per_batch': pb.n_heads, 'edge_nodes_per_batch': pb.n_edge_nodes,
                    'persons_found_per_frame': persons_per_frame, 'parallelism': 'frame-shard x%d' % n_gpus,
+                   'streams': args.streams,
                    'mlp_accumulate': 'f32' if args.fast_mlp else 'f32 mfma + f64 running sums',
                    'weights': 'deterministic hash init (no checkpoint offline)'},
     }
@@ -159,7 +187,8 @@ def main():
             'gemm_share_of_step': gemm_s / elapsed,
             'flop_definition': 'algorithmic 2*M*N*K of the launches (layer-0 edge-node rows de-duplicated)',
         }
-        out['cpu_baseline'] = cpu_baseline(args, frames, calib, gat_sd, prm, mlp_sd)
+        # the CPU baseline is taken on rank 0 at N = 1 only
+        out['cpu_baseline'] = None if distributed else cpu_baseline(args, frames, calib, gat_sd, prm, mlp_sd)
         print(json.dumps(out))
     if distributed:
         dist.barrier()
