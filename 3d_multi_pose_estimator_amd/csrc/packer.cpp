@@ -1,0 +1,561 @@
+// Frame-JSON -> packed batch, native host code.
+//
+// The reference's wire format (panoptic_conversor/get_joints_from_panoptic_model_multi.py:
+// 231-236, 281, 287, 303-307; consumers test/metrics_from_model.py:118-140, 184) is a list of
+// frames; a frame maps camera name -> [ "<JSON text of the skeleton list>", timestamp,
+// "no_image", bodies_3D ]; a skeleton maps joint id string -> [id, x, y, valid, prob], with an
+// optional "ID" entry.  The skeleton list is JSON inside a JSON string, so the reference
+// parses every frame twice in Python (json.load, then json.loads per camera).  Here one pass
+// of a small recursive-descent scanner does both levels and writes the structure-of-arrays
+// batch of include/mpe.h directly; frames are independent, so they are parsed by a pool of
+// threads after a bracket-depth scan has located their extents.
+//
+// Ordering rules are those of MergedMultipleHumansDataset.load_people_view_graph (reference
+// graph_generator.py:573-605), identical to packing.py: cameras in key order, cameras outside
+// used_cameras_skeleton_matching skipped, skeletons without a joint key skipped, numbers
+// converted with strtod (correctly rounded, like Python's float()).
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mpe.h"
+
+namespace {
+
+struct Head {
+    int32_t cam;
+    uint32_t joint_mask, tri_mask;
+    int32_t skeleton_index;
+    double xy[MPE_MAX_JOINTS][2];
+    float vp[MPE_MAX_JOINTS][2];
+};
+
+struct HeadInfo {
+    int32_t cam;
+    uint32_t joint_mask, tri_mask;
+    int32_t skeleton_index;
+};
+
+struct FrameOut {                    // compact per-frame result (J values per head, not MPE_MAX_JOINTS)
+    std::vector<HeadInfo> heads;
+    std::vector<double> xy;          // [heads][J][2]
+    std::vector<float> vp;           // [heads][J][2]
+    std::vector<int32_t> slot_cam, slot_n;
+    std::string error;
+};
+
+struct Cursor {
+    const char *p, *end;
+    bool inner;        // true while scanning text that sits inside a JSON string (one escape level)
+};
+
+inline void skip_ws(Cursor &c) {
+    while (c.p < c.end && (*c.p == ' ' || *c.p == '\n' || *c.p == '\t' || *c.p == '\r')) ++c.p;
+}
+
+// In "inner" mode the text is the body of a JSON string: a quote appears as \" and a
+// backslash as \\ .  The skeleton lists contain only ASCII keys and numbers, so only these
+// two escapes can occur inside them.
+inline bool at_quote(const Cursor &c) {
+    if (c.inner) return c.p + 1 < c.end && c.p[0] == '\\' && c.p[1] == '"';
+    return c.p < c.end && *c.p == '"';
+}
+
+inline void eat_quote(Cursor &c) { c.p += c.inner ? 2 : 1; }
+
+bool read_string(Cursor &c, std::string *out) {
+    if (!at_quote(c)) return false;
+    eat_quote(c);
+    if (out) out->clear();
+    while (c.p < c.end) {
+        if (at_quote(c)) {
+            eat_quote(c);
+            return true;
+        }
+        if (!c.inner && *c.p == '\\') {          // escape at the outer level: copy the escaped char
+            if (c.p + 1 >= c.end) return false;
+            if (out) out->push_back(c.p[1]);
+            c.p += 2;
+            continue;
+        }
+        if (c.inner && *c.p == '"') return false;   // the enclosing string ended unexpectedly
+        if (out) out->push_back(*c.p);
+        ++c.p;
+    }
+    return false;
+}
+
+bool read_number(Cursor &c, double *v) {
+    skip_ws(c);
+    // Clinger fast path: <= 15 significant digits and |exp10| <= 22 are exact in binary64
+    // arithmetic; everything else goes to glibc's strtod (correctly rounded, lock-free).
+    // (libstdc++ 11's from_chars<double> takes the global locale lock on every call.)
+    double d = 0;
+    const char *e = c.p;
+    {
+        const char *q = c.p;
+        bool neg = false;
+        if (q < c.end && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+        uint64_t m = 0;
+        int digits = 0, exp10 = 0;
+        const char *ds = q;
+        bool dropped = false;     // a non-zero digit beyond the 19th was discarded -> inexact
+        while (q < c.end && *q >= '0' && *q <= '9') {
+            if (digits < 19) { m = m * 10 + (uint64_t)(*q - '0'); if (m) ++digits; } else { ++exp10; dropped = dropped || *q != '0'; }
+            ++q;
+        }
+        bool any = q > ds;
+        if (q < c.end && *q == '.') {
+            ++q;
+            const char *fs = q;
+            while (q < c.end && *q >= '0' && *q <= '9') {
+                if (digits < 19) { m = m * 10 + (uint64_t)(*q - '0'); if (m) ++digits; --exp10; } else dropped = dropped || *q != '0';
+                ++q;
+            }
+            any = any || q > fs;
+        }
+        bool ok = any;
+        const bool exact_in = !dropped;
+        if (ok && q < c.end && (*q == 'e' || *q == 'E')) {
+            const char *es = q + 1;
+            bool eneg = false;
+            if (es < c.end && (*es == '-' || *es == '+')) { eneg = *es == '-'; ++es; }
+            int ev = 0;
+            const char *e0 = es;
+            while (es < c.end && *es >= '0' && *es <= '9' && ev < 10000) { ev = ev * 10 + (*es - '0'); ++es; }
+            if (es > e0) { exp10 += eneg ? -ev : ev; q = es; }
+        }
+        static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                     1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+        static const long double p10l[] = {1e0L, 1e1L, 1e2L, 1e3L, 1e4L, 1e5L, 1e6L, 1e7L, 1e8L, 1e9L, 1e10L,
+                                           1e11L, 1e12L, 1e13L, 1e14L, 1e15L, 1e16L, 1e17L, 1e18L, 1e19L, 1e20L,
+                                           1e21L, 1e22L, 1e23L, 1e24L, 1e25L, 1e26L, 1e27L};
+        bool done = false;
+        if (ok && exact_in && digits <= 15 && exp10 >= -22 && exp10 <= 22) {
+            d = (double)m;
+            d = exp10 < 0 ? d / p10[-exp10] : d * p10[exp10];
+            done = true;
+        } else if (ok && exact_in && exp10 >= -27 && exp10 <= 27 && m != 0) {
+            // up to 19 digits: m and 10^|e| are exact in x87 extended precision (64-bit
+            // significand), so m*10^e carries ONE rounding there; rounding that again to
+            // binary64 is exact unless the extended value sits within 1 ulp of a binary64
+            // midpoint -- only then fall back to strtod
+            long double r = (long double)m;
+            r = exp10 < 0 ? r / p10l[-exp10] : r * p10l[exp10];
+            uint64_t mant;
+            memcpy(&mant, &r, sizeof mant);
+            const uint64_t low = mant & 0x7FFu;
+            if (low < 0x3FFu || low > 0x401u) {
+                d = (double)r;
+                done = d >= 2.3e-308 && d <= 1.7e308;      // normal range only
+            }
+        }
+        if (done) {
+            if (neg) d = -d;
+            e = q;
+        } else if (ok) {
+            char *e2 = nullptr;
+            d = strtod(c.p, &e2);
+            e = e2;
+        }
+    }
+    if (e == c.p) {
+        // JSON literals that Python's json accepts where a number may stand
+        if (c.end - c.p >= 4 && !strncmp(c.p, "true", 4)) { *v = 1; c.p += 4; return true; }
+        if (c.end - c.p >= 5 && !strncmp(c.p, "false", 5)) { *v = 0; c.p += 5; return true; }
+        if (c.end - c.p >= 3 && !strncmp(c.p, "NaN", 3)) { *v = NAN; c.p += 3; return true; }
+        return false;
+    }
+    c.p = e;
+    *v = d;
+    return true;
+}
+
+bool skip_value(Cursor &c);
+
+bool skip_container(Cursor &c, char open, char close) {
+    if (*c.p != open) return false;
+    ++c.p;
+    skip_ws(c);
+    if (c.p < c.end && *c.p == close) { ++c.p; return true; }
+    while (c.p < c.end) {
+        skip_ws(c);
+        if (open == '{') {
+            if (!read_string(c, nullptr)) return false;
+            skip_ws(c);
+            if (c.p >= c.end || *c.p != ':') return false;
+            ++c.p;
+        }
+        if (!skip_value(c)) return false;
+        skip_ws(c);
+        if (c.p >= c.end) return false;
+        if (*c.p == ',') { ++c.p; continue; }
+        if (*c.p == close) { ++c.p; return true; }
+        return false;
+    }
+    return false;
+}
+
+bool skip_value(Cursor &c) {
+    skip_ws(c);
+    if (c.p >= c.end) return false;
+    if (at_quote(c)) return read_string(c, nullptr);
+    if (*c.p == '{') return skip_container(c, '{', '}');
+    if (*c.p == '[') return skip_container(c, '[', ']');
+    if (c.end - c.p >= 4 && !strncmp(c.p, "null", 4)) { c.p += 4; return true; }
+    // numbers and bare literals are skipped lexically (no conversion)
+    const char *q = c.p;
+    while (q < c.end && *q != ',' && *q != ']' && *q != '}' && *q != ' ' && *q != '\n' && *q != '\\' && *q != '"') ++q;
+    if (q == c.p) return false;
+    c.p = q;
+    return true;
+}
+
+// one skeleton: {"5": [5, x, y, valid, prob], ..., "ID": n}
+bool parse_skeleton(Cursor &c, int J, Head *h, std::string *err) {
+    skip_ws(c);
+    if (c.p >= c.end || *c.p != '{') { *err = "skeleton is not an object"; return false; }
+    ++c.p;
+    h->joint_mask = h->tri_mask = 0;
+    memset(h->xy, 0, sizeof h->xy);
+    memset(h->vp, 0, sizeof h->vp);
+    skip_ws(c);
+    if (c.p < c.end && *c.p == '}') { ++c.p; return true; }
+    std::string key;
+    while (c.p < c.end) {
+        skip_ws(c);
+        if (!read_string(c, &key)) { *err = "bad joint key"; return false; }
+        skip_ws(c);
+        if (c.p >= c.end || *c.p != ':') { *err = "missing ':'"; return false; }
+        ++c.p;
+        skip_ws(c);
+        if (key == "ID") {
+            if (!skip_value(c)) { *err = "bad ID value"; return false; }
+        } else {
+            char *e = nullptr;
+            const long j = strtol(key.c_str(), &e, 10);
+            if (e == key.c_str() || *e != 0 || j < 0 || j >= J) { *err = "joint id '" + key + "' out of range"; return false; }
+            if (c.p >= c.end || *c.p != '[') { *err = "joint value is not a list"; return false; }
+            ++c.p;
+            double v[5] = {0, 0, 0, 0, 0};
+            int n = 0;
+            while (c.p < c.end) {
+                skip_ws(c);
+                if (*c.p == ']') { ++c.p; break; }
+                double d;
+                if (!read_number(c, &d)) { *err = "bad number in joint"; return false; }
+                if (n < 5) v[n] = d;
+                ++n;
+                skip_ws(c);
+                if (c.p < c.end && *c.p == ',') ++c.p;
+            }
+            if (n < 5) { *err = "joint value needs 5 numbers"; return false; }
+            h->joint_mask |= 1u << j;
+            if (v[0] > 0.) h->tri_mask |= 1u << j;
+            h->xy[j][0] = v[1];
+            h->xy[j][1] = v[2];
+            h->vp[j][0] = (float)v[3];
+            h->vp[j][1] = (float)v[4];
+        }
+        skip_ws(c);
+        if (c.p >= c.end) break;
+        if (*c.p == ',') { ++c.p; continue; }
+        if (*c.p == '}') { ++c.p; return true; }
+        *err = "bad skeleton object";
+        return false;
+    }
+    *err = "unterminated skeleton";
+    return false;
+}
+
+// the camera entry's first element: a JSON string holding the skeleton list (or, leniently,
+// the list itself)
+bool parse_skeleton_list(Cursor &c, int J, int cam, FrameOut *fo, int *n_here) {
+    skip_ws(c);
+    Cursor in = c;
+    bool quoted = false;
+    if (at_quote(c)) {
+        if (c.inner) { fo->error = "doubly nested skeleton string"; return false; }
+        quoted = true;
+        in.p = c.p + 1;
+        in.inner = true;
+    }
+    skip_ws(in);
+    if (in.p >= in.end || *in.p != '[') { fo->error = "skeleton list expected"; return false; }
+    ++in.p;
+    int idx = 0;
+    *n_here = 0;
+    skip_ws(in);
+    if (in.p < in.end && *in.p == ']') {
+        ++in.p;
+    } else {
+        while (in.p < in.end) {
+            Head h;
+            h.cam = cam;
+            h.skeleton_index = idx++;
+            if (!parse_skeleton(in, J, &h, &fo->error)) return false;
+            if (h.joint_mask) {
+                fo->heads.push_back({h.cam, h.joint_mask, h.tri_mask, h.skeleton_index});
+                for (int j = 0; j < J; ++j) {
+                    fo->xy.push_back(h.xy[j][0]);
+                    fo->xy.push_back(h.xy[j][1]);
+                    fo->vp.push_back(h.vp[j][0]);
+                    fo->vp.push_back(h.vp[j][1]);
+                }
+                ++*n_here;
+            }
+            skip_ws(in);
+            if (in.p >= in.end) { fo->error = "unterminated skeleton list"; return false; }
+            if (*in.p == ',') { ++in.p; continue; }
+            if (*in.p == ']') { ++in.p; break; }
+            fo->error = "bad skeleton list";
+            return false;
+        }
+    }
+    if (quoted) {
+        skip_ws(in);
+        if (in.p >= in.end || *in.p != '"') { fo->error = "skeleton string not closed"; return false; }
+        c.p = in.p + 1;
+    } else {
+        c.p = in.p;
+    }
+    return true;
+}
+
+bool parse_frame(const char *b, const char *e, const std::vector<std::string> &cams, int J, FrameOut *fo) {
+    Cursor c{b, e, false};
+    skip_ws(c);
+    if (c.p >= c.end || *c.p != '{') { fo->error = "frame is not an object"; return false; }
+    ++c.p;
+    const int V = (int)cams.size();
+    fo->heads.reserve(32);
+    fo->xy.reserve((size_t)32 * J * 2);
+    fo->vp.reserve((size_t)32 * J * 2);
+    fo->slot_cam.reserve(V);
+    fo->slot_n.reserve(V);
+    skip_ws(c);
+    if (c.p < c.end && *c.p == '}') return true;
+    std::string key;
+    while (c.p < c.end) {
+        skip_ws(c);
+        if (!read_string(c, &key)) { fo->error = "bad camera key"; return false; }
+        skip_ws(c);
+        if (c.p >= c.end || *c.p != ':') { fo->error = "missing ':' after camera"; return false; }
+        ++c.p;
+        int cam = -1;
+        for (int i = 0; i < V; ++i)
+            if (cams[i] == key) { cam = i; break; }
+        skip_ws(c);
+        if (cam < 0) {
+            if (!skip_value(c)) { fo->error = "bad value of unused camera"; return false; }
+        } else {
+            if (c.p >= c.end || *c.p != '[') { fo->error = "camera entry is not a list"; return false; }
+            ++c.p;
+            if ((int)fo->slot_cam.size() >= V) { fo->error = "frame lists more cameras than configured"; return false; }
+            int n_here = 0;
+            if (!parse_skeleton_list(c, J, cam, fo, &n_here)) return false;
+            fo->slot_cam.push_back(cam);
+            fo->slot_n.push_back(n_here);
+            // remaining elements (timestamp, 'no_image', bodies_3D) are not on the hot path
+            while (c.p < c.end) {
+                skip_ws(c);
+                if (*c.p == ',') { ++c.p; if (!skip_value(c)) { fo->error = "bad camera entry"; return false; } continue; }
+                if (*c.p == ']') { ++c.p; break; }
+                fo->error = "bad camera entry";
+                return false;
+            }
+        }
+        skip_ws(c);
+        if (c.p >= c.end) break;
+        if (*c.p == ',') { ++c.p; continue; }
+        if (*c.p == '}') return true;
+        fo->error = "bad frame object";
+        return false;
+    }
+    fo->error = "unterminated frame";
+    return false;
+}
+
+// extents of the elements of the top-level array (bracket depth with string awareness)
+bool split_frames(const char *b, const char *e, std::vector<std::pair<const char *, const char *>> *out, std::string *err) {
+    const char *p = b;
+    while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    if (p >= e) { *err = "empty document"; return false; }
+    if (*p == '{') {            // a single frame
+        out->push_back({p, e});
+        return true;
+    }
+    if (*p != '[') { *err = "top level must be a list of frames"; return false; }
+    ++p;
+    int depth = 0;
+    bool in_str = false;
+    const char *start = nullptr;
+    for (; p < e; ++p) {
+        const char ch = *p;
+        if (in_str) {
+            if (ch == '\\') { ++p; continue; }
+            if (ch == '"') in_str = false;
+            continue;
+        }
+        if (ch == '"') { in_str = true; continue; }
+        if (ch == '{' || ch == '[') {
+            if (depth == 0) start = p;
+            ++depth;
+        } else if (ch == '}' || ch == ']') {
+            if (depth == 0) return true;          // end of the top-level list
+            --depth;
+            if (depth == 0) out->push_back({start, p + 1});
+        }
+    }
+    *err = "unterminated top-level list";
+    return false;
+}
+
+}  // namespace
+
+struct mpe_packed {
+    int32_t V = 0, J = 0, n_frames = 0;
+    std::vector<int32_t> frame_head_off, frame_en_off, slot_cam, slot_n, head_cam, skeleton_index;
+    std::vector<uint32_t> joint_mask, tri_mask;
+    std::vector<double> xy;
+    std::vector<float> vp;
+    std::string err;
+};
+
+static thread_local std::string g_pack_error;
+
+extern "C" {
+
+const char *mpe_pack_last_error(void) { return g_pack_error.c_str(); }
+
+int mpe_pack_json(const char *json, size_t len, const char *const *camera_names, int32_t n_cameras, int32_t n_joints,
+                  int32_t frame_start, int32_t frame_step, int32_t max_frames, int32_t n_threads, mpe_packed **out) {
+    if (!json || !camera_names || !out || n_cameras < 1 || n_cameras > MPE_MAX_CAMERAS || n_joints < 1 ||
+        n_joints > MPE_MAX_JOINTS || frame_step < 1 || frame_start < 0) {
+        g_pack_error = "mpe_pack_json: bad argument";
+        return MPE_ERR_INVALID;
+    }
+    *out = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::string> cams(camera_names, camera_names + n_cameras);
+    std::vector<std::pair<const char *, const char *>> ext;
+    std::string err;
+    if (!split_frames(json, json + len, &ext, &err)) {
+        g_pack_error = err;
+        return MPE_ERR_INVALID;
+    }
+    std::vector<std::pair<const char *, const char *>> sel;
+    for (size_t i = (size_t)frame_start; i < ext.size(); i += (size_t)frame_step) {
+        if (max_frames > 0 && (int32_t)sel.size() >= max_frames) break;
+        sel.push_back(ext[i]);
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const int B = (int)sel.size();
+    std::vector<FrameOut> fo((size_t)B);
+    std::atomic<int> next{0};
+    std::atomic<bool> failed{false};
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= B) return;
+            if (!parse_frame(sel[i].first, sel[i].second, cams, n_joints, &fo[i])) failed = true;
+        }
+    };
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > B) nt = B > 0 ? B : 1;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    const auto t2 = std::chrono::steady_clock::now();
+    if (failed) {
+        for (int i = 0; i < B; ++i)
+            if (!fo[i].error.empty()) {
+                g_pack_error = "frame " + std::to_string(frame_start + i * frame_step) + ": " + fo[i].error;
+                break;
+            }
+        return MPE_ERR_INVALID;
+    }
+    mpe_packed *pk = new (std::nothrow) mpe_packed();
+    if (!pk) return MPE_ERR_NOMEM;
+    pk->V = n_cameras;
+    pk->J = n_joints;
+    pk->n_frames = B;
+    pk->frame_head_off.assign((size_t)B + 1, 0);
+    pk->frame_en_off.assign((size_t)B + 1, 0);
+    pk->slot_cam.assign((size_t)B * n_cameras, -1);
+    pk->slot_n.assign((size_t)B * n_cameras, 0);
+    for (int f = 0; f < B; ++f) {
+        long tot = 0, sq = 0;
+        for (size_t s = 0; s < fo[f].slot_cam.size(); ++s) {
+            pk->slot_cam[(size_t)f * n_cameras + s] = fo[f].slot_cam[s];
+            pk->slot_n[(size_t)f * n_cameras + s] = fo[f].slot_n[s];
+            tot += fo[f].slot_n[s];
+            sq += (long)fo[f].slot_n[s] * fo[f].slot_n[s];
+        }
+        pk->frame_head_off[f + 1] = pk->frame_head_off[f] + (int32_t)tot;
+        pk->frame_en_off[f + 1] = pk->frame_en_off[f] + (int32_t)((tot * tot - sq) / 2);
+    }
+    const size_t H = (size_t)pk->frame_head_off[B];
+    pk->head_cam.resize(H);
+    pk->skeleton_index.resize(H);
+    pk->joint_mask.resize(H);
+    pk->tri_mask.resize(H);
+    pk->xy.assign(H * n_joints * 2, 0.0);
+    pk->vp.assign(H * n_joints * 2, 0.f);
+    for (int f = 0; f < B; ++f) {
+        size_t h = (size_t)pk->frame_head_off[f];
+        const size_t per = (size_t)n_joints * 2;
+        if (!fo[f].heads.empty()) {
+            memcpy(&pk->xy[h * per], fo[f].xy.data(), fo[f].xy.size() * sizeof(double));
+            memcpy(&pk->vp[h * per], fo[f].vp.data(), fo[f].vp.size() * sizeof(float));
+        }
+        for (const HeadInfo &hd : fo[f].heads) {
+            pk->head_cam[h] = hd.cam;
+            pk->skeleton_index[h] = hd.skeleton_index;
+            pk->joint_mask[h] = hd.joint_mask;
+            pk->tri_mask[h] = hd.tri_mask;
+            ++h;
+        }
+    }
+    if (getenv("MPE_PACK_TIMING")) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "mpe_pack_json: split %.1f ms, parse %.1f ms (%d threads), assemble %.1f ms\n", ms(t0, t1), ms(t1, t2), nt,
+                ms(t2, t3));
+    }
+    *out = pk;
+    return MPE_OK;
+}
+
+int mpe_packed_view(const mpe_packed *pk, mpe_packed_arrays *v) {
+    if (!pk || !v) return MPE_ERR_INVALID;
+    v->n_frames = pk->n_frames;
+    v->n_heads = pk->frame_head_off.back();
+    v->n_edge_nodes = pk->frame_en_off.back();
+    v->n_cameras = pk->V;
+    v->n_joints = pk->J;
+    v->frame_head_off = pk->frame_head_off.data();
+    v->frame_en_off = pk->frame_en_off.data();
+    v->slot_cam = pk->slot_cam.data();
+    v->slot_n = pk->slot_n.data();
+    v->head_cam = pk->head_cam.data();
+    v->skeleton_index = pk->skeleton_index.data();
+    v->joint_mask = pk->joint_mask.data();
+    v->tri_mask = pk->tri_mask.data();
+    v->xy = pk->xy.data();
+    v->vp = pk->vp.data();
+    return MPE_OK;
+}
+
+void mpe_packed_free(mpe_packed *pk) { delete pk; }
+
+}  // extern "C"

@@ -47,6 +47,14 @@ class mpe_batch(C.Structure):
     ]
 
 
+class mpe_packed_arrays(C.Structure):
+    _fields_ = [('n_frames', C.c_int32), ('n_heads', C.c_int32), ('n_edge_nodes', C.c_int32),
+                ('n_cameras', C.c_int32), ('n_joints', C.c_int32),
+                ('frame_head_off', c_i32p), ('frame_en_off', c_i32p), ('slot_cam', c_i32p), ('slot_n', c_i32p),
+                ('head_cam', c_i32p), ('skeleton_index', c_i32p), ('joint_mask', c_u32p), ('tri_mask', c_u32p),
+                ('xy', c_f64p), ('vp', c_f32p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/mpe.h declares
 SYMBOLS = {
     'mpe_create': (C.c_int, [C.POINTER(mpe_config), C.POINTER(C.c_void_p)]),
@@ -81,6 +89,11 @@ SYMBOLS = {
                                      C.c_void_p, C.c_int32, C.c_void_p]),
     'mpe_mlp_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     'mpe_dlt_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'mpe_pack_json': (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    'mpe_packed_view': (C.c_int, [C.c_void_p, C.POINTER(mpe_packed_arrays)]),
+    'mpe_packed_free': (None, [C.c_void_p]),
+    'mpe_pack_last_error': (C.c_char_p, []),
     'mpe_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
     'mpe_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -186,3 +186,47 @@ def pairs_of_frame(slot_n_row):
                 for j in range(slot_n_row[b]):
                     out.append((starts[a] + i, starts[b] + j))
     return np.array(out, np.int32).reshape(-1, 2)
+
+
+def pack_json(text, params, frame_start=0, frame_step=1, max_frames=0, n_threads=0):
+    """Native packer (csrc/packer.cpp, `mpe_pack_json`): the whole JSON document (bytes or str,
+    list of frames in the reference's wire format) -> PackedBatch, without Python-level JSON
+    parsing.  Same ordering rules and numbers as `pack_frames`."""
+    import ctypes as C
+
+    from . import lib as L
+    lib = L.load()
+    if isinstance(text, str):
+        text = text.encode()
+    sm = list(params.used_cameras_skeleton_matching)
+    V, J = len(sm), len(params.joint_list)
+    names = (C.c_char_p * V)(*[c.encode() for c in sm])
+    handle = C.c_void_p()
+    rc = lib.mpe_pack_json(text, len(text), names, V, J, frame_start, frame_step, max_frames, n_threads,
+                           C.byref(handle))
+    if rc != 0:
+        raise ValueError('mpe_pack_json: %s' % lib.mpe_pack_last_error().decode())
+    try:
+        v = L.mpe_packed_arrays()
+        lib.mpe_packed_view(handle, C.byref(v))
+
+        def arr(ptr, n, dt):
+            if n == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+        pb = PackedBatch(V, J)
+        B, H = v.n_frames, v.n_heads
+        pb.n_frames = B
+        pb.frame_head_off = arr(v.frame_head_off, B + 1, np.int32)
+        pb.frame_en_off = arr(v.frame_en_off, B + 1, np.int32)
+        pb.slot_cam = arr(v.slot_cam, B * V, np.int32).reshape(B, V)
+        pb.slot_n = arr(v.slot_n, B * V, np.int32).reshape(B, V)
+        pb.head_cam = arr(v.head_cam, H, np.int32)
+        pb.skeleton_index = arr(v.skeleton_index, H, np.int32)
+        pb.joint_mask = arr(v.joint_mask, H, np.uint32)
+        pb.tri_mask = arr(v.tri_mask, H, np.uint32)
+        pb.xy = arr(v.xy, H * J * 2, np.float64).reshape(H, J, 2)
+        pb.vp = arr(v.vp, H * J * 2, np.float32).reshape(H, J, 2)
+        return pb
+    finally:
+        lib.mpe_packed_free(handle)

@@ -11,7 +11,7 @@ import torch
 
 from . import lib as L
 from .calibration import Calibration
-from .packing import DeviceBatch, PackedBatch, pack_frames
+from .packing import DeviceBatch, PackedBatch, pack_frames, pack_json
 
 
 def _f32p(a):
@@ -125,6 +125,10 @@ class Engine:
     # ---- batches ----------------------------------------------------------------------
     def pack(self, frames, keep_json=False):
         return pack_frames(frames, self.params, keep_json=keep_json)
+
+    def pack_json(self, text, frame_start=0, frame_step=1, max_frames=0, n_threads=0):
+        """Native (C++) packer: JSON text of a list of frames -> PackedBatch."""
+        return pack_json(text, self.params, frame_start, frame_step, max_frames, n_threads)
 
     def to_device(self, pb):
         if isinstance(pb, DeviceBatch):

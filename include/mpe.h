@@ -191,6 +191,29 @@ int mpe_mlp_forward(mpe_ctx *ctx, void *stream, const float *d_x, int32_t ld_x, 
 int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t *d_cams,
                   int32_t n, double *d_out);
 
+/* ---- host-side packer (no GPU involved) ---------------------------------------------------
+ * Frame JSON in the reference's wire format (list of frames; frame = {camera: ["<JSON text of
+ * the skeleton list>", timestamp, 'no_image', bodies_3D]}; skeleton = {joint id: [id, x, y,
+ * valid, prob], optional "ID"}; panoptic_conversor/get_joints_from_panoptic_model_multi.py:
+ * 231-236,281,287) -> the host arrays of an mpe_batch, in the reference's head order
+ * (graph_generator.py:573-605).  Replaces json.load + json.loads per camera + the Python
+ * loops of load_people_view_graph.  Frames frame_start, frame_start+frame_step, ... (at most
+ * max_frames, 0 = all) are parsed by n_threads threads (0 = all cores). */
+typedef struct mpe_packed mpe_packed;
+typedef struct {
+    int32_t n_frames, n_heads, n_edge_nodes, n_cameras, n_joints;
+    const int32_t *frame_head_off, *frame_en_off, *slot_cam, *slot_n, *head_cam, *skeleton_index;
+    const uint32_t *joint_mask, *tri_mask;
+    const double *xy;
+    const float *vp;
+} mpe_packed_arrays;
+int mpe_pack_json(const char *json, size_t len, const char *const *camera_names, int32_t n_cameras,
+                  int32_t n_joints, int32_t frame_start, int32_t frame_step, int32_t max_frames,
+                  int32_t n_threads, mpe_packed **out);
+int mpe_packed_view(const mpe_packed *pk, mpe_packed_arrays *view);
+void mpe_packed_free(mpe_packed *pk);
+const char *mpe_pack_last_error(void);
+
 /* Timing probe for bench.py: average duration (ms) of the dominant GEMM launches measured
  * with HIP events on the launch stream during the last mpe_match_batch / mpe_mlp3d_batch
  * when profiling is enabled; see bench.py. */

@@ -120,3 +120,73 @@ def test_shard_range_covers_everything():
                 assert hi - lo <= per
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_native_json_packer_equals_python_packer(name, calib):
+    """csrc/packer.cpp (mpe_pack_json) against packing.pack_frames on the fixture frames."""
+    import json
+    packing = pkg('packing')
+    if not os.path.exists(pkg('lib').LIB_PATH):
+        pytest.skip('library not built')
+    arr, frames = load_case(name)
+    text = json.dumps(frames)
+    a = packing.pack_json(text, calib.params)
+    b = packing.pack_frames(frames, calib.params)
+    for f in ('frame_head_off', 'frame_en_off', 'slot_cam', 'slot_n', 'head_cam', 'skeleton_index', 'joint_mask',
+              'tri_mask', 'xy', 'vp'):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    # stride / limit and a single frame object
+    c = packing.pack_json(text, calib.params, frame_start=1, frame_step=2, max_frames=1)
+    if len(frames) > 1:
+        d = packing.pack_frames(frames[1:2], calib.params)
+        assert np.array_equal(c.xy, d.xy) and np.array_equal(c.head_cam, d.head_cam)
+    e = packing.pack_json(json.dumps(frames[0]), calib.params)
+    assert e.n_frames == 1 and np.array_equal(e.xy, packing.pack_frames(frames[:1], calib.params).xy)
+
+
+def test_native_json_packer_rejects_garbage(calib):
+    packing = pkg('packing')
+    if not os.path.exists(pkg('lib').LIB_PATH):
+        pytest.skip('library not built')
+    for bad in ('', '[{"trackera": 5}]', '[{"trackera": ["[{\\"99\\": [1,2,3,4,5]}]", 0]}]', '[{"trackera": ["[{\\"5\\": [1,2]}]", 0]}]'):
+        with pytest.raises(ValueError):
+            packing.pack_json(bad, calib.params)
+    ok = packing.pack_json('[{}, {"zzz": ["[]", 0]}, {"trackerb": ["[{\\"ID\\": 7}, {\\"5\\": [5, 1.5, 2.5, 1, 0.25]}]", 0.0, "no_image", [{"-1": [1, 2, 3]}]]}]', calib.params)
+    assert ok.n_frames == 3 and ok.n_heads == 1 and ok.skeleton_index.tolist() == [1]
+    assert ok.xy[0, 5].tolist() == [1.5, 2.5] and ok.vp[0, 5].tolist() == [1.0, 0.25]
+
+
+def test_native_json_packer_numbers_are_python_floats(calib):
+    """x, y must come out as exactly the doubles Python's float() gives (the reference feeds
+    them to OpenCV in f64): shortest-repr and full 17-digit forms, tiny and huge magnitudes."""
+    import json
+    import random
+    import struct
+    packing = pkg('packing')
+    if not os.path.exists(pkg('lib').LIB_PATH):
+        pytest.skip('library not built')
+    random.seed(5)
+    vals = []
+    while len(vals) < 36000:
+        k = random.random()
+        if k < 0.35:
+            v = random.uniform(0, 1920)
+        elif k < 0.5:
+            v = round(random.uniform(0, 1920), random.randint(0, 12))
+        elif k < 0.7:
+            v = struct.unpack('d', struct.pack('Q', random.getrandbits(62)))[0]
+        elif k < 0.8:
+            v = float(random.randint(0, 10 ** random.randint(1, 18)))
+        else:
+            v = random.uniform(-1e-5, 1e-5) * 10 ** random.randint(-10, 10)
+        if v != v or abs(v) == float('inf'):
+            continue
+        vals.append(v)
+    sks = []
+    for i in range(0, len(vals), 36):
+        ch = vals[i:i + 36]
+        sks.append({str(j): [j, ch[2 * j], ch[2 * j + 1], 1, 1] for j in range(18)})
+    text = json.dumps([{'trackera': [json.dumps(sks[i:i + 10]), 0]} for i in range(0, len(sks), 10)])
+    pb = packing.pack_json(text, calib.params)
+    assert np.array_equal(pb.xy, np.array(vals).reshape(-1, 18, 2))
