@@ -221,6 +221,180 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// LDS-DMA variant: the K stages are written straight into LDS by `global_load_lds_dwordx4`
+// (no VGPR round trip, no ds_write).  The LDS image is row-major and dense -- row r of a tile
+// is one 128-byte line, its eight 16-byte chunks stored at chunk position c ^ g(r) with
+// g(r) = bit1(r) | bit2(r) << 2 -- so one wave-instruction moves 8 whole 128-B rows (lane i ->
+// row i/8, position i%8; the swizzle is applied on the per-lane SOURCE address) and the
+// fragment reads stay conflict-free ds_read_b128.  Wave w stages exactly the 32 activation
+// rows it consumes; the 80 weight rows are spread over the four waves.  One barrier per
+// stage: [wait own DMA + barrier] -> issue DMA of the next stage into the other buffer ->
+// 80 MFMAs on this one.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int dma_swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <bool LEAKY, bool ACC64>
+__global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
+                                                       const float *__restrict__ W, int ldw,
+                                                       const float *__restrict__ bias, float *__restrict__ C,
+                                                       int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
+                                                       int k_pad, float slope, int ntn, int n_major) {
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    constexpr int ROWF = 32;                   // floats per tile row (dense)
+    constexpr int W_OFF = GEMM_BM * ROWF;      // weight rows follow the activation rows
+
+    int M = m_cap;
+    if (d_m) {
+        int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    const int ntm = (M + GEMM_BM - 1) / GEMM_BM;
+    const int bid = blockIdx.x, nwg = ntm * ntn;
+    if (bid >= nwg) return;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int tm, tn;
+    if (n_major) {
+        tn = swz / ntm;
+        tm = swz - tn * ntm;
+    } else {
+        tm = swz / ntn;
+        tn = swz - tm * ntn;
+    }
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int dr = lane >> 3, dp = lane & 7;          // DMA role: row within the 8-row group, chunk position
+
+    // per-lane source pointers: 4 activation groups (rows 32w + 8g + dr), up to 3 weight groups
+    const float *a_src[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = wave * 32 + g * 8 + dr;
+        int grow = m0 + row;
+        grow = grow < M ? grow : M - 1;
+        a_src[g] = A + (size_t)grow * lda + ((dp ^ dma_swz(row)) << 2);
+    }
+    // weight rows: 10 groups of 8; wave w takes groups w, w+4, w+8 (the last only for w < 2)
+    const float *w_src[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        int grp = wave + 4 * g;
+        if (grp > 9) grp = 9;
+        const int row = grp * 8 + dr;
+        w_src[g] = W + (size_t)(n0 + row) * ldw + ((dp ^ dma_swz(row)) << 2);
+    }
+    const bool w_third = wave < 2;
+
+    const int fq = lane >> 4, fr = lane & 15;
+    const int fsw = dma_swz(fr);
+    int a_rd[MT], w_rd[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * ROWF;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) w_rd[nt] = W_OFF + (nt * 16 + fr) * ROWF;
+    const int c0 = ((fq * 2 + 0) ^ fsw) << 2, c1 = ((fq * 2 + 1) ^ fsw) << 2;
+
+    f32x4 acc[NT][MT];
+    double run[ACC64 ? NT : 1][ACC64 ? MT : 1][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ACC64) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] = 0.0;
+            }
+        }
+
+    const int nk = k_pad / GEMM_BK;
+
+    auto issue = [&](int kt, int buf) {
+        const int koff = kt * GEMM_BK;
+        float *base = lds + buf * STAGE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void *)(a_src[g] + koff),
+                                             (lds_void *)(base + (wave * 32 + g * 8) * ROWF), 16, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void *)(w_src[g] + koff),
+                                             (lds_void *)(base + W_OFF + (wave + 4 * g) * 8 * ROWF), 16, 0, 0);
+        if (w_third)
+            __builtin_amdgcn_global_load_lds((glb_void *)(w_src[2] + koff),
+                                             (lds_void *)(base + W_OFF + (wave + 8) * 8 * ROWF), 16, 0, 0);
+    };
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                       // own DMA landed (vmcnt 0) + everybody's, and everybody
+                                               // is done reading the other buffer
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const int cur = (kt & 1) * STAGE;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int co = hh ? c1 : c0;
+            f32x4 af[MT], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + co]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + co]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
+        }
+        if (ACC64) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] += (double)acc[nt][mt][i];
+                    acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nb = n0 + nt * 16 + fq * 4;
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wave * 32 + mt * 16 + fr;
+            if (m >= M) continue;
+            f32x4 v;
+            if (ACC64) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (float)(run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] + (double)bv[i]);
+            } else {
+                v = acc[nt][mt] + bv;
+            }
+            if (LEAKY) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+            }
+            float *dst = C + (size_t)m * ldc + nb;
+            if (nb + 3 < n) {
+                *reinterpret_cast<f32x4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (nb + i < n) dst[i] = v[i];
+            }
+        }
+    }
+}
+
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64) {
@@ -233,11 +407,20 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
 #define MPE_LAUNCH(L_, A_)                                                                                   \
     hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
                        slope, ntn, n_major, tune)
-    if (leaky && acc64) MPE_LAUNCH(true, true);
+#define MPE_LAUNCH_DMA(L_, A_)                                                                                 \
+    hipLaunchKernelGGL((k_linear_dma<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n,   \
+                       k_pad, slope, ntn, n_major)
+    if (!(tune & 8)) {      // LDS-DMA staging is the default; MPE_GEMM_TUNE=8 selects the register-staged kernel
+        if (leaky && acc64) MPE_LAUNCH_DMA(true, true);
+        else if (leaky) MPE_LAUNCH_DMA(true, false);
+        else if (acc64) MPE_LAUNCH_DMA(false, true);
+        else MPE_LAUNCH_DMA(false, false);
+    } else if (leaky && acc64) MPE_LAUNCH(true, true);
     else if (leaky) MPE_LAUNCH(true, false);
     else if (acc64) MPE_LAUNCH(false, true);
     else MPE_LAUNCH(false, false);
 #undef MPE_LAUNCH
+#undef MPE_LAUNCH_DMA
     return hipGetLastError();
 }
 
