@@ -221,6 +221,7 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
         a.out_slope = ctx->gat_hidden_slope;
         a.ld = ctx->act_ld;
         a.a12 = ctx->a12;
+        int n_rows_ft2 = 0;
         if (l == 0 && dense_in) {
             if ((rc = linear(ctx, s, ctx->xdense, ctx->feat_ld, g.fc1, ctx->hdense, ctx->feat_ld, n_nodes, nullptr, true,
                              ctx->gat_alpha, ctx->gat_acc64)))
@@ -228,9 +229,8 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
             if ((rc = linear(ctx, s, ctx->hdense, ctx->feat_ld, g.fc2, ctx->act[2], ctx->act_ld, n_nodes, nullptr, false,
                              0.f, ctx->gat_acc64)))
                 return rc;
-            HIPCHK(ctx, launch_attn_coef(s, ctx->act[2], ctx->act_ld, n_nodes, g.heads, g.out_dim, g.attn_l, g.attn_r,
-                                         ctx->a12));
             a.ft2 = ctx->act[2];
+            n_rows_ft2 = n_nodes;
         } else if (l == 0) {
             // heads only: edge-node rows are the layer-0 constants
             if ((rc = linear(ctx, s, ctx->x0, ctx->feat_ld, g.fc1, ctx->h0, ctx->feat_ld, b->n_heads, nullptr, true,
@@ -239,9 +239,8 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
             if ((rc = linear(ctx, s, ctx->h0, ctx->feat_ld, g.fc2, ctx->act[1], ctx->act_ld, b->n_heads, nullptr,
                              false, 0.f, ctx->gat_acc64)))
                 return rc;
-            HIPCHK(ctx, launch_attn_coef(s, ctx->act[1], ctx->act_ld, b->n_heads, g.heads, g.out_dim, g.attn_l,
-                                         g.attn_r, ctx->a12));
             a.ft2 = ctx->act[1];
+            n_rows_ft2 = b->n_heads;
             a.en_const_ft2 = ctx->en0_ft2;
             a.en_const_a = ctx->en0_a;
         } else {
@@ -251,9 +250,8 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
             if ((rc = linear(ctx, s, ctx->act[1], ctx->act_ld, g.fc2, ctx->act[2], ctx->act_ld, n_nodes, nullptr,
                              false, 0.f, ctx->gat_acc64)))
                 return rc;
-            HIPCHK(ctx, launch_attn_coef(s, ctx->act[2], ctx->act_ld, n_nodes, g.heads, g.out_dim, g.attn_l, g.attn_r,
-                                         ctx->a12));
             a.ft2 = ctx->act[2];
+            n_rows_ft2 = n_nodes;
         }
         if (last) {
             a.out_mode = 1;
@@ -266,7 +264,8 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
             a.out = ctx->act[0];
             a.ld_out = ctx->act_ld;
         }
-        HIPCHK(ctx, launch_aggregate(s, *b, V, hmax, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair, a));
+        HIPCHK(ctx, launch_gat_attention(s, *b, V, hmax, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair,
+                                         g.attn_l, g.attn_r, ctx->a12, a, n_rows_ft2));
     }
     return MPE_OK;
 }

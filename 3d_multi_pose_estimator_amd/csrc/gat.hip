@@ -12,6 +12,8 @@
 //   edge-node X = (h1,h2):      (h1,X), (h2,X), (X,X)
 //
 // Sums over in-edges run in that order (= DGL's edge order for a destination).
+#include <cstdlib>
+
 #include "mpe_internal.h"
 
 namespace mpe {
@@ -371,6 +373,225 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
         if (a.score_mode) a.out_heads[(size_t)hb + v] = o;
         else a.out[(size_t)(nb + v) * a.ld_out + c] = o;
     }
+}
+
+hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
+                            const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
+                            const int32_t *en_pair, const AggArgs &a);
+
+// ---------------------------------------------------------------------------------------
+// Fused attention stage for frames whose head slice fits in LDS: one workgroup per
+// (frame, attention head).  It loads ft2[:, head, :] of the frame once (N x D' floats),
+// computes a1/a2 (the two bmm of gat2.py:57-58), the edge softmax and the weighted sums, and
+// writes the activated output slice -- ft2 is read once and nothing else touches HBM.
+// Same operation order as k_attn_coef / k_aggregate_en / k_aggregate_heads, so the results
+// are bit-identical to the unfused path (which remains for large frames).
+// ---------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap, int m_cap,
+                                                   const int32_t *__restrict__ head_off,
+                                                   const int32_t *__restrict__ en_off,
+                                                   const int32_t *__restrict__ slot_n,
+                                                   const int32_t *__restrict__ node_off,
+                                                   const int32_t *__restrict__ en_pair,
+                                                   const float *__restrict__ attn_l,
+                                                   const float *__restrict__ attn_r, AggArgs a) {
+#pragma clang fp contract(off)
+    typedef float vecf __attribute__((ext_vector_type(VEC)));
+    extern __shared__ float s_dyn[];
+    const int f = blockIdx.x / a.heads, hh = blockIdx.x - f * a.heads;
+    const int D = a.out_dim, Dp = D | 1;           // odd row stride: conflict-free column walks
+    const int hb = head_off[f], H = head_off[f + 1] - hb;
+    const int eb = en_off[f], M = en_off[f + 1] - eb;
+    const int N = H + M, nb = node_off[f];
+    if (M <= 0 || N > n_cap || M > m_cap) return;   // frames without a graph produce nothing
+    float *s_ft = s_dyn;                            // [n_cap][Dp]
+    float *s_a1 = s_ft + (size_t)n_cap * Dp;        // [n_cap]
+    float *s_a2 = s_a1 + n_cap;                     // [n_cap]
+    float *s_wen = s_a2 + n_cap;                    // [m_cap][3] softmax weights of edge-nodes
+    float *s_wh = s_wen + (size_t)m_cap * 3;        // [hmax][max_deg] softmax weights of heads
+    int *s_src = reinterpret_cast<int *>(s_wh + (size_t)(max_deg - 1) * max_deg);   // [hmax][max_deg]
+    int *s_deg = s_src + (size_t)(max_deg - 1) * max_deg;                           // [hmax]
+    int *s_pair = s_deg + (max_deg - 1);                                            // [m_cap] h1 << 16 | h2
+    float *s_att = reinterpret_cast<float *>(s_pair + m_cap);                       // [2][D] attn_l | attn_r
+    const int t = threadIdx.x;
+    const bool l0 = a.en_const_ft2 != nullptr;
+    const int c0 = hh * D;
+    const int DV = D / VEC;
+
+    // phase 1: feature slice -> LDS (layer 0: ft2 holds head rows only, edge-nodes share one row)
+    for (int i = t; i < N * DV; i += blockDim.x) {
+        const int node = i / DV, d = (i - node * DV) * VEC;
+        const float *src;
+        if (l0) src = node < H ? a.ft2 + (size_t)(hb + node) * a.ld + c0 + d : a.en_const_ft2 + c0 + d;
+        else src = a.ft2 + (size_t)(nb + node) * a.ld + c0 + d;
+        const vecf v = *reinterpret_cast<const vecf *>(src);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) s_ft[node * Dp + d + k] = v[k];
+    }
+    for (int m = t; m < M; m += blockDim.x)
+        s_pair[m] = (en_pair[2 * (size_t)(eb + m)] << 16) | en_pair[2 * (size_t)(eb + m) + 1];
+    for (int d = t; d < 2 * D; d += blockDim.x) s_att[d] = d < D ? attn_l[c0 + d] : attn_r[c0 + d - D];
+    // in-edge lists of the heads (ascending edge id), one thread per head
+    for (int hd_ = t; hd_ < H; hd_ += blockDim.x) {
+        const int32_t *sn = slot_n + (size_t)f * V;
+        int s = 0, start = 0;
+        while (s < V && hd_ >= start + sn[s]) { start += sn[s]; ++s; }
+        const int i = hd_ - start, ns = sn[s];
+        int *src = s_src + hd_ * max_deg;
+        int deg = 0;
+        src[deg++] = hd_;
+        int base = H;
+        for (int p = 0; p < V; ++p)
+            for (int q = p + 1; q < V; ++q) {
+                const int np_ = sn[p], nq = sn[q];
+                if (q == s) {
+                    for (int k = 0; k < np_; ++k) src[deg++] = base + k * ns + i;
+                } else if (p == s) {
+                    for (int k = 0; k < nq; ++k) src[deg++] = base + i * nq + k;
+                }
+                base += np_ * nq;
+            }
+        s_deg[hd_] = deg;
+    }
+    __syncthreads();
+    // phase 2: a1 = <ft, attn_l[head]>, a2 = <ft, attn_r[head]>
+    for (int node = t; node < N; node += blockDim.x) {
+        const float *fv = s_ft + node * Dp;
+        float x1 = 0.f, x2 = 0.f;
+        for (int d = 0; d < D; ++d) {
+            x1 = __builtin_fmaf(fv[d], s_att[d], x1);
+            x2 = __builtin_fmaf(fv[d], s_att[D + d], x2);
+        }
+        s_a1[node] = x1;
+        s_a2[node] = x2;
+    }
+    __syncthreads();
+    // phase 3: softmax weights.  Edge-node X: in-edges (h1, h2, X); head h: its list.
+    for (int m = t; m < M; m += blockDim.x) {
+        const int pr = s_pair[m];
+        const int h1 = pr >> 16, h2 = pr & 0xFFFF, x = H + m;
+        const float a2v = s_a2[x];
+        float e1 = s_a1[h1] + a2v, e2 = s_a1[h2] + a2v, e3 = s_a1[x] + a2v;
+        e1 = e1 > 0.f ? e1 : e1 * a.alpha;
+        e2 = e2 > 0.f ? e2 : e2 * a.alpha;
+        e3 = e3 > 0.f ? e3 : e3 * a.alpha;
+        const float mx = fmaxf(fmaxf(e1, e2), e3);
+        const float x1 = expf(e1 - mx), x2 = expf(e2 - mx), x3 = expf(e3 - mx);
+        const float sum = (x1 + x2) + x3;
+        s_wen[m * 3 + 0] = x1 / sum;
+        s_wen[m * 3 + 1] = x2 / sum;
+        s_wen[m * 3 + 2] = x3 / sum;
+    }
+    if (!a.score_mode || a.out_heads) {
+        for (int h = t; h < H; h += blockDim.x) {
+            const int deg = s_deg[h];
+            const int *src = s_src + h * max_deg;
+            float *w = s_wh + h * max_deg;
+            const float a2v = s_a2[h];
+            float mx = -INFINITY;
+            for (int e = 0; e < deg; ++e) {
+                float x = s_a1[src[e]] + a2v;
+                x = x > 0.f ? x : x * a.alpha;
+                w[e] = x;
+                mx = fmaxf(mx, x);
+            }
+            float sum = 0.f;
+            for (int e = 0; e < deg; ++e) {
+                const float ex = expf(w[e] - mx);
+                w[e] = ex;
+                sum = sum + ex;
+            }
+            for (int e = 0; e < deg; ++e) w[e] = w[e] / sum;
+        }
+    }
+    __syncthreads();
+    // phase 4: weighted sums in edge order, activation, store
+    const int first = (a.score_mode && !a.out_heads) ? H : 0;
+    for (int i = first * DV + t; i < N * DV; i += blockDim.x) {
+        const int node = i / DV, d = (i - node * DV) * VEC;
+        vecf o;
+        if (node >= H) {
+            const int m = node - H;
+            const int pr = s_pair[m];
+            const int h1 = pr >> 16, h2 = pr & 0xFFFF;
+            const float w1 = s_wen[m * 3 + 0], w2 = s_wen[m * 3 + 1], w3 = s_wen[m * 3 + 2];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float acc = s_ft[h1 * Dp + d + k] * w1;
+                acc = acc + s_ft[h2 * Dp + d + k] * w2;
+                acc = acc + s_ft[node * Dp + d + k] * w3;
+                o[k] = agg_activate(acc, a.out_mode, a.out_slope);
+            }
+        } else {
+            const int deg = s_deg[node];
+            const int *src = s_src + node * max_deg;
+            const float *w = s_wh + node * max_deg;
+            float acc[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+            for (int e = 0; e < deg; ++e) {
+                const float we = w[e];
+                const float *fv = s_ft + src[e] * Dp + d;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float mm = fv[k] * we;
+                    acc[k] = acc[k] + mm;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = agg_activate(acc[k], a.out_mode, a.out_slope);
+        }
+        if (a.score_mode) {
+            if (node >= H) a.out[(size_t)eb + (node - H)] = o[0];
+            else a.out_heads[(size_t)hb + node] = o[0];
+        } else {
+            *reinterpret_cast<vecf *>(a.out + (size_t)(nb + node) * a.ld_out + c0 + d) = o;
+        }
+    }
+}
+
+// LDS bytes of k_gat_fused for frames of up to `hmax` heads (0 = does not fit)
+static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_cap) {
+    const int mc = hmax * hmax * (V - 1) / (2 * V) + 1;
+    const int nc = hmax + mc;
+    const int Dp = out_dim | 1;
+    const size_t deg = (size_t)hmax + 1;
+    const size_t bytes = ((size_t)nc * Dp + 2 * (size_t)nc + (size_t)mc * 3 + (size_t)hmax * deg + 2 * (size_t)out_dim) * sizeof(float) +
+                         ((size_t)hmax * deg + hmax + mc) * sizeof(int);
+    *n_cap = nc;
+    *m_cap = mc;
+    return bytes;
+}
+
+hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
+                                const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
+                                const int32_t *en_pair, const float *attn_l, const float *attn_r, float *a12,
+                                const AggArgs &a, int n_rows_ft2) {
+    int n_cap, m_cap;
+    const size_t shm = fused_lds_bytes(max_heads_per_frame, V, a.out_dim, &n_cap, &m_cap);
+    static const bool no_fuse = getenv("MPE_NO_FUSED_ATTENTION") != nullptr;
+    if (shm <= 64 * 1024 && !no_fuse && b.n_frames > 0) {
+        int vec = 1;
+        if (!a.score_mode && a.ld % 4 == 0 && a.ld_out % 4 == 0) {
+            if (a.out_dim % 4 == 0) vec = 4;
+            else if (a.out_dim % 2 == 0) vec = 2;
+        }
+#define MPE_FUSED(V_)                                                                                       \
+    hipLaunchKernelGGL(k_gat_fused<V_>, dim3(b.n_frames * a.heads), dim3(256), shm, s, V, max_heads_per_frame + 1, \
+                       n_cap, m_cap, b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, en_pair, attn_l,   \
+                       attn_r, a)
+        if (vec == 4) MPE_FUSED(4);
+        else if (vec == 2) MPE_FUSED(2);
+        else MPE_FUSED(1);
+#undef MPE_FUSED
+        return hipGetLastError();
+    }
+    hipError_t e = launch_attn_coef(s, a.ft2, a.ld, n_rows_ft2, a.heads, a.out_dim, attn_l, attn_r, a12);
+    if (e != hipSuccess) return e;
+    AggArgs a2 = a;
+    a2.a12 = a12;
+    return launch_aggregate(s, b, V, max_heads_per_frame, node_off, head_frame, en_frame, en_pair, a2);
 }
 
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,

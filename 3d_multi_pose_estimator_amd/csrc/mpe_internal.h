@@ -132,6 +132,11 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
                             const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
                             const int32_t *en_pair, const AggArgs &a);
 
+hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
+                                const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
+                                const int32_t *en_pair, const float *attn_l, const float *attn_r, float *a12,
+                                const AggArgs &a, int n_rows_ft2);
+
 // cluster.hip
 size_t cluster_keys_per_frame(int max_heads_per_frame);
 size_t cluster_scratch_per_frame(int max_heads_per_frame);
