@@ -10,7 +10,7 @@ rank processes its own 1k-frame shard (frames are independent)
 poses are all-gathered over RCCL each step; value = frames of all ranks / max-over-ranks time.
 
 The JSON line also carries
-  roofline      fp32-MFMA GEMM kernel (k_linear): algorithmic FLOPs of its launches / their
+  roofline      fp32-MFMA GEMM kernel (k_linear_dma): algorithmic FLOPs of its launches / their
                 summed duration, measured with HIP events on the launch stream inside the
                 timed region; peak = 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md)
   cpu_baseline  the CPU oracle (oracle/oracle_np.py, a port of the reference's algorithm on
@@ -179,7 +179,7 @@ def main():
         gemm_s = prof['gemm_ms'] * 1e-3
         achieved = prof['gemm_flop'] / gemm_s / 1e12 if gemm_s > 0 else 0.0
         out['roofline'] = {
-            'kernel': 'mpe::k_linear (fp32 MFMA 16x16x4 GEMM + bias + LeakyReLU)', 'bound': 'mfma',
+            'kernel': 'mpe::k_linear_dma (fp32 MFMA 16x16x4 GEMM, LDS-DMA staging, fused bias + LeakyReLU)', 'bound': 'mfma',
             'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(),
             'launches': prof['gemm_launches'], 'avg_launch_ms': prof['gemm_ms'] / max(1, prof['gemm_launches']),
