@@ -255,8 +255,10 @@ def make_frame(calib, frame_index, spec=None, seed=1234):
                 order = np.argsort(hash_uniform(seed, st + 40 + k, len(skeletons)), kind='stable')
                 skeletons = [skeletons[i] for i in order]
                 own = [own[i] for i in order]
-        gt_cm = [{('-1' if j == 2 else str(j)): [float(c) * 100.0 for c in pts[p, j]] for j in range(J)}
-                 for p in range(P)]
+        # bodies_3D is aligned with the skeleton list, as the converter writes it
+        # (get_joints_from_panoptic_model_multi.py:281-287): one GT body per 2D skeleton
+        gt_cm = [({('-1' if j == 2 else str(j)): [float(c) * 100.0 for c in pts[o, j]] for j in range(J)} if o >= 0 else {})
+                 for o in own]
         frame[cam] = [json.dumps(skeletons), float(frame_index), 'no_image', gt_cm]
         owner[cam] = own
     return frame, {'persons': pts, 'owner': owner}

@@ -20,3 +20,13 @@ def test_model_harness_runs():
     m = importlib.import_module('3d_multi_pose_estimator_amd.harness.metrics_from_model')
     out = m.main(['--synthetic', '24', '--random-weights', '--batch', '16'])
     assert 25 in out
+
+
+def test_sm_metrics_harness():
+    """Clustering-quality harness (reference test/sm_metrics.py): the ground-truth pairing as
+    scores must give a perfect grouping; the metric code is exercised end to end."""
+    m = importlib.import_module('3d_multi_pose_estimator_amd.harness.sm_metrics')
+    out = m.main(['--synthetic', '32', '--random-weights', '--teacher-scores', '--batch', '16'])
+    assert out['rand score'] > 0.999 and out['v_measure'] > 0.999
+    out2 = m.main(['--synthetic', '16', '--random-weights', '--batch', '16'])
+    assert 0.0 <= out2['homogeneity'] <= 1.0

@@ -116,9 +116,18 @@ def test_gat_scores_vs_golden(variant, name):
         np.testing.assert_allclose(sh.cpu().numpy(), want[:H], rtol=0, atol=2e-5)
 
 
-def test_cluster_known_answers_bit_exact(engine, calib):
+@pytest.mark.parametrize('variant', ['lds', 'global_scratch'])
+def test_cluster_known_answers_bit_exact(engine, calib, variant):
+    """400 known answers of the reference's get_person_proposal_from_network_output, through
+    both clustering kernels: k_cluster_lds (keys sorted in LDS) and k_cluster_big (frames whose
+    edge-node capacity exceeds the LDS budget: global scratch + heapsort)."""
     arr = np.load(os.path.join(GOLDEN, 'cluster_cases.npz'))
     packing = pkg('packing')
+    big = None
+    if variant == 'global_scratch':
+        # capacity of 40 skeletons per camera -> 200 heads per frame -> keys do not fit LDS
+        big = pkg('pipeline').Engine(calib.params, calib, max_frames=64, max_persons_per_camera=40)
+        engine = big
     V = engine.V
     # assemble all cases into batches of <= 64 frames
     cases = range(int(arr['n']))
@@ -157,6 +166,8 @@ def test_cluster_known_answers_bit_exact(engine, calib):
             want = arr['c%d_persons' % i]
             assert n_persons[f] == len(want), i
             assert np.array_equal(persons[f, :len(want)], want), i
+    if big is not None:
+        big.close()
 
 
 @pytest.mark.parametrize('variant,name', ALL_CASES)
