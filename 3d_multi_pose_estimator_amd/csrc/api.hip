@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <new>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "mpe_internal.h"
@@ -102,11 +103,15 @@ struct GemmProf {
 };
 
 int linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, const Linear &L, float *C, int ldc, int m,
-           const int32_t *d_m, bool leaky, float slope, bool acc64 = false) {
+           const int32_t *d_m, bool leaky, float slope, bool acc64 = false, const int32_t *a_rows = nullptr,
+           const int32_t *c_rows = nullptr, double flop_override = -1.0) {
     if (m <= 0) return MPE_OK;
     if (lda < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", lda, L.ldw);
-    GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0);
-    HIPCHK(ctx, launch_linear(s, A, lda, L.w, L.ldw, L.b, C, ldc, m, d_m, L.out_dim, L.ldw, leaky, slope, acc64));
+    const bool host_m = !d_m || flop_override >= 0.0;
+    GemmProf gp(ctx, s, flop_override >= 0.0 ? flop_override : (d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim),
+                host_m ? 0 : L.out_dim, host_m ? 0 : L.in_dim);
+    HIPCHK(ctx, launch_linear(s, A, lda, L.w, L.ldw, L.b, C, ldc, m, d_m, L.out_dim, L.ldw, leaky, slope, acc64, a_rows,
+                              c_rows));
     return MPE_OK;
 }
 
@@ -160,6 +165,26 @@ int ensure_gat_workspace(mpe_ctx *ctx) {
                                  ctx->en0_a));
     HIPCHK(ctx, hipDeviceSynchronize());
     ctx->en0_ready = true;
+    // layer-0 fc1 grouped by camera: a head row is e_0 plus the J*10 block of its own camera,
+    // so fc1(row) = W1[:, block_c] . feat + (b1 + W1[:,0]); K shrinks from F to J*10.
+    {
+        const int blk = J * 10;
+        ctx->l0_ld = round_up(blk, LD_ALIGN);
+        if ((rc = dev_alloc(ctx, &ctx->xc, (size_t)ctx->cfg.max_heads * ctx->l0_ld))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->cam_count, (size_t)V))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->cam_list, (size_t)V * ctx->cfg.max_heads))) return rc;
+        std::vector<float> wc((size_t)g0.in_dim * blk), bc(g0.in_dim);
+        for (int n = 0; n < g0.in_dim; ++n) bc[n] = b1[n] + w1[(size_t)n * g0.fc1.ldw + 0];
+        for (int c = 0; c < V; ++c) {
+            for (int n = 0; n < g0.in_dim; ++n)
+                memcpy(&wc[(size_t)n * blk], &w1[(size_t)n * g0.fc1.ldw + 2 + c * blk], blk * sizeof(float));
+            if ((rc = upload_linear(ctx, wc.data(), bc.data(), g0.in_dim, blk, &ctx->l0_fc1[c]))) return rc;
+        }
+        // pays when the camera block is a small part of the row (K shrinks V-fold); at V = 5 the
+        // five short launches cost as much as the one dense GEMM they replace (measured)
+        ctx->l0_grouped = V >= 8;
+        if (const char *e = getenv("MPE_L0_GROUPED")) ctx->l0_grouped = atoi(e) != 0;
+    }
     return MPE_OK;
 }
 
@@ -207,6 +232,10 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
         HIPCHK(ctx, hipMemcpy2DAsync(ctx->xdense, (size_t)ctx->feat_ld * sizeof(float), d_feats,
                                      (size_t)ld_feats * sizeof(float), (size_t)ctx->gat[0].in_dim * sizeof(float),
                                      n_nodes, hipMemcpyDeviceToDevice, s));
+    } else if (ctx->l0_grouped) {
+        HIPCHK(ctx, launch_head_features(s, ctx->d_cfg, *b, J, ctx->xc, ctx->l0_ld, 0, 0, false));
+        HIPCHK(ctx, launch_group_heads(s, b->n_heads, V, b->d_head_cam, ctx->cam_count, ctx->cam_list,
+                                       ctx->cfg.max_heads));
     } else {
         HIPCHK(ctx, launch_head_features(s, ctx->d_cfg, *b, J, ctx->x0, ctx->feat_ld, 0, 0, true));
     }
@@ -233,8 +262,18 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
             n_rows_ft2 = n_nodes;
         } else if (l == 0) {
             // heads only: edge-node rows are the layer-0 constants
-            if ((rc = linear(ctx, s, ctx->x0, ctx->feat_ld, g.fc1, ctx->h0, ctx->feat_ld, b->n_heads, nullptr, true,
-                             ctx->gat_alpha, ctx->gat_acc64)))
+            if (ctx->l0_grouped) {
+                // one launch per camera over that camera's heads (device-side count), rows gathered
+                // from the compact features and scattered back to head order
+                const double flop_each = 2.0 * b->n_heads * (double)g.in_dim * (J * 10) / V;
+                for (int c = 0; c < V; ++c)
+                    if ((rc = linear(ctx, s, ctx->xc, ctx->l0_ld, ctx->l0_fc1[c], ctx->h0, ctx->feat_ld, b->n_heads,
+                                     ctx->cam_count + c, true, ctx->gat_alpha, ctx->gat_acc64,
+                                     ctx->cam_list + (size_t)c * ctx->cfg.max_heads,
+                                     ctx->cam_list + (size_t)c * ctx->cfg.max_heads, flop_each)))
+                        return rc;
+            } else if ((rc = linear(ctx, s, ctx->x0, ctx->feat_ld, g.fc1, ctx->h0, ctx->feat_ld, b->n_heads, nullptr,
+                                    true, ctx->gat_alpha, ctx->gat_acc64)))
                 return rc;
             if ((rc = linear(ctx, s, ctx->h0, ctx->feat_ld, g.fc2, ctx->act[1], ctx->act_ld, b->n_heads, nullptr,
                              false, 0.f, ctx->gat_acc64)))

@@ -142,6 +142,25 @@ hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batc
     return hipGetLastError();
 }
 
+// heads of every camera (order inside a camera is irrelevant: rows are independent)
+__global__ void k_group_heads(int n_heads, const int32_t *__restrict__ head_cam, int32_t *__restrict__ cam_count,
+                              int32_t *__restrict__ cam_list, int list_stride) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_heads) return;
+    const int c = head_cam[h];
+    const int pos = atomicAdd(&cam_count[c], 1);
+    cam_list[(size_t)c * list_stride + pos] = h;
+}
+
+hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *head_cam, int32_t *cam_count,
+                              int32_t *cam_list, int list_stride) {
+    hipError_t e = hipMemsetAsync(cam_count, 0, (size_t)V * sizeof(int32_t), s);
+    if (e != hipSuccess || n_heads <= 0) return e;
+    hipLaunchKernelGGL(k_group_heads, dim3((n_heads + 255) / 256), dim3(256), 0, s, n_heads, head_cam, cam_count,
+                       cam_list, list_stride);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 // attention coefficients a1 = <ft2[n,h,:], attn_l[h,:]>, a2 with attn_r  (gat2.py:57-58)
 // ---------------------------------------------------------------------------------------

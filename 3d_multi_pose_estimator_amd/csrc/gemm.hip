@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
                                                        const float *__restrict__ W, int ldw,
                                                        const float *__restrict__ bias, float *__restrict__ C,
                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
-                                                       int k_pad, float slope, int ntn, int n_major) {
+                                                       int k_pad, float slope, int ntn, int n_major,
+                                                       const int32_t *__restrict__ a_rows,
+                                                       const int32_t *__restrict__ c_rows) {
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
     constexpr int ROWF = 32;                   // floats per tile row (dense)
     constexpr int W_OFF = GEMM_BM * ROWF;      // weight rows follow the activation rows
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
         const int row = wave * 32 + g * 8 + dr;
         int grow = m0 + row;
         grow = grow < M ? grow : M - 1;
+        if (a_rows) grow = a_rows[grow];           // gathered rows (grouped layer-0 GEMM)
         a_src[g] = A + (size_t)grow * lda + ((dp ^ dma_swz(row)) << 2);
     }
     // weight rows: 10 groups of 8; wave w takes groups w, w+4, w+8 (the last only for w < 2)
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
             }
-            float *dst = C + (size_t)m * ldc + nb;
+            const int mo = c_rows ? c_rows[m] : m;
+            float *dst = C + (size_t)mo * ldc + nb;
             if (nb + 3 < n) {
                 *reinterpret_cast<f32x4 *>(dst) = v;
             } else {
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
 
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
-                         float slope, bool acc64) {
+                         float slope, bool acc64, const int32_t *a_rows, const int32_t *c_rows) {
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
     const int ntn = (n + GEMM_BN - 1) / GEMM_BN;
@@ -409,8 +413,8 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
                        slope, ntn, n_major, tune)
 #define MPE_LAUNCH_DMA(L_, A_)                                                                                 \
     hipLaunchKernelGGL((k_linear_dma<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n,   \
-                       k_pad, slope, ntn, n_major)
-    if (!(tune & 8)) {      // LDS-DMA staging is the default; MPE_GEMM_TUNE=8 selects the register-staged kernel
+                       k_pad, slope, ntn, n_major, a_rows, c_rows)
+    if (!(tune & 8) || a_rows || c_rows) {      // LDS-DMA staging is the default; MPE_GEMM_TUNE=8 selects the register-staged kernel
         if (leaky && acc64) MPE_LAUNCH_DMA(true, true);
         else if (leaky) MPE_LAUNCH_DMA(true, false);
         else if (acc64) MPE_LAUNCH_DMA(false, true);

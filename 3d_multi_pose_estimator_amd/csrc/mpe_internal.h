@@ -75,6 +75,13 @@ struct mpe_ctx {
     float *h0 = nullptr;           // [max_heads][feat_ld] fc1 output of layer 0
     float *xdense = nullptr;       // [max_nodes][feat_ld] caller-provided dense rows (API mirror only)
     float *hdense = nullptr;
+    // layer 0 grouped by camera: only the own-camera block of a head row is non-zero
+    float *xc = nullptr;           // [max_heads][l0_ld] compact J*10 features
+    int l0_ld = 0;
+    mpe::Linear l0_fc1[MPE_MAX_CAMERAS];   // fc1 restricted to the camera's column block, bias + W[:,0]
+    int32_t *cam_count = nullptr;  // [V]
+    int32_t *cam_list = nullptr;   // [V][max_heads] head indices of each camera
+    bool l0_grouped = true;
     float *act[3] = {nullptr, nullptr, nullptr};   // [max_nodes][act_ld]
     float *a12 = nullptr;          // [max_nodes][2*16]
     int32_t *head_frame = nullptr; // [max_heads]
@@ -105,7 +112,9 @@ namespace mpe {
 // gemm.hip
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
-                         float slope, bool acc64);
+                         float slope, bool acc64, const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr);
+hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *head_cam, int32_t *cam_count,
+                              int32_t *cam_list, int list_stride);
 
 // gat.hip
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
