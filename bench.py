@@ -40,6 +40,8 @@ def main():
     ap.add_argument('--mode', choices=['mlp', 'tri'], default='mlp')
     ap.add_argument('--cpu-sample', type=int, default=40, help='frames of the CPU baseline sample (0 = skip)')
     ap.add_argument('--fast-mlp', action='store_true', help='plain fp32 accumulation in the MLP GEMMs')
+    ap.add_argument('--preset', default='PANOPTIC', choices=['PANOPTIC', 'ARPLAB', 'RING23'],
+                    help='camera rig; RING23 = the 23-view stress rig of BASELINE.json configs[4] (fp32 here)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)')
     ap.add_argument('--streams', type=int, default=1, choices=[1, 2],
                     help='2 = software pipeline across steps: matching of batch i+1 overlaps the 3D stage of batch i')
@@ -68,8 +70,8 @@ def main():
     cal = importlib.import_module(PKG + '.calibration')
     par = importlib.import_module(PKG + '.parameters')
     pipeline = importlib.import_module(PKG + '.pipeline')
-    params = par.parameters
-    calib = cal.Calibration(params)
+    params = par.select(args.preset)
+    calib = cal.Calibration(params, syn.ring_transform_manager(params) if args.preset == 'RING23' else None)
     V, J = len(params.used_cameras_skeleton_matching), len(params.joint_list)
     nf = 2 + V * J * 10
     # logit shift chosen so that nearly every pair clears the 0.5 threshold: the greedy
@@ -167,8 +169,8 @@ def main():
         'value': value, 'unit': 'frames/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': ('c2: Panoptic 5-view x %d-person, GAT match + %s, %d-frame batch per GPU'
-                                % (args.persons, 'MLP 3D' if args.mode == 'mlp' else 'DLT triangulation', B)),
+        'config': {'workload': ('%s: %d-view x %d-person, GAT match + %s, %d-frame batch per GPU'
+                                % ('c2 Panoptic' if args.preset == 'PANOPTIC' else args.preset, V, args.persons, 'MLP 3D' if args.mode == 'mlp' else 'DLT triangulation', B)),
                    'frames_per_step_per_gpu': B, 'heads_per_batch': pb.n_heads, 'edge_nodes_per_batch': pb.n_edge_nodes,
                    'persons_found_per_frame': persons_per_frame, 'parallelism': 'frame-shard x%d' % n_gpus,
                    'streams': args.streams,
