@@ -296,3 +296,46 @@ def test_batch_vs_oracle(engine, calib, gat_weights, mlp_weights):
             assert np.min(np.diff(s)) < 1e-4
     assert exact >= 44, (exact, flagged)
     assert worst_pose < 1.2e-5
+
+
+def test_mpjpe_equal_to_reference_path(engine, calib, mlp_weights):
+    """North star: "MPJPE equal to reference within 0.01 mm".  Same clusters (ground-truth
+    pairing through the clustering kernel), both 3D stages, MPJPE against the synthetic ground
+    truth computed for the HIP path and for the CPU oracle."""
+    onp = oracle()
+    syn = pkg('synthetic')
+    common = pkg('harness.common')
+    spec = syn.FrameSpec(persons=4, noise_px=1.0)
+    frames, owners, gts = [], [], []
+    for i in range(24):
+        f, gt = syn.make_frame(calib, 500 + i, spec)
+        frames.append(onp.processed_input(f))
+        owners.append(gt['owner'])
+        gts.append(gt['persons'])
+    db = engine.to_device(engine.pack(frames, keep_json=True))
+    persons, n_persons = engine.cluster(db, common.teacher_scores(db, owners))
+    poses, valid = engine.mlp3d(db, persons, n_persons)
+    tri, jv = engine.triangulate(db, persons, n_persons)
+    persons, n_persons = persons.cpu().numpy(), n_persons.cpu().numpy()
+    poses, tri, jv = poses.cpu().numpy(), tri.cpu().numpy(), jv.cpu().numpy()
+    sm = list(calib.params.used_cameras_skeleton_matching)
+    used = calib.params.used_joints
+
+    def mpjpe(pred, gt_people):
+        return min(float(np.mean([np.linalg.norm(pred[j] - g[j]) for j in used])) for g in gt_people)
+    e = {'mlp_gpu': [], 'mlp_cpu': [], 'tri_gpu': [], 'tri_cpu': []}
+    for f in range(len(frames)):
+        assert n_persons[f] == 4
+        for k in range(4):
+            sk = onp.person_skeletons(list(persons[f, k]), db.host.jsons_for_head[f], sm)
+            row, kept = onp.mlp_input_row(sk, calib)
+            cpu_pose = onp.decode_pose(onp.mlp_forward(mlp_weights, row[None])[0], 18)
+            cpu_tri = onp.triangulate_person(sk, calib)
+            e['mlp_gpu'].append(mpjpe(poses[f, k], gts[f]))
+            e['mlp_cpu'].append(mpjpe(cpu_pose, gts[f]))
+            e['tri_gpu'].append(mpjpe(tri[f, k], gts[f]))
+            e['tri_cpu'].append(mpjpe(np.stack([cpu_tri.get(j, np.zeros(3)) for j in range(18)]), gts[f]))
+    m = {k: float(np.mean(v)) for k, v in e.items()}
+    assert abs(m['mlp_gpu'] - m['mlp_cpu']) < 1e-5          # 0.01 mm
+    assert abs(m['tri_gpu'] - m['tri_cpu']) < 1e-8
+    assert m['tri_gpu'] < 0.01                               # 1 px of noise -> millimetres
