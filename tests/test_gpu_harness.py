@@ -30,3 +30,14 @@ def test_sm_metrics_harness():
     assert out['rand score'] > 0.999 and out['v_measure'] > 0.999
     out2 = m.main(['--synthetic', '16', '--random-weights', '--batch', '16'])
     assert 0.0 <= out2['homogeneity'] <= 1.0
+
+
+def test_reprojection_error_harness():
+    """reference test/reprojection_error.py: triangulated joints of correctly grouped, noise-free
+    detections reproject onto the detections (sub-pixel; the radial-only model of the metric
+    ignores the small tangential terms of the generator's lens model)."""
+    m = importlib.import_module('3d_multi_pose_estimator_amd.harness.reprojection_error')
+    out = m.main(['--synthetic', '16', '--random-weights', '--teacher-scores', '--batch', '16'])
+    tri = [v for (kind, cam), v in out.items() if kind == 'triang']
+    assert len(tri) == 5 and max(t[1] for t in tri) < 2.0
+    assert any(kind == 'est' for kind, _ in out)
