@@ -134,7 +134,20 @@ class Engine:
         if isinstance(pb, DeviceBatch):
             return pb
         assert isinstance(pb, PackedBatch)
+        self.check_capacity(pb)
         return pb.to(self.device)
+
+    def check_capacity(self, pb):
+        """The kernels size their LDS / scratch from the capacities given at construction; a
+        batch beyond them must be rejected here (the C ABI cannot see per-frame counts)."""
+        if pb.n_frames > self.max_frames:
+            raise ValueError('batch of %d frames exceeds max_frames=%d' % (pb.n_frames, self.max_frames))
+        if pb.n_frames and pb.max_heads_per_frame() > self.hpf:
+            raise ValueError('a frame holds %d skeletons, capacity is %d (raise max_persons_per_camera / '
+                             'max_heads_per_frame)' % (pb.max_heads_per_frame(), self.hpf))
+        if pb.V != self.V or pb.J != self.J:
+            raise ValueError('batch packed for %d cameras x %d joints, engine built for %d x %d'
+                             % (pb.V, pb.J, self.V, self.J))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -339,3 +339,49 @@ def test_mpjpe_equal_to_reference_path(engine, calib, mlp_weights):
     assert abs(m['mlp_gpu'] - m['mlp_cpu']) < 1e-5          # 0.01 mm
     assert abs(m['tri_gpu'] - m['tri_cpu']) < 1e-8
     assert m['tri_gpu'] < 0.01                               # 1 px of noise -> millimetres
+
+
+def test_ragged_and_empty_frames(engine, calib, gat_weights, mlp_weights):
+    """Edge cases of the reference's skip rules inside one batch: an empty frame, a frame with a
+    single camera (heads but no cross-camera pair -> no graph, metrics_from_model.py:195-196), a
+    camera whose skeletons have no joints, and normal frames around them."""
+    onp = oracle()
+    syn = pkg('synthetic')
+    sd, prm = gat_weights
+    normal = [onp.processed_input(syn.make_frame(calib, 900 + i)[0]) for i in range(3)]
+    one_cam = {'trackerb': normal[0]['trackerb']}
+    hollow = dict(normal[1])
+    hollow['trackera'] = ['[{"ID": 1}, {}]', 0]
+    frames = [normal[0], {}, one_cam, hollow, normal[2]]
+    db = engine.to_device(engine.pack(frames))
+    scores, persons, n_persons = engine.match(db)
+    poses, valid = engine.mlp3d(db, persons, n_persons)
+    tri, jv = engine.triangulate(db, persons, n_persons)
+    torch.cuda.synchronize()
+    n_persons = n_persons.cpu().numpy()
+    assert n_persons[1] == 0 and n_persons[2] == 0
+    scores = scores.cpu().numpy()
+    sm = list(calib.params.used_cameras_skeleton_matching)
+    for f in (0, 3, 4):
+        h0, H, e0, M = db.host.frame_counts(f)
+        res = onp.run_frame(frames[f], calib, sd, prm, mlp_weights, mode='mlp')
+        np.testing.assert_allclose(scores[e0:e0 + M], res['scores'], rtol=0, atol=2e-5)
+        head_cam = [sm.index(c) for c in res['graph']['nodes_camera'][:H]]
+        own = onp.cluster(scores[e0:e0 + M], res['graph']['pairs'], H, head_cam, len(sm))
+        assert n_persons[f] == len(own)
+        assert np.array_equal(persons[f, :len(own)].cpu().numpy(), np.array(own, np.int32).reshape(-1, len(sm)))
+    assert not valid[1].any() and not valid[2].any()
+
+
+def test_capacity_is_enforced(calib):
+    syn = pkg('synthetic')
+    onp = oracle()
+    eng = pkg('pipeline').Engine(calib.params, calib, max_frames=2, max_persons_per_camera=2)
+    try:
+        frame = onp.processed_input(syn.make_frame(calib, 1)[0])       # 4 skeletons per camera
+        with pytest.raises(ValueError):
+            eng.to_device(eng.pack([frame]))
+        with pytest.raises(ValueError):
+            eng.to_device(eng.pack([{}, {}, {}]))
+    finally:
+        eng.close()
