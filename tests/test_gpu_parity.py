@@ -385,3 +385,65 @@ def test_capacity_is_enforced(calib):
             eng.to_device(eng.pack([{}, {}, {}]))
     finally:
         eng.close()
+
+
+def test_full_size_batch_properties(calib, gat_weights, mlp_weights):
+    """BASELINE configs[1] at full size (1000 frames, 5 views x 4 persons).  Size-independent
+    properties: (1) frames are independent units, so any split / reordering of the batch gives
+    bit-identical per-frame results (scores, clusters, poses); (2) structural invariants of the
+    clustering output; (3) a 25-frame sample agrees with the CPU oracle."""
+    onp = oracle()
+    syn = pkg('synthetic')
+    sd, prm = gat_weights
+    eng = pkg('pipeline').Engine(calib.params, calib, max_frames=1000, max_persons_per_camera=4)
+    try:
+        eng.load_gat(sd, prm)
+        eng.load_mlp(mlp_weights)
+        specs = [syn.FrameSpec(persons=4), syn.FrameSpec(persons=4, noise_px=2.0, joint_drop=0.1),
+                 syn.FrameSpec(persons=3), syn.FrameSpec(persons=4, cameras=['trackere', 'trackerb', 'trackera', 'trackerd'])]
+        uniq = [onp.processed_input(syn.make_frame(calib, 2000 + i, specs[i % 4])[0]) for i in range(100)]
+        frames = [uniq[(7 * i) % 100] for i in range(1000)]
+
+        def run(fr):
+            db = eng.to_device(eng.pack(fr))
+            sc, p, n = eng.match(db)
+            poses, valid = eng.mlp3d(db, p, n)
+            tri, jv = eng.triangulate(db, p, n)
+            torch.cuda.synchronize()
+            return db, sc.cpu().numpy(), p.cpu().numpy(), n.cpu().numpy(), poses.cpu().numpy(), tri.cpu().numpy()
+        db, sc, p, n, poses, tri = run(frames)
+        assert db.n_frames == 1000
+        # (1a) ten chunks of 100
+        e_off = db.host.frame_en_off
+        for c in range(0, 1000, 100):
+            _, sc2, p2, n2, poses2, tri2 = run(frames[c:c + 100])
+            assert np.array_equal(sc2, sc[e_off[c]:e_off[c + 100]])
+            assert np.array_equal(p2, p[c:c + 100]) and np.array_equal(n2, n[c:c + 100])
+            assert np.array_equal(poses2, poses[c:c + 100]) and np.array_equal(tri2, tri[c:c + 100])
+        # (1b) reversed order
+        _, scr, pr, nr, posesr, trir = run(frames[::-1])
+        assert np.array_equal(pr[::-1], p) and np.array_equal(nr[::-1], n)
+        assert np.array_equal(posesr[::-1], poses) and np.array_equal(trir[::-1], tri)
+        # (2) invariants: a head belongs to at most one person, every person spans >= 2 cameras,
+        #     the head sits in the camera column it was detected by
+        for f in range(1000):
+            h0, H, e0, M = db.host.frame_counts(f)
+            seen = set()
+            for k in range(n[f]):
+                members = [(c, h) for c, h in enumerate(p[f, k]) if h >= 0]
+                assert len(members) >= calib.params.min_number_of_views
+                for c, h in members:
+                    assert h < H and db.host.head_cam[h0 + h] == c and h not in seen
+                    seen.add(h)
+            assert (p[f, n[f]:] == -1).all()
+        # (3) oracle on a sample
+        sm = list(calib.params.used_cameras_skeleton_matching)
+        for f in range(0, 1000, 40):
+            h0, H, e0, M = db.host.frame_counts(f)
+            res = onp.run_frame(frames[f], calib, sd, prm, mlp_weights, mode='mlp')
+            np.testing.assert_allclose(sc[e0:e0 + M], res['scores'], rtol=0, atol=2e-5)
+            head_cam = [sm.index(c) for c in res['graph']['nodes_camera'][:H]]
+            own = onp.cluster(sc[e0:e0 + M], res['graph']['pairs'], H, head_cam, len(sm))
+            assert n[f] == len(own) and np.array_equal(p[f, :len(own)], np.array(own, np.int32).reshape(-1, len(sm)))
+    finally:
+        eng.close()
