@@ -188,6 +188,29 @@ int ensure_gat_workspace(mpe_ctx *ctx) {
     return MPE_OK;
 }
 
+unsigned short f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);          // round to nearest even
+    return (unsigned short)(u >> 16);
+}
+
+int ensure_bf16_weights(mpe_ctx *ctx, Linear *L) {
+    if (L->w16) return MPE_OK;
+    const int rows = round_up(L->out_dim, GEMM_BN);
+    L->ldw16 = round_up(L->in_dim, 128);
+    std::vector<float> w((size_t)rows * L->ldw);
+    HIPCHK(ctx, hipMemcpy(w.data(), L->w, w.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<unsigned short> wb((size_t)rows * L->ldw16, 0);
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < L->in_dim; ++k) wb[(size_t)r * L->ldw16 + k] = f32_to_bf16(w[(size_t)r * L->ldw + k]);
+    int rc = dev_alloc(ctx, &L->w16, wb.size(), false);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy(L->w16, wb.data(), wb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    return MPE_OK;
+}
+
 int ensure_mlp_workspace(mpe_ctx *ctx) {
     if (ctx->mlp_rows) return MPE_OK;
     if (ctx->mlp_layers <= 0) return fail(ctx, MPE_ERR_STATE, "MLP parameters not set");
@@ -203,8 +226,8 @@ int ensure_mlp_workspace(mpe_ctx *ctx) {
             return fail(ctx, MPE_ERR_INVALID, "MLP layer %d input width mismatch", l);
         widest = widest > ctx->mlp[l].out_dim ? widest : ctx->mlp[l].out_dim;
     }
-    ctx->mlp_ld_in = round_up(ctx->mlp[0].in_dim, LD_ALIGN);
-    ctx->mlp_ld_hidden = round_up(widest, LD_ALIGN);
+    ctx->mlp_ld_in = round_up(ctx->mlp[0].in_dim, 128);       // 128: K stage of the bf16 variant
+    ctx->mlp_ld_hidden = round_up(widest, 128);
     const size_t rows = (size_t)ctx->cfg.max_frames * ctx->cfg.max_persons_per_frame;
     int rc;
     if ((rc = dev_alloc(ctx, &ctx->mlp_rows, rows * ctx->mlp_ld_in))) return rc;
@@ -572,8 +595,15 @@ static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int 
     for (int l = 0; l < ctx->mlp_layers; ++l) {
         float *out = ctx->mlp_act[l & 1];
         const bool last = l == ctx->mlp_layers - 1;
-        if ((rc = linear(ctx, s, in, ld_in, ctx->mlp[l], out, ctx->mlp_ld_hidden, m, d_m, !last, ctx->mlp_slope,
-                         ctx->mlp_acc64)))
+        if (ctx->mlp_bf16) {
+            Linear &L = ctx->mlp[l];
+            if ((rc = ensure_bf16_weights(ctx, &L))) return rc;
+            if (ld_in < L.ldw16) return fail(ctx, MPE_ERR_INVALID, "bf16 GEMM needs an input stride >= %d", L.ldw16);
+            GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0);
+            HIPCHK(ctx, launch_linear_bf16(s, in, ld_in, L.w16, L.ldw16, L.b, out, ctx->mlp_ld_hidden, m, d_m, L.out_dim,
+                                           L.ldw16, !last, ctx->mlp_slope));
+        } else if ((rc = linear(ctx, s, in, ld_in, ctx->mlp[l], out, ctx->mlp_ld_hidden, m, d_m, !last, ctx->mlp_slope,
+                                ctx->mlp_acc64)))
             return rc;
         in = out;
         ld_in = ctx->mlp_ld_hidden;
@@ -643,8 +673,11 @@ int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t
 
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
     if (!ctx) return MPE_ERR_INVALID;
-    ctx->gat_acc64 = gat_acc64 != 0;
-    ctx->mlp_acc64 = mlp_acc64 != 0;
+    if (gat_acc64 < 0 || gat_acc64 > 1 || mlp_acc64 < 0 || mlp_acc64 > 2)
+        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0|1, MLP 0|1|2");
+    ctx->gat_acc64 = gat_acc64 == 1;
+    ctx->mlp_acc64 = mlp_acc64 == 1;
+    ctx->mlp_bf16 = mlp_acc64 == 2;
     return MPE_OK;
 }
 

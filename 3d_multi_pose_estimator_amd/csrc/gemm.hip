@@ -399,6 +399,177 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// bf16 variant (reduced precision, BASELINE.json configs[4]: "bf16 MLP MFMA GEMM"):
+// C = act(bf16(A) * W_bf16^T + b) with fp32 accumulation on v_mfma_f32_16x16x32_bf16
+// (16x the fp32 MFMA rate).  Activations stay fp32 in memory and are rounded to bf16 while
+// they are staged (v_cvt_pk_bf16_f32); weights are converted once at upload.  Tile 128x80x128:
+// a 256-B LDS row holds the 128 k of one tile row as sixteen 16-byte chunks stored at chunk
+// position c ^ (row & 15), which makes both the ds_write_b128 of the staging pass and the
+// ds_read_b128 fragment reads conflict-free.  Single LDS buffer (52 KB, 3 WG/CU), register
+// prefetch of the next stage, two barriers per stage.  Not used on the parity path.
+// ---------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+constexpr int BF_BK = 128;
+constexpr int BF_ROWB = BF_BK * 2;                       // bytes per tile row
+constexpr int BF_A_PASSES = GEMM_BM * 16 / 256;          // 16 chunks per row, 256 threads -> 8
+constexpr int BF_W_PASSES = GEMM_BN * 16 / 256;          // 5
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    bf2 v = {(__bf16)lo, (__bf16)hi};                    // v_cvt_pk_bf16_f32, round to nearest even
+    unsigned u;
+    __builtin_memcpy(&u, &v, 4);
+    return u;
+}
+
+template <bool LEAKY>
+__global__ __launch_bounds__(256, 2) void k_linear_bf16(const float *__restrict__ A, int lda,
+                                                        const unsigned short *__restrict__ Wb, int ldw,
+                                                        const float *__restrict__ bias, float *__restrict__ C,
+                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
+                                                        int k_pad, float slope, int ntn, int n_major) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(GEMM_BM + GEMM_BN) * BF_ROWB];
+    int M = m_cap;
+    if (d_m) {
+        int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    const int ntm = (M + GEMM_BM - 1) / GEMM_BM;
+    const int bid = blockIdx.x, nwg = ntm * ntn;
+    if (bid >= nwg) return;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int tm, tn;
+    if (n_major) {
+        tn = swz / ntm;
+        tm = swz - tn * ntm;
+    } else {
+        tm = swz / ntn;
+        tn = swz - tm * ntn;
+    }
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int sc = tid & 15, sr = tid >> 4;              // staging role: chunk 0..15, row 0..15 (+16 per pass)
+
+    const float *a_src[BF_A_PASSES];
+    int a_dst[BF_A_PASSES];
+#pragma unroll
+    for (int p = 0; p < BF_A_PASSES; ++p) {
+        const int row = p * 16 + sr;
+        int grow = m0 + row;
+        grow = grow < M ? grow : M - 1;
+        a_src[p] = A + (size_t)grow * lda + sc * 8;
+        a_dst[p] = row * BF_ROWB + ((sc ^ (row & 15)) << 4);
+    }
+    const unsigned short *w_src[BF_W_PASSES];
+    int w_dst[BF_W_PASSES];
+#pragma unroll
+    for (int p = 0; p < BF_W_PASSES; ++p) {
+        const int row = p * 16 + sr;
+        w_src[p] = Wb + (size_t)(n0 + row) * ldw + sc * 8;
+        w_dst[p] = (GEMM_BM + row) * BF_ROWB + ((sc ^ (row & 15)) << 4);
+    }
+    const int fq = lane >> 4, fr = lane & 15;
+    int a_rd[MT], w_rd[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * BF_ROWB;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) w_rd[nt] = (GEMM_BM + nt * 16 + fr) * BF_ROWB;
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 pa[BF_A_PASSES], pw[BF_W_PASSES];
+    const int nk = k_pad / BF_BK;
+
+    auto load = [&](int kt) {
+        const int koff = kt * BF_BK;
+#pragma unroll
+        for (int p = 0; p < BF_A_PASSES; ++p) {
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(a_src[p] + koff);
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(a_src[p] + koff + 4);
+            pa[p] = (u32x4){pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]),
+                            pack_bf16(hi[2], hi[3])};
+        }
+#pragma unroll
+        for (int p = 0; p < BF_W_PASSES; ++p) pw[p] = *reinterpret_cast<const u32x4 *>(w_src[p] + koff);
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int p = 0; p < BF_A_PASSES; ++p) *reinterpret_cast<u32x4 *>(&lds[a_dst[p]]) = pa[p];
+#pragma unroll
+        for (int p = 0; p < BF_W_PASSES; ++p) *reinterpret_cast<u32x4 *>(&lds[w_dst[p]]) = pw[p];
+    };
+
+    load(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store();
+        __syncthreads();
+        if (kt + 1 < nk) load(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int co = ((s * 4 + fq) ^ fr) << 4;
+            bf16x8 af[MT], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8 *>(&lds[a_rd[mt] + co]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const bf16x8 *>(&lds[w_rd[nt] + co]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nb = n0 + nt * 16 + fq * 4;
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wave * 32 + mt * 16 + fr;
+            if (m >= M) continue;
+            f32x4 v = acc[nt][mt] + bv;
+            if (LEAKY) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+            }
+            float *dst = C + (size_t)m * ldc + nb;
+            if (nb + 3 < n) {
+                *reinterpret_cast<f32x4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (nb + i < n) dst[i] = v[i];
+            }
+        }
+    }
+}
+
+hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsigned short *Wb, int ldw,
+                              const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad,
+                              bool leaky, float slope) {
+    if (m_cap <= 0 || n <= 0) return hipSuccess;
+    const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
+    const int ntn = (n + GEMM_BN - 1) / GEMM_BN;
+    const int n_major = (size_t)n * k_pad * 2 > (size_t)(2u << 20) ? 1 : 0;
+    dim3 grid(ntm * ntn), block(256);
+    if (leaky)
+        hipLaunchKernelGGL(k_linear_bf16<true>, grid, block, 0, s, A, lda, Wb, ldw, bias, C, ldc, m_cap, d_m, n, k_pad,
+                           slope, ntn, n_major);
+    else
+        hipLaunchKernelGGL(k_linear_bf16<false>, grid, block, 0, s, A, lda, Wb, ldw, bias, C, ldc, m_cap, d_m, n, k_pad,
+                           slope, ntn, n_major);
+    return hipGetLastError();
+}
+
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64, const int32_t *a_rows, const int32_t *c_rows) {

@@ -19,6 +19,8 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 struct Linear {                // one nn.Linear, zero padded on the device
     float *w = nullptr;        // [round_up(out, GEMM_BN)][ldw]
     float *b = nullptr;        // [round_up(out, GEMM_BN)]
+    unsigned short *w16 = nullptr;   // optional bf16 copy [rows][ldw16] (reduced-precision mode)
+    int ldw16 = 0;
     int in_dim = 0, out_dim = 0, ldw = 0;
 };
 
@@ -64,6 +66,7 @@ struct mpe_ctx {
     int mlp_layers = 0;
     float mlp_slope = 0.1f;
     bool mlp_acc64 = true;         // f64 running sums in the MLP GEMMs (parity mode)
+    bool mlp_bf16 = false;         // reduced precision: bf16 MFMA for the MLP GEMMs
     bool gat_acc64 = false;
     mpe::Linear mlp[MPE_MAX_MLP_LAYERS];
     bool mlp_ready[MPE_MAX_MLP_LAYERS] = {};
@@ -115,6 +118,10 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
                          float slope, bool acc64, const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr);
 hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *head_cam, int32_t *cam_count,
                               int32_t *cam_list, int list_stride);
+
+hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsigned short *Wb, int ldw,
+                              const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad,
+                              bool leaky, float slope);
 
 // gat.hip
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,

@@ -194,7 +194,7 @@ class Engine:
     def mlp_input_rows(self, db, persons, n_persons):
         B = db.n_frames
         width = self.V * self.J * self.params.numbers_per_joint
-        ld = (width + 31) // 32 * 32
+        ld = (width + 127) // 128 * 128
         rows = torch.zeros((B * self.pcap, ld), dtype=torch.float32, device=self.device)
         valid = torch.zeros((B * self.pcap,), dtype=torch.uint8, device=self.device)
         self._chk(self.lib.mpe_mlp_input_rows(self.ctx, self._stream(), C.byref(db.struct), _ptr(persons),
@@ -204,7 +204,7 @@ class Engine:
     def mlp_forward(self, x):
         """x [m, in_dim] f32 (device) -> [m, out_dim]."""
         m, k = x.shape
-        ld = (k + 31) // 32 * 32
+        ld = (k + 127) // 128 * 128
         xp = torch.zeros((m, ld), dtype=torch.float32, device=self.device)
         xp[:, :k] = x
         y = torch.empty((m, self.mlp_out), dtype=torch.float32, device=self.device)
@@ -237,8 +237,10 @@ class Engine:
         self._chk(self.lib.mpe_dlt_pairs(self.ctx, self._stream(), _ptr(pts), _ptr(cams), n, _ptr(out)))
         return out
 
-    def set_precision(self, gat_acc64=False, mlp_acc64=True):
-        self._chk(self.lib.mpe_set_precision(self.ctx, int(gat_acc64), int(mlp_acc64)))
+    def set_precision(self, gat_acc64=False, mlp_acc64=True, mlp_bf16=False):
+        """GAT: plain fp32 MFMA chain or f64 running sums; MLP: fp32 / f64 running sums (default,
+        parity) / bf16 MFMA (reduced precision, BASELINE configs[4])."""
+        self._chk(self.lib.mpe_set_precision(self.ctx, int(gat_acc64), 2 if mlp_bf16 else int(mlp_acc64)))
 
     def linear(self, x, w, b, slope=None, acc64=False):
         """act(x @ w.T + b) through the MFMA GEMM (parity tests). x device [m,k]; w,b host."""

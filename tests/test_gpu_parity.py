@@ -447,3 +447,26 @@ def test_full_size_batch_properties(calib, gat_weights, mlp_weights):
             assert n[f] == len(own) and np.array_equal(p[f, :len(own)], np.array(own, np.int32).reshape(-1, len(sm)))
     finally:
         eng.close()
+
+
+def test_bf16_mlp_mode_is_close_but_not_parity(calib, mlp_weights):
+    """Reduced-precision variant of BASELINE configs[4] (bf16 MFMA for the MLP GEMMs): ~3
+    significant digits per layer.  Checked against the fp32 result with a bf16-sized bound;
+    the parity path never uses it."""
+    arr, _ = load_case('c4_5x10')
+    x = torch.from_numpy(arr['f0_mlp_in'])
+    eng = pkg('pipeline').Engine(calib.params, calib, max_frames=4, max_persons_per_camera=10)
+    try:
+        eng.load_mlp(mlp_weights)
+        y32 = eng.mlp_forward(x.cuda()).cpu().numpy()
+        eng.set_precision(False, False, mlp_bf16=True)
+        y16 = eng.mlp_forward(x.cuda()).cpu().numpy()
+        eng.set_precision(False, True)
+        y32b = eng.mlp_forward(x.cuda()).cpu().numpy()
+    finally:
+        eng.close()
+    np.testing.assert_allclose(y32, arr['f0_mlp_out'], rtol=0, atol=1.5e-6)
+    assert np.array_equal(y32, y32b)                      # switching modes back is clean
+    scale = np.abs(arr['f0_mlp_out']).max()
+    d = np.abs(y16 - arr['f0_mlp_out']).max()
+    assert 1e-5 < d < 0.05 * scale, (d, scale)            # visibly reduced precision, but sane
