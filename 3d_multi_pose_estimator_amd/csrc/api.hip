@@ -533,17 +533,6 @@ int mpe_set_threshold(mpe_ctx *ctx, float threshold) {
     return MPE_OK;
 }
 
-int mpe_gat_debug_layer(mpe_ctx *ctx, void *stream, int32_t, float *d_out, int32_t ld_out, int32_t n_rows) {
-    // copies the current content of the hidden-activation buffer (valid right after a
-    // forward that was stopped by setting the layer count) -- see tests
-    if (!ctx || !d_out) return MPE_ERR_INVALID;
-    if (!ctx->act[0]) return fail(ctx, MPE_ERR_STATE, "no forward pass has run");
-    HIPCHK(ctx, hipMemcpy2DAsync(d_out, (size_t)ld_out * sizeof(float), ctx->act[0], (size_t)ctx->act_ld * sizeof(float),
-                                 (size_t)(ld_out < ctx->act_ld ? ld_out : ctx->act_ld) * sizeof(float), n_rows,
-                                 hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
-    return MPE_OK;
-}
-
 int mpe_cluster_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float *d_scores, int32_t *d_persons,
                       int32_t *d_n_persons) {
     int rc = check_batch(ctx, b);

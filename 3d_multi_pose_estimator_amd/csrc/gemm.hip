@@ -70,11 +70,6 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
         tn = swz - tm * ntn;
     }
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-    if (tune & 1) {
-        // de-synchronise the workgroups that share a CU (they run the same program in lockstep)
-        const int ph = (bid >> 3) % 3;
-        for (int i = 0; i < ph * 4; ++i) __builtin_amdgcn_s_sleep(3);
-    }
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // global->LDS staging role: 8 rows x 8 chunks (16 B) per wave and pass
@@ -159,7 +154,6 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
             for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + ((hh ^ fsw) << 2)]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + ((hh ^ fsw) << 2)]);
-            if (tune & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -167,7 +161,6 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
-            if (tune & 2) __builtin_amdgcn_s_setprio(0);
         }
         if (ACC64) {
 #pragma unroll

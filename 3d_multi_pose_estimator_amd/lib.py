@@ -82,7 +82,6 @@ SYMBOLS = {
     'mpe_gat_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_void_p]),
     'mpe_set_threshold': (C.c_int, [C.c_void_p, C.c_float]),
-    'mpe_gat_debug_layer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     'mpe_cluster_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     'mpe_mlp_input_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,

@@ -174,8 +174,6 @@ int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float 
                     float *d_scores_en, float *d_scores_heads);
 /* CLASSIFICATION_THRESHOLD of get_person_proposal_from_network_output (default from mpe_config) */
 int mpe_set_threshold(mpe_ctx *ctx, float threshold);
-int mpe_gat_debug_layer(mpe_ctx *ctx, void *stream, int32_t layer, float *d_out, int32_t ld_out,
-                        int32_t n_rows);
 
 /* get_person_proposal_from_network_output on caller-provided scores. */
 int mpe_cluster_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float *d_scores,
