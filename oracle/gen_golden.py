@@ -246,7 +246,7 @@ def main(variant='panoptic'):
         meta['cases'][name] = {'frames': len(idxs)}
         print(name, 'ok', {k: v.shape for k, v in arrays.items() if k.startswith('f0_') and hasattr(v, 'shape')})
 
-    if variant == 'panoptic':
+    if variant in ('panoptic', 'ring23'):
         gen_cluster_cases(ref, meta)
     with open(os.path.join(OUT, 'meta.json'), 'w') as fh:
         json.dump(meta, fh, indent=1)
@@ -275,10 +275,16 @@ def gen_cluster_cases(ref, meta):
     rng = np.random.default_rng(2024)
     fn = ref['skeleton_matching_utils'].get_person_proposal_from_network_output
     cases = []
-    for ci in range(400):
-        ncam = int(rng.integers(2, 6))
-        order = list(rng.permutation(5)[:ncam])
-        counts = [int(rng.integers(1, 5 if ci % 4 else 11)) for _ in order]
+    big = len(cams) > 8          # 23-camera rig: many cameras, few skeletons each (set growth, long BFS)
+    for ci in range(120 if big else 400):
+        if big:
+            ncam = int(rng.integers(6, len(cams) + 1))
+            order = list(rng.permutation(len(cams))[:ncam])
+            counts = [int(rng.integers(1, 4)) for _ in order]
+        else:
+            ncam = int(rng.integers(2, 6))
+            order = list(rng.permutation(5)[:ncam])
+            counts = [int(rng.integers(1, 5 if ci % 4 else 11)) for _ in order]
         slots = []
         hid = 0
         for c, n in zip(order, counts):
