@@ -18,6 +18,9 @@
 // lane 0 then replays the sequential greedy rules and the component walk on LDS-resident
 // state (a few hundred dependent steps of ~64-cycle LDS latency instead of HBM latency).
 // Frames whose edge-node count does not fit the LDS budget use the global-scratch variant.
+#include <cstdlib>
+#include <cstring>
+
 #include "mpe_internal.h"
 
 namespace mpe {
@@ -111,7 +114,7 @@ __device__ inline uint64_t make_key(float score, float thr, int m) {
 
 // the sequential part, shared by both variants; every array lives in `W` (LDS or global)
 struct Work {
-    int32_t *seen, *order, *linked, *human, *cfh, *ea, *eb, *done, *lvl, *nxt, *tabA, *tabB;
+    int32_t *seen, *order, *linked, *human, *cfh, *ea, *eb, *done, *lvl, *nxt, *off, *adj, *tabA, *tabB;
 };
 
 __device__ inline Work carve(int32_t *base, int hmax, int table_cap) {
@@ -126,7 +129,9 @@ __device__ inline Work carve(int32_t *base, int hmax, int table_cap) {
     w.done = w.eb + hmax;
     w.lvl = w.done + hmax;
     w.nxt = w.lvl + hmax;
-    w.tabA = w.nxt + hmax;
+    w.off = w.nxt + hmax;            // [hmax + 1] CSR offsets of the accepted-edge graph
+    w.adj = w.off + hmax + 1;        // [2 * hmax] neighbours (accepted edges form a forest: < hmax edges)
+    w.tabA = w.adj + 2 * hmax;
     w.tabB = w.tabA + table_cap;
     return w;
 }
@@ -186,6 +191,28 @@ __device__ inline int greedy_and_components(const Work &w, const uint64_t *keys,
         w.linked[a] = (int32_t)((uint32_t)w.linked[a] | bb);
         w.linked[b] = (int32_t)((uint32_t)w.linked[b] | ba);
     }
+    // adjacency lists in edge-creation order (the iteration order of networkx's adj dicts).
+    // Every accepted edge joins two different groups, so ne < H.
+    for (int h = 0; h < H; ++h) w.seen[h] = 0;
+    for (int e = 0; e < ne; ++e) {
+        w.seen[w.ea[e]]++;
+        w.seen[w.eb[e]]++;
+    }
+    {
+        int acc = 0;
+        for (int h = 0; h < H; ++h) {
+            const int d = w.seen[h];
+            w.off[h] = acc;
+            w.seen[h] = acc;
+            acc += d;
+        }
+        w.off[H] = acc;
+    }
+    for (int e = 0; e < ne; ++e) {
+        const int a = w.ea[e], b = w.eb[e];
+        w.adj[w.seen[a]++] = b;
+        w.adj[w.seen[b]++] = a;
+    }
     int np = 0;
     for (int oi = 0; oi < n_nodes; ++oi) {
         const int v = w.order[oi];
@@ -201,11 +228,9 @@ __device__ inline int greedy_and_components(const Work &w, const uint64_t *keys,
             int nn = 0;
             for (int li = 0; li < nl; ++li) {
                 const int x = L[li];
-                for (int e = 0; e < ne; ++e) {
-                    int wv = -1;
-                    if (w.ea[e] == x) wv = w.eb[e];
-                    else if (w.eb[e] == x) wv = w.ea[e];
-                    if (wv >= 0 && !pyset_contains(set, wv)) {
+                for (int i = w.off[x], i1 = w.off[x + 1]; i < i1; ++i) {
+                    const int wv = w.adj[i];
+                    if (!pyset_contains(set, wv)) {
                         pyset_add(set, wv);
                         N[nn++] = wv;
                     }
@@ -264,7 +289,7 @@ int cluster_table_cap(int hmax) {
 size_t cluster_keys_per_frame(int hmax) { return (size_t)hmax * hmax / 2 + 1; }
 
 size_t cluster_scratch_per_frame(int hmax) {
-    return (size_t)10 * hmax + 2 * (size_t)cluster_table_cap(hmax);
+    return (size_t)13 * hmax + 1 + 2 * (size_t)cluster_table_cap(hmax);
 }
 
 // ---- LDS variant: keys [n_pow2] u64 | pairs [n_pow2] u32 | work arrays ------------------
@@ -291,7 +316,7 @@ __global__ __launch_bounds__(64) void k_cluster_lds(const DevCfg *__restrict__ c
     }
     uint32_t *s_pair = reinterpret_cast<uint32_t *>(s_keys + n_pow2);
     int32_t *s_work = reinterpret_cast<int32_t *>(s_pair + n_pow2);
-    int32_t *s_cam = s_work + 10 * hmax + 2 * table_cap;
+    int32_t *s_cam = s_work + 13 * hmax + 1 + 2 * table_cap;
     const float thr = cfg->threshold;
     // smallest power of two covering this frame's edge-nodes
     int n = 64;
@@ -330,6 +355,298 @@ __global__ __launch_bounds__(64) void k_cluster_lds(const DevCfg *__restrict__ c
         h2 = (int)(pr & 0xFFFFu);
     };
     n_persons[f] = greedy_and_components(w, s_keys, n, pair_of, H, M, s_cam, V, cfg->min_views, pcap, out);
+}
+
+// ---- wave-register variant (<= 64 heads per frame) ----------------------------------------
+// The sequential rules run on the scalar unit: per-head state lives one head per lane in
+// VGPRs (camera, linked-camera mask, human index; cameras-of-human one human per lane; the
+// accepted edges one edge per lane) and every step reads/writes it with v_readlane /
+// a one-lane select at a uniform index -- a few cycles instead of a ~100-cycle LDS round trip per
+// dependent access.  The pending matchings of a 64-key chunk are tested against the current
+// state in parallel (a rejected matching changes nothing), so the serial part is one round per
+// ACCEPTED matching; the relabelling of a merged group is one vector select; the neighbours of
+// a node are a ballot over the edge lanes (ascending lane = edge-creation order); CPython's set
+// table (8 -> 32 -> 128 slots for <= 64 keys) is two VGPRs and is only walked for components
+// that hold two heads of one camera.  Same rules, same orders, same results as
+// greedy_and_components.
+#define MPE_RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
+// write `val` into lane `idx` (uniform): a compare + select on the vector unit
+__device__ inline int wl(int old, int val, int idx) { return (int)threadIdx.x == idx ? val : old; }
+
+struct RegSet {
+    int t0, t1;            // table slots 0..63 / 64..127, one per lane (-1 = empty)
+    int mask, fill;
+};
+
+__device__ inline int rs_get(const RegSet &s, int j) { return j < 64 ? MPE_RL(s.t0, j) : MPE_RL(s.t1, j - 64); }
+
+__device__ inline void rs_put(RegSet &s, int j, int key) {
+    if (j < 64) s.t0 = wl(s.t0, key, j);
+    else s.t1 = wl(s.t1, key, j - 64);
+}
+
+__device__ inline int rs_probe(const RegSet &s, int key, bool stop_on_equal, bool *found) {
+    unsigned perturb = (unsigned)key;
+    int i = key & s.mask;
+    *found = false;
+    while (true) {
+        int probes = (i + 9 <= s.mask) ? 9 : 0;
+        int j = i;
+        while (true) {
+            const int cur = rs_get(s, j);
+            if (cur == -1) return j;
+            if (stop_on_equal && cur == key) {
+                *found = true;
+                return j;
+            }
+            ++j;
+            if (probes == 0) break;
+            --probes;
+        }
+        perturb >>= 5;
+        i = (int)(((unsigned)i * 5u + 1u + perturb) & (unsigned)s.mask);
+    }
+}
+
+// returns true when `key` was not in the set yet
+__device__ inline bool rs_add(RegSet &s, int key) {
+    bool found;
+    const int j = rs_probe(s, key, true, &found);
+    if (found) return false;
+    rs_put(s, j, key);
+    s.fill++;
+    if (s.fill * 5 < s.mask * 3) return true;
+    const int minused = s.fill * 4;
+    int newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    RegSet n{-1, -1, newsize - 1, s.fill};
+    // re-insert in table order (CPython set_table_resize); slots beyond the old mask hold -1
+    for (int half = 0; half < 2; ++half) {
+        const int t = half ? s.t1 : s.t0;
+        unsigned long long bits = __ballot(t != -1);
+        while (bits) {
+            const int i = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            bool f2;
+            const int k = MPE_RL(t, i);
+            rs_put(n, rs_probe(n, k, false, &f2), k);
+        }
+    }
+    s = n;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_cluster_wave(const DevCfg *__restrict__ cfg, int n_frames,
+                                                     const int32_t *__restrict__ head_off,
+                                                     const int32_t *__restrict__ en_off,
+                                                     const int32_t *__restrict__ head_cam,
+                                                     const int32_t *__restrict__ en_pair,
+                                                     const float *__restrict__ scores, int pcap, int n_pow2,
+                                                     int32_t *__restrict__ persons, int32_t *__restrict__ n_persons) {
+    extern __shared__ uint64_t s_keys[];
+    const int f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int V = cfg->V;
+    const int lane = threadIdx.x;
+    const int h0 = head_off[f], H = head_off[f + 1] - h0;
+    const int e0 = en_off[f], M = en_off[f + 1] - e0;
+    int32_t *out = persons + (size_t)f * pcap * V;
+    if (M <= 0 || H > 64 || M > n_pow2) {
+        for (int i = lane; i < pcap * V; i += 64) out[i] = -1;
+        if (lane == 0) n_persons[f] = 0;
+        return;
+    }
+    uint32_t *s_pair = reinterpret_cast<uint32_t *>(s_keys + n_pow2);
+    const float thr = cfg->threshold;
+    const int min_views = cfg->min_views;
+    int n = 64;
+    while (n < M) n <<= 1;
+    for (int m = lane; m < n; m += 64) {
+        uint64_t key = KEY_NONE;
+        if (m < M) {
+            const int h1 = en_pair[2 * (size_t)(e0 + m)], h2 = en_pair[2 * (size_t)(e0 + m) + 1];
+            s_pair[m] = ((uint32_t)h1 << 16) | (uint32_t)h2;
+            key = make_key(scores[e0 + m], thr, m);
+        }
+        s_keys[m] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < n / 2; t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const bool up = (i & k) == 0;
+                const uint64_t x = s_keys[i], y = s_keys[p];
+                if ((x > y) == up) {
+                    s_keys[i] = y;
+                    s_keys[p] = x;
+                }
+            }
+            __syncthreads();
+        }
+
+    // ---- per-lane state ----
+    int32_t *s_aux = reinterpret_cast<int32_t *>(s_pair + n_pow2);      // [4][64] scratch ints
+    int32_t *s_first = s_aux, *s_ord = s_aux + 64, *s_gor = s_aux + 128, *s_gcnt = s_aux + 192;
+    const int camv = lane < H ? head_cam[h0 + lane] : 0;
+    int linkedv = (int)(1u << camv);
+    int humanv = -1, cfhv = 0, eav = -1, ebv = -1;
+
+    // G.add_node order = first appearance in the edge scan (h1 then h2 of every edge-node):
+    // first[h] = min(2m + position), rank of first[h] among the heads that appear
+    s_first[lane] = 0x7FFFFFFF;
+    s_gor[lane] = 0;
+    s_gcnt[lane] = 0;
+    __syncthreads();
+    for (int m = lane; m < M; m += 64) {
+        const uint32_t pr = s_pair[m];
+        atomicMin(&s_first[pr >> 16], 2 * m);
+        atomicMin(&s_first[pr & 0xFFFFu], 2 * m + 1);
+    }
+    __syncthreads();
+    const int firstv = s_first[lane];
+    const int n_nodes = __popcll(__ballot(firstv != 0x7FFFFFFF));
+    {
+        int rank = 0;
+        for (int l = 0; l < H; ++l) rank += MPE_RL(firstv, l) < firstv ? 1 : 0;
+        if (firstv != 0x7FFFFFFF) s_ord[rank] = lane;
+    }
+    __syncthreads();
+    const int orderv = lane < n_nodes ? s_ord[lane] : 0;
+
+    // greedy merge over the sorted keys, 64 at a time.  A rejected matching changes nothing, so
+    // all pending keys of the chunk are tested against the current state at once (one key per
+    // lane); the first lane that passes is exactly the next matching the sequential rules accept.
+    int cur = 0, ne = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const uint64_t key = s_keys[k0 + lane];
+        const bool valid = key != KEY_NONE;
+        const uint32_t pr = valid ? s_pair[(uint32_t)key] : 0u;
+        const int h1 = (int)(pr >> 16), h2 = (int)(pr & 0xFFFFu);
+        const bool first1 = pair_first_is_h1(h1, h2);
+        const int a_l = first1 ? h1 : h2, b_l = first1 ? h2 : h1;
+        const uint32_t ba_l = 1u << __shfl(camv, a_l), bb_l = 1u << __shfl(camv, b_l);
+        const int cnt = __popcll(__ballot(valid));             // sorted: the valid keys are a prefix
+        int start = 0;
+        while (true) {
+            const uint32_t la_l = (uint32_t)__shfl(linkedv, a_l), lb_l = (uint32_t)__shfl(linkedv, b_l);
+            const int ha_l = __shfl(humanv, a_l), hb_l = __shfl(humanv, b_l);
+            // the cross-lane reads stay outside any per-lane condition: ds_bpermute returns 0 for
+            // source lanes that are masked off
+            const uint32_t ca_x = (uint32_t)__shfl(cfhv, ha_l >= 0 ? ha_l : 0);
+            const uint32_t cb_x = (uint32_t)__shfl(cfhv, hb_l >= 0 ? hb_l : 0);
+            const uint32_t ca_l = ha_l >= 0 ? ca_x : 0u, cb_l = hb_l >= 0 ? cb_x : 0u;
+            const bool rej = (lb_l & ba_l) || (la_l & bb_l) || (ca_l & bb_l) || (cb_l & ba_l) ||
+                             (ha_l >= 0 && hb_l >= 0 && (cb_l & ca_l));
+            const unsigned long long pass = __ballot(valid && lane >= start && !rej);
+            if (!pass) break;
+            const int q = __builtin_ctzll(pass);
+            const int a = MPE_RL(a_l, q), b = MPE_RL(b_l, q);
+            const uint32_t ba = (uint32_t)MPE_RL(ba_l, q), bb = (uint32_t)MPE_RL(bb_l, q);
+            const uint32_t la = (uint32_t)MPE_RL(la_l, q), lb = (uint32_t)MPE_RL(lb_l, q);
+            const int ha = MPE_RL(ha_l, q), hb = MPE_RL(hb_l, q);
+            const uint32_t ca = (uint32_t)MPE_RL(ca_l, q), cb = (uint32_t)MPE_RL(cb_l, q);
+            if (ha < 0 && hb < 0) {
+                humanv = wl(humanv, cur, a);
+                humanv = wl(humanv, cur, b);
+                cfhv = wl(cfhv, (int)(ba | bb), cur);
+                ++cur;
+            } else if (ha >= 0 && hb < 0) {
+                humanv = wl(humanv, ha, b);
+                cfhv = wl(cfhv, (int)(ca | bb), ha);
+            } else if (hb >= 0 && ha < 0) {
+                humanv = wl(humanv, hb, a);
+                cfhv = wl(cfhv, (int)(cb | ba), hb);
+            } else {
+                humanv = humanv == hb ? ha : humanv;       // the absorbed group's camera list is dropped (:97-102)
+            }
+            eav = wl(eav, a, ne);
+            ebv = wl(ebv, b, ne);
+            ++ne;
+            linkedv = wl(linkedv, (int)(la | bb), a);
+            linkedv = wl(linkedv, (int)(lb | ba), b);
+            start = q + 1;
+        }
+        if (cnt < 64) break;
+    }
+
+    // connected components in node-insertion order.  The accepted edges join heads of one human
+    // index, so a component is the set of lanes with equal humanv (or a single unmatched head).
+    // Only the ITERATION ORDER of networkx's result set can matter, and only when two heads of
+    // one camera share a component (possible through the dropped camera list above): then the
+    // BFS + CPython set emulation decides; otherwise each camera slot has one candidate.
+    if (humanv >= 0) {
+        atomicOr(&s_gor[humanv], 1 << camv);
+        atomicAdd(&s_gcnt[humanv], 1);
+    }
+    for (int i = lane; i < pcap * V; i += 64) out[i] = -1;
+    __threadfence_block();                                   // the -1 fill lands before any person row
+    __syncthreads();
+    const bool plainv = __popc((unsigned)s_gor[lane]) == s_gcnt[lane];   // lane = human index
+    unsigned long long done = 0;
+    int np = 0;
+    for (int oi = 0; oi < n_nodes; ++oi) {
+        const int v = MPE_RL(orderv, oi);
+        if ((done >> v) & 1ull) continue;
+        const int g = MPE_RL(humanv, v);
+        if (g < 0 || MPE_RL((int)plainv, g)) {
+            const unsigned long long memb = g >= 0 ? __ballot(humanv == g) : (1ull << v);
+            done |= memb;
+            if (__popcll(memb) >= min_views && np < pcap) {
+                if ((memb >> lane) & 1ull) out[(size_t)np * V + camv] = lane;
+                ++np;
+            }
+            continue;
+        }
+        // networkx _plain_bfs + CPython set order
+        RegSet set{-1, -1, 7, 0};
+        rs_add(set, v);
+        int lvlv = 0, nxtv = 0;
+        lvlv = wl(lvlv, v, 0);
+        int nl = 1;
+        bool full = set.fill == n_nodes;
+        while (nl > 0 && !full) {
+            int nn = 0;
+            for (int li = 0; li < nl; ++li) {
+                const int x = MPE_RL(lvlv, li);
+                unsigned long long nb = __ballot(eav == x || ebv == x);   // unused edge lanes hold -1
+                while (nb) {
+                    const int e = __builtin_ctzll(nb);
+                    nb &= nb - 1;
+                    const int ae = MPE_RL(eav, e), be = MPE_RL(ebv, e);
+                    const int wv = ae == x ? be : ae;
+                    if (rs_add(set, wv)) nxtv = wl(nxtv, wv, nn++);
+                }
+                if (set.fill == n_nodes) {
+                    full = true;
+                    break;
+                }
+            }
+            const int t = lvlv;
+            lvlv = nxtv;
+            nxtv = t;
+            nl = nn;
+        }
+        const bool emit = set.fill >= min_views && np < pcap;
+        int res = -1;                                            // lane c: the head of camera c
+        for (int half = 0; half < 2; ++half) {
+            const int t = half ? set.t1 : set.t0;
+            unsigned long long bits = __ballot(t != -1);
+            while (bits) {
+                const int i = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const int h = MPE_RL(t, i);
+                done |= 1ull << h;
+                res = wl(res, h, MPE_RL(camv, h));               // later in set order wins, as in the reference
+            }
+        }
+        if (emit) {
+            if (lane < V && res >= 0) out[(size_t)np * V + lane] = res;
+            ++np;
+        }
+    }
+    if (lane == 0) n_persons[f] = np;
 }
 
 // ---- global-scratch variant (frames too large for LDS) ---------------------------------
@@ -385,8 +702,24 @@ hipError_t launch_cluster(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, 
     int n_pow2 = 64;
     while ((size_t)n_pow2 < m_cap) n_pow2 <<= 1;
     const size_t shm = (size_t)n_pow2 * (sizeof(uint64_t) + sizeof(uint32_t)) +
-                       ((size_t)10 * hmax + 2 * (size_t)table_cap + hmax) * sizeof(int32_t);
-    if (shm <= 96 * 1024) {
+                       ((size_t)13 * hmax + 1 + 2 * (size_t)table_cap + hmax) * sizeof(int32_t);
+    // kernel choice: per-lane registers when a frame cannot hold more than 64 heads; LDS work
+    // arrays up to the LDS budget; global scratch beyond.  MPE_CLUSTER_KERNEL=wave|lds|big
+    // overrides (tests run the known answers through every variant).
+    const char *force = getenv("MPE_CLUSTER_KERNEL");
+    const bool want_wave = force ? !strcmp(force, "wave") : hmax <= 64;
+    const size_t shm_wave = (size_t)n_pow2 * (sizeof(uint64_t) + sizeof(uint32_t)) + 256 * sizeof(int32_t);
+    if (want_wave && shm_wave <= 96 * 1024) {
+        if (shm_wave > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cluster_wave),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_wave);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_cluster_wave, dim3(b.n_frames), dim3(64), shm_wave, s, cfg, b.n_frames, b.d_frame_head_off,
+                           b.d_frame_en_off, b.d_head_cam, en_pair, scores, pcap, n_pow2, persons, n_persons);
+        return hipGetLastError();
+    }
+    if (shm <= 96 * 1024 && !(force && !strcmp(force, "big"))) {
         if (shm > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cluster_lds),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

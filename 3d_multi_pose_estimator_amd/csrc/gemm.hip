@@ -393,6 +393,193 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
 }
 
 // ---------------------------------------------------------------------------------------
+// Latency variant for small batches (online use: one frame per call).  With a handful of rows a
+// 128x80 tile leaves the chip empty and every workgroup walks K serially at 80 MFMAs per
+// stage, most of them on padding.  Here one WAVE owns one 16x16 output tile and streams its
+// 16 activation rows and 16 weight rows straight from global memory into MFMA fragments (no
+// LDS, no barriers), SK_DEPTH K-stages in flight per wave.  The k order inside a 32-deep stage,
+// the fp32 chain and the f64 flush cadence are exactly those of k_linear_dma, so a batch of one
+// frame and a batch of a thousand give bit-identical rows.  Small M makes this kernel
+// weight-bandwidth bound: every weight element is read once.
+// ---------------------------------------------------------------------------------------
+constexpr int SK_DEPTH = 8;
+
+template <bool LEAKY, bool ACC64>
+__global__ __launch_bounds__(256) void k_linear_skinny(const float *__restrict__ A, int lda,
+                                                        const float *__restrict__ W, int ldw,
+                                                        const float *__restrict__ bias, float *__restrict__ C,
+                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
+                                                        int k_pad, float slope, int nt16,
+                                                        const int32_t *__restrict__ a_rows,
+                                                        const int32_t *__restrict__ c_rows) {
+    int M = m_cap;
+    if (d_m) {
+        int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);      // the 4 waves of a block share activation rows
+    const int tm = gw / nt16, tn = gw - tm * nt16;
+    if (tm * 16 >= M) return;                                // no barriers below: waves may leave early
+    const int fq = lane >> 4, fr = lane & 15;
+
+    int grow = tm * 16 + fr;
+    grow = grow < M ? grow : M - 1;
+    if (a_rows) grow = a_rows[grow];
+    const float *pa = A + (size_t)grow * lda + 8 * fq;       // stage kt: k = 32 kt + 8 fq + {0..7}
+    const float *pw = W + (size_t)(tn * 16 + fr) * ldw + 8 * fq;
+
+    const int nk = k_pad / GEMM_BK;
+    f32x4 ra[SK_DEPTH][2], rw[SK_DEPTH][2];
+#pragma unroll
+    for (int d = 0; d < SK_DEPTH; ++d) {
+        const int ko = (d < nk ? d : nk - 1) * GEMM_BK;
+        ra[d][0] = *reinterpret_cast<const f32x4 *>(pa + ko);
+        ra[d][1] = *reinterpret_cast<const f32x4 *>(pa + ko + 4);
+        rw[d][0] = *reinterpret_cast<const f32x4 *>(pw + ko);
+        rw[d][1] = *reinterpret_cast<const f32x4 *>(pw + ko + 4);
+    }
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    double run[4] = {0.0, 0.0, 0.0, 0.0};
+    auto stage = [&](const f32x4 &a0, const f32x4 &a1, const f32x4 &w0, const f32x4 &w1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[s], a0[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], a1[s], acc, 0, 0, 0);
+        if (ACC64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) run[i] += (double)acc[i];
+            acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    int kt0 = 0;
+    for (; kt0 + SK_DEPTH <= nk; kt0 += SK_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < SK_DEPTH; ++d) {
+            stage(ra[d][0], ra[d][1], rw[d][0], rw[d][1]);
+            int kn = kt0 + d + SK_DEPTH;                     // refill the slot in place (clamped: no branch)
+            kn = (kn < nk ? kn : nk - 1) * GEMM_BK;
+            ra[d][0] = *reinterpret_cast<const f32x4 *>(pa + kn);
+            ra[d][1] = *reinterpret_cast<const f32x4 *>(pa + kn + 4);
+            rw[d][0] = *reinterpret_cast<const f32x4 *>(pw + kn);
+            rw[d][1] = *reinterpret_cast<const f32x4 *>(pw + kn + 4);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < SK_DEPTH; ++d)
+        if (kt0 + d < nk) stage(ra[d][0], ra[d][1], rw[d][0], rw[d][1]);
+
+    const int m = tm * 16 + fr;
+    if (m >= M) return;
+    const int nb = tn * 16 + fq * 4;
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+    f32x4 v;
+    if (ACC64) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)(run[i] + (double)bv[i]);
+    } else {
+        v = acc + bv;
+    }
+    if (LEAKY) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+    }
+    const int mo = c_rows ? c_rows[m] : m;
+    float *dst = C + (size_t)mo * ldc + nb;
+    if (nb + 3 < n) {
+        *reinterpret_cast<f32x4 *>(dst) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (nb + i < n) dst[i] = v[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Latency variant with f64 running sums (the MLP at small batch): with ACC64 every 32-deep
+// stage is its own fp32 MFMA chain, so the stages of one 16x16 tile are independent until the
+// f64 sum.  The KS waves of a workgroup take the stages round-robin, park their fp32 stage
+// results in LDS (1 KB per stage), and after one barrier each of 256 threads adds "its" element
+// over the stages IN STAGE ORDER in f64 -- the same additions in the same order as
+// k_linear_dma<ACC64>, hence the same bits, with the serial MFMA chain cut KS-fold.
+// ---------------------------------------------------------------------------------------
+constexpr int SKS_DEPTH = 4;
+
+template <bool LEAKY, int KS>
+__global__ __launch_bounds__(64 * KS) void k_linear_skinny_ks(const float *__restrict__ A, int lda,
+                                                             const float *__restrict__ W, int ldw,
+                                                             const float *__restrict__ bias, float *__restrict__ C,
+                                                             int ldc, int m_cap, const int32_t *__restrict__ d_m,
+                                                             int n, int k_pad, float slope, int nt16,
+                                                             const int32_t *__restrict__ a_rows,
+                                                             const int32_t *__restrict__ c_rows) {
+    extern __shared__ __attribute__((aligned(16))) float s_part[];       // [nk][64 lanes][4]
+    int M = m_cap;
+    if (d_m) {
+        int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    const int tm = blockIdx.x / nt16, tn = blockIdx.x - tm * nt16;
+    if (tm * 16 >= M) return;                                // whole workgroup leaves: no barrier reached
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fq = lane >> 4, fr = lane & 15;
+    int grow = tm * 16 + fr;
+    grow = grow < M ? grow : M - 1;
+    if (a_rows) grow = a_rows[grow];
+    const float *pa = A + (size_t)grow * lda + 8 * fq;
+    const float *pw = W + (size_t)(tn * 16 + fr) * ldw + 8 * fq;
+    const int nk = k_pad / GEMM_BK;
+    const int mine = nk > wave ? (nk - wave + KS - 1) / KS : 0;          // stages wave, wave+KS, ...
+
+    f32x4 ra[SKS_DEPTH][2], rw[SKS_DEPTH][2];
+    auto load = [&](int d, int i) {                          // i-th own stage (clamped: no branch)
+        int ii = i < mine ? i : mine - 1;
+        ii = ii < 0 ? 0 : ii;
+        const int ko = (wave + ii * KS < nk ? wave + ii * KS : nk - 1) * GEMM_BK;
+        ra[d][0] = *reinterpret_cast<const f32x4 *>(pa + ko);
+        ra[d][1] = *reinterpret_cast<const f32x4 *>(pa + ko + 4);
+        rw[d][0] = *reinterpret_cast<const f32x4 *>(pw + ko);
+        rw[d][1] = *reinterpret_cast<const f32x4 *>(pw + ko + 4);
+    };
+#pragma unroll
+    for (int d = 0; d < SKS_DEPTH; ++d) load(d, d);
+    auto stage = [&](int d, int i) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rw[d][0][s], ra[d][0][s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rw[d][1][s], ra[d][1][s], acc, 0, 0, 0);
+        *reinterpret_cast<f32x4 *>(&s_part[((wave + i * KS) * 64 + lane) * 4]) = acc;
+    };
+    int i0 = 0;
+    for (; i0 + SKS_DEPTH <= mine; i0 += SKS_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < SKS_DEPTH; ++d) {
+            stage(d, i0 + d);
+            load(d, i0 + d + SKS_DEPTH);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < SKS_DEPTH; ++d)
+        if (i0 + d < mine) stage(d, i0 + d);
+    __syncthreads();
+
+    const int t = threadIdx.x;
+    if (t >= 256) return;
+    double run = 0.0;
+    for (int s = 0; s < nk; ++s) run += (double)s_part[s * 256 + t];     // stage order, as the tile kernel
+    const int el = t >> 2, i = t & 3;                        // element (lane el, component i) of the MFMA tile
+    const int m = tm * 16 + (el & 15), nb = tn * 16 + (el >> 4) * 4 + i;
+    if (m >= M || nb >= n) return;
+    float v = (float)(run + (double)bias[nb]);
+    if (LEAKY) v = v > 0.f ? v : v * slope;
+    const int mo = c_rows ? c_rows[m] : m;
+    C[(size_t)mo * ldc + nb] = v;
+}
+
+// ---------------------------------------------------------------------------------------
 // bf16 variant (reduced precision, BASELINE.json configs[4]: "bf16 MLP MFMA GEMM"):
 // C = act(bf16(A) * W_bf16^T + b) with fp32 accumulation on v_mfma_f32_16x16x32_bf16
 // (16x the fp32 MFMA rate).  Activations stay fp32 in memory and are rounded to bf16 while
@@ -571,6 +758,44 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
     const int ntn = (n + GEMM_BN - 1) / GEMM_BN;
     static const int tune = getenv("MPE_GEMM_TUNE") ? atoi(getenv("MPE_GEMM_TUNE")) : 0;
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
+    // small batches: one wave per 16x16 tile while that still leaves SIMDs idle (k_linear_skinny)
+    static const int skinny_waves = getenv("MPE_SKINNY_WAVES") ? atoi(getenv("MPE_SKINNY_WAVES")) : 1024;
+    const int nt16 = (n + 15) / 16;
+    const long waves16 = (long)((m_cap + 15) / 16) * nt16;
+    if (waves16 <= skinny_waves && !(tune & 8) && acc64 && k_pad / GEMM_BK <= 128 && k_pad / GEMM_BK >= 8) {
+        // K split over the waves of a workgroup, ordered f64 reduction through LDS
+        const size_t shm = (size_t)(k_pad / GEMM_BK) * 1024;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_skinny_ks<true, 8>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_skinny_ks<false, 8>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        dim3 kgrid((unsigned)waves16), kblock(512);
+        if (leaky)
+            hipLaunchKernelGGL((k_linear_skinny_ks<true, 8>), kgrid, kblock, shm, s, A, lda, W, ldw, bias, C, ldc, m_cap,
+                               d_m, n, k_pad, slope, nt16, a_rows, c_rows);
+        else
+            hipLaunchKernelGGL((k_linear_skinny_ks<false, 8>), kgrid, kblock, shm, s, A, lda, W, ldw, bias, C, ldc, m_cap,
+                               d_m, n, k_pad, slope, nt16, a_rows, c_rows);
+        return hipGetLastError();
+    }
+    if (waves16 <= skinny_waves && !(tune & 8)) {
+        dim3 sgrid((unsigned)((waves16 + 3) / 4)), sblock(256);
+#define MPE_LAUNCH_SK(L_, A_)                                                                                  \
+    hipLaunchKernelGGL((k_linear_skinny<L_, A_>), sgrid, sblock, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, \
+                       k_pad, slope, nt16, a_rows, c_rows)
+        if (leaky && acc64) MPE_LAUNCH_SK(true, true);
+        else if (leaky) MPE_LAUNCH_SK(true, false);
+        else if (acc64) MPE_LAUNCH_SK(false, true);
+        else MPE_LAUNCH_SK(false, false);
+#undef MPE_LAUNCH_SK
+        return hipGetLastError();
+    }
     dim3 grid(ntm * ntn), block(256);
 #define MPE_LAUNCH(L_, A_)                                                                                   \
     hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(128) void k_mlp_rows(const DevCfg *__restrict__ cfg
     const int np_f = n_persons[f];
     const size_t slot = (size_t)f * pcap + p;
     if (p >= np_f) {
-        if (!person_off && threadIdx.x == 0 && valid) valid[slot] = 0;
+        if (threadIdx.x == 0 && valid) valid[slot] = 0;
         return;
     }
     const size_t r = person_off ? (size_t)person_off[f] + p : slot;

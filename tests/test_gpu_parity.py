@@ -81,6 +81,22 @@ def test_linear_vs_torch_fp32(engine, m, k, n, slope):
     assert e_gpu <= max(2.0 * e_cpu, 2.5e-7 * scale), (e_gpu, e_cpu)
 
 
+@pytest.mark.parametrize('k,n,slope', [(902, 400, None), (400, 320, 0.15), (1260, 3072, 0.1), (1024, 54, None)])
+def test_linear_small_batch_rows_identical(engine, k, n, slope):
+    """The latency kernel (one wave per 16x16 tile, chosen for small batches) keeps the k order,
+    fp32 chain and f64 flush cadence of the throughput kernel: the same row gives the same bits
+    whether it travels in a batch of 37 or of 3000."""
+    g = torch.Generator().manual_seed(k + n)
+    x = torch.randn(3000, k, generator=g)
+    w = (torch.randn(n, k, generator=g) / np.sqrt(k)).numpy()
+    b = torch.randn(n, generator=g).numpy()
+    for acc64 in (False, True):
+        big = engine.linear(x.cuda(), w, b, slope, acc64=acc64).cpu()
+        for m in (1, 16, 37):
+            small = engine.linear(x[:m].cuda(), w, b, slope, acc64=acc64).cpu()
+            assert torch.equal(small, big[:m]), (acc64, m, (small - big[:m]).abs().max().item())
+
+
 @pytest.mark.parametrize('variant,name', ALL_CASES)
 def test_head_features_vs_golden(variant, name):
     engine = engine_for(variant)
@@ -116,15 +132,21 @@ def test_gat_scores_vs_golden(variant, name):
         np.testing.assert_allclose(sh.cpu().numpy(), want[:H], rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize('variant', ['lds', 'global_scratch', 'ring23'])
-def test_cluster_known_answers_bit_exact(engine, calib, variant):
-    """400 known answers of the reference's get_person_proposal_from_network_output, through
-    both clustering kernels: k_cluster_lds (keys sorted in LDS) and k_cluster_big (frames whose
-    edge-node capacity exceeds the LDS budget: global scratch + heapsort)."""
-    arr = np.load(os.path.join(GOLDEN, 'ring23' if variant == 'ring23' else '', 'cluster_cases.npz'))
+@pytest.mark.parametrize('variant', ['wave', 'lds', 'global_scratch', 'ring23', 'ring23_wave'])
+def test_cluster_known_answers_bit_exact(engine, calib, variant, monkeypatch):
+    """400 (+120 with 23 cameras) known answers of the reference's
+    get_person_proposal_from_network_output, through every clustering kernel: k_cluster_wave
+    (<= 64 heads per frame: state in wave registers), k_cluster_lds (work arrays in LDS) and
+    k_cluster_big (frames whose edge-node capacity exceeds the LDS budget: global scratch +
+    heapsort)."""
+    arr = np.load(os.path.join(GOLDEN, 'ring23' if variant.startswith('ring23') else '', 'cluster_cases.npz'))
     packing = pkg('packing')
     big = None
-    if variant == 'ring23':         # 23 cameras: larger components, CPython set growth 8 -> 32 -> 128
+    if variant == 'lds':
+        monkeypatch.setenv('MPE_CLUSTER_KERNEL', 'lds')
+    if variant == 'ring23_wave':    # every case has <= 64 heads; the engine's capacity (230) would pick LDS
+        monkeypatch.setenv('MPE_CLUSTER_KERNEL', 'wave')
+    if variant.startswith('ring23'):  # 23 cameras: larger components, CPython set growth 8 -> 32 -> 128
         engine = engine_for('ring23')
     if variant == 'global_scratch':
         # capacity of 40 skeletons per camera -> 200 heads per frame -> keys do not fit LDS

@@ -1,0 +1,36 @@
+"""Diagnostic: how often do the clusters of the HIP path equal the oracle's on random frames,
+with plain fp32 MFMA chains vs f64 running sums in the GAT GEMMs; and the score deviation."""
+import importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import oracle_np as onp
+PKG = '3d_multi_pose_estimator_amd'
+syn = importlib.import_module(PKG + '.synthetic'); cal = importlib.import_module(PKG + '.calibration')
+par = importlib.import_module(PKG + '.parameters'); pipeline = importlib.import_module(PKG + '.pipeline')
+calib = cal.Calibration(par.parameters)
+sd = syn.gat_state_dict(7, 902, logit_gain=25.0, logit_shift=0.698); prm = syn.gat_params(902)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+specs = [syn.FrameSpec(persons=4), syn.FrameSpec(persons=3, joint_drop=0.2, noise_px=1.5), syn.FrameSpec(persons=5)]
+frames = [onp.processed_input(syn.make_frame(calib, 3000 + i, specs[i % 3])[0]) for i in range(n)]
+sm = list(calib.params.used_cameras_skeleton_matching)
+ref = []
+for f in frames:
+    g = onp.build_graph(f, calib)
+    sc = onp.gat_forward(sd, prm, g['feats'], g['src'], g['dst'])[g['H']:].numpy()
+    head_cam = [sm.index(c) for c in g['nodes_camera'][:g['H']]]
+    ref.append((sc, onp.cluster(sc, g['pairs'], g['H'], head_cam, len(sm))))
+eng = pipeline.Engine(par.parameters, calib, max_frames=n, max_persons_per_camera=6)
+eng.load_gat(sd, prm)
+db = eng.to_device(eng.pack(frames))
+for acc in (False, True):
+    eng.set_precision(acc, True)
+    scores, persons, n_persons = eng.match(db)
+    scores, persons, n_persons = scores.cpu().numpy(), persons.cpu().numpy(), n_persons.cpu().numpy()
+    exact, dmax = 0, 0.0
+    for f in range(n):
+        h0, H, e0, M = db.host.frame_counts(f)
+        dmax = max(dmax, float(np.abs(scores[e0:e0 + M] - ref[f][0]).max()))
+        want = np.array(ref[f][1], np.int32).reshape(-1, len(sm))
+        if n_persons[f] == len(want) and np.array_equal(persons[f, :len(want)], want): exact += 1
+    print('gat_acc64=%s: clusters equal to the oracle in %d of %d frames, max |score diff| %.2e' % (acc, exact, n, dmax))
