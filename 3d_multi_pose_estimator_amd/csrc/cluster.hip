@@ -136,6 +136,55 @@ __device__ inline Work carve(int32_t *base, int hmax, int table_cap) {
     return w;
 }
 
+// networkx 3.4.2 _plain_bfs from `v` over the CSR adjacency (w.off / w.adj), result in `set`
+__device__ inline void bfs_component(const Work &w, int v, int n_nodes, PySet &set) {
+    pyset_init(set);
+    pyset_add(set, v);
+    int nl = 1;
+    w.lvl[0] = v;
+    bool full = set.fill == n_nodes;
+    int32_t *L = w.lvl, *N = w.nxt;
+    while (nl > 0 && !full) {
+        int nn = 0;
+        for (int li = 0; li < nl; ++li) {
+            const int x = L[li];
+            for (int i = w.off[x], i1 = w.off[x + 1]; i < i1; ++i) {
+                const int wv = w.adj[i];
+                if (!pyset_contains(set, wv)) {
+                    pyset_add(set, wv);
+                    N[nn++] = wv;
+                }
+            }
+            if (set.fill == n_nodes) { full = true; break; }
+        }
+        int32_t *t = L; L = N; N = t;
+        nl = nn;
+    }
+}
+
+// adjacency lists in edge-creation order (the iteration order of networkx's adj dicts).
+// Every accepted edge joins two different groups, so ne < H.
+__device__ inline void build_csr(const Work &w, int H, int ne) {
+    for (int h = 0; h < H; ++h) w.seen[h] = 0;
+    for (int e = 0; e < ne; ++e) {
+        w.seen[w.ea[e]]++;
+        w.seen[w.eb[e]]++;
+    }
+    int acc = 0;
+    for (int h = 0; h < H; ++h) {
+        const int d = w.seen[h];
+        w.off[h] = acc;
+        w.seen[h] = acc;
+        acc += d;
+    }
+    w.off[H] = acc;
+    for (int e = 0; e < ne; ++e) {
+        const int a = w.ea[e], b = w.eb[e];
+        w.adj[w.seen[a]++] = b;
+        w.adj[w.seen[b]++] = a;
+    }
+}
+
 // greedy merge over the sorted keys + connected components; returns the number of persons
 template <typename PairFn>
 __device__ inline int greedy_and_components(const Work &w, const uint64_t *keys, int n_keys, PairFn pair_of, int H,
@@ -191,55 +240,13 @@ __device__ inline int greedy_and_components(const Work &w, const uint64_t *keys,
         w.linked[a] = (int32_t)((uint32_t)w.linked[a] | bb);
         w.linked[b] = (int32_t)((uint32_t)w.linked[b] | ba);
     }
-    // adjacency lists in edge-creation order (the iteration order of networkx's adj dicts).
-    // Every accepted edge joins two different groups, so ne < H.
-    for (int h = 0; h < H; ++h) w.seen[h] = 0;
-    for (int e = 0; e < ne; ++e) {
-        w.seen[w.ea[e]]++;
-        w.seen[w.eb[e]]++;
-    }
-    {
-        int acc = 0;
-        for (int h = 0; h < H; ++h) {
-            const int d = w.seen[h];
-            w.off[h] = acc;
-            w.seen[h] = acc;
-            acc += d;
-        }
-        w.off[H] = acc;
-    }
-    for (int e = 0; e < ne; ++e) {
-        const int a = w.ea[e], b = w.eb[e];
-        w.adj[w.seen[a]++] = b;
-        w.adj[w.seen[b]++] = a;
-    }
+    build_csr(w, H, ne);
     int np = 0;
     for (int oi = 0; oi < n_nodes; ++oi) {
         const int v = w.order[oi];
         if (w.done[v]) continue;
         PySet set{w.tabA, w.tabB, 7, 0};
-        pyset_init(set);
-        pyset_add(set, v);
-        int nl = 1;
-        w.lvl[0] = v;
-        bool full = set.fill == n_nodes;
-        int32_t *L = w.lvl, *N = w.nxt;
-        while (nl > 0 && !full) {
-            int nn = 0;
-            for (int li = 0; li < nl; ++li) {
-                const int x = L[li];
-                for (int i = w.off[x], i1 = w.off[x + 1]; i < i1; ++i) {
-                    const int wv = w.adj[i];
-                    if (!pyset_contains(set, wv)) {
-                        pyset_add(set, wv);
-                        N[nn++] = wv;
-                    }
-                }
-                if (set.fill == n_nodes) { full = true; break; }
-            }
-            int32_t *t = L; L = N; N = t;
-            nl = nn;
-        }
+        bfs_component(w, v, n_nodes, set);
         const int cnt = set.fill;
         int32_t *pout = (cnt >= min_views && np < pcap) ? out + (size_t)np * V : nullptr;
         for (int i = 0; i <= set.mask; ++i) {
@@ -286,7 +293,13 @@ int cluster_table_cap(int hmax) {
     return mask + 1;
 }
 
-size_t cluster_keys_per_frame(int hmax) { return (size_t)hmax * hmax / 2 + 1; }
+size_t cluster_keys_per_frame(int hmax) {
+    // >= the largest edge-node count of a frame; a power of two (>= 512) because the workgroup
+    // kernel pads its bitonic sort to one when it sorts in this scratch
+    size_t need = (size_t)hmax * hmax / 2 + 1, n = 512;
+    while (n < need) n <<= 1;
+    return n;
+}
 
 size_t cluster_scratch_per_frame(int hmax) {
     return (size_t)13 * hmax + 1 + 2 * (size_t)cluster_table_cap(hmax);
@@ -649,6 +662,239 @@ __global__ __launch_bounds__(64) void k_cluster_wave(const DevCfg *__restrict__ 
     if (lane == 0) n_persons[f] = np;
 }
 
+// ---- workgroup variant for large frames (> 64 heads: 5 x 10+, 23 cameras) ----------------
+// One workgroup of 256 threads per frame.  Only the matchings above the threshold are kept
+// (compaction) and bitonic-sorted -- in LDS up to CB_KCAP keys, in the frame's global key
+// scratch beyond.  The greedy rules run as in k_cluster_wave: 256 pending matchings are tested
+// against the LDS-resident state at once, the first one that passes is applied by its own
+// thread, one round per accepted matching.  Components are the human-index groups; their output
+// order is the rank of their first node in G's insertion order, computed in parallel; thread 0
+// replays _plain_bfs + the CPython set only for groups that hold two heads of one camera.
+constexpr int CB_THREADS = 256;
+constexpr int CB_KCAP = 8192;
+constexpr int CB_INF = 0x7FFFFFFF;
+
+__global__ __launch_bounds__(CB_THREADS) void k_cluster_block(const DevCfg *__restrict__ cfg, int n_frames,
+                                                              const int32_t *__restrict__ head_off,
+                                                              const int32_t *__restrict__ en_off,
+                                                              const int32_t *__restrict__ head_cam,
+                                                              const int32_t *__restrict__ en_pair,
+                                                              const float *__restrict__ scores, int pcap, int hmax,
+                                                              int table_cap, uint64_t *__restrict__ keys_all,
+                                                              size_t keys_per_frame, int32_t *__restrict__ persons,
+                                                              int32_t *__restrict__ n_persons) {
+    extern __shared__ uint64_t s_keys[];                      // [CB_KCAP], then the int arrays
+    const int f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int V = cfg->V;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int h0 = head_off[f], H = head_off[f + 1] - h0;
+    const int e0 = en_off[f], M = en_off[f + 1] - e0;
+    int32_t *out = persons + (size_t)f * pcap * V;
+    for (int i = t; i < pcap * V; i += CB_THREADS) out[i] = -1;
+    if (M <= 0 || H > hmax || (size_t)M > keys_per_frame) {
+        if (t == 0) n_persons[f] = 0;
+        return;
+    }
+    const Work w = carve(reinterpret_cast<int32_t *>(s_keys + CB_KCAP), hmax, table_cap);
+    int32_t *s_cam = w.tabB + table_cap;
+    int32_t *s_first = s_cam + hmax, *s_gor = s_first + hmax, *s_gcnt = s_gor + hmax;
+    int32_t *s_gfirst = s_gcnt + hmax, *s_gnp = s_gfirst + hmax;
+    int32_t *s_sc = s_gnp + hmax;                             // scalars
+    enum { NVALID = 0, NE, CUR, MFROM, MTO, Q0, Q1, Q2, Q3, NNODES, SLOT, NP, NONPLAIN };
+    int32_t *s_rank = w.done, *s_ord = w.order;
+    const float thr = cfg->threshold;
+    const int min_views = cfg->min_views;
+    const int32_t *prs = en_pair + 2 * (size_t)e0;
+
+    if (t < 16) s_sc[t] = 0;
+    for (int h = t; h < H; h += CB_THREADS) {
+        const int c = head_cam[h0 + h];
+        s_cam[h] = c;
+        w.linked[h] = (int32_t)(1u << c);
+        w.human[h] = -1;
+        w.cfh[h] = 0;
+        s_first[h] = CB_INF;
+        s_gor[h] = 0;
+        s_gcnt[h] = 0;
+        s_gfirst[h] = CB_INF;
+        s_gnp[h] = -1;
+    }
+    __threadfence_block();                                    // the -1 fill lands before any person row
+    __syncthreads();
+
+    // matchings above the threshold: count, then compact (order is irrelevant, the sort follows);
+    // first appearance of every head in the edge scan on the way
+    {
+        int mine = 0;
+        for (int m = t; m < M; m += CB_THREADS) {
+            mine += scores[e0 + m] > thr ? 1 : 0;
+            atomicMin(&s_first[prs[2 * m]], 2 * m);
+            atomicMin(&s_first[prs[2 * m + 1]], 2 * m + 1);
+        }
+        if (mine) atomicAdd(&s_sc[NVALID], mine);
+    }
+    __syncthreads();
+    const int n_valid = s_sc[NVALID];
+    int n = 2 * CB_THREADS;
+    while (n < n_valid) n <<= 1;
+    uint64_t *keys = n <= CB_KCAP ? s_keys : keys_all + (size_t)f * keys_per_frame;
+    for (int m = t; m < M; m += CB_THREADS) {
+        const uint64_t key = make_key(scores[e0 + m], thr, m);
+        if (key != KEY_NONE) keys[atomicAdd(&s_sc[SLOT], 1)] = key;
+    }
+    for (int i = n_valid + t; i < n; i += CB_THREADS) keys[i] = KEY_NONE;
+    // G.add_node order: rank of the first appearance
+    for (int h = t; h < H; h += CB_THREADS) {
+        const int fv = s_first[h];
+        if (fv == CB_INF) continue;
+        int rank = 0;
+        for (int l = 0; l < H; ++l) rank += s_first[l] < fv ? 1 : 0;
+        s_rank[h] = rank;
+        s_ord[rank] = h;
+        atomicAdd(&s_sc[NNODES], 1);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int x = t; x < n / 2; x += CB_THREADS) {
+                const int i = ((x & ~(j - 1)) << 1) | (x & (j - 1));
+                const int p = i | j;
+                const bool up = (i & k) == 0;
+                const uint64_t a = keys[i], b = keys[p];
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[p] = a;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    const int n_nodes = s_sc[NNODES];
+
+    // greedy rules, 256 pending matchings per chunk, one round per accepted matching
+    for (int k0 = 0; k0 < n_valid; k0 += CB_THREADS) {
+        const bool valid = k0 + t < n_valid;
+        int h1 = 0, h2 = 0;
+        if (valid) {
+            const int m = (int)(uint32_t)keys[k0 + t];
+            h1 = prs[2 * m];
+            h2 = prs[2 * m + 1];
+        }
+        const bool first1 = pair_first_is_h1(h1, h2);
+        const int a = first1 ? h1 : h2, b = first1 ? h2 : h1;
+        const uint32_t ba = 1u << s_cam[a], bb = 1u << s_cam[b];
+        int start = 0;
+        while (true) {
+            __syncthreads();                                  // state of the previous round is final
+            const uint32_t la = (uint32_t)w.linked[a], lb = (uint32_t)w.linked[b];
+            const int ha = w.human[a], hb = w.human[b];
+            const uint32_t ca = ha >= 0 ? (uint32_t)w.cfh[ha] : 0u, cb = hb >= 0 ? (uint32_t)w.cfh[hb] : 0u;
+            const bool rej = (lb & ba) || (la & bb) || (ca & bb) || (cb & ba) || (ha >= 0 && hb >= 0 && (cb & ca));
+            const unsigned long long bal = __ballot(valid && t >= start && !rej);
+            if (lane == 0) s_sc[Q0 + wave] = bal ? wave * 64 + __builtin_ctzll(bal) : CB_INF;
+            __syncthreads();
+            const int q = min(min(s_sc[Q0], s_sc[Q1]), min(s_sc[Q2], s_sc[Q3]));
+            if (q == CB_INF) break;
+            if (t == q) {
+                int mfrom = -1;
+                if (ha < 0 && hb < 0) {
+                    const int cur = s_sc[CUR];
+                    w.human[a] = cur;
+                    w.human[b] = cur;
+                    w.cfh[cur] = (int32_t)(ba | bb);
+                    s_sc[CUR] = cur + 1;
+                } else if (ha >= 0 && hb < 0) {
+                    w.human[b] = ha;
+                    w.cfh[ha] = (int32_t)(ca | bb);
+                } else if (hb >= 0 && ha < 0) {
+                    w.human[a] = hb;
+                    w.cfh[hb] = (int32_t)(cb | ba);
+                } else {
+                    mfrom = hb;                               // relabelled by everybody below; the absorbed
+                    s_sc[MTO] = ha;                           // group's camera list is dropped (:97-102)
+                }
+                s_sc[MFROM] = mfrom;
+                const int ne = s_sc[NE];
+                w.ea[ne] = a;
+                w.eb[ne] = b;
+                s_sc[NE] = ne + 1;
+                w.linked[a] = (int32_t)(la | bb);
+                w.linked[b] = (int32_t)(lb | ba);
+            }
+            __syncthreads();
+            const int mfrom = s_sc[MFROM];
+            if (mfrom >= 0) {
+                const int mto = s_sc[MTO];
+                for (int h = t; h < H; h += CB_THREADS)
+                    if (w.human[h] == mfrom) w.human[h] = mto;
+            }
+            start = q + 1;
+        }
+    }
+    __syncthreads();
+
+    // components = human-index groups (+ unmatched single heads)
+    for (int h = t; h < H; h += CB_THREADS) {
+        const int g = w.human[h];
+        if (g < 0) continue;
+        atomicOr(&s_gor[g], 1 << s_cam[h]);
+        atomicAdd(&s_gcnt[g], 1);
+        atomicMin(&s_gfirst[g], s_rank[h]);
+    }
+    __syncthreads();
+    const int n_groups = s_sc[CUR];
+    const bool singles = min_views <= 1;
+    auto emitted_before = [&](int fr) {
+        int c = 0;
+        for (int g = 0; g < n_groups; ++g) c += (s_gcnt[g] >= min_views && s_gcnt[g] > 0 && s_gfirst[g] < fr) ? 1 : 0;
+        if (singles)
+            for (int h = 0; h < H; ++h) c += (w.human[h] < 0 && s_first[h] != CB_INF && s_rank[h] < fr) ? 1 : 0;
+        return c;
+    };
+    for (int g = t; g < n_groups; g += CB_THREADS) {
+        const int cnt = s_gcnt[g];
+        if (cnt <= 0 || cnt < min_views) continue;
+        const int idx = emitted_before(s_gfirst[g]);
+        atomicAdd(&s_sc[NP], 1);
+        if (idx >= pcap) continue;
+        s_gnp[g] = idx;
+        if (__popc((unsigned)s_gor[g]) != cnt) s_sc[NONPLAIN] = 1;
+    }
+    if (singles)
+        for (int h = t; h < H; h += CB_THREADS) {
+            if (w.human[h] >= 0 || s_first[h] == CB_INF) continue;
+            const int idx = emitted_before(s_rank[h]);
+            atomicAdd(&s_sc[NP], 1);
+            if (idx < pcap) out[(size_t)idx * V + s_cam[h]] = h;
+        }
+    __syncthreads();
+    for (int h = t; h < H; h += CB_THREADS) {
+        const int g = w.human[h];
+        if (g < 0) continue;
+        const int idx = s_gnp[g];
+        if (idx >= 0 && __popc((unsigned)s_gor[g]) == s_gcnt[g]) out[(size_t)idx * V + s_cam[h]] = h;
+    }
+    if (t == 0) {
+        n_persons[f] = s_sc[NP] < pcap ? s_sc[NP] : pcap;
+        if (s_sc[NONPLAIN]) {
+            // two heads of one camera in a group: networkx's set iteration order picks the winner
+            build_csr(w, H, s_sc[NE]);
+            for (int g = 0; g < n_groups; ++g) {
+                const int idx = s_gnp[g];
+                if (idx < 0 || __popc((unsigned)s_gor[g]) == s_gcnt[g]) continue;
+                PySet set{w.tabA, w.tabB, 7, 0};
+                bfs_component(w, s_ord[s_gfirst[g]], n_nodes, set);
+                for (int i = 0; i <= set.mask; ++i) {
+                    const int h = set.tab[i];
+                    if (h >= 0) out[(size_t)idx * V + s_cam[h]] = h;
+                }
+            }
+        }
+    }
+}
+
 // ---- global-scratch variant (frames too large for LDS) ---------------------------------
 __global__ __launch_bounds__(64) void k_cluster_big(const DevCfg *__restrict__ cfg, int n_frames,
                                                     const int32_t *__restrict__ head_off,
@@ -717,6 +963,22 @@ hipError_t launch_cluster(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, 
         }
         hipLaunchKernelGGL(k_cluster_wave, dim3(b.n_frames), dim3(64), shm_wave, s, cfg, b.n_frames, b.d_frame_head_off,
                            b.d_frame_en_off, b.d_head_cam, en_pair, scores, pcap, n_pow2, persons, n_persons);
+        return hipGetLastError();
+    }
+    const size_t shm_block = (size_t)CB_KCAP * sizeof(uint64_t) +
+                             ((size_t)19 * hmax + 1 + 2 * (size_t)table_cap + 16) * sizeof(int32_t);
+    const bool want_block = force ? !strcmp(force, "block") : true;
+    if (want_block && shm_block <= 128 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cluster_block),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k_cluster_block, dim3(b.n_frames), dim3(CB_THREADS), shm_block, s, cfg, b.n_frames,
+                           b.d_frame_head_off, b.d_frame_en_off, b.d_head_cam, en_pair, scores, pcap, hmax, table_cap,
+                           keys, keys_per_frame, persons, n_persons);
         return hipGetLastError();
     }
     if (shm <= 96 * 1024 && !(force && !strcmp(force, "big"))) {

@@ -132,26 +132,21 @@ def test_gat_scores_vs_golden(variant, name):
         np.testing.assert_allclose(sh.cpu().numpy(), want[:H], rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize('variant', ['wave', 'lds', 'global_scratch', 'ring23', 'ring23_wave'])
+@pytest.mark.parametrize('variant', ['wave', 'lds', 'big', 'block', 'ring23', 'ring23_wave', 'ring23_big'])
 def test_cluster_known_answers_bit_exact(engine, calib, variant, monkeypatch):
     """400 (+120 with 23 cameras) known answers of the reference's
     get_person_proposal_from_network_output, through every clustering kernel: k_cluster_wave
-    (<= 64 heads per frame: state in wave registers), k_cluster_lds (work arrays in LDS) and
-    k_cluster_big (frames whose edge-node capacity exceeds the LDS budget: global scratch +
-    heapsort)."""
+    (<= 64 heads per frame: state in wave registers), k_cluster_block (larger frames: one
+    workgroup per frame), and the two sequential variants kept as cross-checks, k_cluster_lds
+    (work arrays in LDS) and k_cluster_big (global scratch + heapsort)."""
     arr = np.load(os.path.join(GOLDEN, 'ring23' if variant.startswith('ring23') else '', 'cluster_cases.npz'))
     packing = pkg('packing')
-    big = None
-    if variant == 'lds':
-        monkeypatch.setenv('MPE_CLUSTER_KERNEL', 'lds')
-    if variant == 'ring23_wave':    # every case has <= 64 heads; the engine's capacity (230) would pick LDS
-        monkeypatch.setenv('MPE_CLUSTER_KERNEL', 'wave')
+    kernel = {'wave': 'wave', 'lds': 'lds', 'big': 'big', 'block': 'block', 'ring23': None,
+              'ring23_wave': 'wave', 'ring23_big': 'big'}[variant]
+    if kernel:                      # the default choice follows the engine's capacity: wave <= 64 heads < block
+        monkeypatch.setenv('MPE_CLUSTER_KERNEL', kernel)
     if variant.startswith('ring23'):  # 23 cameras: larger components, CPython set growth 8 -> 32 -> 128
         engine = engine_for('ring23')
-    if variant == 'global_scratch':
-        # capacity of 40 skeletons per camera -> 200 heads per frame -> keys do not fit LDS
-        big = pkg('pipeline').Engine(calib.params, calib, max_frames=64, max_persons_per_camera=40)
-        engine = big
     V = engine.V
     # assemble all cases into batches of <= 64 frames
     cases = range(int(arr['n']))
@@ -191,8 +186,51 @@ def test_cluster_known_answers_bit_exact(engine, calib, variant, monkeypatch):
             want = arr['c%d_persons' % i]
             assert n_persons[f] == len(want), i
             assert np.array_equal(persons[f, :len(want)], want), i
-    if big is not None:
-        big.close()
+
+
+def test_cluster_large_frames_vs_oracle(monkeypatch):
+    """23 cameras x 10 skeletons = 230 heads, 25 300 edge-nodes per frame: more matchings above
+    the threshold than the LDS sort holds (global-scratch sort of k_cluster_block), long chains of
+    merges, components with repeated cameras.  Oracle = the restated reference rules."""
+    onp = oracle()
+    packing = pkg('packing')
+    e = env('ring23')
+    engine = pkg('pipeline').Engine(e.params, e.calib, max_frames=3, max_persons_per_camera=10)
+    V, P = engine.V, 10
+    rng = np.random.default_rng(5)
+    slot_n = np.full(V, P, np.int32)
+    pairs = packing.pairs_of_frame(slot_n)
+    H, M = V * P, len(pairs)
+    head_cam = np.repeat(np.arange(V, dtype=np.int32), P)
+    person_of = np.tile(rng.permutation(P), V)                      # hidden identity of every head
+    same = person_of[pairs[:, 0]] == person_of[pairs[:, 1]]
+    cases = [rng.random(M).astype(np.float32),                                          # half above 0.5
+             np.where(same, 0.97, 0.03).astype(np.float32) + rng.normal(0, 0.02, M).astype(np.float32),
+             np.where(same ^ (rng.random(M) < 0.15), 0.9, 0.1).astype(np.float32) + rng.normal(0, 0.05, M).astype(np.float32)]
+    B = len(cases)
+    pb = packing.PackedBatch(V, engine.J)
+    pb.n_frames = B
+    pb.slot_cam = np.tile(np.arange(V, dtype=np.int32), (B, 1))
+    pb.slot_n = np.tile(slot_n, (B, 1))
+    pb.frame_head_off = np.arange(B + 1, dtype=np.int32) * H
+    pb.frame_en_off = np.arange(B + 1, dtype=np.int32) * M
+    pb.head_cam = np.tile(head_cam, B)
+    pb.joint_mask = np.ones(B * H, np.uint32)
+    pb.tri_mask = np.ones(B * H, np.uint32)
+    pb.xy = np.zeros((B * H, engine.J, 2))
+    pb.vp = np.zeros((B * H, engine.J, 2), np.float32)
+    db = engine.to_device(pb)
+    want = [np.array(onp.cluster(sc, pairs, H, list(head_cam), V), np.int32).reshape(-1, V) for sc in cases]
+    assert (cases[0] > 0.5).sum() > 8192
+    for kernel in ('block', 'big'):
+        monkeypatch.setenv('MPE_CLUSTER_KERNEL', kernel)
+        persons, n_persons = engine.cluster(db, torch.from_numpy(np.concatenate(cases)))
+        persons, n_persons = persons.cpu().numpy(), n_persons.cpu().numpy()
+        for f in range(B):
+            keep = min(len(want[f]), engine.pcap)
+            assert n_persons[f] == keep, (kernel, f)
+            assert np.array_equal(persons[f, :keep], want[f][:keep]), (kernel, f)
+    engine.close()
 
 
 @pytest.mark.parametrize('variant,name', ALL_CASES)
