@@ -115,6 +115,28 @@ int linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, const Linear &L
     return MPE_OK;
 }
 
+unsigned short f32_to_bf16(float f);
+int ensure_bf16_weights(mpe_ctx *ctx, Linear *L);
+
+// GEMM of a GAT layer: fp32 MFMA (parity) or, in the reduced-precision mode, bf16 MFMA with an
+// optional fp16 result (`out_half`: C is the same buffer seen as fp16 rows, ldc in halves)
+int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, float *C, int ldc, int m,
+               const int32_t *d_m, bool leaky, float slope, bool out_half, const int32_t *a_rows = nullptr,
+               const int32_t *c_rows = nullptr, double flop_override = -1.0) {
+    if (!ctx->gat_reduced)
+        return linear(ctx, s, A, lda, L, C, ldc, m, d_m, leaky, slope, ctx->gat_acc64, a_rows, c_rows, flop_override);
+    if (m <= 0) return MPE_OK;
+    int rc = ensure_bf16_weights(ctx, &L);
+    if (rc) return rc;
+    if (lda < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", lda, L.ldw);
+    const bool host_m = !d_m || flop_override >= 0.0;
+    GemmProf gp(ctx, s, flop_override >= 0.0 ? flop_override : (d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim),
+                host_m ? 0 : L.out_dim, host_m ? 0 : L.in_dim);
+    HIPCHK(ctx, launch_linear_bf16(s, A, lda, L.w16, L.ldw16, L.b, C, ldc, m, d_m, L.out_dim, L.ldw16, leaky, slope,
+                                   L.ldw, out_half, a_rows, c_rows));
+    return MPE_OK;
+}
+
 int ensure_gat_workspace(mpe_ctx *ctx) {
     if (ctx->act[0]) return MPE_OK;
     for (int l = 0; l < ctx->gat_layers; ++l)
@@ -264,22 +286,25 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
     }
     const int L = ctx->gat_layers;
     for (int l = 0; l < L; ++l) {
-        const GatLayer &g = ctx->gat[l];
+        GatLayer &g = ctx->gat[l];
         const bool last = l == L - 1;
         AggArgs a{};
         a.heads = g.heads;
         a.out_dim = g.out_dim;
         a.alpha = ctx->gat_alpha;
         a.out_slope = ctx->gat_hidden_slope;
-        a.ld = ctx->act_ld;
+        const bool red = ctx->gat_reduced;
+        a.ft_half = red ? 1 : 0;
+        a.ld = red ? 2 * ctx->act_ld : ctx->act_ld;       // fp16 rows keep the byte stride of the fp32 rows
+        const int ld_ft = a.ld;
         a.a12 = ctx->a12;
         int n_rows_ft2 = 0;
         if (l == 0 && dense_in) {
-            if ((rc = linear(ctx, s, ctx->xdense, ctx->feat_ld, g.fc1, ctx->hdense, ctx->feat_ld, n_nodes, nullptr, true,
-                             ctx->gat_alpha, ctx->gat_acc64)))
+            if ((rc = gat_linear(ctx, s, ctx->xdense, ctx->feat_ld, g.fc1, ctx->hdense, ctx->feat_ld, n_nodes, nullptr,
+                                 true, ctx->gat_alpha, false)))
                 return rc;
-            if ((rc = linear(ctx, s, ctx->hdense, ctx->feat_ld, g.fc2, ctx->act[2], ctx->act_ld, n_nodes, nullptr, false,
-                             0.f, ctx->gat_acc64)))
+            if ((rc = gat_linear(ctx, s, ctx->hdense, ctx->feat_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
+                                 0.f, red)))
                 return rc;
             a.ft2 = ctx->act[2];
             n_rows_ft2 = n_nodes;
@@ -290,27 +315,27 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
                 // from the compact features and scattered back to head order
                 const double flop_each = 2.0 * b->n_heads * (double)g.in_dim * (J * 10) / V;
                 for (int c = 0; c < V; ++c)
-                    if ((rc = linear(ctx, s, ctx->xc, ctx->l0_ld, ctx->l0_fc1[c], ctx->h0, ctx->feat_ld, b->n_heads,
-                                     ctx->cam_count + c, true, ctx->gat_alpha, ctx->gat_acc64,
-                                     ctx->cam_list + (size_t)c * ctx->cfg.max_heads,
-                                     ctx->cam_list + (size_t)c * ctx->cfg.max_heads, flop_each)))
+                    if ((rc = gat_linear(ctx, s, ctx->xc, ctx->l0_ld, ctx->l0_fc1[c], ctx->h0, ctx->feat_ld, b->n_heads,
+                                         ctx->cam_count + c, true, ctx->gat_alpha, false,
+                                         ctx->cam_list + (size_t)c * ctx->cfg.max_heads,
+                                         ctx->cam_list + (size_t)c * ctx->cfg.max_heads, flop_each)))
                         return rc;
-            } else if ((rc = linear(ctx, s, ctx->x0, ctx->feat_ld, g.fc1, ctx->h0, ctx->feat_ld, b->n_heads, nullptr,
-                                    true, ctx->gat_alpha, ctx->gat_acc64)))
+            } else if ((rc = gat_linear(ctx, s, ctx->x0, ctx->feat_ld, g.fc1, ctx->h0, ctx->feat_ld, b->n_heads, nullptr,
+                                        true, ctx->gat_alpha, false)))
                 return rc;
-            if ((rc = linear(ctx, s, ctx->h0, ctx->feat_ld, g.fc2, ctx->act[1], ctx->act_ld, b->n_heads, nullptr,
-                             false, 0.f, ctx->gat_acc64)))
+            if ((rc = gat_linear(ctx, s, ctx->h0, ctx->feat_ld, g.fc2, ctx->act[1], ld_ft, b->n_heads, nullptr, false,
+                                 0.f, red)))
                 return rc;
             a.ft2 = ctx->act[1];
             n_rows_ft2 = b->n_heads;
             a.en_const_ft2 = ctx->en0_ft2;
             a.en_const_a = ctx->en0_a;
         } else {
-            if ((rc = linear(ctx, s, ctx->act[0], ctx->act_ld, g.fc1, ctx->act[1], ctx->act_ld, n_nodes, nullptr, true,
-                             ctx->gat_alpha, ctx->gat_acc64)))
+            if ((rc = gat_linear(ctx, s, ctx->act[0], ctx->act_ld, g.fc1, ctx->act[1], ctx->act_ld, n_nodes, nullptr,
+                                 true, ctx->gat_alpha, false)))
                 return rc;
-            if ((rc = linear(ctx, s, ctx->act[1], ctx->act_ld, g.fc2, ctx->act[2], ctx->act_ld, n_nodes, nullptr,
-                             false, 0.f, ctx->gat_acc64)))
+            if ((rc = gat_linear(ctx, s, ctx->act[1], ctx->act_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
+                                 0.f, red)))
                 return rc;
             a.ft2 = ctx->act[2];
             n_rows_ft2 = n_nodes;
@@ -662,9 +687,10 @@ int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t
 
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
     if (!ctx) return MPE_ERR_INVALID;
-    if (gat_acc64 < 0 || gat_acc64 > 1 || mlp_acc64 < 0 || mlp_acc64 > 2)
-        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0|1, MLP 0|1|2");
+    if (gat_acc64 < 0 || gat_acc64 > 2 || mlp_acc64 < 0 || mlp_acc64 > 2)
+        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0|1|2, MLP 0|1|2");
     ctx->gat_acc64 = gat_acc64 == 1;
+    ctx->gat_reduced = gat_acc64 == 2;
     ctx->mlp_acc64 = mlp_acc64 == 1;
     ctx->mlp_bf16 = mlp_acc64 == 2;
     return MPE_OK;

@@ -161,6 +161,32 @@ hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *
     return hipGetLastError();
 }
 
+// Feature rows of the attention stage are fp32, or fp16 in the reduced-precision mode
+// (BASELINE.json configs[4]); `half` is uniform per launch.  Arithmetic stays fp32.
+__device__ __forceinline__ float ld_ft(const float *base, size_t idx, int half) {
+    return half ? (float)reinterpret_cast<const _Float16 *>(base)[idx] : base[idx];
+}
+
+template <int VEC>
+__device__ __forceinline__ void ld_ftv(const float *base, size_t idx, int half, float *out) {
+    if (half) {
+        typedef _Float16 hv __attribute__((ext_vector_type(VEC)));
+        const hv v = *reinterpret_cast<const hv *>(reinterpret_cast<const _Float16 *>(base) + idx);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] = (float)v[k];
+    } else {
+        typedef float fv __attribute__((ext_vector_type(VEC)));
+        const fv v = *reinterpret_cast<const fv *>(base + idx);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] = v[k];
+    }
+}
+
+template <>
+__device__ __forceinline__ void ld_ftv<1>(const float *base, size_t idx, int half, float *out) {
+    out[0] = ld_ft(base, idx, half);
+}
+
 // ---------------------------------------------------------------------------------------
 // attention coefficients a1 = <ft2[n,h,:], attn_l[h,:]>, a2 with attn_r  (gat2.py:57-58)
 // ---------------------------------------------------------------------------------------
@@ -168,14 +194,15 @@ constexpr int COEF_ROWS = 8;
 
 __global__ __launch_bounds__(256) void k_attn_coef(const float *__restrict__ ft2, int ld, int n_rows, int heads,
                                                    int out_dim, const float *__restrict__ attn_l,
-                                                   const float *__restrict__ attn_r, float *__restrict__ a12) {
+                                                   const float *__restrict__ attn_r, float *__restrict__ a12,
+                                                   int ft_half) {
     extern __shared__ float s_ft[];                 // [COEF_ROWS][hd]
     const int hd = heads * out_dim;
     const int r0 = blockIdx.x * COEF_ROWS;
     const int nr = min(COEF_ROWS, n_rows - r0);
     for (int i = threadIdx.x; i < nr * hd; i += blockDim.x) {
         const int r = i / hd, c = i - r * hd;
-        s_ft[r * hd + c] = ft2[(size_t)(r0 + r) * ld + c];
+        s_ft[r * hd + c] = ld_ft(ft2, (size_t)(r0 + r) * ld + c, ft_half);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nr * heads * 2; i += blockDim.x) {
@@ -190,12 +217,12 @@ __global__ __launch_bounds__(256) void k_attn_coef(const float *__restrict__ ft2
 }
 
 hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,
-                            const float *attn_l, const float *attn_r, float *a12) {
+                            const float *attn_l, const float *attn_r, float *a12, int ft_half) {
     if (n_rows <= 0) return hipSuccess;
     const int grid = (n_rows + COEF_ROWS - 1) / COEF_ROWS;
     const size_t shm = (size_t)COEF_ROWS * heads * out_dim * sizeof(float);
     hipLaunchKernelGGL(k_attn_coef, dim3(grid), dim3(256), shm, s, ft2, ld, n_rows, heads, out_dim, attn_l, attn_r,
-                       a12);
+                       a12, ft_half);
     return hipGetLastError();
 }
 
@@ -240,25 +267,22 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
         const int h1 = en_pair[2 * (size_t)m], h2 = en_pair[2 * (size_t)m + 1];
         const int hh = c / a.out_dim;
         const float *ra1, *ra2, *ra3;     // a1|a2 rows of h1, h2, self
-        const float *f1, *f2, *f3;        // feature rows
+        float v1[VEC], v2[VEC], v3[VEC];  // feature rows
         if (l0) {
             ra1 = a.a12 + (size_t)(hb + h1) * 32;
             ra2 = a.a12 + (size_t)(hb + h2) * 32;
             ra3 = a.en_const_a;
-            f1 = a.ft2 + (size_t)(hb + h1) * a.ld;
-            f2 = a.ft2 + (size_t)(hb + h2) * a.ld;
-            f3 = a.en_const_ft2;
+            ld_ftv<VEC>(a.ft2, (size_t)(hb + h1) * a.ld + c, a.ft_half, v1);
+            ld_ftv<VEC>(a.ft2, (size_t)(hb + h2) * a.ld + c, a.ft_half, v2);
+            ld_ftv<VEC>(a.en_const_ft2, (size_t)c, 0, v3);
         } else {
             ra1 = a.a12 + (size_t)(nb + h1) * 32;
             ra2 = a.a12 + (size_t)(nb + h2) * 32;
             ra3 = a.a12 + (size_t)(nb + v) * 32;
-            f1 = a.ft2 + (size_t)(nb + h1) * a.ld;
-            f2 = a.ft2 + (size_t)(nb + h2) * a.ld;
-            f3 = a.ft2 + (size_t)(nb + v) * a.ld;
+            ld_ftv<VEC>(a.ft2, (size_t)(nb + h1) * a.ld + c, a.ft_half, v1);
+            ld_ftv<VEC>(a.ft2, (size_t)(nb + h2) * a.ld + c, a.ft_half, v2);
+            ld_ftv<VEC>(a.ft2, (size_t)(nb + v) * a.ld + c, a.ft_half, v3);
         }
-        const vecf v1 = *reinterpret_cast<const vecf *>(f1 + c);
-        const vecf v2 = *reinterpret_cast<const vecf *>(f2 + c);
-        const vecf v3 = *reinterpret_cast<const vecf *>(f3 + c);
         const float a2v = ra3[16 + hh];
         float e1 = ra1[hh] + a2v, e2 = ra2[hh] + a2v, e3 = ra3[hh] + a2v;
         e1 = e1 > 0.f ? e1 : e1 * a.alpha;
@@ -383,8 +407,8 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
         for (int e = 0; e < deg; ++e) {
             const int u = s_src[r * max_deg + e];
             float fv;
-            if (l0) fv = u >= H ? a.en_const_ft2[c] : a.ft2[(size_t)(hb + u) * a.ld + c];
-            else fv = a.ft2[(size_t)(nb + u) * a.ld + c];
+            if (l0) fv = u >= H ? a.en_const_ft2[c] : ld_ft(a.ft2, (size_t)(hb + u) * a.ld + c, a.ft_half);
+            else fv = ld_ft(a.ft2, (size_t)(nb + u) * a.ld + c, a.ft_half);
             const float m = fv * s_alpha[((size_t)r * max_deg + e) * heads + hh];
             acc = acc + m;
         }
@@ -441,10 +465,9 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     // phase 1: feature slice -> LDS (layer 0: ft2 holds head rows only, edge-nodes share one row)
     for (int i = t; i < N * DV; i += blockDim.x) {
         const int node = i / DV, d = (i - node * DV) * VEC;
-        const float *src;
-        if (l0) src = node < H ? a.ft2 + (size_t)(hb + node) * a.ld + c0 + d : a.en_const_ft2 + c0 + d;
-        else src = a.ft2 + (size_t)(nb + node) * a.ld + c0 + d;
-        const vecf v = *reinterpret_cast<const vecf *>(src);
+        float v[VEC];
+        if (l0 && node >= H) ld_ftv<VEC>(a.en_const_ft2, (size_t)(c0 + d), 0, v);
+        else ld_ftv<VEC>(a.ft2, (size_t)((l0 ? hb : nb) + node) * a.ld + c0 + d, a.ft_half, v);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) s_ft[node * Dp + d + k] = v[k];
     }
@@ -606,7 +629,7 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
 #undef MPE_FUSED
         return hipGetLastError();
     }
-    hipError_t e = launch_attn_coef(s, a.ft2, a.ld, n_rows_ft2, a.heads, a.out_dim, attn_l, attn_r, a12);
+    hipError_t e = launch_attn_coef(s, a.ft2, a.ld, n_rows_ft2, a.heads, a.out_dim, attn_l, attn_r, a12, a.ft_half);
     if (e != hipSuccess) return e;
     AggArgs a2 = a;
     a2.a12 = a12;

@@ -603,12 +603,14 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return u;
 }
 
-template <bool LEAKY>
+template <bool LEAKY, bool OUT16>
 __global__ __launch_bounds__(256, 2) void k_linear_bf16(const float *__restrict__ A, int lda,
                                                         const unsigned short *__restrict__ Wb, int ldw,
                                                         const float *__restrict__ bias, float *__restrict__ C,
                                                         int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
-                                                        int k_pad, float slope, int ntn, int n_major) {
+                                                        int k_pad, float slope, int ntn, int n_major, int k_lim,
+                                                        const int32_t *__restrict__ a_rows,
+                                                        const int32_t *__restrict__ c_rows) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[(GEMM_BM + GEMM_BN) * BF_ROWB];
     int M = m_cap;
     if (d_m) {
@@ -639,6 +641,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_bf16(const float *__restrict_
         const int row = p * 16 + sr;
         int grow = m0 + row;
         grow = grow < M ? grow : M - 1;
+        if (a_rows) grow = a_rows[grow];
         a_src[p] = A + (size_t)grow * lda + sc * 8;
         a_dst[p] = row * BF_ROWB + ((sc ^ (row & 15)) << 4);
     }
@@ -669,10 +672,16 @@ __global__ __launch_bounds__(256, 2) void k_linear_bf16(const float *__restrict_
 
     auto load = [&](int kt) {
         const int koff = kt * BF_BK;
+        // activation rows are valid (and zero padded) up to k_lim columns only; the rest of the
+        // 128-deep stage is zeros
+        const bool in_row = koff + sc * 8 < k_lim;
 #pragma unroll
         for (int p = 0; p < BF_A_PASSES; ++p) {
-            const f32x4 lo = *reinterpret_cast<const f32x4 *>(a_src[p] + koff);
-            const f32x4 hi = *reinterpret_cast<const f32x4 *>(a_src[p] + koff + 4);
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+            if (in_row) {
+                lo = *reinterpret_cast<const f32x4 *>(a_src[p] + koff);
+                hi = *reinterpret_cast<const f32x4 *>(a_src[p] + koff + 4);
+            }
             pa[p] = (u32x4){pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]),
                             pack_bf16(hi[2], hi[3])};
         }
@@ -721,7 +730,20 @@ __global__ __launch_bounds__(256, 2) void k_linear_bf16(const float *__restrict_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
             }
-            float *dst = C + (size_t)m * ldc + nb;
+            const int mo = c_rows ? c_rows[m] : m;
+            if (OUT16) {                       // fp16 rows for the attention stage (ldc in halves)
+                _Float16 *dst = reinterpret_cast<_Float16 *>(C) + (size_t)mo * ldc + nb;
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                if (nb + 3 < n) {
+                    *reinterpret_cast<h4 *>(dst) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < n) dst[i] = (_Float16)v[i];
+                }
+                continue;
+            }
+            float *dst = C + (size_t)mo * ldc + nb;
             if (nb + 3 < n) {
                 *reinterpret_cast<f32x4 *>(dst) = v;
             } else {
@@ -735,18 +757,22 @@ __global__ __launch_bounds__(256, 2) void k_linear_bf16(const float *__restrict_
 
 hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsigned short *Wb, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad,
-                              bool leaky, float slope) {
+                              bool leaky, float slope, int k_lim, bool out_half, const int32_t *a_rows,
+                              const int32_t *c_rows) {
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
     const int ntn = (n + GEMM_BN - 1) / GEMM_BN;
     const int n_major = (size_t)n * k_pad * 2 > (size_t)(2u << 20) ? 1 : 0;
+    if (k_lim <= 0 || k_lim > k_pad) k_lim = k_pad;
     dim3 grid(ntm * ntn), block(256);
-    if (leaky)
-        hipLaunchKernelGGL(k_linear_bf16<true>, grid, block, 0, s, A, lda, Wb, ldw, bias, C, ldc, m_cap, d_m, n, k_pad,
-                           slope, ntn, n_major);
-    else
-        hipLaunchKernelGGL(k_linear_bf16<false>, grid, block, 0, s, A, lda, Wb, ldw, bias, C, ldc, m_cap, d_m, n, k_pad,
-                           slope, ntn, n_major);
+#define MPE_LAUNCH_BF(L_, H_)                                                                                    \
+    hipLaunchKernelGGL((k_linear_bf16<L_, H_>), grid, block, 0, s, A, lda, Wb, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
+                       slope, ntn, n_major, k_lim, a_rows, c_rows)
+    if (leaky && out_half) MPE_LAUNCH_BF(true, true);
+    else if (leaky) MPE_LAUNCH_BF(true, false);
+    else if (out_half) MPE_LAUNCH_BF(false, true);
+    else MPE_LAUNCH_BF(false, false);
+#undef MPE_LAUNCH_BF
     return hipGetLastError();
 }
 

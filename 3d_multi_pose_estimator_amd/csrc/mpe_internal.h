@@ -68,6 +68,7 @@ struct mpe_ctx {
     bool mlp_acc64 = true;         // f64 running sums in the MLP GEMMs (parity mode)
     bool mlp_bf16 = false;         // reduced precision: bf16 MFMA for the MLP GEMMs
     bool gat_acc64 = false;
+    bool gat_reduced = false;      // reduced precision: bf16 MFMA GEMMs + fp16 feature rows in the attention stage
     mpe::Linear mlp[MPE_MAX_MLP_LAYERS];
     bool mlp_ready[MPE_MAX_MLP_LAYERS] = {};
     // workspace (sized at create / grown when weights define the widths)
@@ -121,7 +122,8 @@ hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *
 
 hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsigned short *Wb, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad,
-                              bool leaky, float slope);
+                              bool leaky, float slope, int k_lim = 0, bool out_half = false,
+                              const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr);
 
 // gat.hip
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
@@ -129,10 +131,11 @@ hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *no
 hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
                                 int ld_feat, int col0, int stride_cam, bool dense);
 hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,
-                            const float *attn_l, const float *attn_r, float *a12);
+                            const float *attn_l, const float *attn_r, float *a12, int ft_half = 0);
 struct AggArgs {
-    const float *ft2;          // rows of transformed features
-    int ld;
+    const float *ft2;          // rows of transformed features (fp16 rows when ft_half, reduced precision)
+    int ld;                    // row stride in elements of that type
+    int ft_half;
     const float *a12;          // [rows][32]: a1[0..15] | a2[0..15]
     int heads, out_dim;
     float alpha, out_slope;    // attention LeakyReLU slope; activation applied to the output

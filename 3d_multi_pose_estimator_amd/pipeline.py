@@ -237,10 +237,12 @@ class Engine:
         self._chk(self.lib.mpe_dlt_pairs(self.ctx, self._stream(), _ptr(pts), _ptr(cams), n, _ptr(out)))
         return out
 
-    def set_precision(self, gat_acc64=False, mlp_acc64=True, mlp_bf16=False):
-        """GAT: plain fp32 MFMA chain or f64 running sums; MLP: fp32 / f64 running sums (default,
-        parity) / bf16 MFMA (reduced precision, BASELINE configs[4])."""
-        self._chk(self.lib.mpe_set_precision(self.ctx, int(gat_acc64), 2 if mlp_bf16 else int(mlp_acc64)))
+    def set_precision(self, gat_acc64=False, mlp_acc64=True, mlp_bf16=False, gat_reduced=False):
+        """GAT: plain fp32 MFMA chain / f64 running sums / reduced (bf16 MFMA GEMMs + fp16 feature
+        rows in the attention stage); MLP: fp32 / f64 running sums (default, parity) / bf16 MFMA.
+        The reduced modes are BASELINE configs[4]; they are never used on the parity path."""
+        self._chk(self.lib.mpe_set_precision(self.ctx, 2 if gat_reduced else int(gat_acc64),
+                                             2 if mlp_bf16 else int(mlp_acc64)))
 
     def linear(self, x, w, b, slope=None, acc64=False):
         """act(x @ w.T + b) through the MFMA GEMM (parity tests). x device [m,k]; w,b host."""

@@ -42,6 +42,9 @@ def main():
     ap.add_argument('--fast-mlp', action='store_true', help='plain fp32 accumulation in the MLP GEMMs')
     ap.add_argument('--bf16-mlp', action='store_true',
                     help='reduced precision (NOT the parity path): bf16 MFMA for the MLP GEMMs, configs[4] style')
+    ap.add_argument('--reduced', action='store_true',
+                    help='configs[4] precision (NOT the parity path): bf16 MFMA for the GAT and MLP GEMMs, fp16 '
+                         'feature rows in the attention stage')
     ap.add_argument('--preset', default='PANOPTIC', choices=['PANOPTIC', 'ARPLAB', 'RING23'],
                     help='camera rig; RING23 = the 23-view stress rig of BASELINE.json configs[4] (fp32 here)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)')
@@ -100,6 +103,8 @@ def main():
         eng.set_precision(False, False)
     if args.bf16_mlp:
         eng.set_precision(False, False, mlp_bf16=True)
+    if args.reduced:
+        eng.set_precision(False, False, mlp_bf16=True, gat_reduced=True)
     pb = eng.pack(frames)
     db = eng.to_device(pb)
     torch.cuda.synchronize(device)
@@ -172,13 +177,13 @@ def main():
         'metric': 'frames/sec (5-view Panoptic, 4 persons) at 1/2/4/8 GPUs; MPJPE vs ref',
         'value': value, 'unit': 'frames/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16 (MLP) / f32' if args.bf16_mlp else 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'bf16 GEMMs / f16 attention rows' if args.reduced else ('bf16 (MLP) / f32' if args.bf16_mlp else 'f32'), 'data': 'synthetic',
         'config': {'workload': ('%s: %d-view x %d-person, GAT match + %s, %d-frame batch per GPU'
                                 % ('c2 Panoptic' if args.preset == 'PANOPTIC' else args.preset, V, args.persons, 'MLP 3D' if args.mode == 'mlp' else 'DLT triangulation', B)),
                    'frames_per_step_per_gpu': B, 'heads_per_batch': pb.n_heads, 'edge_nodes_per_batch': pb.n_edge_nodes,
                    'persons_found_per_frame': persons_per_frame, 'parallelism': 'frame-shard x%d' % n_gpus,
                    'streams': args.streams,
-                   'mlp_accumulate': 'bf16 mfma (reduced precision)' if args.bf16_mlp else ('f32' if args.fast_mlp else 'f32 mfma + f64 running sums'),
+                   'mlp_accumulate': 'bf16 mfma (reduced precision)' if (args.bf16_mlp or args.reduced) else ('f32' if args.fast_mlp else 'f32 mfma + f64 running sums'),
                    'weights': 'deterministic hash init (no checkpoint offline)'},
     }
     if rank == 0:
@@ -192,7 +197,7 @@ def main():
             'flop_per_step': prof['gemm_flop'] / args.steps,
             'gemm_share_of_step': gemm_s / elapsed,
             'flop_definition': 'algorithmic 2*M*N*K of the launches (layer-0 edge-node rows de-duplicated)'
-                               + ('; NOTE: --bf16-mlp mixes bf16 launches into this fp32 roofline' if args.bf16_mlp else ''),
+                               + ('; NOTE: reduced-precision run, bf16 launches are priced against the fp32 peak here' if (args.bf16_mlp or args.reduced) else ''),
         }
         # the CPU baseline is taken on rank 0 at N = 1 only
         out['cpu_baseline'] = None if distributed else cpu_baseline(args, frames, calib, gat_sd, prm, mlp_sd)

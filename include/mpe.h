@@ -118,7 +118,10 @@ int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_d
  * carries about one rounding, like a blocked CPU sgemm.  Defaults: GAT 0, MLP 1 (the MLP's
  * K is up to 3072 and its 3D output is held to the 1e-3 mm parity bound).  MLP mode 2 is the
  * reduced-precision variant of BASELINE.json configs[4]: weights and staged activations in
- * bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~3 significant digits; not parity). */
+ * bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~3 significant digits; not parity).
+ * GAT mode 2 is the other half of that config: fc1/fc2 on the bf16 MFMA and the transformed
+ * features (ft2) stored as fp16 rows for the attention stage (coefficients, softmax and sums
+ * stay fp32; the layer-0 edge-node constants stay fp32). */
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64);
 
 /* ---- batch entry points ---------------------------------------------------------------

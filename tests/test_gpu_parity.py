@@ -533,3 +533,32 @@ def test_bf16_mlp_mode_is_close_but_not_parity(calib, mlp_weights):
     scale = np.abs(arr['f0_mlp_out']).max()
     d = np.abs(y16 - arr['f0_mlp_out']).max()
     assert 1e-5 < d < 0.05 * scale, (d, scale)            # visibly reduced precision, but sane
+
+
+@pytest.mark.parametrize('variant,name', [('panoptic', 'c2_5x4_clean'), ('panoptic', 'c4_5x10'), ('ring23', None)])
+def test_reduced_gat_mode_is_close_but_not_parity(variant, name):
+    """Reduced-precision GAT of BASELINE configs[4]: fc1/fc2 on the bf16 MFMA, ft2 stored as fp16
+    rows for the attention stage.  5x4 runs the fused attention kernel, 5x10 and the 23-camera
+    frames the unfused kernels (and, with 23 cameras, the per-camera grouped layer-0 GEMM).
+    Scores stay within a few 1e-2 of the fp32 scores; switching back restores the fp32 bits."""
+    engine = engine_for(variant)
+    if name is None:
+        arr, frames = load_case(sorted(c for v, c in ALL_CASES if v == variant)[0], variant)
+    else:
+        arr, frames = load_case(name, variant)
+    db = engine.to_device(engine.pack([_pi(f) for f in frames]))
+    s32, h32 = engine.gat_scores(db, heads=True)
+    s32, h32 = s32.cpu().numpy(), h32.cpu().numpy()
+    try:
+        engine.set_precision(gat_reduced=True)
+        s16, h16 = engine.gat_scores(db, heads=True)
+        s16, h16 = s16.cpu().numpy(), h16.cpu().numpy()
+    finally:
+        engine.set_precision()
+    s32b = engine.gat_scores(db).cpu().numpy()
+    assert np.array_equal(s32, s32b)
+    d = max(np.abs(s16 - s32).max(), np.abs(h16 - h32).max())
+    assert 1e-6 < d < 0.08, d                                  # visibly reduced precision, but sane
+    # well separated decisions are unchanged
+    far = np.abs(s32 - 0.5) > 0.1
+    assert np.array_equal(s16[far] > 0.5, s32[far] > 0.5)
