@@ -230,8 +230,8 @@ __device__ __forceinline__ int dma_swz(int row) { return ((row >> 1) & 1) | (((r
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <bool LEAKY, bool ACC64>
-__global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
+template <bool LEAKY, bool ACC64, int NTT>
+__global__ __launch_bounds__(256, (ACC64 && NTT == 5) ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
                                                        const float *__restrict__ W, int ldw,
                                                        const float *__restrict__ bias, float *__restrict__ C,
                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
         tm = swz / ntn;
         tn = swz - tm * ntn;
     }
-    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    constexpr int BN = NTT * 16;
+    const int m0 = tm * GEMM_BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int dr = lane >> 3, dp = lane & 7;          // DMA role: row within the 8-row group, chunk position
@@ -275,30 +276,31 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
         if (a_rows) grow = a_rows[grow];           // gathered rows (grouped layer-0 GEMM)
         a_src[g] = A + (size_t)grow * lda + ((dp ^ dma_swz(row)) << 2);
     }
-    // weight rows: 10 groups of 8; wave w takes groups w, w+4, w+8 (the last only for w < 2)
+    // weight rows: 2*NTT groups of 8; wave w takes groups w, w+4 and (NTT = 5 only) w+8 for w < 2
+    constexpr int WG = NTT * 2;
     const float *w_src[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         int grp = wave + 4 * g;
-        if (grp > 9) grp = 9;
+        if (grp > WG - 1) grp = WG - 1;
         const int row = grp * 8 + dr;
         w_src[g] = W + (size_t)(n0 + row) * ldw + ((dp ^ dma_swz(row)) << 2);
     }
-    const bool w_third = wave < 2;
+    const bool w_third = wave + 8 < WG;
 
     const int fq = lane >> 4, fr = lane & 15;
     const int fsw = dma_swz(fr);
-    int a_rd[MT], w_rd[NT];
+    int a_rd[MT], w_rd[NTT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * ROWF;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) w_rd[nt] = W_OFF + (nt * 16 + fr) * ROWF;
+    for (int nt = 0; nt < NTT; ++nt) w_rd[nt] = W_OFF + (nt * 16 + fr) * ROWF;
     const int c0 = ((fq * 2 + 0) ^ fsw) << 2, c1 = ((fq * 2 + 1) ^ fsw) << 2;
 
-    f32x4 acc[NT][MT];
-    double run[ACC64 ? NT : 1][ACC64 ? MT : 1][4];
+    f32x4 acc[NTT][MT];
+    double run[ACC64 ? NTT : 1][ACC64 ? MT : 1][4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -335,22 +337,22 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int co = hh ? c1 : c0;
-            f32x4 af[MT], wf[NT];
+            f32x4 af[MT], wf[NTT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + co]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + co]);
+            for (int nt = 0; nt < NTT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + co]);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
         }
         if (ACC64) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear_dma(const float *
     }
 
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NTT; ++nt) {
         const int nb = n0 + nt * 16 + fq * 4;
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
 #pragma unroll
@@ -826,14 +828,34 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
 #define MPE_LAUNCH(L_, A_)                                                                                   \
     hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
                        slope, ntn, n_major, tune)
-#define MPE_LAUNCH_DMA(L_, A_)                                                                                 \
-    hipLaunchKernelGGL((k_linear_dma<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n,   \
-                       k_pad, slope, ntn, n_major, a_rows, c_rows)
+#define MPE_LAUNCH_DMA(L_, A_, N_)                                                                                \
+    hipLaunchKernelGGL((k_linear_dma<L_, A_, N_>), dim3(ntm * ntn_), block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, \
+                       d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows)
     if (!(tune & 8) || a_rows || c_rows) {      // LDS-DMA staging is the default; MPE_GEMM_TUNE=8 selects the register-staged kernel
-        if (leaky && acc64) MPE_LAUNCH_DMA(true, true);
-        else if (leaky) MPE_LAUNCH_DMA(true, false);
-        else if (acc64) MPE_LAUNCH_DMA(false, true);
-        else MPE_LAUNCH_DMA(false, false);
+        // tile width: 80 features (5 MFMA tiles per wave) by default; 64 when that spreads the tiles
+        // more evenly over the 256 CUs (MLP layers at a few thousand person rows) and the 64-wide
+        // grid stays inside the padded weight rows
+        static const int force_bn = getenv("MPE_GEMM_BN") ? atoi(getenv("MPE_GEMM_BN")) : 0;
+        const int ntn64 = (n + 63) / 64;
+        bool bn64 = false;
+        if (ntn64 * 64 <= ntn * GEMM_BN) {
+            auto cost = [&](int tiles, double per_tile) {       // time ~ tiles on the busiest CU x tile cost
+                return (double)((tiles + 255) / 256) * per_tile;
+            };
+            bn64 = cost(ntm * ntn64, 64.0 * 1.04) < cost(ntm * ntn, 80.0);
+            if (force_bn == 64) bn64 = true;
+            if (force_bn == 80) bn64 = false;
+        }
+        const int ntn_ = bn64 ? ntn64 : ntn;
+        if (bn64) {
+            if (leaky && acc64) MPE_LAUNCH_DMA(true, true, 4);
+            else if (leaky) MPE_LAUNCH_DMA(true, false, 4);
+            else if (acc64) MPE_LAUNCH_DMA(false, true, 4);
+            else MPE_LAUNCH_DMA(false, false, 4);
+        } else if (leaky && acc64) MPE_LAUNCH_DMA(true, true, 5);
+        else if (leaky) MPE_LAUNCH_DMA(true, false, 5);
+        else if (acc64) MPE_LAUNCH_DMA(false, true, 5);
+        else MPE_LAUNCH_DMA(false, false, 5);
     } else if (leaky && acc64) MPE_LAUNCH(true, true);
     else if (leaky) MPE_LAUNCH(true, false);
     else if (acc64) MPE_LAUNCH(false, true);
