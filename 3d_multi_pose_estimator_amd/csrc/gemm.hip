@@ -842,7 +842,7 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
             auto cost = [&](int tiles, double per_tile) {       // time ~ tiles on the busiest CU x tile cost
                 return (double)((tiles + 255) / 256) * per_tile;
             };
-            bn64 = cost(ntm * ntn64, 64.0 * 1.04) < cost(ntm * ntn, 80.0);
+            bn64 = cost(ntm * ntn64, 64.0) <= cost(ntm * ntn, 80.0);   // measured: per-feature cost is equal
             if (force_bn == 64) bn64 = true;
             if (force_bn == 80) bn64 = false;
         }
