@@ -442,7 +442,12 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
 #pragma clang fp contract(off)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     extern __shared__ float s_dyn[];
-    const int f = blockIdx.x / a.heads, hh = blockIdx.x - f * a.heads;
+    // XCD-aware order: workgroups with equal (id % 8) share an L2; the attention heads of one
+    // frame read neighbouring 160-byte pieces of the same rows, so they go to the same XCD
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
+    const int vid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int f = vid / a.heads, hh = vid - f * a.heads;
     const int D = a.out_dim, Dp = D | 1;           // odd row stride: conflict-free column walks
     const int hb = head_off[f], H = head_off[f + 1] - hb;
     const int eb = en_off[f], M = en_off[f + 1] - eb;
@@ -457,6 +462,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     int *s_deg = s_src + (size_t)(max_deg - 1) * max_deg;                           // [hmax]
     int *s_pair = s_deg + (max_deg - 1);                                            // [m_cap] h1 << 16 | h2
     float *s_att = reinterpret_cast<float *>(s_pair + m_cap);                       // [2][D] attn_l | attn_r
+    float *s_hred = s_att + 2 * D;                                                  // [hmax] per-head max / sum
     const int t = threadIdx.x;
     const bool l0 = a.en_const_ft2 != nullptr;
     const int c0 = hh * D;
@@ -526,25 +532,41 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
         s_wen[m * 3 + 2] = x3 / sum;
     }
     if (!a.score_mode || a.out_heads) {
+        // heads: one (head, in-edge) pair per thread for the logits, exponentials and divisions;
+        // only the max and the edge-ordered sum walk a head's list serially
+        const int n_pairs = H * max_deg;
+        for (int i = t; i < n_pairs; i += blockDim.x) {
+            const int h = i / max_deg, e = i - h * max_deg;
+            if (e < s_deg[h]) {
+                float x = s_a1[s_src[i]] + s_a2[h];
+                s_wh[i] = x > 0.f ? x : x * a.alpha;
+            }
+        }
+        __syncthreads();
         for (int h = t; h < H; h += blockDim.x) {
             const int deg = s_deg[h];
-            const int *src = s_src + h * max_deg;
-            float *w = s_wh + h * max_deg;
-            const float a2v = s_a2[h];
+            const float *w = s_wh + h * max_deg;
             float mx = -INFINITY;
-            for (int e = 0; e < deg; ++e) {
-                float x = s_a1[src[e]] + a2v;
-                x = x > 0.f ? x : x * a.alpha;
-                w[e] = x;
-                mx = fmaxf(mx, x);
-            }
+            for (int e = 0; e < deg; ++e) mx = fmaxf(mx, w[e]);
+            s_hred[h] = mx;
+        }
+        __syncthreads();
+        for (int i = t; i < n_pairs; i += blockDim.x) {
+            const int h = i / max_deg, e = i - h * max_deg;
+            if (e < s_deg[h]) s_wh[i] = expf(s_wh[i] - s_hred[h]);
+        }
+        __syncthreads();
+        for (int h = t; h < H; h += blockDim.x) {
+            const int deg = s_deg[h];
+            const float *w = s_wh + h * max_deg;
             float sum = 0.f;
-            for (int e = 0; e < deg; ++e) {
-                const float ex = expf(w[e] - mx);
-                w[e] = ex;
-                sum = sum + ex;
-            }
-            for (int e = 0; e < deg; ++e) w[e] = w[e] / sum;
+            for (int e = 0; e < deg; ++e) sum = sum + w[e];
+            s_hred[h] = sum;
+        }
+        __syncthreads();
+        for (int i = t; i < n_pairs; i += blockDim.x) {
+            const int h = i / max_deg, e = i - h * max_deg;
+            if (e < s_deg[h]) s_wh[i] = s_wh[i] / s_hred[h];
         }
     }
     __syncthreads();
@@ -599,7 +621,7 @@ static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_c
     const int nc = hmax + mc;
     const int Dp = out_dim | 1;
     const size_t deg = (size_t)hmax + 1;
-    const size_t bytes = ((size_t)nc * Dp + 2 * (size_t)nc + (size_t)mc * 3 + (size_t)hmax * deg + 2 * (size_t)out_dim) * sizeof(float) +
+    const size_t bytes = ((size_t)nc * Dp + 2 * (size_t)nc + (size_t)mc * 3 + (size_t)hmax * deg + 2 * (size_t)out_dim + hmax) * sizeof(float) +
                          ((size_t)hmax * deg + hmax + mc) * sizeof(int);
     *n_cap = nc;
     *m_cap = mc;
