@@ -562,3 +562,68 @@ def test_reduced_gat_mode_is_close_but_not_parity(variant, name):
     # well separated decisions are unchanged
     far = np.abs(s32 - 0.5) > 0.1
     assert np.array_equal(s16[far] > 0.5, s32[far] > 0.5)
+
+
+def test_cluster_kernels_agree_on_random_frames(calib, monkeypatch):
+    """All four clustering kernels (two parallel formulations, two sequential replays) must give
+    the same persons on frames they were not tuned on: random camera occupancy (empty cameras,
+    up to 12 skeletons), score ties on a coarse grid, scores at the threshold, NaN scores, many
+    more than 64 / 256 matchings above the threshold (chunk boundaries of the parallel rounds).
+    The sequential kernels are pinned to the reference by the known answers."""
+    packing = pkg('packing')
+    eng = pkg('pipeline').Engine(calib.params, calib, max_frames=256, max_persons_per_camera=13)
+    try:
+        V = eng.V
+        rng = np.random.default_rng(11)
+        B = 256
+        slot_n = rng.integers(0, 13, size=(B, V)).astype(np.int32)
+        slot_n[rng.random((B, V)) < 0.15] = 0
+        slot_n[:8] = 12                                             # full frames: 60 heads, 1440 edge-nodes
+        slot_n[8:12] = [13, 13, 13, 13, 12]                         # 64 heads: every lane of the wave kernel in use
+        pb = packing.PackedBatch(V, eng.J)
+        pb.n_frames = B
+        pb.slot_cam = np.tile(np.arange(V, dtype=np.int32), (B, 1))
+        for f in range(B):
+            rng.shuffle(pb.slot_cam[f])
+        pb.slot_n = slot_n
+        tot = slot_n.sum(1)
+        ens = (tot * tot - (slot_n * slot_n).sum(1)) // 2
+        pb.frame_head_off = np.concatenate([[0], np.cumsum(tot)]).astype(np.int32)
+        pb.frame_en_off = np.concatenate([[0], np.cumsum(ens)]).astype(np.int32)
+        pb.head_cam = np.concatenate([np.repeat(pb.slot_cam[f], slot_n[f]) for f in range(B)]).astype(np.int32)
+        n = int(tot.sum())
+        pb.joint_mask = np.ones(n, np.uint32)
+        pb.tri_mask = np.ones(n, np.uint32)
+        pb.xy = np.zeros((n, eng.J, 2))
+        pb.vp = np.zeros((n, eng.J, 2), np.float32)
+        M = int(ens.sum())
+        kind = rng.integers(0, 4, size=B)
+        scores = np.empty(M, np.float32)
+        for f in range(B):
+            s = slice(pb.frame_en_off[f], pb.frame_en_off[f + 1])
+            m = ens[f]
+            if kind[f] == 0:
+                scores[s] = rng.random(m)
+            elif kind[f] == 1:
+                scores[s] = np.round(rng.random(m) * 8) / 8            # ties, values exactly 0.5
+            elif kind[f] == 2:
+                scores[s] = 0.5 + rng.random(m) * 0.5                  # everything matches
+            else:
+                x = rng.random(m).astype(np.float32)
+                x[rng.random(m) < 0.05] = np.nan
+                scores[s] = x
+        db = eng.to_device(pb)
+        sc = torch.from_numpy(scores)
+        res = {}
+        for kernel in ('lds', 'wave', 'block', 'big'):
+            monkeypatch.setenv('MPE_CLUSTER_KERNEL', kernel)
+            persons, n_persons = eng.cluster(db, sc)
+            res[kernel] = (persons.cpu().numpy(), n_persons.cpu().numpy())
+        assert res['lds'][1].max() > 4 and (tot > 0).sum() > 200
+        for kernel in ('wave', 'block', 'big'):
+            assert np.array_equal(res[kernel][1], res['lds'][1]), kernel
+            for f in range(B):
+                k = res['lds'][1][f]
+                assert np.array_equal(res[kernel][0][f, :k], res['lds'][0][f, :k]), (kernel, f)
+    finally:
+        eng.close()
