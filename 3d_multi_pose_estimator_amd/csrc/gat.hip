@@ -461,8 +461,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     int *s_src = reinterpret_cast<int *>(s_wh + (size_t)(max_deg - 1) * max_deg);   // [hmax][max_deg]
     int *s_deg = s_src + (size_t)(max_deg - 1) * max_deg;                           // [hmax]
     int *s_pair = s_deg + (max_deg - 1);                                            // [m_cap] h1 << 16 | h2
-    float *s_att = reinterpret_cast<float *>(s_pair + m_cap);                       // [2][D] attn_l | attn_r
-    float *s_hred = s_att + 2 * D;                                                  // [hmax] per-head max / sum
+    float *s_hred = reinterpret_cast<float *>(s_pair + m_cap);                      // [hmax] per-head max / sum
     const int t = threadIdx.x;
     const bool l0 = a.en_const_ft2 != nullptr;
     const int c0 = hh * D;
@@ -479,7 +478,6 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     }
     for (int m = t; m < M; m += blockDim.x)
         s_pair[m] = (en_pair[2 * (size_t)(eb + m)] << 16) | en_pair[2 * (size_t)(eb + m) + 1];
-    for (int d = t; d < 2 * D; d += blockDim.x) s_att[d] = d < D ? attn_l[c0 + d] : attn_r[c0 + d - D];
     // in-edge lists of the heads (ascending edge id), one thread per head
     for (int hd_ = t; hd_ < H; hd_ += blockDim.x) {
         const int32_t *sn = slot_n + (size_t)f * V;
@@ -507,9 +505,10 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     for (int node = t; node < N; node += blockDim.x) {
         const float *fv = s_ft + node * Dp;
         float x1 = 0.f, x2 = 0.f;
+        // the attention vectors are uniform: read through the scalar cache, not LDS
         for (int d = 0; d < D; ++d) {
-            x1 = __builtin_fmaf(fv[d], s_att[d], x1);
-            x2 = __builtin_fmaf(fv[d], s_att[D + d], x2);
+            x1 = __builtin_fmaf(fv[d], attn_l[c0 + d], x1);
+            x2 = __builtin_fmaf(fv[d], attn_r[c0 + d], x2);
         }
         s_a1[node] = x1;
         s_a2[node] = x2;
