@@ -3,7 +3,18 @@
 // Replaces every nn.Linear(+LeakyReLU) call site of the path: GraphAttention2 fc1/fc2
 // (reference gat2.py:53-55) and PoseEstimatorMLP (reference utils/mlp.py:8-28).
 //
-// gfx950 design
+// Kernels in this file (one numerical definition, several shapes)
+//   k_linear_dma    default: tile 128 x 80|64 x 32, K stages written into LDS by
+//                   global_load_lds_dwordx4, 4 waves x (32 rows x all features)
+//   k_linear        the register-staged predecessor (MPE_GEMM_TUNE=8), kept for A/B
+//   k_linear_skinny / k_linear_skinny_ks   one wave per 16x16 tile for small batches
+//   k_linear_bf16   reduced precision (BASELINE configs[4]), not on the parity path
+// The default-path kernels (k_linear_dma, k_linear_skinny*) walk K in 32-deep stages; inside a
+// stage lane group q of the MFMA takes k = 8q..8q+3 (first four MFMAs) then 8q+4..8q+7, so a row
+// gives the same bits whichever of them, and whatever batch size, computed it (tested).  ACC64 adds each stage's fp32 result into f64 running sums.
+//
+// gfx950 design of the register-staged kernel (k_linear_dma keeps its tile, fragment layout
+// and epilogue; its own header describes the LDS image the DMA writes)
 //   * v_mfma_f32_16x16x4_f32 (exact f32 fma chain, 256 FLOP/clk/CU): the model's widths
 //     (400, 320, 160, 912, 3072, 2048, 1024) are multiples of 16, not of 32/128, so the
 //     16-wide tile wastes <2 % where a 128-wide tile would waste up to 22 %.
