@@ -8,8 +8,9 @@ PKG = '3d_multi_pose_estimator_amd'
 cal = importlib.import_module(PKG + '.calibration'); par = importlib.import_module(PKG + '.parameters')
 pipeline = importlib.import_module(PKG + '.pipeline'); L = importlib.import_module(PKG + '.lib')
 eng = pipeline.Engine(par.parameters, cal.Calibration(par.parameters), max_frames=8, max_persons_per_camera=4)
-shapes = [(400, 400, 1, 'gat 400'), (902, 400, 1, 'gat L0'), (3072, 3072, 3, 'mlp 3072'), (1024, 1024, 3, 'mlp 1024')]
-ms_ = [4, 16, 64, 180, 360, 720, 1440, 2880]
+shapes = [(400, 400, 1, 'gat 400'), (902, 400, 1, 'gat L0'), (3072, 3072, 3, 'mlp 3072'), (1024, 1024, 3, 'mlp 1024'),
+          (1024, 54, 2, 'mlp 54')]
+ms_ = [4, 16, 64, 180, 360, 720, 1440, 2880, 5000]
 print('MPE_SKINNY_WAVES=%s' % os.environ.get('MPE_SKINNY_WAVES'))
 for k, n, flags, name in shapes:
     w = (np.random.rand(n, k).astype(np.float32) - 0.5); b = np.random.rand(n).astype(np.float32)
