@@ -1,0 +1,461 @@
+// Diagnostic: what rate does a pure v_mfma_f32_16x16x4_f32 loop reach on this board (no memory
+// traffic at all)?  Gives the practical ceiling the GEMM's 157.3 TFLOP/s "peak" should be read
+// against.   hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// same loop with eight different random operand pairs per lane (data toggling as in a real GEMM)
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_rand(float *out, int iters, const float *rnd) {
+    f32x4 acc[NACC];
+    float a[8], b[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        a[r] = rnd[(threadIdx.x * 16 + r) & 4095];
+        b[r] = rnd[(threadIdx.x * 16 + 8 + r + blockIdx.x) & 4095];
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[(r + i) & 7], acc[i], 0, 0, 0);
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma(float *out, int iters, float a, float b) {
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <int NACC>
+void run(int blocks_per_cu, int cus) {
+    const int grid = cus * blocks_per_cu, iters = 4000;
+    float *out;
+    hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_mfma<NACC>, dim3(grid), dim3(256), 0, 0, out, 100, 1.0f, 0.5f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_mfma<NACC>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 0.5f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)grid * 4 * iters * 8 * NACC * 2048.0;
+    printf("accumulators/wave %2d, workgroups/CU %d: %.1f TFLOP/s (%.2f ms)\n", NACC, blocks_per_cu, flop / ms / 1e9, ms);
+    hipFree(out);
+}
+
+// GEMM-shaped inner loop without global traffic: per "stage" 2 x (2 + 5) ds_read_b128 fragment
+// loads from LDS, then 2 x 40 MFMAs on them (the k_linear_dma loop minus DMA and barrier).
+// PIPE = 0: loads, wait, MFMAs (what the compiler makes of the GEMM source);
+// PIPE = 1: the loads of the next half-stage are issued before the MFMAs of the current one.
+template <int PIPE>
+__global__ __launch_bounds__(256, 3) void k_lds_mfma(float *out, int iters, const float *rnd) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 6656];
+    for (int i = threadIdx.x; i < 2 * 6656; i += 256) lds[i] = rnd[i & 4095];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fq = lane >> 4, fr = lane & 15;
+    int a_rd[2], w_rd[5];
+    for (int mt = 0; mt < 2; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * 32;
+    for (int nt = 0; nt < 5; ++nt) w_rd[nt] = 4096 + (nt * 16 + fr) * 32;
+    const int sw = ((fr >> 1) & 1) | (((fr >> 2) & 1) << 2);
+    const int c0 = ((fq * 2 + 0) ^ sw) << 2, c1 = ((fq * 2 + 1) ^ sw) << 2;
+    f32x4 acc[5][2];
+    for (int nt = 0; nt < 5; ++nt)
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 af[2][2], wf[2][5];
+    auto load = [&](int slot, int base, int co) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[slot][mt] = *reinterpret_cast<const f32x4 *>(&lds[base + a_rd[mt] + co]);
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) wf[slot][nt] = *reinterpret_cast<const f32x4 *>(&lds[base + w_rd[nt] + co]);
+    };
+    auto mfmas = [&](int slot) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][nt][s], af[slot][mt][s], acc[nt][mt], 0, 0, 0);
+    };
+    if (PIPE == 0) {
+        for (int it = 0; it < iters; ++it) {
+            const int base = (it & 1) * 6656;
+            load(0, base, c0);
+            mfmas(0);
+            load(0, base, c1);
+            mfmas(0);
+        }
+    } else {
+        load(0, 0, c0);
+        for (int it = 0; it < iters; ++it) {
+            const int base = (it & 1) * 6656, nbase = ((it + 1) & 1) * 6656;
+            load(1, base, c1);
+            mfmas(0);
+            load(0, nbase, c0);
+            mfmas(1);
+        }
+    }
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 5; ++nt)
+        for (int mt = 0; mt < 2; ++mt) sum += acc[nt][mt];
+    out[blockIdx.x * 256 + threadIdx.x] = sum[0] + sum[1] + sum[2] + sum[3];
+}
+
+// the same loop with the real staging: per stage one barrier and 7 (6) global_load_lds_dwordx4
+// per wave that bring the next 32-deep stage of a 128-row activation tile and an 80-row weight
+// tile from global memory (MODE 1), or the barrier alone (MODE 0)
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == 2 ? 2 : 3) void k_stage_mfma(float *out, int nk, const float *A, const float *W, int ld, int rows_a, int share, long long *clk = nullptr) {
+    const long long t_c0 = (long long)__builtin_readcyclecounter(), t_w0 = (long long)__builtin_amdgcn_s_memrealtime();
+    constexpr int NBUF = MODE == 2 ? 3 : 2;
+    __shared__ __attribute__((aligned(1024))) float lds[NBUF * 6656];
+    for (int i = threadIdx.x; i < NBUF * 6656; i += 256) lds[i] = A[i & 4095];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fq = lane >> 4, fr = lane & 15, dr = lane >> 3, dp = lane & 7;
+    auto swz = [](int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); };
+    int a_rd[2], w_rd[5];
+    for (int mt = 0; mt < 2; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * 32;
+    for (int nt = 0; nt < 5; ++nt) w_rd[nt] = 4096 + (nt * 16 + fr) * 32;
+    const int c0 = ((fq * 2 + 0) ^ swz(fr)) << 2, c1 = ((fq * 2 + 1) ^ swz(fr)) << 2;
+    const float *a_src[4], *w_src[3];
+    // `share` consecutive workgroups read the same activation tile (as the feature tiles of one
+    // row block do in the GEMM), each a different weight tile
+    const int m0 = ((blockIdx.x / share) * 128) % rows_a;
+    for (int g = 0; g < 4; ++g) {
+        const int row = wave * 32 + g * 8 + dr;
+        a_src[g] = A + (size_t)(m0 + row) * ld + ((dp ^ swz(row)) << 2);
+    }
+    for (int g = 0; g < 3; ++g) {
+        int grp = wave + 4 * g;
+        if (grp > 9) grp = 9;
+        const int row = grp * 8 + dr;
+        w_src[g] = W + (size_t)((blockIdx.x % share) * 80 + row) * ld + ((dp ^ swz(row)) << 2);
+    }
+    const bool w_third = wave < 2;
+    auto issue = [&](int kt, int buf) {
+        const int koff = kt * 32;
+        float *base = lds + buf * 6656;
+        if (MODE != 4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[g] + koff), (lds_void_t *)(base + (wave * 32 + g * 8) * 32), 16, 0, 0);
+        }
+        if (MODE == 3) return;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(w_src[g] + koff), (lds_void_t *)(base + 4096 + (wave + 4 * g) * 8 * 32), 16, 0, 0);
+        if (w_third)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(w_src[2] + koff), (lds_void_t *)(base + 4096 + (wave + 8) * 8 * 32), 16, 0, 0);
+    };
+    f32x4 acc[5][2];
+    for (int nt = 0; nt < 5; ++nt)
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (MODE >= 1) issue(0, 0);
+    if (MODE == 2 && nk > 1) issue(1, 1);
+    int cbuf = 0, nbuf = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+        int cur;
+        if (MODE == 2) {
+            if (kt + 1 < nk) {
+                if (w_third) __builtin_amdgcn_s_waitcnt(0xF77);
+                else __builtin_amdgcn_s_waitcnt(0xF76);
+            } else {
+                __builtin_amdgcn_s_waitcnt(0xF70);
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue(kt + 2, nbuf);
+            cur = cbuf * 6656;
+            cbuf = cbuf == 2 ? 0 : cbuf + 1;
+            nbuf = nbuf == 2 ? 0 : nbuf + 1;
+        } else {
+            __syncthreads();
+            if ((MODE == 1 || MODE >= 3) && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+            cur = (kt & 1) * 6656;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int co = hh ? c1 : c0;
+            f32x4 af[2], wf[5];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + co]);
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + co]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
+        }
+    }
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 5; ++nt)
+        for (int mt = 0; mt < 2; ++mt) sum += acc[nt][mt];
+    out[blockIdx.x * 256 + threadIdx.x] = sum[0] + sum[1] + sum[2] + sum[3];
+    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = (long long)__builtin_readcyclecounter() - t_c0;
+        clk[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_w0;
+    }
+}
+
+// cross-stage software pipeline: three LDS buffers; the barrier at the top of stage kt certifies
+// stage kt+1 (requested a whole stage earlier), so the first-half fragments of stage kt+1 are
+// read while the second half of stage kt is still in the MFMA pipe and no wave starts a stage
+// with empty registers
+__global__ __launch_bounds__(256, 2) void k_stage_pipe(float *out, int nk, const float *A, const float *W, int ld, int rows_a, int share) {
+    __shared__ __attribute__((aligned(1024))) float lds[3 * 6656];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fq = lane >> 4, fr = lane & 15, dr = lane >> 3, dp = lane & 7;
+    auto swz = [](int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); };
+    int a_rd[2], w_rd[5];
+    for (int mt = 0; mt < 2; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * 32;
+    for (int nt = 0; nt < 5; ++nt) w_rd[nt] = 4096 + (nt * 16 + fr) * 32;
+    const int c0 = ((fq * 2 + 0) ^ swz(fr)) << 2, c1 = ((fq * 2 + 1) ^ swz(fr)) << 2;
+    const float *a_src[4], *w_src[3];
+    const int m0 = ((blockIdx.x / share) * 128) % rows_a;
+    for (int g = 0; g < 4; ++g) {
+        const int row = wave * 32 + g * 8 + dr;
+        a_src[g] = A + (size_t)(m0 + row) * ld + ((dp ^ swz(row)) << 2);
+    }
+    for (int g = 0; g < 3; ++g) {
+        int grp = wave + 4 * g;
+        if (grp > 9) grp = 9;
+        const int row = grp * 8 + dr;
+        w_src[g] = W + (size_t)((blockIdx.x % share) * 80 + row) * ld + ((dp ^ swz(row)) << 2);
+    }
+    const bool w_third = wave < 2;
+    auto issue = [&](int kt, int buf) {
+        const int koff = kt * 32;
+        float *base = lds + buf * 6656;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[g] + koff), (lds_void_t *)(base + (wave * 32 + g * 8) * 32), 16, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(w_src[g] + koff), (lds_void_t *)(base + 4096 + (wave + 4 * g) * 8 * 32), 16, 0, 0);
+        if (w_third)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(w_src[2] + koff), (lds_void_t *)(base + 4096 + (wave + 8) * 8 * 32), 16, 0, 0);
+    };
+    f32x4 acc[5][2];
+    for (int nt = 0; nt < 5; ++nt)
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 af[2][2], wf[2][5];
+    auto load = [&](int slot, int base, int co) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[slot][mt] = *reinterpret_cast<const f32x4 *>(&lds[base + a_rd[mt] + co]);
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) wf[slot][nt] = *reinterpret_cast<const f32x4 *>(&lds[base + w_rd[nt] + co]);
+    };
+    auto mfmas = [&](int slot) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][nt][s], af[slot][mt][s], acc[nt][mt], 0, 0, 0);
+    };
+    issue(0, 0);
+    __syncthreads();
+    if (nk > 1) issue(1, 1);
+    load(0, 0, c0);
+    int cb = 0;                                   // buffer of the current stage
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                          // stage kt+1 landed everywhere; buffer of stage kt-1 is free
+        const int nb = cb == 2 ? 0 : cb + 1, pb = cb == 0 ? 2 : cb - 1;
+        if (kt + 2 < nk) issue(kt + 2, pb);
+        load(1, cb * 6656, c1);
+        mfmas(0);
+        if (kt + 1 < nk) load(0, nb * 6656, c0);
+        mfmas(1);
+        cb = nb;
+    }
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 5; ++nt)
+        for (int mt = 0; mt < 2; ++mt) sum += acc[nt][mt];
+    out[blockIdx.x * 256 + threadIdx.x] = sum[0] + sum[1] + sum[2] + sum[3];
+}
+
+void run_pipe(int blocks_per_cu, int cus, int nk, int share, int rows_a) {
+    const int grid = cus * blocks_per_cu, ld = nk * 32;
+    float *out, *A, *W;
+    hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+    hipMalloc(&A, (size_t)(rows_a + 128) * ld * sizeof(float));
+    hipMalloc(&W, (size_t)(share * 80) * ld * sizeof(float));
+    hipMemset(A, 0x3c, (size_t)(rows_a + 128) * ld * sizeof(float));
+    hipMemset(W, 0x3c, (size_t)(share * 80) * ld * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_stage_pipe, dim3(grid), dim3(256), 0, 0, out, nk, A, W, ld, rows_a, share);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_stage_pipe, dim3(grid), dim3(256), 0, 0, out, nk, A, W, ld, rows_a, share);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 4.0 * grid * 4 * (double)nk * 80 * 2048.0;
+    printf("cross-stage pipeline (3 buffers, fragments read one half-stage ahead), K = %d, %d rows, workgroups/CU %d: %.1f TFLOP/s (%.2f ms)\n", nk * 32, rows_a, blocks_per_cu, flop / ms / 1e9, ms / 4);
+    hipFree(out);
+    hipFree(A);
+    hipFree(W);
+}
+
+template <int MODE>
+void run_stage(int blocks_per_cu, int cus, int nk, int share = 5, int rows_a = 65536) {
+    const int grid = cus * blocks_per_cu, ld = nk * 32;
+    float *out, *A, *W;
+    hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+    hipMalloc(&A, (size_t)(rows_a + 128) * ld * sizeof(float));
+    hipMalloc(&W, (size_t)(share * 80) * ld * sizeof(float));
+    hipMemset(A, 0x3c, (size_t)(rows_a + 128) * ld * sizeof(float));     // 0x3c3c3c3c = 0.0115 as float
+    hipMemset(W, 0x3c, (size_t)(share * 80) * ld * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_stage_mfma<MODE>, dim3(grid), dim3(256), 0, 0, out, nk, A, W, ld, rows_a, share);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    long long *clk;
+    hipMalloc(&clk, 16);
+    hipMemset(clk, 0, 16);
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_stage_mfma<MODE>, dim3(grid), dim3(256), 0, 0, out, nk, A, W, ld, rows_a, share, clk);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    long long hclk[2];
+    hipMemcpy(hclk, clk, 16, hipMemcpyDeviceToHost);
+    int wall_khz = 0;
+    hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+    printf("   [one workgroup: %lld shader cycles in %lld wall ticks at %d kHz -> shader clock %.0f MHz]\n", hclk[0], hclk[1], wall_khz, wall_khz > 0 ? (double)hclk[0] / ((double)hclk[1] / wall_khz) / 1e3 : 0.0);
+    const double flop = 4.0 * grid * 4 * (double)nk * 80 * 2048.0;
+    printf("%s, K = %d, %d workgroups share an activation tile, %d rows, workgroups/CU %d: %.1f TFLOP/s (%.2f ms)\n", MODE == 3 ? "barrier + LDS-DMA of the activation tile only (4 per wave)" : MODE == 4 ? "barrier + LDS-DMA of the weight tile only (2.5 per wave)" : MODE == 2 ? "barrier + LDS-DMA, 3 buffers, 2 stages in flight" : MODE ? "barrier + LDS-DMA staging per stage" : "barrier per stage", nk * 32, share, rows_a, blocks_per_cu, flop / ms / 1e9, ms / 4);
+    hipFree(out);
+    hipFree(A);
+    hipFree(W);
+}
+
+template <int PIPE>
+void run_lds(int blocks_per_cu, int cus, const float *rnd) {
+    const int grid = cus * blocks_per_cu, iters = 3000;
+    float *out;
+    hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_lds_mfma<PIPE>, dim3(grid), dim3(256), 0, 0, out, 100, rnd);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_lds_mfma<PIPE>, dim3(grid), dim3(256), 0, 0, out, iters, rnd);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)grid * 4 * iters * 80 * 2048.0;
+    printf("LDS fragments + MFMA, %s, workgroups/CU %d: %.1f TFLOP/s (%.2f ms)\n", PIPE ? "reads one half-stage ahead" : "reads then MFMAs", blocks_per_cu, flop / ms / 1e9, ms);
+    hipFree(out);
+}
+
+template <int NACC>
+void run_rand(int blocks_per_cu, int cus) {
+    const int grid = cus * blocks_per_cu, iters = 4000;
+    float *out, *rnd;
+    hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+    hipMalloc(&rnd, 4096 * sizeof(float));
+    float h[4096];
+    unsigned x = 12345;
+    for (int i = 0; i < 4096; ++i) {
+        x = x * 1664525u + 1013904223u;
+        h[i] = (float)(x >> 8) / 16777216.f - 0.5f;
+    }
+    hipMemcpy(rnd, h, sizeof h, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_mfma_rand<NACC>, dim3(grid), dim3(256), 0, 0, out, 100, rnd);
+    hipDeviceSynchronize();
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_mfma_rand<NACC>, dim3(grid), dim3(256), 0, 0, out, iters, rnd);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flop = (double)grid * 4 * iters * 8 * NACC * 2048.0;
+        printf("random operands, accumulators/wave %2d, workgroups/CU %d: %.1f TFLOP/s (%.2f ms)\n", NACC, blocks_per_cu, flop / ms / 1e9, ms);
+    }
+    hipFree(out);
+    hipFree(rnd);
+}
+
+int main() {
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    printf("%s, %d CUs, clock %d MHz\n", p.name, p.multiProcessorCount, p.clockRate / 1000);
+    run<10>(1, p.multiProcessorCount);
+    run<10>(2, p.multiProcessorCount);
+    run<10>(3, p.multiProcessorCount);
+    run<4>(3, p.multiProcessorCount);
+    run<1>(4, p.multiProcessorCount);
+    run_rand<10>(3, p.multiProcessorCount);
+    run_rand<10>(1, p.multiProcessorCount);
+    {
+        float *rnd;
+        hipMalloc(&rnd, 4096 * sizeof(float));
+        float h[4096];
+        unsigned x = 777;
+        for (int i = 0; i < 4096; ++i) {
+            x = x * 1664525u + 1013904223u;
+            h[i] = (float)(x >> 8) / 16777216.f - 0.5f;
+        }
+        hipMemcpy(rnd, h, sizeof h, hipMemcpyHostToDevice);
+        for (int b = 1; b <= 3; ++b) run_lds<0>(b, p.multiProcessorCount, rnd);
+        for (int b = 1; b <= 3; ++b) run_lds<1>(b, p.multiProcessorCount, rnd);
+        run_stage<0>(3, p.multiProcessorCount, 96);
+        run_stage<1>(3, p.multiProcessorCount, 96, 5, 65536);       // no reuse across workgroups: HBM bound
+        run_stage<1>(6, p.multiProcessorCount, 96, 38, 4096);       // MLP-like: 4096 rows x 3040 features
+        run_stage<1>(27, p.multiProcessorCount, 13, 5, 180224);     // GAT-like: 180k rows x 400 features
+        run_stage<1>(27, p.multiProcessorCount, 13, 5, 8192);       // same tiles, operands cache resident
+        run_stage<1>(2, p.multiProcessorCount, 96, 5, 8192);
+        run_stage<2>(2, p.multiProcessorCount, 96, 5, 8192);
+        run_stage<2>(26, p.multiProcessorCount, 13, 5, 8192);
+        run_stage<1>(1, p.multiProcessorCount, 96, 5, 8192);
+        run_stage<3>(3, p.multiProcessorCount, 96, 5, 8192);
+        run_pipe(2, p.multiProcessorCount, 96, 5, 8192);
+        run_pipe(1, p.multiProcessorCount, 96, 5, 8192);
+        run_pipe(26, p.multiProcessorCount, 13, 5, 180224);
+        run_stage<4>(3, p.multiProcessorCount, 96, 5, 8192);
+    }
+    return 0;
+}
