@@ -51,7 +51,7 @@ int upload_linear(mpe_ctx *ctx, const float *w, const float *b, int out_dim, int
     L->in_dim = in_dim;
     L->out_dim = out_dim;
     L->ldw = round_up(in_dim, LD_ALIGN);
-    const int rows = round_up(out_dim, GEMM_BN);
+    const int rows = weight_rows(out_dim);
     int rc = dev_alloc(ctx, &L->w, (size_t)rows * L->ldw);
     if (rc) return rc;
     rc = dev_alloc(ctx, &L->b, (size_t)rows);
@@ -220,7 +220,7 @@ unsigned short f32_to_bf16(float f) {
 
 int ensure_bf16_weights(mpe_ctx *ctx, Linear *L) {
     if (L->w16) return MPE_OK;
-    const int rows = round_up(L->out_dim, GEMM_BN);
+    const int rows = weight_rows(L->out_dim);
     L->ldw16 = round_up(L->in_dim, 128);
     std::vector<float> w((size_t)rows * L->ldw);
     HIPCHK(ctx, hipMemcpy(w.data(), L->w, w.size() * sizeof(float), hipMemcpyDeviceToHost));

@@ -242,16 +242,17 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 template <bool LEAKY, bool ACC64, int NTT>
-__global__ __launch_bounds__(256, (ACC64 && NTT == 5) ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
+__global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
                                                        const float *__restrict__ W, int ldw,
                                                        const float *__restrict__ bias, float *__restrict__ C,
                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
                                                        int k_pad, float slope, int ntn, int n_major,
                                                        const int32_t *__restrict__ a_rows,
                                                        const int32_t *__restrict__ c_rows) {
-    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    extern __shared__ __attribute__((aligned(1024))) float lds[];   // 2 stages of (128 + 16 NTT) rows x 128 B
     constexpr int ROWF = 32;                   // floats per tile row (dense)
     constexpr int W_OFF = GEMM_BM * ROWF;      // weight rows follow the activation rows
+    constexpr int STAGE = (GEMM_BM + NTT * 16) * ROWF;
 
     int M = m_cap;
     if (d_m) {
@@ -293,17 +294,16 @@ __global__ __launch_bounds__(256, (ACC64 && NTT == 5) ? 2 : 3) void k_linear_dma
         if (a_rows) grow = a_rows[grow];           // gathered rows (grouped layer-0 GEMM)
         a_src[g] = A + (size_t)grow * lda + ((dp ^ dma_swz(row)) << 2);
     }
-    // weight rows: 2*NTT groups of 8; wave w takes groups w, w+4 and (NTT = 5 only) w+8 for w < 2
-    constexpr int WG = NTT * 2;
-    const float *w_src[3];
+    // weight rows: 2*NTT groups of 8, dealt round-robin to the four waves
+    constexpr int WG = NTT * 2, WPW = (WG + 3) / 4;
+    const float *w_src[WPW];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
+    for (int g = 0; g < WPW; ++g) {
         int grp = wave + 4 * g;
         if (grp > WG - 1) grp = WG - 1;
         const int row = grp * 8 + dr;
         w_src[g] = W + (size_t)(n0 + row) * ldw + ((dp ^ dma_swz(row)) << 2);
     }
-    const bool w_third = wave + 8 < WG;
 
     const int fq = lane >> 4, fr = lane & 15;
     const int fsw = dma_swz(fr);
@@ -337,12 +337,10 @@ __global__ __launch_bounds__(256, (ACC64 && NTT == 5) ? 2 : 3) void k_linear_dma
             __builtin_amdgcn_global_load_lds((glb_void *)(a_src[g] + koff),
                                              (lds_void *)(base + (wave * 32 + g * 8) * ROWF), 16, 0, 0);
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-            __builtin_amdgcn_global_load_lds((glb_void *)(w_src[g] + koff),
-                                             (lds_void *)(base + W_OFF + (wave + 4 * g) * 8 * ROWF), 16, 0, 0);
-        if (w_third)
-            __builtin_amdgcn_global_load_lds((glb_void *)(w_src[2] + koff),
-                                             (lds_void *)(base + W_OFF + (wave + 8) * 8 * ROWF), 16, 0, 0);
+        for (int g = 0; g < WPW; ++g)
+            if ((g + 1) * 4 <= WG || wave + 4 * g < WG)
+                __builtin_amdgcn_global_load_lds((glb_void *)(w_src[g] + koff),
+                                                 (lds_void *)(base + W_OFF + (wave + 4 * g) * 8 * ROWF), 16, 0, 0);
     };
 
     issue(0, 0);
@@ -795,6 +793,17 @@ hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsi
     return hipGetLastError();
 }
 
+static size_t dma_lds_bytes(int ntt) { return (size_t)2 * (GEMM_BM + ntt * 16) * 32 * sizeof(float); }
+
+// the wide-tile instantiations use more than 64 KB of dynamic LDS
+static bool dma_set_lds_attributes() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma<true, false, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(10));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma<false, false, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(10));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma<true, false, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(13));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma<false, false, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(13));
+    return true;
+}
+
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64, const int32_t *a_rows, const int32_t *c_rows) {
@@ -846,33 +855,48 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
     hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
                        slope, ntn, n_major, tune)
 #define MPE_LAUNCH_DMA(L_, A_, N_)                                                                                \
-    hipLaunchKernelGGL((k_linear_dma<L_, A_, N_>), dim3(ntm * ntn_), block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, \
-                       d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows)
+    hipLaunchKernelGGL((k_linear_dma<L_, A_, N_>), dim3(ntm * ntn_), block, dma_lds_bytes(N_), s, A, lda, W, ldw, bias, \
+                       C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows)
     if (!(tune & 8) || a_rows || c_rows) {      // LDS-DMA staging is the default; MPE_GEMM_TUNE=8 selects the register-staged kernel
-        // tile width: 80 features (5 MFMA tiles per wave) by default; 64 when that spreads the tiles
-        // more evenly over the 256 CUs (MLP layers at a few thousand person rows) and the 64-wide
-        // grid stays inside the padded weight rows
+        // Feature-tile width: 64 or 80, whichever leaves fewer (tiles on the busiest CU) x width;
+        // the MLP layers at a few thousand person rows balance exactly with 64.  160 and 208
+        // (fewer staged bytes and DMA requests per MFMA, +10 % in the isolated loop of
+        // tools/mfma_peak.hip) are compiled for experiments (MPE_GEMM_BN) but did not pay in the
+        // full kernel and need plain fp32 accumulation.  The padded weight rows cover any tile
+        // that starts below n.
         static const int force_bn = getenv("MPE_GEMM_BN") ? atoi(getenv("MPE_GEMM_BN")) : 0;
-        const int ntn64 = (n + 63) / 64;
-        bool bn64 = false;
-        if (ntn64 * 64 <= ntn * GEMM_BN) {
-            auto cost = [&](int tiles, double per_tile) {       // time ~ tiles on the busiest CU x tile cost
-                return (double)((tiles + 255) / 256) * per_tile;
-            };
-            bn64 = cost(ntm * ntn64, 64.0) <= cost(ntm * ntn, 80.0);   // measured: per-feature cost is equal
-            if (force_bn == 64) bn64 = true;
-            if (force_bn == 80) bn64 = false;
+        static const bool attr = dma_set_lds_attributes();
+        (void)attr;
+        const int widths[4] = {64, 80, 160, 208};
+        int best = 1;
+        double best_cost = 1e300;
+        for (int i = 0; i < 4; ++i) {
+            if (i >= 2 && (acc64 || force_bn != widths[i])) continue;
+            const int tiles = ntm * ((n + widths[i] - 1) / widths[i]);
+            const double cost = force_bn == widths[i] ? -1.0 : (double)((tiles + 255) / 256) * widths[i];
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = i;
+            }
         }
-        const int ntn_ = bn64 ? ntn64 : ntn;
-        if (bn64) {
-            if (leaky && acc64) MPE_LAUNCH_DMA(true, true, 4);
-            else if (leaky) MPE_LAUNCH_DMA(true, false, 4);
-            else if (acc64) MPE_LAUNCH_DMA(false, true, 4);
-            else MPE_LAUNCH_DMA(false, false, 4);
-        } else if (leaky && acc64) MPE_LAUNCH_DMA(true, true, 5);
-        else if (leaky) MPE_LAUNCH_DMA(true, false, 5);
-        else if (acc64) MPE_LAUNCH_DMA(false, true, 5);
-        else MPE_LAUNCH_DMA(false, false, 5);
+        const int ntn_ = (n + widths[best] - 1) / widths[best];
+#define MPE_DMA_WIDTH(N_)                                    \
+    do {                                                     \
+        if (leaky && acc64) MPE_LAUNCH_DMA(true, true, N_);  \
+        else if (leaky) MPE_LAUNCH_DMA(true, false, N_);     \
+        else if (acc64) MPE_LAUNCH_DMA(false, true, N_);     \
+        else MPE_LAUNCH_DMA(false, false, N_);               \
+    } while (0)
+        if (best == 0) MPE_DMA_WIDTH(4);
+        else if (best == 1) MPE_DMA_WIDTH(5);
+        else if (best == 2) {
+            if (leaky) MPE_LAUNCH_DMA(true, false, 10);
+            else MPE_LAUNCH_DMA(false, false, 10);
+        } else {
+            if (leaky) MPE_LAUNCH_DMA(true, false, 13);
+            else MPE_LAUNCH_DMA(false, false, 13);
+        }
+#undef MPE_DMA_WIDTH
     } else if (leaky && acc64) MPE_LAUNCH(true, true);
     else if (leaky) MPE_LAUNCH(true, false);
     else if (acc64) MPE_LAUNCH(false, true);

@@ -12,13 +12,17 @@ namespace mpe {
 constexpr int GEMM_BM = 128;   // activation rows per workgroup
 constexpr int GEMM_BN = 80;    // output features per workgroup (5 MFMA tiles of 16)
 constexpr int GEMM_BK = 32;    // K depth per LDS stage
+constexpr int GEMM_BN_MAX = 208;   // widest feature tile of the GEMM variants (13 MFMA tiles)
+// rows a weight matrix / bias vector is padded to: any feature tile that starts below out_dim
+// stays inside the allocation
+inline int weight_rows(int out_dim) { return (out_dim + 15) / 16 * 16 + GEMM_BN_MAX; }
 constexpr int LD_ALIGN = 32;   // every activation / weight row stride is a multiple of this
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 struct Linear {                // one nn.Linear, zero padded on the device
-    float *w = nullptr;        // [round_up(out, GEMM_BN)][ldw]
-    float *b = nullptr;        // [round_up(out, GEMM_BN)]
+    float *w = nullptr;        // [weight_rows(out)][ldw]
+    float *b = nullptr;        // [weight_rows(out)]
     unsigned short *w16 = nullptr;   // optional bf16 copy [rows][ldw16] (reduced-precision mode)
     int ldw16 = 0;
     int in_dim = 0, out_dim = 0, ldw = 0;

@@ -331,6 +331,104 @@ void run_pipe(int blocks_per_cu, int cus, int nk, int share, int rows_a) {
     hipFree(W);
 }
 
+
+// wider feature tiles: NT MFMA tiles (16 features each) per wave, i.e. fewer staged bytes and
+// DMA requests per MFMA (128 x 16*NT tile, double-buffered, plain schedule)
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_stage_wide(float *out, int nk, const float *A, const float *W, int ld, int rows_a, int share) {
+    constexpr int BN = NT * 16, STG = (128 + BN) * 32, WOFF = 128 * 32, WG = NT * 2;
+    extern __shared__ __attribute__((aligned(1024))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fq = lane >> 4, fr = lane & 15, dr = lane >> 3, dp = lane & 7;
+    auto swz = [](int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); };
+    int a_rd[2], w_rd[NT];
+    for (int mt = 0; mt < 2; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * 32;
+    for (int nt = 0; nt < NT; ++nt) w_rd[nt] = WOFF + (nt * 16 + fr) * 32;
+    const int c0 = ((fq * 2 + 0) ^ swz(fr)) << 2, c1 = ((fq * 2 + 1) ^ swz(fr)) << 2;
+    constexpr int WPW = (WG + 3) / 4;                  // weight groups per wave (last may be partial)
+    const float *a_src[4], *w_src[WPW];
+    const int m0 = ((blockIdx.x / share) * 128) % rows_a;
+    for (int g = 0; g < 4; ++g) {
+        const int row = wave * 32 + g * 8 + dr;
+        a_src[g] = A + (size_t)(m0 + row) * ld + ((dp ^ swz(row)) << 2);
+    }
+    for (int g = 0; g < WPW; ++g) {
+        int grp = wave + 4 * g;
+        if (grp > WG - 1) grp = WG - 1;
+        const int row = grp * 8 + dr;
+        w_src[g] = W + (size_t)((blockIdx.x % share) * BN + row) * ld + ((dp ^ swz(row)) << 2);
+    }
+    auto issue = [&](int kt, int buf) {
+        const int koff = kt * 32;
+        float *base = lds + buf * STG;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[g] + koff), (lds_void_t *)(base + (wave * 32 + g * 8) * 32), 16, 0, 0);
+#pragma unroll
+        for (int g = 0; g < WPW; ++g)
+            if (wave + 4 * g < WG)
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(w_src[g] + koff), (lds_void_t *)(base + WOFF + (wave + 4 * g) * 8 * 32), 16, 0, 0);
+    };
+    f32x4 acc[NT][2];
+    for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const int cur = (kt & 1) * STG;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int co = hh ? c1 : c0;
+            f32x4 af[2], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + co]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + co]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
+        }
+    }
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < 2; ++mt) sum += acc[nt][mt];
+    out[blockIdx.x * 256 + threadIdx.x] = sum[0] + sum[1] + sum[2] + sum[3];
+}
+
+template <int NT>
+void run_wide(int blocks_per_cu, int cus, int nk, int share, int rows_a) {
+    const int grid = cus * blocks_per_cu, ld = nk * 32, BN = NT * 16;
+    const size_t shm = (size_t)2 * (128 + BN) * 32 * sizeof(float);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_wide<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    float *out, *A, *W;
+    hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+    hipMalloc(&A, (size_t)(rows_a + 128) * ld * sizeof(float));
+    hipMalloc(&W, (size_t)(share * BN) * ld * sizeof(float));
+    hipMemset(A, 0x3c, (size_t)(rows_a + 128) * ld * sizeof(float));
+    hipMemset(W, 0x3c, (size_t)(share * BN) * ld * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_stage_wide<NT>, dim3(grid), dim3(256), shm, 0, out, nk, A, W, ld, rows_a, share);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_stage_wide<NT>, dim3(grid), dim3(256), shm, 0, out, nk, A, W, ld, rows_a, share);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 4.0 * grid * 4 * (double)nk * 16 * NT * 2048.0;
+    printf("128 x %d tile (LDS %zu KB), K = %d, workgroups/CU %d: %.1f TFLOP/s (%.2f ms) [%s]\n", BN, shm / 1024, nk * 32, blocks_per_cu, flop / ms / 1e9, ms / 4, hipGetErrorString(hipGetLastError()));
+    hipFree(out);
+    hipFree(A);
+    hipFree(W);
+}
+
 template <int MODE>
 void run_stage(int blocks_per_cu, int cus, int nk, int share = 5, int rows_a = 65536) {
     const int grid = cus * blocks_per_cu, ld = nk * 32;
@@ -453,6 +551,12 @@ int main() {
         run_stage<1>(1, p.multiProcessorCount, 96, 5, 8192);
         run_stage<3>(3, p.multiProcessorCount, 96, 5, 8192);
         run_pipe(2, p.multiProcessorCount, 96, 5, 8192);
+        run_wide<5>(3, p.multiProcessorCount, 96, 5, 8192);
+        run_wide<10>(2, p.multiProcessorCount, 96, 5, 8192);
+        run_wide<10>(1, p.multiProcessorCount, 96, 5, 8192);
+        run_wide<13>(1, p.multiProcessorCount, 96, 2, 8192);
+        run_wide<10>(16, p.multiProcessorCount, 13, 5, 180224);
+        run_wide<13>(14, p.multiProcessorCount, 13, 2, 180224);
         run_pipe(1, p.multiProcessorCount, 96, 5, 8192);
         run_pipe(26, p.multiProcessorCount, 13, 5, 180224);
         run_stage<4>(3, p.multiProcessorCount, 96, 5, 8192);
