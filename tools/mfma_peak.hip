@@ -335,7 +335,7 @@ void run_pipe(int blocks_per_cu, int cus, int nk, int share, int rows_a) {
 // wider feature tiles: NT MFMA tiles (16 features each) per wave, i.e. fewer staged bytes and
 // DMA requests per MFMA (128 x 16*NT tile, double-buffered, plain schedule)
 template <int NT>
-__global__ __launch_bounds__(256, 1) void k_stage_wide(float *out, int nk, const float *A, const float *W, int ld, int rows_a, int share) {
+__global__ __launch_bounds__(256, NT > 10 ? 1 : NT > 5 ? 2 : 3) void k_stage_wide(float *out, int nk, const float *A, const float *W, int ld, int rows_a, int share, float *Cout = nullptr, int ldc = 0) {
     constexpr int BN = NT * 16, STG = (128 + BN) * 32, WOFF = 128 * 32, WG = NT * 2;
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -394,6 +394,19 @@ __global__ __launch_bounds__(256, 1) void k_stage_wide(float *out, int nk, const
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
         }
     }
+    if (Cout) {                                    // the GEMM's epilogue: every lane stores 4 consecutive features
+        const int n0 = (blockIdx.x % share) * BN;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4 v = acc[nt][mt];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * 0.15f;
+                *reinterpret_cast<f32x4 *>(Cout + (size_t)(m0 + wave * 32 + mt * 16 + fr) * ldc + n0 + nt * 16 + fq * 4) = v;
+            }
+        return;
+    }
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     for (int nt = 0; nt < NT; ++nt)
         for (int mt = 0; mt < 2; ++mt) sum += acc[nt][mt];
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void k_stage_wide(float *out, int nk, const
 }
 
 template <int NT>
-void run_wide(int blocks_per_cu, int cus, int nk, int share, int rows_a) {
+void run_wide(int blocks_per_cu, int cus, int nk, int share, int rows_a, bool write_c = false) {
     const int grid = cus * blocks_per_cu, ld = nk * 32, BN = NT * 16;
     const size_t shm = (size_t)2 * (128 + BN) * 32 * sizeof(float);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_wide<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -414,16 +427,20 @@ void run_wide(int blocks_per_cu, int cus, int nk, int share, int rows_a) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_stage_wide<NT>, dim3(grid), dim3(256), shm, 0, out, nk, A, W, ld, rows_a, share);
+    float *Cc = nullptr;
+    const int ldc = share * BN;
+    if (write_c) hipMalloc(&Cc, (size_t)(rows_a + 128) * ldc * sizeof(float));
+    hipLaunchKernelGGL(k_stage_wide<NT>, dim3(grid), dim3(256), shm, 0, out, nk, A, W, ld, rows_a, share, Cc, ldc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_stage_wide<NT>, dim3(grid), dim3(256), shm, 0, out, nk, A, W, ld, rows_a, share);
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_stage_wide<NT>, dim3(grid), dim3(256), shm, 0, out, nk, A, W, ld, rows_a, share, Cc, ldc);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double flop = 4.0 * grid * 4 * (double)nk * 16 * NT * 2048.0;
-    printf("128 x %d tile (LDS %zu KB), K = %d, workgroups/CU %d: %.1f TFLOP/s (%.2f ms) [%s]\n", BN, shm / 1024, nk * 32, blocks_per_cu, flop / ms / 1e9, ms / 4, hipGetErrorString(hipGetLastError()));
+    printf("128 x %d tile (LDS %zu KB), K = %d, %d rows%s, workgroups/CU %d: %.1f TFLOP/s (%.2f ms) [%s]\n", BN, shm / 1024, nk * 32, rows_a, write_c ? ", result tile written" : "", blocks_per_cu, flop / ms / 1e9, ms / 4, hipGetErrorString(hipGetLastError()));
+    if (Cc) hipFree(Cc);
     hipFree(out);
     hipFree(A);
     hipFree(W);
@@ -557,6 +574,9 @@ int main() {
         run_wide<13>(1, p.multiProcessorCount, 96, 2, 8192);
         run_wide<10>(16, p.multiProcessorCount, 13, 5, 180224);
         run_wide<13>(14, p.multiProcessorCount, 13, 2, 180224);
+        run_wide<5>(27, p.multiProcessorCount, 13, 5, 180224);
+        run_wide<5>(27, p.multiProcessorCount, 13, 5, 180224, true);
+        run_wide<10>(16, p.multiProcessorCount, 13, 2, 180224, true);
         run_pipe(1, p.multiProcessorCount, 96, 5, 8192);
         run_pipe(26, p.multiProcessorCount, 13, 5, 180224);
         run_stage<4>(3, p.multiProcessorCount, 96, 5, 8192);
