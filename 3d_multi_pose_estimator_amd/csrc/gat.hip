@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
 
 constexpr int AGG_ROWS = 4;
 
+template <int VEC>
 __global__ __launch_bounds__(256) void k_aggregate_heads(
     int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
     const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off,
@@ -394,27 +395,41 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
     }
     __syncthreads();
 
-    // phase D: out[v][c] = sum_e round(alpha[e][h(c)] * ft2[src_e][c]), then activation
-    for (int i = t; i < AGG_ROWS * hd; i += blockDim.x) {
-        const int r = i / hd, c = i - r * hd;
+    // phase D: out[v][c] = sum_e round(alpha[e][h(c)] * ft2[src_e][c]), then activation;
+    // VEC consecutive columns (of one attention head) per thread, each summed in edge order
+    const int per_row = hd / VEC;
+    for (int i = t; i < AGG_ROWS * per_row; i += blockDim.x) {
+        const int r = i / per_row, c = (i - r * per_row) * VEC;
         const int deg = s_deg[r];
         if (deg == 0) continue;
         const int f = s_f[r], v = s_v[r], H = s_H[r];
         const int hh = c / a.out_dim;
         const int32_t nb = node_off[f], hb = head_off[f];
         const bool l0 = a.en_const_ft2 != nullptr;
-        float acc = 0.f;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
         for (int e = 0; e < deg; ++e) {
             const int u = s_src[r * max_deg + e];
-            float fv;
-            if (l0) fv = u >= H ? a.en_const_ft2[c] : ld_ft(a.ft2, (size_t)(hb + u) * a.ld + c, a.ft_half);
-            else fv = ld_ft(a.ft2, (size_t)(nb + u) * a.ld + c, a.ft_half);
-            const float m = fv * s_alpha[((size_t)r * max_deg + e) * heads + hh];
-            acc = acc + m;
+            float fv[VEC];
+            if (l0 && u >= H) ld_ftv<VEC>(a.en_const_ft2, (size_t)c, 0, fv);
+            else ld_ftv<VEC>(a.ft2, (size_t)((l0 ? hb : nb) + u) * a.ld + c, a.ft_half, fv);
+            const float w = s_alpha[((size_t)r * max_deg + e) * heads + hh];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float m = fv[k] * w;
+                acc[k] = acc[k] + m;
+            }
         }
-        const float o = agg_activate(acc, a.out_mode, a.out_slope);
-        if (a.score_mode) a.out_heads[(size_t)hb + v] = o;
-        else a.out[(size_t)(nb + v) * a.ld_out + c] = o;
+        if (a.score_mode) {
+            a.out_heads[(size_t)hb + v] = agg_activate(acc[0], a.out_mode, a.out_slope);
+        } else {
+            typedef float vecf __attribute__((ext_vector_type(VEC)));
+            vecf o;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = agg_activate(acc[k], a.out_mode, a.out_slope);
+            *reinterpret_cast<vecf *>(a.out + (size_t)(nb + v) * a.ld_out + c) = o;
+        }
     }
 }
 
@@ -683,8 +698,18 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
         if (max_deg < 3) max_deg = 3;
         const size_t shm = (size_t)AGG_ROWS * max_deg * (a.heads * sizeof(float) + sizeof(int));
         const int grid = (b.n_heads + AGG_ROWS - 1) / AGG_ROWS;
-        hipLaunchKernelGGL(k_aggregate_heads, dim3(grid), dim3(256), shm, s, b.n_heads, V, max_deg,
-                           b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a);
+        int vec = 1;
+        if (!a.score_mode && a.ld % 4 == 0 && a.ld_out % 4 == 0) {
+            if (a.out_dim % 4 == 0) vec = 4;
+            else if (a.out_dim % 2 == 0) vec = 2;
+        }
+#define MPE_HEADS(V_)                                                                                   \
+    hipLaunchKernelGGL(k_aggregate_heads<V_>, dim3(grid), dim3(256), shm, s, b.n_heads, V, max_deg,         \
+                       b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a)
+        if (vec == 4) MPE_HEADS(4);
+        else if (vec == 2) MPE_HEADS(2);
+        else MPE_HEADS(1);
+#undef MPE_HEADS
     }
     return hipGetLastError();
 }
