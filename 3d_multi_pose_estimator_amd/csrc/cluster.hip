@@ -663,14 +663,15 @@ __global__ __launch_bounds__(64) void k_cluster_wave(const DevCfg *__restrict__ 
 }
 
 // ---- workgroup variant for large frames (> 64 heads: 5 x 10+, 23 cameras) ----------------
-// One workgroup of 256 threads per frame.  Only the matchings above the threshold are kept
+// One workgroup of 1024 threads per frame.  Only the matchings above the threshold are kept
 // (compaction) and bitonic-sorted -- in LDS up to CB_KCAP keys, in the frame's global key
-// scratch beyond.  The greedy rules run as in k_cluster_wave: 256 pending matchings are tested
+// scratch beyond.  The greedy rules run as in k_cluster_wave: 1024 pending matchings are tested
 // against the LDS-resident state at once, the first one that passes is applied by its own
 // thread, one round per accepted matching.  Components are the human-index groups; their output
 // order is the rank of their first node in G's insertion order, computed in parallel; thread 0
 // replays _plain_bfs + the CPython set only for groups that hold two heads of one camera.
-constexpr int CB_THREADS = 256;
+constexpr int CB_THREADS = 1024;
+constexpr int CB_WAVES = CB_THREADS / 64;
 constexpr int CB_KCAP = 8192;
 constexpr int CB_INF = 0x7FFFFFFF;
 
@@ -701,13 +702,13 @@ __global__ __launch_bounds__(CB_THREADS) void k_cluster_block(const DevCfg *__re
     int32_t *s_first = s_cam + hmax, *s_gor = s_first + hmax, *s_gcnt = s_gor + hmax;
     int32_t *s_gfirst = s_gcnt + hmax, *s_gnp = s_gfirst + hmax;
     int32_t *s_sc = s_gnp + hmax;                             // scalars
-    enum { NVALID = 0, NE, CUR, MFROM, MTO, Q0, Q1, Q2, Q3, NNODES, SLOT, NP, NONPLAIN };
+    enum { NVALID = 0, NE, CUR, MFROM, MTO, NNODES, SLOT, NP, NONPLAIN, Q0 };   // Q0 .. Q0 + CB_WAVES - 1
     int32_t *s_rank = w.done, *s_ord = w.order;
     const float thr = cfg->threshold;
     const int min_views = cfg->min_views;
     const int32_t *prs = en_pair + 2 * (size_t)e0;
 
-    if (t < 16) s_sc[t] = 0;
+    if (t < 16 + CB_WAVES) s_sc[t] = 0;
     for (int h = t; h < H; h += CB_THREADS) {
         const int c = head_cam[h0 + h];
         s_cam[h] = c;
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_cluster_block(const DevCfg *__re
         }
     const int n_nodes = s_sc[NNODES];
 
-    // greedy rules, 256 pending matchings per chunk, one round per accepted matching
+    // greedy rules, 1024 pending matchings per chunk, one round per accepted matching
     for (int k0 = 0; k0 < n_valid; k0 += CB_THREADS) {
         const bool valid = k0 + t < n_valid;
         int h1 = 0, h2 = 0;
@@ -795,7 +796,9 @@ __global__ __launch_bounds__(CB_THREADS) void k_cluster_block(const DevCfg *__re
             const unsigned long long bal = __ballot(valid && t >= start && !rej);
             if (lane == 0) s_sc[Q0 + wave] = bal ? wave * 64 + __builtin_ctzll(bal) : CB_INF;
             __syncthreads();
-            const int q = min(min(s_sc[Q0], s_sc[Q1]), min(s_sc[Q2], s_sc[Q3]));
+            int q = CB_INF;
+#pragma unroll
+            for (int wv = 0; wv < CB_WAVES; ++wv) q = min(q, s_sc[Q0 + wv]);
             if (q == CB_INF) break;
             if (t == q) {
                 int mfrom = -1;
@@ -966,7 +969,7 @@ hipError_t launch_cluster(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, 
         return hipGetLastError();
     }
     const size_t shm_block = (size_t)CB_KCAP * sizeof(uint64_t) +
-                             ((size_t)19 * hmax + 1 + 2 * (size_t)table_cap + 16) * sizeof(int32_t);
+                             ((size_t)19 * hmax + 1 + 2 * (size_t)table_cap + 16 + CB_WAVES) * sizeof(int32_t);
     const bool want_block = force ? !strcmp(force, "block") : true;
     if (want_block && shm_block <= 128 * 1024) {
         static bool attr_done = false;
