@@ -32,5 +32,13 @@ for acc in (False, True):
         h0, H, e0, M = db.host.frame_counts(f)
         dmax = max(dmax, float(np.abs(scores[e0:e0 + M] - ref[f][0]).max()))
         want = np.array(ref[f][1], np.int32).reshape(-1, len(sm))
-        if n_persons[f] == len(want) and np.array_equal(persons[f, :len(want)], want): exact += 1
+        if n_persons[f] == len(want) and np.array_equal(persons[f, :len(want)], want):
+            exact += 1
+        elif acc:
+            # a differing frame must be explained by a near-tie: two matchings whose oracle scores are
+            # closer than the score noise, or a score within the noise of the threshold
+            r = np.sort(ref[f][0][ref[f][0] > 0.3])
+            gap = np.diff(r).min() if len(r) > 1 else 1.0
+            thr = np.abs(ref[f][0] - 0.5).min()
+            print('  frame %d differs: smallest gap between sorted oracle scores %.2e, closest score to the threshold %.2e' % (f, gap, thr))
     print('gat_acc64=%s: clusters equal to the oracle in %d of %d frames, max |score diff| %.2e' % (acc, exact, n, dmax))
