@@ -686,7 +686,8 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
 #define MPE_EN(V_)                                                                                      \
     hipLaunchKernelGGL(k_aggregate_en<V_>, dim3(blocks), dim3(256), 0, s, b.n_edge_nodes, b.d_frame_head_off, \
                        b.d_frame_en_off, node_off, en_frame, en_pair, a)
-        if (vec == 4) MPE_EN(4);
+        if (vec == 4 && a.ft_half && a.out_dim % 8 == 0) MPE_EN(8);    // fp16 rows: 8 columns = one 16-byte load
+        else if (vec == 4) MPE_EN(4);
         else if (vec == 2) MPE_EN(2);
         else MPE_EN(1);
 #undef MPE_EN
@@ -706,7 +707,8 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
 #define MPE_HEADS(V_)                                                                                   \
     hipLaunchKernelGGL(k_aggregate_heads<V_>, dim3(grid), dim3(256), shm, s, b.n_heads, V, max_deg,         \
                        b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a)
-        if (vec == 4) MPE_HEADS(4);
+        if (vec == 4 && a.ft_half && a.out_dim % 8 == 0) MPE_HEADS(8);
+        else if (vec == 4) MPE_HEADS(4);
         else if (vec == 2) MPE_HEADS(2);
         else MPE_HEADS(1);
 #undef MPE_HEADS
