@@ -148,6 +148,8 @@ def main():
             dist.all_gather_into_tensor(step.np_buf, n_persons)
         return poses, n_persons
 
+    step()                       # initialisation (workspace, LDS attributes, communicator): not a warmup step
+    torch.cuda.synchronize(device)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(device)
