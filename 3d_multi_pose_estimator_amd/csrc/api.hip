@@ -30,6 +30,33 @@ int fail(mpe_ctx *ctx, int code, const char *fmt, ...) {
             return fail(ctx, MPE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// Every entry point runs on the device the context was created on (one process per GPU is the
+// deployment, but a second context on another device in the same process must also work).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const mpe_ctx *ctx) {
+        if (!ctx) return;
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != ctx->device) {
+            prev = cur;
+            (void)hipSetDevice(ctx->device);
+        }
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+void dev_free(mpe_ctx *ctx, void *p) {
+    if (!p) return;
+    for (size_t i = 0; i < ctx->owned.size(); ++i)
+        if (ctx->owned[i] == p) {
+            (void)hipFree(p);
+            ctx->owned.erase(ctx->owned.begin() + i);
+            return;
+        }
+}
+
 template <typename T>
 int dev_alloc(mpe_ctx *ctx, T **p, size_t count, bool zero = true) {
     void *q = nullptr;
@@ -46,8 +73,16 @@ int dev_alloc(mpe_ctx *ctx, T **p, size_t count, bool zero = true) {
     return MPE_OK;
 }
 
+void free_linear(mpe_ctx *ctx, Linear *L) {
+    dev_free(ctx, L->w);
+    dev_free(ctx, L->b);
+    dev_free(ctx, L->w16);
+    *L = Linear();
+}
+
 int upload_linear(mpe_ctx *ctx, const float *w, const float *b, int out_dim, int in_dim, Linear *L) {
     if (!w || out_dim <= 0 || in_dim <= 0) return fail(ctx, MPE_ERR_INVALID, "bad linear layer %dx%d", out_dim, in_dim);
+    free_linear(ctx, L);                   // a layer set twice does not keep its first copies
     L->in_dim = in_dim;
     L->out_dim = out_dim;
     L->ldw = round_up(in_dim, LD_ALIGN);
@@ -137,8 +172,24 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
     return MPE_OK;
 }
 
+void drop_gat_workspace(mpe_ctx *ctx) {
+    float **bufs[] = {&ctx->x0, &ctx->h0, &ctx->xdense, &ctx->hdense, &ctx->act[0], &ctx->act[1], &ctx->act[2],
+                      &ctx->a12, &ctx->en0_ft2, &ctx->en0_a, &ctx->xc};
+    for (float **p : bufs) {
+        dev_free(ctx, *p);
+        *p = nullptr;
+    }
+    dev_free(ctx, ctx->cam_count);
+    dev_free(ctx, ctx->cam_list);
+    ctx->cam_count = ctx->cam_list = nullptr;
+    for (int c = 0; c < MPE_MAX_CAMERAS; ++c) free_linear(ctx, &ctx->l0_fc1[c]);
+    ctx->en0_ready = false;
+    ctx->gat_ws_ready = false;
+}
+
 int ensure_gat_workspace(mpe_ctx *ctx) {
-    if (ctx->act[0]) return MPE_OK;
+    if (ctx->gat_ws_ready) return MPE_OK;
+    drop_gat_workspace(ctx);               // leftovers of an attempt that failed half way
     for (int l = 0; l < ctx->gat_layers; ++l)
         if (!ctx->gat_ready[l]) return fail(ctx, MPE_ERR_STATE, "GAT layer %d has no weights", l);
     if (ctx->gat_layers <= 0) return fail(ctx, MPE_ERR_STATE, "GAT parameters not set");
@@ -175,6 +226,11 @@ int ensure_gat_workspace(mpe_ctx *ctx) {
     }
     float *d_c1 = nullptr;
     if ((rc = dev_alloc(ctx, &d_c1, (size_t)ctx->feat_ld))) return rc;
+    struct Tmp {                           // the staging row is only needed inside this function
+        mpe_ctx *c;
+        float *p;
+        ~Tmp() { dev_free(c, p); }
+    } tmp{ctx, d_c1};
     if ((rc = dev_alloc(ctx, &ctx->en0_ft2, (size_t)ctx->act_ld))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->en0_a, 32))) return rc;
     HIPCHK(ctx, hipMemcpy(d_c1, c1.data(), c1.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -207,6 +263,7 @@ int ensure_gat_workspace(mpe_ctx *ctx) {
         ctx->l0_grouped = V >= 8;
         if (const char *e = getenv("MPE_L0_GROUPED")) ctx->l0_grouped = atoi(e) != 0;
     }
+    ctx->gat_ws_ready = true;              // last step: a failure above leaves the flag false and is retried
     return MPE_OK;
 }
 
@@ -234,7 +291,12 @@ int ensure_bf16_weights(mpe_ctx *ctx, Linear *L) {
 }
 
 int ensure_mlp_workspace(mpe_ctx *ctx) {
-    if (ctx->mlp_rows) return MPE_OK;
+    if (ctx->mlp_ws_ready) return MPE_OK;
+    float **bufs[] = {&ctx->mlp_rows, &ctx->mlp_act[0], &ctx->mlp_act[1]};
+    for (float **p : bufs) {
+        dev_free(ctx, *p);
+        *p = nullptr;
+    }
     if (ctx->mlp_layers <= 0) return fail(ctx, MPE_ERR_STATE, "MLP parameters not set");
     for (int l = 0; l < ctx->mlp_layers; ++l)
         if (!ctx->mlp_ready[l]) return fail(ctx, MPE_ERR_STATE, "MLP layer %d has no weights", l);
@@ -255,6 +317,93 @@ int ensure_mlp_workspace(mpe_ctx *ctx) {
     if ((rc = dev_alloc(ctx, &ctx->mlp_rows, rows * ctx->mlp_ld_in))) return rc;
     for (int i = 0; i < 2; ++i)
         if ((rc = dev_alloc(ctx, &ctx->mlp_act[i], rows * ctx->mlp_ld_hidden))) return rc;
+    ctx->mlp_ws_ready = true;
+    return MPE_OK;
+}
+
+// Where the input rows of a GAT layer come from
+enum GatInput {
+    GAT_IN_IMPLICIT,   // layer 0, production: head rows featurised on the device, edge-node rows constant
+    GAT_IN_DENSE0,     // layer 0, caller-provided dense rows already copied into ctx->xdense
+    GAT_IN_ACT         // layer > 0: rows in ctx->act[0]
+};
+
+// fc1 -> LeakyReLU(alpha) -> fc2 of layer l (gat2.py:53-55): leaves ft2 in a->ft2 / n_rows_ft2
+int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, GatInput in, AggArgs *a, int *n_rows_ft2) {
+    GatLayer &g = ctx->gat[l];
+    const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints;
+    const int n_nodes = b->n_heads + b->n_edge_nodes;
+    const bool red = ctx->gat_reduced;
+    const int ld_ft = red ? 2 * ctx->act_ld : ctx->act_ld;   // fp16 rows keep the byte stride of the fp32 rows
+    int rc;
+    if (in == GAT_IN_DENSE0) {
+        if ((rc = gat_linear(ctx, s, ctx->xdense, ctx->feat_ld, g.fc1, ctx->hdense, ctx->feat_ld, n_nodes, nullptr,
+                             true, ctx->gat_alpha, false)))
+            return rc;
+        if ((rc = gat_linear(ctx, s, ctx->hdense, ctx->feat_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
+                             0.f, red)))
+            return rc;
+        a->ft2 = ctx->act[2];
+        *n_rows_ft2 = n_nodes;
+    } else if (in == GAT_IN_IMPLICIT) {
+        // heads only: edge-node rows are the layer-0 constants
+        if (ctx->l0_grouped) {
+            // one launch per camera over that camera's heads (device-side count), rows gathered
+            // from the compact features and scattered back to head order
+            const double flop_each = 2.0 * b->n_heads * (double)g.in_dim * (J * 10) / V;
+            for (int c = 0; c < V; ++c)
+                if ((rc = gat_linear(ctx, s, ctx->xc, ctx->l0_ld, ctx->l0_fc1[c], ctx->h0, ctx->feat_ld, b->n_heads,
+                                     ctx->cam_count + c, true, ctx->gat_alpha, false,
+                                     ctx->cam_list + (size_t)c * ctx->cfg.max_heads,
+                                     ctx->cam_list + (size_t)c * ctx->cfg.max_heads, flop_each)))
+                    return rc;
+        } else if ((rc = gat_linear(ctx, s, ctx->x0, ctx->feat_ld, g.fc1, ctx->h0, ctx->feat_ld, b->n_heads, nullptr,
+                                    true, ctx->gat_alpha, false)))
+            return rc;
+        if ((rc = gat_linear(ctx, s, ctx->h0, ctx->feat_ld, g.fc2, ctx->act[1], ld_ft, b->n_heads, nullptr, false,
+                             0.f, red)))
+            return rc;
+        a->ft2 = ctx->act[1];
+        *n_rows_ft2 = b->n_heads;
+        a->en_const_ft2 = ctx->en0_ft2;
+        a->en_const_a = ctx->en0_a;
+    } else {
+        if ((rc = gat_linear(ctx, s, ctx->act[0], ctx->act_ld, g.fc1, ctx->act[1], ctx->act_ld, n_nodes, nullptr,
+                             true, ctx->gat_alpha, false)))
+            return rc;
+        if ((rc = gat_linear(ctx, s, ctx->act[1], ctx->act_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
+                             0.f, red)))
+            return rc;
+        a->ft2 = ctx->act[2];
+        *n_rows_ft2 = n_nodes;
+    }
+    return MPE_OK;
+}
+
+AggArgs gat_agg_args(const mpe_ctx *ctx, int l) {
+    const GatLayer &g = ctx->gat[l];
+    AggArgs a{};
+    a.heads = g.heads;
+    a.out_dim = g.out_dim;
+    a.alpha = ctx->gat_alpha;
+    a.out_slope = ctx->gat_hidden_slope;
+    a.ft_half = ctx->gat_reduced ? 1 : 0;
+    a.ld = ctx->gat_reduced ? 2 * ctx->act_ld : ctx->act_ld;
+    a.a12 = ctx->a12;
+    return a;
+}
+
+int gat_attention(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, const AggArgs &a, int n_rows_ft2) {
+    const GatLayer &g = ctx->gat[l];
+    HIPCHK(ctx, launch_gat_attention(s, *b, ctx->cfg.n_cameras, ctx->cfg.max_heads_per_frame, ctx->node_off,
+                                     ctx->head_frame, ctx->en_frame, ctx->en_pair, g.attn_l, g.attn_r, ctx->a12, a,
+                                     n_rows_ft2));
+    return MPE_OK;
+}
+
+int gat_topology(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b) {
+    HIPCHK(ctx, launch_topology(s, *b, ctx->cfg.n_cameras, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair,
+                                ctx->cfg.max_heads_per_frame, ctx->d_status));
     return MPE_OK;
 }
 
@@ -264,8 +413,7 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
     if (rc) return rc;
     const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints;
     const int n_nodes = b->n_heads + b->n_edge_nodes;
-    const int hmax = ctx->cfg.max_heads_per_frame;
-    HIPCHK(ctx, launch_topology(s, *b, V, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair));
+    if ((rc = gat_topology(ctx, s, b))) return rc;
     const bool dense_in = d_feats != nullptr;   // caller-provided N x F rows (GAT2.forward(inputs, g))
     if (dense_in) {
         if (ld_feats < ctx->gat[0].in_dim) return fail(ctx, MPE_ERR_INVALID, "feature stride too small");
@@ -286,62 +434,14 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
     }
     const int L = ctx->gat_layers;
     for (int l = 0; l < L; ++l) {
-        GatLayer &g = ctx->gat[l];
         const bool last = l == L - 1;
-        AggArgs a{};
-        a.heads = g.heads;
-        a.out_dim = g.out_dim;
-        a.alpha = ctx->gat_alpha;
-        a.out_slope = ctx->gat_hidden_slope;
-        const bool red = ctx->gat_reduced;
-        a.ft_half = red ? 1 : 0;
-        a.ld = red ? 2 * ctx->act_ld : ctx->act_ld;       // fp16 rows keep the byte stride of the fp32 rows
-        const int ld_ft = a.ld;
-        a.a12 = ctx->a12;
+        AggArgs a = gat_agg_args(ctx, l);
         int n_rows_ft2 = 0;
-        if (l == 0 && dense_in) {
-            if ((rc = gat_linear(ctx, s, ctx->xdense, ctx->feat_ld, g.fc1, ctx->hdense, ctx->feat_ld, n_nodes, nullptr,
-                                 true, ctx->gat_alpha, false)))
-                return rc;
-            if ((rc = gat_linear(ctx, s, ctx->hdense, ctx->feat_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
-                                 0.f, red)))
-                return rc;
-            a.ft2 = ctx->act[2];
-            n_rows_ft2 = n_nodes;
-        } else if (l == 0) {
-            // heads only: edge-node rows are the layer-0 constants
-            if (ctx->l0_grouped) {
-                // one launch per camera over that camera's heads (device-side count), rows gathered
-                // from the compact features and scattered back to head order
-                const double flop_each = 2.0 * b->n_heads * (double)g.in_dim * (J * 10) / V;
-                for (int c = 0; c < V; ++c)
-                    if ((rc = gat_linear(ctx, s, ctx->xc, ctx->l0_ld, ctx->l0_fc1[c], ctx->h0, ctx->feat_ld, b->n_heads,
-                                         ctx->cam_count + c, true, ctx->gat_alpha, false,
-                                         ctx->cam_list + (size_t)c * ctx->cfg.max_heads,
-                                         ctx->cam_list + (size_t)c * ctx->cfg.max_heads, flop_each)))
-                        return rc;
-            } else if ((rc = gat_linear(ctx, s, ctx->x0, ctx->feat_ld, g.fc1, ctx->h0, ctx->feat_ld, b->n_heads, nullptr,
-                                        true, ctx->gat_alpha, false)))
-                return rc;
-            if ((rc = gat_linear(ctx, s, ctx->h0, ctx->feat_ld, g.fc2, ctx->act[1], ld_ft, b->n_heads, nullptr, false,
-                                 0.f, red)))
-                return rc;
-            a.ft2 = ctx->act[1];
-            n_rows_ft2 = b->n_heads;
-            a.en_const_ft2 = ctx->en0_ft2;
-            a.en_const_a = ctx->en0_a;
-        } else {
-            if ((rc = gat_linear(ctx, s, ctx->act[0], ctx->act_ld, g.fc1, ctx->act[1], ctx->act_ld, n_nodes, nullptr,
-                                 true, ctx->gat_alpha, false)))
-                return rc;
-            if ((rc = gat_linear(ctx, s, ctx->act[1], ctx->act_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
-                                 0.f, red)))
-                return rc;
-            a.ft2 = ctx->act[2];
-            n_rows_ft2 = n_nodes;
-        }
+        if ((rc = gat_layer_linear(ctx, s, b, l, l > 0 ? GAT_IN_ACT : dense_in ? GAT_IN_DENSE0 : GAT_IN_IMPLICIT, &a,
+                                   &n_rows_ft2)))
+            return rc;
         if (last) {
-            a.out_mode = 1;
+            a.out_mode = ctx->gat_out_mode;
             a.score_mode = 1;
             a.out = d_scores_en;
             a.out_heads = d_scores_heads;
@@ -351,9 +451,18 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
             a.out = ctx->act[0];
             a.ld_out = ctx->act_ld;
         }
-        HIPCHK(ctx, launch_gat_attention(s, *b, V, hmax, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair,
-                                         g.attn_l, g.attn_r, ctx->a12, a, n_rows_ft2));
+        if ((rc = gat_attention(ctx, s, b, l, a, n_rows_ft2))) return rc;
     }
+    return MPE_OK;
+}
+
+// stage-level entry points: caller rows [n_nodes][ld] <-> workspace rows
+int copy_rows_in(mpe_ctx *ctx, hipStream_t s, float *dst, int ld_dst, const float *src, int ld_src, int cols, int rows) {
+    if (rows <= 0) return MPE_OK;
+    // the GEMMs read whole padded rows: columns beyond `cols` must be finite (they meet zero weights)
+    HIPCHK(ctx, hipMemsetAsync(dst, 0, (size_t)rows * ld_dst * sizeof(float), s));
+    HIPCHK(ctx, hipMemcpy2DAsync(dst, (size_t)ld_dst * sizeof(float), src, (size_t)ld_src * sizeof(float),
+                                 (size_t)cols * sizeof(float), rows, hipMemcpyDeviceToDevice, s));
     return MPE_OK;
 }
 
@@ -378,6 +487,10 @@ int mpe_create(const mpe_config *cfg, mpe_ctx **out) {
     mpe_ctx *ctx = new (std::nothrow) mpe_ctx();
     if (!ctx) return MPE_ERR_NOMEM;
     ctx->cfg = *cfg;
+    if (hipGetDevice(&ctx->device) != hipSuccess) {
+        delete ctx;
+        return MPE_ERR_HIP;
+    }
     DevCfg &h = ctx->hcfg;
     memset(&h, 0, sizeof h);
     h.V = cfg->n_cameras;
@@ -403,6 +516,7 @@ int mpe_create(const mpe_config *cfg, mpe_ctx **out) {
     int rc = MPE_OK;
     do {
         if ((rc = dev_alloc(ctx, &ctx->d_cfg, 1))) break;
+        if ((rc = dev_alloc(ctx, &ctx->d_status, 1))) break;
         if (hipMemcpy(ctx->d_cfg, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) { rc = MPE_ERR_HIP; break; }
         if ((rc = dev_alloc(ctx, &ctx->head_frame, (size_t)cfg->max_heads))) break;
         if ((rc = dev_alloc(ctx, &ctx->en_frame, (size_t)cfg->max_edge_nodes))) break;
@@ -427,6 +541,7 @@ int mpe_create(const mpe_config *cfg, mpe_ctx **out) {
 
 void mpe_destroy(mpe_ctx *ctx) {
     if (!ctx) return;
+    DeviceGuard dg(ctx);
     (void)hipDeviceSynchronize();
     for (void *p : ctx->owned) (void)hipFree(p);
     for (auto &r : ctx->prof) {
@@ -440,8 +555,9 @@ void mpe_destroy(mpe_ctx *ctx) {
 
 int mpe_set_gat_params(mpe_ctx *ctx, int32_t n_layers, float alpha, float hidden_slope) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     if (n_layers < 2 || n_layers > MPE_MAX_GAT_LAYERS) return fail(ctx, MPE_ERR_INVALID, "bad GAT layer count %d", n_layers);
-    if (ctx->act[0]) return fail(ctx, MPE_ERR_STATE, "GAT weights are frozen after the first batch");
+    if (ctx->gat_ws_ready) return fail(ctx, MPE_ERR_STATE, "GAT weights are frozen after the first batch");
     ctx->gat_layers = n_layers;
     ctx->gat_alpha = alpha;
     ctx->gat_hidden_slope = hidden_slope;
@@ -452,11 +568,16 @@ int mpe_set_gat_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t heads
                       const float *fc1_b, const float *fc2_w, const float *fc2_b, const float *attn_l,
                       const float *attn_r) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     if (layer < 0 || layer >= ctx->gat_layers) return fail(ctx, MPE_ERR_INVALID, "GAT layer index %d out of range", layer);
-    if (ctx->act[0]) return fail(ctx, MPE_ERR_STATE, "GAT weights are frozen after the first batch");
+    if (ctx->gat_ws_ready) return fail(ctx, MPE_ERR_STATE, "GAT weights are frozen after the first batch");
     if (!fc1_w || !fc1_b || !fc2_w || !fc2_b || !attn_l || !attn_r || heads < 1 || out_dim < 1)
         return fail(ctx, MPE_ERR_INVALID, "GAT layer %d: missing tensor", layer);
     GatLayer &g = ctx->gat[layer];
+    dev_free(ctx, g.attn_l);               // a layer set twice does not keep its first copies
+    dev_free(ctx, g.attn_r);
+    g.attn_l = g.attn_r = nullptr;
+    ctx->gat_ready[layer] = false;
     g.in_dim = in_dim;
     g.heads = heads;
     g.out_dim = out_dim;
@@ -473,8 +594,9 @@ int mpe_set_gat_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t heads
 
 int mpe_set_mlp_params(mpe_ctx *ctx, int32_t n_layers, float slope) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     if (n_layers < 1 || n_layers > MPE_MAX_MLP_LAYERS) return fail(ctx, MPE_ERR_INVALID, "bad MLP layer count %d", n_layers);
-    if (ctx->mlp_rows) return fail(ctx, MPE_ERR_STATE, "MLP weights are frozen after the first batch");
+    if (ctx->mlp_ws_ready) return fail(ctx, MPE_ERR_STATE, "MLP weights are frozen after the first batch");
     ctx->mlp_layers = n_layers;
     ctx->mlp_slope = slope;
     return MPE_OK;
@@ -482,8 +604,9 @@ int mpe_set_mlp_params(mpe_ctx *ctx, int32_t n_layers, float slope) {
 
 int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_dim, const float *w, const float *b) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     if (layer < 0 || layer >= ctx->mlp_layers) return fail(ctx, MPE_ERR_INVALID, "MLP layer index %d out of range", layer);
-    if (ctx->mlp_rows) return fail(ctx, MPE_ERR_STATE, "MLP weights are frozen after the first batch");
+    if (ctx->mlp_ws_ready) return fail(ctx, MPE_ERR_STATE, "MLP weights are frozen after the first batch");
     if (!w || !b) return fail(ctx, MPE_ERR_INVALID, "MLP layer %d: missing tensor", layer);
     int rc = upload_linear(ctx, w, b, out_dim, in_dim, &ctx->mlp[layer]);
     if (rc) return rc;
@@ -505,6 +628,7 @@ int mpe_upload_linear(mpe_ctx *ctx, const float *w, const float *b, int32_t out_
 
 int mpe_free_device(mpe_ctx *ctx, void *d_ptr) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     for (size_t i = 0; i < ctx->owned.size(); ++i)
         if (ctx->owned[i] == d_ptr) {
             (void)hipFree(d_ptr);
@@ -518,6 +642,7 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
                const float *d_bias, float *d_c, int32_t ldc, int32_t m, const int32_t *d_m, int32_t n, int32_t k,
                int32_t slope_on, float slope) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     if (!d_a || !d_w || !d_bias || !d_c || m < 0 || n < 1 || k < 1)
         return fail(ctx, MPE_ERR_INVALID, "mpe_linear: bad argument");
     if (ldw % LD_ALIGN || ldw < k || lda < ldw || ldc % 4 || ldc < n)
@@ -535,6 +660,7 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
 int mpe_head_features(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_feat) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    DeviceGuard dg(ctx);
     if (!d_feat) return fail(ctx, MPE_ERR_INVALID, "d_feat is NULL");
     HIPCHK(ctx, launch_head_features(static_cast<hipStream_t>(stream), ctx->d_cfg, *b, ctx->cfg.n_joints, d_feat,
                                      ctx->cfg.n_joints * 10, 0, 0, false));
@@ -545,12 +671,106 @@ int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float 
                     float *d_scores_en, float *d_scores_heads) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    DeviceGuard dg(ctx);
     if (!d_scores_en) return fail(ctx, MPE_ERR_INVALID, "d_scores_en is NULL");
     return run_gat(ctx, static_cast<hipStream_t>(stream), b, d_scores_en, d_scores_heads, d_feats, ld_feats);
 }
 
+int mpe_set_gat_output(mpe_ctx *ctx, int32_t mode) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (mode != 1 && mode != 2) return fail(ctx, MPE_ERR_INVALID, "GAT output mode: 1 = sigmoid, 2 = identity");
+    ctx->gat_out_mode = mode;
+    return MPE_OK;
+}
+
+int mpe_sync_status(mpe_ctx *ctx, void *stream) {
+    if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t st = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&st, ctx->d_status, sizeof st, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof st, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (st & 1)
+        return fail(ctx, MPE_ERR_CAPACITY, "a frame holds more than max_heads_per_frame = %d skeletons; its scores are "
+                    "zero and it produced no persons", ctx->cfg.max_heads_per_frame);
+    return MPE_OK;
+}
+
+static int stage_layer_checks(mpe_ctx *ctx, const mpe_batch *b, int32_t layer, const void *in, int32_t ld_in, int cols_in,
+                              const void *out, int32_t ld_out, int cols_out) {
+    if (layer < 0 || layer >= ctx->gat_layers) return fail(ctx, MPE_ERR_INVALID, "GAT layer index %d out of range", layer);
+    if (!in || !out || ld_in < cols_in || ld_out < cols_out)
+        return fail(ctx, MPE_ERR_INVALID, "stage entry point: need ld_in >= %d and ld_out >= %d", cols_in, cols_out);
+    (void)b;
+    return MPE_OK;
+}
+
+int mpe_gat_layer(mpe_ctx *ctx, void *stream, const mpe_batch *b, int32_t layer, const float *d_in, int32_t ld_in,
+                  float *d_out, int32_t ld_out, int32_t activation) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    DeviceGuard dg(ctx);
+    if ((rc = ensure_gat_workspace(ctx))) return rc;
+    if (activation < 0 || activation > 2) return fail(ctx, MPE_ERR_INVALID, "activation: 0 LeakyReLU, 1 sigmoid, 2 none");
+    if (layer < 0 || layer >= ctx->gat_layers) return fail(ctx, MPE_ERR_INVALID, "GAT layer index %d out of range", layer);
+    const GatLayer &g = ctx->gat[layer];
+    const int hd = g.heads * g.out_dim;
+    if ((rc = stage_layer_checks(ctx, b, layer, d_in, ld_in, g.in_dim, d_out, ld_out, hd))) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n_nodes = b->n_heads + b->n_edge_nodes;
+    if ((rc = gat_topology(ctx, s, b))) return rc;
+    if (layer == 0) {
+        if (!ctx->xdense) {
+            if ((rc = dev_alloc(ctx, &ctx->xdense, (size_t)ctx->max_nodes * ctx->feat_ld))) return rc;
+            if ((rc = dev_alloc(ctx, &ctx->hdense, (size_t)ctx->max_nodes * ctx->feat_ld))) return rc;
+        }
+        if ((rc = copy_rows_in(ctx, s, ctx->xdense, ctx->feat_ld, d_in, ld_in, g.in_dim, n_nodes))) return rc;
+    } else if ((rc = copy_rows_in(ctx, s, ctx->act[0], ctx->act_ld, d_in, ld_in, g.in_dim, n_nodes)))
+        return rc;
+    AggArgs a = gat_agg_args(ctx, layer);
+    int n_rows_ft2 = 0;
+    if ((rc = gat_layer_linear(ctx, s, b, layer, layer == 0 ? GAT_IN_DENSE0 : GAT_IN_ACT, &a, &n_rows_ft2))) return rc;
+    a.out_mode = activation;
+    a.out = ctx->act[0];
+    a.ld_out = ctx->act_ld;
+    if ((rc = gat_attention(ctx, s, b, layer, a, n_rows_ft2))) return rc;
+    if (n_nodes > 0)
+        HIPCHK(ctx, hipMemcpy2DAsync(d_out, (size_t)ld_out * sizeof(float), ctx->act[0], (size_t)ctx->act_ld * sizeof(float),
+                                     (size_t)hd * sizeof(float), n_nodes, hipMemcpyDeviceToDevice, s));
+    return MPE_OK;
+}
+
+int mpe_edge_softmax_aggregate(mpe_ctx *ctx, void *stream, const mpe_batch *b, int32_t layer, const float *d_ft2,
+                               int32_t ld_ft2, float *d_out, int32_t ld_out) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    DeviceGuard dg(ctx);
+    if ((rc = ensure_gat_workspace(ctx))) return rc;
+    if (layer < 0 || layer >= ctx->gat_layers) return fail(ctx, MPE_ERR_INVALID, "GAT layer index %d out of range", layer);
+    if (ctx->gat_reduced) return fail(ctx, MPE_ERR_STATE, "mpe_edge_softmax_aggregate takes fp32 rows (reduced mode is on)");
+    const GatLayer &g = ctx->gat[layer];
+    const int hd = g.heads * g.out_dim;
+    if ((rc = stage_layer_checks(ctx, b, layer, d_ft2, ld_ft2, hd, d_out, ld_out, hd))) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n_nodes = b->n_heads + b->n_edge_nodes;
+    if ((rc = gat_topology(ctx, s, b))) return rc;
+    if ((rc = copy_rows_in(ctx, s, ctx->act[2], ctx->act_ld, d_ft2, ld_ft2, hd, n_nodes))) return rc;
+    AggArgs a = gat_agg_args(ctx, layer);
+    a.ft2 = ctx->act[2];
+    a.out_mode = 2;
+    a.out = ctx->act[0];
+    a.ld_out = ctx->act_ld;
+    if ((rc = gat_attention(ctx, s, b, layer, a, n_nodes))) return rc;
+    if (n_nodes > 0)
+        HIPCHK(ctx, hipMemcpy2DAsync(d_out, (size_t)ld_out * sizeof(float), ctx->act[0], (size_t)ctx->act_ld * sizeof(float),
+                                     (size_t)hd * sizeof(float), n_nodes, hipMemcpyDeviceToDevice, s));
+    return MPE_OK;
+}
+
 int mpe_set_threshold(mpe_ctx *ctx, float threshold) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     if (!(threshold >= 0.f)) return fail(ctx, MPE_ERR_INVALID, "threshold must be >= 0");
     ctx->hcfg.threshold = threshold;
     ctx->cfg.threshold = threshold;
@@ -562,9 +782,10 @@ int mpe_cluster_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const floa
                       int32_t *d_n_persons) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    DeviceGuard dg(ctx);
     if (!d_scores || !d_persons || !d_n_persons) return fail(ctx, MPE_ERR_INVALID, "mpe_cluster_batch: NULL output");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIPCHK(ctx, launch_topology(s, *b, ctx->cfg.n_cameras, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair));
+    if ((rc = gat_topology(ctx, s, b))) return rc;
     HIPCHK(ctx, launch_cluster(s, ctx->d_cfg, *b, ctx->en_pair, d_scores, ctx->cfg.max_persons_per_frame,
                                ctx->cfg.max_heads_per_frame, ctx->cl_keys, ctx->cl_keys_per_frame, ctx->cl_scratch,
                                ctx->cl_scratch_per_frame, d_persons, d_n_persons));
@@ -575,6 +796,7 @@ int mpe_match_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_sco
                     int32_t *d_n_persons) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    DeviceGuard dg(ctx);
     if (!d_persons || !d_n_persons) return fail(ctx, MPE_ERR_INVALID, "mpe_match_batch: NULL output");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *scores = d_scores;
@@ -592,6 +814,7 @@ int mpe_mlp_input_rows(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int
                        const int32_t *d_n_persons, float *d_rows, int32_t ld_rows, uint8_t *d_valid) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    DeviceGuard dg(ctx);
     const int width = ctx->cfg.n_cameras * ctx->cfg.n_joints * ctx->cfg.numbers_per_joint;
     if (!d_persons || !d_n_persons || !d_rows || ld_rows < width)
         return fail(ctx, MPE_ERR_INVALID, "mpe_mlp_input_rows: bad argument");
@@ -629,6 +852,7 @@ static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int 
 
 int mpe_mlp_forward(mpe_ctx *ctx, void *stream, const float *d_x, int32_t ld_x, int32_t m, float *d_y, int32_t ld_y) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     int rc = ensure_mlp_workspace(ctx);
     if (rc) return rc;
     if (!d_x || !d_y || m < 0) return fail(ctx, MPE_ERR_INVALID, "mpe_mlp_forward: bad argument");
@@ -649,6 +873,7 @@ int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_
                     const int32_t *d_n_persons, float *d_poses, uint8_t *d_valid) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    DeviceGuard dg(ctx);
     if ((rc = ensure_mlp_workspace(ctx))) return rc;
     if (!d_persons || !d_n_persons || !d_poses) return fail(ctx, MPE_ERR_INVALID, "mpe_mlp3d_batch: NULL argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -670,6 +895,7 @@ int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const 
                           const int32_t *d_n_persons, double *d_poses, uint8_t *d_joint_valid, uint32_t flags) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    DeviceGuard dg(ctx);
     if (!d_persons || !d_n_persons || !d_poses || !d_joint_valid)
         return fail(ctx, MPE_ERR_INVALID, "mpe_triangulate_batch: NULL argument");
     HIPCHK(ctx, launch_triangulate(static_cast<hipStream_t>(stream), ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints,
@@ -680,6 +906,7 @@ int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const 
 
 int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t *d_cams, int32_t n, double *d_out) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     if (!d_pts || !d_cams || !d_out || n < 0) return fail(ctx, MPE_ERR_INVALID, "mpe_dlt_pairs: bad argument");
     HIPCHK(ctx, launch_dlt_pairs(static_cast<hipStream_t>(stream), ctx->d_cfg, d_pts, d_cams, n, d_out));
     return MPE_OK;
@@ -687,6 +914,7 @@ int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t
 
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     if (gat_acc64 < 0 || gat_acc64 > 2 || mlp_acc64 < 0 || mlp_acc64 > 2)
         return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0|1|2, MLP 0|1|2");
     ctx->gat_acc64 = gat_acc64 == 1;
@@ -698,6 +926,7 @@ int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
 
 int mpe_profile_enable(mpe_ctx *ctx, int32_t on) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     ctx->profiling = on != 0;
     ctx->prof_used = 0;
     return MPE_OK;
@@ -705,6 +934,7 @@ int mpe_profile_enable(mpe_ctx *ctx, int32_t on) {
 
 int mpe_profile_read(mpe_ctx *ctx, double *gemm_ms, double *gemm_flop, int64_t *gemm_launches, double *total_ms) {
     if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
     HIPCHK(ctx, hipDeviceSynchronize());
     int32_t dev_m = 0;
     HIPCHK(ctx, hipMemcpy(&dev_m, ctx->mlp_count, sizeof dev_m, hipMemcpyDeviceToHost));

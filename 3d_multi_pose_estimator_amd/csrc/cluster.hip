@@ -455,7 +455,8 @@ __global__ __launch_bounds__(64) void k_cluster_wave(const DevCfg *__restrict__ 
                                                      const int32_t *__restrict__ head_cam,
                                                      const int32_t *__restrict__ en_pair,
                                                      const float *__restrict__ scores, int pcap, int n_pow2,
-                                                     int32_t *__restrict__ persons, int32_t *__restrict__ n_persons) {
+                                                     int hmax, int32_t *__restrict__ persons,
+                                                     int32_t *__restrict__ n_persons) {
     extern __shared__ uint64_t s_keys[];
     const int f = blockIdx.x;
     if (f >= n_frames) return;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(64) void k_cluster_wave(const DevCfg *__restrict__ 
     const int h0 = head_off[f], H = head_off[f + 1] - h0;
     const int e0 = en_off[f], M = en_off[f + 1] - e0;
     int32_t *out = persons + (size_t)f * pcap * V;
-    if (M <= 0 || H > 64 || M > n_pow2) {
+    if (M <= 0 || H > 64 || H > hmax || M > n_pow2) {
         for (int i = lane; i < pcap * V; i += 64) out[i] = -1;
         if (lane == 0) n_persons[f] = 0;
         return;
@@ -965,19 +966,19 @@ hipError_t launch_cluster(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, 
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(k_cluster_wave, dim3(b.n_frames), dim3(64), shm_wave, s, cfg, b.n_frames, b.d_frame_head_off,
-                           b.d_frame_en_off, b.d_head_cam, en_pair, scores, pcap, n_pow2, persons, n_persons);
+                           b.d_frame_en_off, b.d_head_cam, en_pair, scores, pcap, n_pow2, hmax, persons, n_persons);
         return hipGetLastError();
     }
     const size_t shm_block = (size_t)CB_KCAP * sizeof(uint64_t) +
                              ((size_t)19 * hmax + 1 + 2 * (size_t)table_cap + 16 + CB_WAVES) * sizeof(int32_t);
     const bool want_block = force ? !strcmp(force, "block") : true;
     if (want_block && shm_block <= 128 * 1024) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static PerDeviceFlag attr_done;
+        if (!attr_done.test()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cluster_block),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) return e;
-            attr_done = true;
+            attr_done.set();
         }
         hipLaunchKernelGGL(k_cluster_block, dim3(b.n_frames), dim3(CB_THREADS), shm_block, s, cfg, b.n_frames,
                            b.d_frame_head_off, b.d_frame_en_off, b.d_head_cam, en_pair, scores, pcap, hmax, table_cap,

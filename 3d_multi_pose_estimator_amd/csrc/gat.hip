@@ -24,7 +24,8 @@ namespace mpe {
 __global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head_off,
                            const int32_t *__restrict__ en_off, const int32_t *__restrict__ slot_n,
                            int32_t *__restrict__ node_off, int32_t *__restrict__ head_frame,
-                           int32_t *__restrict__ en_frame, int32_t *__restrict__ en_pair) {
+                           int32_t *__restrict__ en_frame, int32_t *__restrict__ en_pair, int hmax,
+                           int32_t *__restrict__ status) {
     const int f = blockIdx.x;
     __shared__ int s_n[MPE_MAX_CAMERAS], s_start[MPE_MAX_CAMERAS];
     const int h0 = head_off[f], H = head_off[f + 1] - h0;
@@ -37,6 +38,9 @@ __global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head
             acc += s_n[s];
         }
         node_off[f] = h0 + e0;
+        // per-frame capacity (the host side of the C ABI sees batch totals only): such a frame is
+        // skipped by the attention and clustering kernels and reported by mpe_sync_status
+        if (H > hmax && status) atomicOr(status, 1);
         if (f == n_frames - 1) node_off[n_frames] = head_off[n_frames] + en_off[n_frames];
     }
     __syncthreads();
@@ -56,10 +60,11 @@ __global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head
 }
 
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
-                           int32_t *en_frame, int32_t *en_pair) {
+                           int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status) {
     if (b.n_frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_topology, dim3(b.n_frames), dim3(128), 0, s, b.n_frames, V, b.d_frame_head_off,
-                       b.d_frame_en_off, b.d_slot_n, node_off, head_frame, en_frame, en_pair);
+                       b.d_frame_en_off, b.d_slot_n, node_off, head_frame, en_frame, en_pair, max_heads_per_frame,
+                       status);
     return hipGetLastError();
 }
 
@@ -327,7 +332,8 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
     if (t < AGG_ROWS) {
         const int gh = row0 + t;
         int deg = 0;
-        if (gh < n_heads) {
+        // heads of a frame beyond max_heads_per_frame are skipped (their list would not fit)
+        if (gh < n_heads && head_off[head_frame[gh] + 1] - head_off[head_frame[gh]] <= max_deg - 1) {
             const int f = head_frame[gh];
             const int v = gh - head_off[f];
             const int H = head_off[f + 1] - head_off[f];
@@ -467,7 +473,13 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     const int hb = head_off[f], H = head_off[f + 1] - hb;
     const int eb = en_off[f], M = en_off[f + 1] - eb;
     const int N = H + M, nb = node_off[f];
-    if (M <= 0 || N > n_cap || M > m_cap) return;   // frames without a graph produce nothing
+    if (M <= 0) return;                             // frames without a graph produce nothing
+    if (H > max_deg - 1 || N > n_cap || M > m_cap) {
+        // frame beyond max_heads_per_frame (k_topology raised the status flag): defined output
+        if (a.score_mode)
+            for (int m = threadIdx.x; m < M; m += blockDim.x) a.out[(size_t)eb + m] = 0.f;
+        return;
+    }
     float *s_ft = s_dyn;                            // [n_cap][Dp]
     float *s_a1 = s_ft + (size_t)n_cap * Dp;        // [n_cap]
     float *s_a2 = s_a1 + n_cap;                     // [n_cap]

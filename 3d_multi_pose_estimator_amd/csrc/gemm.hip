@@ -819,15 +819,15 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
     if (waves16 <= skinny_waves && !(tune & 8) && acc64 && k_pad / GEMM_BK <= 128 && k_pad / GEMM_BK >= 8) {
         // K split over the waves of a workgroup, ordered f64 reduction through LDS
         const size_t shm = (size_t)(k_pad / GEMM_BK) * 1024;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static PerDeviceFlag attr_done;
+        if (!attr_done.test()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_skinny_ks<true, 8>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_skinny_ks<false, 8>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) return e;
-            attr_done = true;
+            attr_done.set();
         }
         dim3 kgrid((unsigned)waves16), kblock(512);
         if (leaky)
@@ -865,8 +865,11 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
         // full kernel and need plain fp32 accumulation.  The padded weight rows cover any tile
         // that starts below n.
         static const int force_bn = getenv("MPE_GEMM_BN") ? atoi(getenv("MPE_GEMM_BN")) : 0;
-        static const bool attr = dma_set_lds_attributes();
-        (void)attr;
+        static PerDeviceFlag dma_attr;
+        if (!dma_attr.test()) {
+            dma_set_lds_attributes();
+            dma_attr.set();
+        }
         const int widths[4] = {64, 80, 160, 208};
         int best = 1;
         double best_cost = 1e300;

@@ -46,6 +46,18 @@ struct DevCfg {                // calibration + scalars, lives in device memory
     double dist[MPE_MAX_CAMERAS][5];
 };
 
+// hipFuncSetAttribute (dynamic-LDS opt-in) is per DEVICE: remember which devices have it
+struct PerDeviceFlag {
+    bool done[64] = {};
+    static int dev() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d & 63;
+    }
+    bool test() const { return done[dev()]; }
+    void set() { done[dev()] = true; }
+};
+
 struct ProfileRec {
     hipEvent_t start, stop;
     double flop;      // known on the host, or
@@ -56,6 +68,11 @@ struct ProfileRec {
 
 struct mpe_ctx {
     mpe_config cfg;
+    int device = 0;                // HIP device the context was created on (every entry point switches to it)
+    int32_t *d_status = nullptr;   // device-side status word: bit 0 = a frame exceeded max_heads_per_frame
+    bool gat_ws_ready = false;     // set only after the LAST step of ensure_gat_workspace succeeded
+    bool mlp_ws_ready = false;
+    int gat_out_mode = 1;          // activation of the last GAT layer: 1 = sigmoid, 2 = identity (logits)
     mpe::DevCfg hcfg;
     mpe::DevCfg *d_cfg = nullptr;
     std::string err;
@@ -131,7 +148,7 @@ hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsi
 
 // gat.hip
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
-                           int32_t *en_frame, int32_t *en_pair);
+                           int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status);
 hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
                                 int ld_feat, int col0, int stride_cam, bool dense);
 hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,

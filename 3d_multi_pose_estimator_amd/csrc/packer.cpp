@@ -161,9 +161,22 @@ bool read_number(Cursor &c, double *v) {
             if (neg) d = -d;
             e = q;
         } else if (ok) {
+            // the buffer is length-delimited, not NUL-terminated: hand strtod a bounded copy of
+            // the token [c.p, q) (q = end of the digits / fraction / exponent scanned above)
+            char tok[128];
+            std::string big;
+            const size_t n = (size_t)(q - c.p);
+            const char *src = tok;
+            if (n < sizeof tok) {
+                memcpy(tok, c.p, n);
+                tok[n] = 0;
+            } else {
+                big.assign(c.p, n);
+                src = big.c_str();
+            }
             char *e2 = nullptr;
-            d = strtod(c.p, &e2);
-            e = e2;
+            d = strtod(src, &e2);
+            e = c.p + (e2 - src);
         }
     }
     if (e == c.p) {
@@ -181,7 +194,7 @@ bool read_number(Cursor &c, double *v) {
 bool skip_value(Cursor &c);
 
 bool skip_container(Cursor &c, char open, char close) {
-    if (*c.p != open) return false;
+    if (c.p >= c.end || *c.p != open) return false;
     ++c.p;
     skip_ws(c);
     if (c.p < c.end && *c.p == close) { ++c.p; return true; }
@@ -246,9 +259,11 @@ bool parse_skeleton(Cursor &c, int J, Head *h, std::string *err) {
             ++c.p;
             double v[5] = {0, 0, 0, 0, 0};
             int n = 0;
+            bool closed = false;
             while (c.p < c.end) {
                 skip_ws(c);
-                if (*c.p == ']') { ++c.p; break; }
+                if (c.p >= c.end) break;
+                if (*c.p == ']') { ++c.p; closed = true; break; }
                 double d;
                 if (!read_number(c, &d)) { *err = "bad number in joint"; return false; }
                 if (n < 5) v[n] = d;
@@ -256,6 +271,7 @@ bool parse_skeleton(Cursor &c, int J, Head *h, std::string *err) {
                 skip_ws(c);
                 if (c.p < c.end && *c.p == ',') ++c.p;
             }
+            if (!closed) { *err = "unterminated joint value"; return false; }
             if (n < 5) { *err = "joint value needs 5 numbers"; return false; }
             h->joint_mask |= 1u << j;
             if (v[0] > 0.) h->tri_mask |= 1u << j;
@@ -364,13 +380,16 @@ bool parse_frame(const char *b, const char *e, const std::vector<std::string> &c
             fo->slot_cam.push_back(cam);
             fo->slot_n.push_back(n_here);
             // remaining elements (timestamp, 'no_image', bodies_3D) are not on the hot path
+            bool closed = false;
             while (c.p < c.end) {
                 skip_ws(c);
+                if (c.p >= c.end) break;
                 if (*c.p == ',') { ++c.p; if (!skip_value(c)) { fo->error = "bad camera entry"; return false; } continue; }
-                if (*c.p == ']') { ++c.p; break; }
+                if (*c.p == ']') { ++c.p; closed = true; break; }
                 fo->error = "bad camera entry";
                 return false;
             }
+            if (!closed) { fo->error = "unterminated camera entry"; return false; }
         }
         skip_ws(c);
         if (c.p >= c.end) break;

@@ -97,8 +97,6 @@ class GAT2(nn.Module):
             # re-derived on the device from the packed skeletons instead
             if not (own is not None and inputs.shape == own.shape and torch.equal(inputs.cpu().float(), own)):
                 feats = inputs
+        eng.set_gat_output(sigmoid=self.final_activation is not None)     # None: raw logits (gat2.py:146-148)
         sc, sh = eng.gat_scores(db, heads=True, feats=feats)
-        out = torch.cat([sh, sc]).reshape(-1, 1, 1)
-        if self.final_activation is None:
-            out = torch.logit(out)
-        return out
+        return torch.cat([sh, sc]).reshape(-1, 1, 1)

@@ -81,6 +81,12 @@ SYMBOLS = {
     'mpe_head_features': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p]),
     'mpe_gat_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_void_p]),
+    'mpe_set_gat_output': (C.c_int, [C.c_void_p, C.c_int32]),
+    'mpe_gat_layer': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_int32, C.c_void_p, C.c_int32,
+                                C.c_void_p, C.c_int32, C.c_int32]),
+    'mpe_edge_softmax_aggregate': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_int32, C.c_void_p,
+                                             C.c_int32, C.c_void_p, C.c_int32]),
+    'mpe_sync_status': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mpe_set_threshold': (C.c_int, [C.c_void_p, C.c_float]),
     'mpe_cluster_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
                                     C.c_void_p]),

@@ -54,8 +54,49 @@ class PackedBatch:
         return DeviceBatch(self, device)
 
 
+ARRAYS = (('frame_head_off', np.int32), ('frame_en_off', np.int32), ('slot_cam', np.int32), ('slot_n', np.int32),
+          ('head_cam', np.int32), ('joint_mask', np.uint32), ('tri_mask', np.uint32), ('xy', np.float64),
+          ('vp', np.float32))
+
+
+class BatchArena:
+    """The nine arrays of one packed batch as views of ONE contiguous byte buffer (256-byte
+    aligned pieces), so that a batch travels host -> device as a single copy from pinned memory
+    (8.6 KB per 5x4 frame) instead of nine.  `where` = 'pinned' (host, page-locked), 'host' (pageable) or a device."""
+
+    def __init__(self, pb, where):
+        import torch
+        self.offsets = {}
+        off = 0
+        for name, dt in ARRAYS:
+            n = int(np.asarray(getattr(pb, name)).size)
+            self.offsets[name] = (off, n, dt)
+            off += (n * np.dtype(dt).itemsize + 255) // 256 * 256
+        self.nbytes = max(off, 256)
+        if where == 'pinned':
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8).pin_memory()
+        elif where == 'host':                      # pageable (layout tests without a GPU)
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8)
+        else:
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=where)
+
+    def fill(self, pb):
+        """Host arenas only: copy the batch's arrays into the pinned buffer."""
+        host = self.buf.numpy()
+        for name, (off, n, dt) in self.offsets.items():
+            src = np.ascontiguousarray(getattr(pb, name)).reshape(-1).view(dt) if n else np.zeros(0, dt)
+            host[off: off + n * np.dtype(dt).itemsize].view(dt)[:] = src
+        return self
+
+    def ptr(self, name):
+        return self.buf.data_ptr() + self.offsets[name][0]
+
+
 class DeviceBatch:
-    def __init__(self, pb, device):
+    def __init__(self, pb, device, arena=None):
+        """arena = None: nine independent device tensors uploaded from pageable numpy arrays
+        (tests, one-off calls).  arena = a device BatchArena: the struct points into it and the
+        data arrives with `upload(pinned_arena)` (one async copy, stream-ordered)."""
         import ctypes as C
 
         import torch
@@ -63,20 +104,30 @@ class DeviceBatch:
         from . import lib as L
         self.host = pb
         self.device = torch.device(device)
-
-        def up(a):
-            return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-        self.t = {
-            'frame_head_off': up(pb.frame_head_off), 'frame_en_off': up(pb.frame_en_off),
-            'slot_cam': up(pb.slot_cam), 'slot_n': up(pb.slot_n), 'head_cam': up(pb.head_cam),
-            'joint_mask': up(pb.joint_mask.view(np.int32)), 'tri_mask': up(pb.tri_mask.view(np.int32)),
-            'xy': up(pb.xy), 'vp': up(pb.vp),
-        }
+        self.arena = arena
         s = L.mpe_batch()
         s.n_frames, s.n_heads, s.n_edge_nodes = pb.n_frames, pb.n_heads, pb.n_edge_nodes
-        for k, v in self.t.items():
-            setattr(s, 'd_' + k, C.c_void_p(v.data_ptr()))
+        if arena is None:
+            def up(a):
+                return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            self.t = {
+                'frame_head_off': up(pb.frame_head_off), 'frame_en_off': up(pb.frame_en_off),
+                'slot_cam': up(pb.slot_cam), 'slot_n': up(pb.slot_n), 'head_cam': up(pb.head_cam),
+                'joint_mask': up(pb.joint_mask.view(np.int32)), 'tri_mask': up(pb.tri_mask.view(np.int32)),
+                'xy': up(pb.xy), 'vp': up(pb.vp),
+            }
+            for k, v in self.t.items():
+                setattr(s, 'd_' + k, C.c_void_p(v.data_ptr()))
+        else:
+            for name, _ in ARRAYS:
+                setattr(s, 'd_' + name, C.c_void_p(arena.ptr(name)))
         self.struct = s
+
+    def upload(self, pinned):
+        """One H2D copy of the whole batch from a pinned BatchArena of the same layout, on the
+        current stream."""
+        assert self.arena is not None and pinned.nbytes == self.arena.nbytes
+        self.arena.buf.copy_(pinned.buf, non_blocking=True)
 
     @property
     def n_frames(self):

@@ -174,6 +174,33 @@ class Engine:
                                            _ptr(sc), _ptr(sh)))
         return (sc[:db.n_edge_nodes], sh[:db.n_heads]) if heads else sc[:db.n_edge_nodes]
 
+    def set_gat_output(self, sigmoid=True):
+        """Last-layer activation: sigmoid (deployed model) or identity (final_activation=None)."""
+        self._chk(self.lib.mpe_set_gat_output(self.ctx, 1 if sigmoid else 2))
+
+    def gat_layer(self, db, layer, x, activation=0):
+        """One GraphAttention2 layer + the activation GAT2.forward applies (mpe_gat_layer).
+        x [n_nodes, in_dim] rows in node order -> [n_nodes, heads*out_dim]."""
+        x = x.to(self.device, torch.float32).contiguous()
+        _, nh, od = self.gat_dims[layer]
+        out = torch.empty((x.shape[0], nh * od), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.mpe_gat_layer(self.ctx, self._stream(), C.byref(db.struct), layer, _ptr(x), x.shape[1],
+                                         _ptr(out), out.shape[1], int(activation)))
+        return out
+
+    def edge_softmax_aggregate(self, db, layer, ft2):
+        """The DGL half of a layer (gat2.py:57-66): ft2 [n_nodes, heads*out_dim] -> aggregated rows."""
+        ft2 = ft2.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(ft2)
+        self._chk(self.lib.mpe_edge_softmax_aggregate(self.ctx, self._stream(), C.byref(db.struct), layer, _ptr(ft2),
+                                                      ft2.shape[1], _ptr(out), out.shape[1]))
+        return out
+
+    def sync_status(self):
+        """Synchronise and raise MpeError(MPE_ERR_CAPACITY) if a frame of a batch since the last
+        call exceeded max_heads_per_frame (detected on the device)."""
+        self._chk(self.lib.mpe_sync_status(self.ctx, self._stream()))
+
     def set_threshold(self, thr):
         self._chk(self.lib.mpe_set_threshold(self.ctx, float(thr)))
 

@@ -1,18 +1,38 @@
 """Throughput benchmark of the MI355X inference path (contract: see the task's bench rules).
 
-One step = one pass of the hot path over one resident batch of synthetic frames:
-mpe_match_batch (featurise + GAT + clustering) followed by mpe_mlp3d_batch (MLP 3D), i.e.
-BASELINE.json configs[1] ("Panoptic 5-view, 4-person; GATv2 match + MLP 3D, 1k-frame batch on
-1 MI355X").  With --mode tri the 3D stage is the DLT triangulation path (configs[2]).
+One step = one pass of the hot path over one batch of synthetic frames: mpe_match_batch
+(featurise + GAT + clustering) followed by mpe_mlp3d_batch (MLP 3D), i.e. BASELINE.json
+configs[1] ("Panoptic 5-view, 4-person; GATv2 match + MLP 3D, 1k-frame batch on 1 MI355X").
+With --mode tri the 3D stage is the DLT triangulation path (configs[2]).
 
-Inputs (packed 2D skeletons) are resident in HBM before the timed region.  With N > 1 every
-rank processes its own 1k-frame shard (frames are independent) and the 3D
-poses are all-gathered over RCCL each step; value = frames of all ranks / max-over-ranks time.
+Launch.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N
+rank processes ITSELF (fresh children, started before this process makes any GPU call; RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relays rank 0's JSON line; under
+torchrun (`python -m torch.distributed.run ... bench.py --gpus N`) the ranks already exist and
+are used as they are.  One process per GPU, RCCL (`--backend nccl`) for the only exchange of the
+path: one all-gather of the 3D poses per step.
+
+Scaling modes.  Default (weak): every rank processes its own `--frames`-frame shard per step.
+`--total-frames T` (strong, configs[3]: 100 000 frames of 5 views x 10 persons over 8 GPUs): the
+T frames are cut into contiguous shards (distributed.shard_range), every rank runs its shard and
+all ranks receive all T results (distributed.all_gather_results).
+
+What is timed.  `value` = whole-job frames/s with the packed 2D skeletons already resident in HBM
+when the timed region starts and the poses left in HBM (barrier + synchronize on both sides, max
+over ranks).  A second timed region of the same steps measures the contract form of SURVEY.md
+§8(d) -- packed batch in pinned host memory -> one H2D copy -> compute -> D2H of poses and person
+counts into pinned memory, double-buffered on a copy stream -- and is reported beside it as
+`io_inclusive` (never as `value`).
 
 The JSON line also carries
-  roofline      fp32-MFMA GEMM kernel (k_linear_dma): algorithmic FLOPs of its launches / their
-                summed duration, measured with HIP events on the launch stream inside the
-                timed region; peak = 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md)
+  roofline      fp32-MFMA GEMM kernel: algorithmic FLOPs of its launches / their summed duration,
+                measured with HIP events on the launch stream inside the timed region; peak =
+                157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md); `hbm` = compulsory bytes of the
+                path per second / 8 TB/s; `traffic` = fabric bytes per GEMM
+                launch from the committed rocprofv3 PMC passes (offline, see traffic_source)
+  parity        HIP results of the sampled frames against the CPU oracle: fraction of frames with
+                identical clusters, max |3D difference| in mm on those, MPJPE difference in mm
+                against the synthetic ground truth
   cpu_baseline  the CPU oracle (oracle/oracle_np.py, a port of the reference's algorithm on
                 torch-CPU) timed on rank 0 on a bounded sample of the same frames.
 """
@@ -20,6 +40,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,17 +50,21 @@ sys.path.insert(0, ROOT)
 PKG = '3d_multi_pose_estimator_amd'
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_HBM_TBS = 8.0
+TRAFFIC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--frames', type=int, default=1000, help='frames per rank and step')
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--frames', type=int, default=1000, help='frames per rank and step (weak scaling)')
+    ap.add_argument('--total-frames', type=int, default=0,
+                    help='strong scaling: this many frames per step in total, sharded over the ranks (configs[3]: 100000 with --persons 10)')
     ap.add_argument('--persons', type=int, default=4)
     ap.add_argument('--mode', choices=['mlp', 'tri'], default='mlp')
-    ap.add_argument('--cpu-sample', type=int, default=40, help='frames of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=40, help='frames of the CPU baseline / parity sample (0 = skip)')
     ap.add_argument('--fast-mlp', action='store_true', help='plain fp32 accumulation in the MLP GEMMs')
     ap.add_argument('--bf16-mlp', action='store_true',
                     help='reduced precision (NOT the parity path): bf16 MFMA for the MLP GEMMs, configs[4] style')
@@ -47,11 +73,69 @@ def main():
                          'feature rows in the attention stage')
     ap.add_argument('--preset', default='PANOPTIC', choices=['PANOPTIC', 'ARPLAB', 'RING23'],
                     help='camera rig; RING23 = the 23-view stress rig of BASELINE.json configs[4] (fp32 here)')
-    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse)')
     ap.add_argument('--streams', type=int, default=1, choices=[1, 2],
                     help='2 = software pipeline across steps: matching of batch i+1 overlaps the 3D stage of batch i')
-    args = ap.parse_args()
+    ap.add_argument('--no-io', action='store_true', help='skip the second (pinned host -> poses in pinned host) timed region')
+    ap.add_argument('--no-profile', action='store_true', help='no per-GEMM HIP events (roofline comes out null)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='no GPU work: exercises launch, rendezvous, sharding and the all-gather with stand-in results '
+                         '(CPU tests of the N > 1 path); prints no throughput')
+    return ap.parse_args(argv)
 
+
+# --------------------------------------------------------------------------------------------
+# parent: start N ranks
+# --------------------------------------------------------------------------------------------
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """Parent of `python bench.py --gpus N`: N fresh rank processes, never a re-exec of a process
+    that has touched the GPU (this one has not: no torch.cuda call was made).  Rank 0 inherits
+    stdout, so its JSON line is this command's output."""
+    n = args.gpus
+    if not args.dry_run and args.backend == 'nccl':
+        import torch
+        have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if have < n:
+            print('bench.py: --gpus %d requested but %d GPU(s) visible' % (n, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.update({'WORLD_SIZE': str(n), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(free_port()),
+                'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'MPE_BENCH_SPAWNED': '1'})
+    procs = []
+    for r in range(n):
+        e = dict(env)
+        e['RANK'] = e['LOCAL_RANK'] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + 3000
+    try:
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+            rc = rc or p.returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:                            # exact PIDs of our own children only
+            if p.poll() is None:
+                p.kill()
+    if rc:
+        print('bench.py: a rank exited with code %d' % rc, file=sys.stderr)
+    return rc
+
+
+# --------------------------------------------------------------------------------------------
+# one rank
+# --------------------------------------------------------------------------------------------
+
+def run_rank(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -59,22 +143,40 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if rank == 0:
+            print('bench.py: --gpus %d but WORLD_SIZE=%d; the launcher decides: running %d ranks'
+                  % (args.gpus, world, world), file=sys.stderr)
     distributed = world > 1
+    use_gpu = not args.dry_run
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if args.backend == 'nccl':
+        if args.backend == 'nccl' and use_gpu:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-    n_gpus = world if distributed else 1
+            dist.init_process_group('gloo' if not use_gpu else args.backend, rank=rank, world_size=world)
+    dmod = importlib.import_module(PKG + '.distributed')
+
+    # ---- workload ---------------------------------------------------------------------------
+    strong = args.total_frames > 0
+    if strong:
+        lo, hi, per = dmod.shard_range(args.total_frames, rank, world)
+        B, cap, total = hi - lo, per, args.total_frames
+    else:
+        B = cap = args.frames
+        lo, total = rank * B, B * world
+
+    if args.dry_run:
+        return dry_run(args, dist, dmod, world, rank, B, cap, total, strong)
+
     device = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
-
     syn = importlib.import_module(PKG + '.synthetic')
     cal = importlib.import_module(PKG + '.calibration')
     par = importlib.import_module(PKG + '.parameters')
     pipeline = importlib.import_module(PKG + '.pipeline')
+    packing = importlib.import_module(PKG + '.packing')
     params = par.select(args.preset)
     calib = cal.Calibration(params, syn.ring_transform_manager(params) if args.preset == 'RING23' else None)
     V, J = len(params.used_cameras_skeleton_matching), len(params.joint_list)
@@ -86,17 +188,16 @@ def main():
     in_dim = len(params.cameras) * J * params.numbers_per_joint
     mlp_sd = syn.mlp_state_dict(11, in_dim)
 
-    B = args.frames
     spec = syn.FrameSpec(persons=args.persons)
-    # distinct frames per rank (frame index = global index)
-    uniq = min(B, 250)
-    frames = []
+    uniq = max(1, min(B, 250))                 # distinct frames per rank (frame index = global index)
+    frames, gts = [], []
     for i in range(uniq):
-        f, _ = syn.make_frame(calib, rank * B + i, spec)
+        f, gt = syn.make_frame(calib, lo + i, spec)
         frames.append({c: [f[c][0], f[c][1]] for c in f})
+        gts.append(gt['persons'])
     frames = [frames[i % uniq] for i in range(B)]
 
-    eng = pipeline.Engine(params, calib, max_frames=B, max_persons_per_camera=args.persons, device=str(device))
+    eng = pipeline.Engine(params, calib, max_frames=max(cap, 1), max_persons_per_camera=args.persons, device=str(device))
     eng.load_gat(gat_sd, prm)
     eng.load_mlp(mlp_sd)
     if args.fast_mlp:
@@ -106,18 +207,24 @@ def main():
     if args.reduced:
         eng.set_precision(False, False, mlp_bf16=True, gat_reduced=True)
     pb = eng.pack(frames)
+    eng.check_capacity(pb)
     db = eng.to_device(pb)
     torch.cuda.synchronize(device)
 
-    gather_buf = None
     s_match = torch.cuda.Stream(device) if args.streams == 2 else None
     s_3d = torch.cuda.Stream(device) if args.streams == 2 else None
-    keep = []          # tensors produced on one stream and consumed on the other stay referenced
+    keep = []          # tensors produced on one stream and consumed on another stay referenced
 
-    def stage3d(persons, n_persons):
+    def stage3d(batch, persons, n_persons):
         if args.mode == 'mlp':
-            return eng.mlp3d(db, persons, n_persons)[0]
-        return eng.triangulate(db, persons, n_persons)[0]
+            return eng.mlp3d(batch, persons, n_persons)[0]
+        return eng.triangulate(batch, persons, n_persons)[0]
+
+    def gather(poses, n_persons):
+        """The path's only exchange: every rank receives the poses of all shards."""
+        if not distributed:
+            return poses, n_persons
+        return dmod.all_gather_results(dmod.pad_to(poses, cap), dmod.pad_to(n_persons, cap), cap * world)
 
     def step():
         if args.streams == 2:
@@ -129,7 +236,7 @@ def main():
                 ev.record(s_match)
             with torch.cuda.stream(s_3d):
                 s_3d.wait_event(ev)
-                poses = stage3d(persons, n_persons)
+                poses = stage3d(db, persons, n_persons)
             keep.append((persons, n_persons, poses))
             if len(keep) > 4:
                 keep.pop(0)
@@ -138,107 +245,280 @@ def main():
             torch.cuda.current_stream(device).wait_stream(s_3d)
         else:
             _, persons, n_persons = eng.match(db, want_scores=False)
-            poses = stage3d(persons, n_persons)
-        if distributed:
-            nonlocal gather_buf
-            if gather_buf is None:
-                gather_buf = torch.empty((world * poses.shape[0],) + tuple(poses.shape[1:]), dtype=poses.dtype, device=device)
-                step.np_buf = torch.empty((world * B,), dtype=torch.int32, device=device)
-            dist.all_gather_into_tensor(gather_buf, poses)
-            dist.all_gather_into_tensor(step.np_buf, n_persons)
+            poses = stage3d(db, persons, n_persons)
+        gather(poses, n_persons)
         return poses, n_persons
 
+    def timed(fn, steps):
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        out = None
+        for i in range(steps):
+            out = fn(i)
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
     step()                       # initialisation (workspace, LDS attributes, communicator): not a warmup step
-    torch.cuda.synchronize(device)
+    eng.sync_status()
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(device)
-    if distributed:
-        dist.barrier()
-    eng.profile(True)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        poses, n_persons = step()
-    torch.cuda.synchronize(device)
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_read()
+    if not args.no_profile:
+        eng.profile(True)
+    elapsed, (poses, n_persons) = timed(lambda i: step(), args.steps)
+    prof = eng.profile_read() if not args.no_profile else None
     eng.profile(False)
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    persons_per_frame = float(n_persons.float().mean().item())
-    total_frames = B * n_gpus * args.steps
-    value = total_frames / elapsed
+    # ---- contract form: pinned host -> H2D -> compute -> D2H into pinned host, double-buffered ----
+    io = None
+    if not args.no_io and args.streams == 1:
+        io = io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, timed, distributed, total)
 
+    persons_per_frame = float(n_persons.float().mean().item()) if B else 0.0
+    value = total * args.steps / elapsed
+    reduced = args.reduced or args.bf16_mlp
     out = {
         'metric': 'frames/sec (5-view Panoptic, 4 persons) at 1/2/4/8 GPUs; MPJPE vs ref',
-        'value': value, 'unit': 'frames/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16 GEMMs / f16 attention rows' if args.reduced else ('bf16 (MLP) / f32' if args.bf16_mlp else 'f32'), 'data': 'synthetic',
-        'config': {'workload': ('%s: %d-view x %d-person, GAT match + %s, %d-frame batch per GPU'
-                                % ('c2 Panoptic' if args.preset == 'PANOPTIC' else args.preset, V, args.persons, 'MLP 3D' if args.mode == 'mlp' else 'DLT triangulation', B)),
-                   'frames_per_step_per_gpu': B, 'heads_per_batch': pb.n_heads, 'edge_nodes_per_batch': pb.n_edge_nodes,
-                   'persons_found_per_frame': persons_per_frame, 'parallelism': 'frame-shard x%d' % n_gpus,
+        'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
+        'vs_baseline': None,
+        'dtype': 'bf16 GEMMs / f16 attention rows' if args.reduced else ('bf16 (MLP) / f32' if args.bf16_mlp else 'f32'),
+        'data': 'synthetic',
+        'config': {'workload': ('%s: %d-view x %d-person, GAT match + %s, %s'
+                                % ('c2 Panoptic' if args.preset == 'PANOPTIC' else args.preset, V, args.persons,
+                                   'MLP 3D' if args.mode == 'mlp' else 'DLT triangulation',
+                                   ('%d frames per step sharded over %d GPU(s)' % (total, world)) if strong
+                                   else '%d-frame batch per GPU' % B)),
+                   'frames_per_step_per_gpu': B, 'frames_per_step_total': total,
+                   'heads_per_batch': pb.n_heads, 'edge_nodes_per_batch': pb.n_edge_nodes,
+                   'persons_found_per_frame': persons_per_frame, 'parallelism': 'frame-shard x%d' % world,
+                   'world_size_seen': dist.get_world_size() if distributed else 1,
+                   'backend': (args.backend + (' (RCCL)' if args.backend == 'nccl' else '')) if distributed else None,
+                   'launcher': 'bench.py spawn' if os.environ.get('MPE_BENCH_SPAWNED') else ('torchrun' if distributed else 'single'),
+                   'inputs': 'resident in HBM (value); pinned-host form in io_inclusive',
                    'streams': args.streams,
-                   'mlp_accumulate': 'bf16 mfma (reduced precision)' if (args.bf16_mlp or args.reduced) else ('f32' if args.fast_mlp else 'f32 mfma + f64 running sums'),
+                   'mlp_accumulate': 'bf16 mfma (reduced precision)' if reduced else ('f32' if args.fast_mlp else 'f32 mfma + f64 running sums'),
                    'weights': 'deterministic hash init (no checkpoint offline)'},
+        'io_inclusive': io,
     }
     if rank == 0:
-        gemm_s = prof['gemm_ms'] * 1e-3
-        achieved = prof['gemm_flop'] / gemm_s / 1e12 if gemm_s > 0 else 0.0
-        out['roofline'] = {
-            'kernel': 'mpe::k_linear_dma (fp32 MFMA 16x16x4 GEMM, LDS-DMA staging, fused bias + LeakyReLU)', 'bound': 'mfma',
-            'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(),
-            'launches': prof['gemm_launches'], 'avg_launch_ms': prof['gemm_ms'] / max(1, prof['gemm_launches']),
-            'flop_per_step': prof['gemm_flop'] / args.steps,
-            'gemm_share_of_step': gemm_s / elapsed,
-            'flop_definition': 'algorithmic 2*M*N*K of the launches (layer-0 edge-node rows de-duplicated)'
-                               + ('; NOTE: reduced-precision run, bf16 launches are priced against the fp32 peak here' if (args.bf16_mlp or args.reduced) else ''),
-        }
-        # the CPU baseline is taken on rank 0 at N = 1 only
-        out['cpu_baseline'] = None if distributed else cpu_baseline(args, frames, calib, gat_sd, prm, mlp_sd)
-        print(json.dumps(out))
+        out['roofline'] = roofline(args, prof, elapsed, total, world, V, J, args.persons, reduced)
+        # the CPU baseline and the parity sample are taken on rank 0 at N = 1 only
+        base, par_ = (None, None) if distributed else cpu_baseline_and_parity(
+            args, np, torch, frames, gts, calib, gat_sd, prm, mlp_sd, eng, db, uniq)
+        out['cpu_baseline'] = base
+        out['parity'] = par_
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    return 0
+
+
+def io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, timed, distributed, total):
+    """SURVEY.md §8(d) metric as written: from compact 2D keypoints in host pinned memory to 3D
+    poses back in host pinned memory.  Two buffer sets; the H2D of step i+1 and the D2H of step
+    i-1 run on a copy stream while step i computes."""
+    pinned = packing.BatchArena(pb, 'pinned').fill(pb)
+    sets = []
+    for _ in range(2):
+        arena = packing.BatchArena(pb, device)
+        sets.append({'db': packing.DeviceBatch(pb, device, arena=arena), 'h2d': torch.cuda.Event(),
+                     'done': torch.cuda.Event(), 'd2h': torch.cuda.Event(), 'out': None, 'host': None})
+    copy_s = torch.cuda.Stream(device)
+    comp_s = torch.cuda.current_stream(device)
+    first = [True, True]
+
+    def step(i):
+        b = sets[i & 1]
+        with torch.cuda.stream(copy_s):
+            if not first[i & 1]:
+                copy_s.wait_event(b['done'])            # the batch buffer is free once step i-2 has computed
+            b['db'].upload(pinned)
+            b['h2d'].record(copy_s)
+        comp_s.wait_event(b['h2d'])
+        if not first[i & 1]:
+            comp_s.wait_event(b['d2h'])                 # step i-2's results have left the output tensors
+        _, persons, n_persons = eng.match(b['db'], want_scores=False)
+        poses = stage3d(b['db'], persons, n_persons)
+        poses, n_persons = gather(poses, n_persons)
+        b['done'].record(comp_s)
+        if b['host'] is None:
+            b['host'] = (torch.empty(poses.shape, dtype=poses.dtype).pin_memory(),
+                         torch.empty(n_persons.shape, dtype=n_persons.dtype).pin_memory())
+        b['out'] = (poses, n_persons, persons)          # keep the tensors alive until their D2H is done
+        with torch.cuda.stream(copy_s):
+            copy_s.wait_event(b['done'])
+            b['host'][0].copy_(poses, non_blocking=True)
+            b['host'][1].copy_(n_persons, non_blocking=True)
+            b['d2h'].record(copy_s)
+        first[i & 1] = False
+        return poses, n_persons
+
+    for i in range(max(2, args.warmup)):
+        step(i)
+    dt, _ = timed(step, args.steps)
+    return {'value': total * args.steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / args.steps,
+            'h2d_bytes_per_step': int(pinned.nbytes),
+            'd2h_bytes_per_step': int(sum(t.numel() * t.element_size() for t in sets[0]['host'])),
+            'what': 'packed batch in pinned host memory -> one H2D copy -> match + 3D stage -> D2H of poses and '
+                    'n_persons into pinned host memory; double-buffered on a copy stream'}
+
+
+def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
+    if prof is None:
+        return None
+    gemm_s = prof['gemm_ms'] * 1e-3
+    achieved = prof['gemm_flop'] / gemm_s / 1e12 if gemm_s > 0 else 0.0
+    traffic, src = pmc_traffic()
+    # compulsory HBM bytes of the path per frame (SURVEY.md §8(d)): compact input H*J*4 floats + H
+    # camera ids, output P*54*4 + H*4, weights once per batch per GPU
+    H = V * persons
+    in_b = H * J * 4 * 4 + H * 4
+    out_b = persons * J * 3 * 4 + H * 4
+    nf = 2 + V * J * 10
+    syn = importlib.import_module(PKG + '.synthetic')
+    w_b = 4 * (sum(d * d + d + d * h * o + h * o + 2 * h * o for d, h, o in syn.gat_layer_dims(nf))
+               + sum(i * o + o for i, o in syn.mlp_layer_dims(V * J * 14)))
+    frames_per_gpu_step = total / world
+    bytes_per_frame = in_b + out_b + w_b / max(1.0, frames_per_gpu_step)
+    per_gpu_fps = total * args.steps / elapsed / world
+    hbm_tbs = per_gpu_fps * bytes_per_frame / 1e12
+    return {
+        'kernel': 'mpe::k_linear_dma (fp32 MFMA 16x16x4 GEMM, LDS-DMA staging, fused bias + LeakyReLU)', 'bound': 'mfma',
+        'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': src,
+        'launches': prof['gemm_launches'], 'avg_launch_ms': prof['gemm_ms'] / max(1, prof['gemm_launches']),
+        'flop_per_step': prof['gemm_flop'] / args.steps,
+        'gemm_share_of_step': gemm_s / elapsed,
+        'flop_definition': 'algorithmic 2*M*N*K of the launches (layer-0 edge-node rows de-duplicated)'
+                           + ('; NOTE: reduced-precision run, bf16 launches are priced against the fp32 peak here' if reduced else ''),
+        'hbm': {'achieved': hbm_tbs, 'peak': PEAK_HBM_TBS, 'unit': 'TB/s', 'frac': hbm_tbs / PEAK_HBM_TBS,
+                'bytes_per_frame': bytes_per_frame,
+                'definition': 'compulsory bytes of the whole path per frame (packed input + poses + weights once per '
+                              'batch) x frames/s per GPU; tiny by construction: the path is MFMA-bound'},
+    }
 
 
 def pmc_traffic():
-    """Fabric bytes per k_linear launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950
-    2x FETCH correction); None when the file is absent.  PMC cannot be sampled from inside
-    the process, so this is the offline measurement, not a live one."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    try:
-        with open(path) as fh:
-            return json.load(fh)['k_linear_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
+    """Fabric bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
+    (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 2x FETCH correction).  PMC cannot be sampled
+    from inside the process: this is an OFFLINE measurement and says which file it came from."""
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as fh:
+                return json.load(fh)['k_linear_bytes_per_launch'], 'offline: profiles/' + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def cpu_baseline(args, frames, calib, gat_sd, prm, mlp_sd):
-    """CPU port (the oracle) on a bounded sample of the same frames, rank 0 only."""
+def cpu_baseline_and_parity(args, np, torch, frames, gts, calib, gat_sd, prm, mlp_sd, eng, db, uniq):
+    """CPU port (the oracle) on a bounded sample of the same frames, rank 0 only; its results double
+    as the parity sample for the HIP results of those frames (SURVEY.md §8(d) parity fields)."""
     if args.cpu_sample <= 0:
-        return None
-    import torch
+        return None, None
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     onp = importlib.import_module('oracle_np')
-    n = min(args.cpu_sample, len(frames))
+    n = min(args.cpu_sample, len(frames), uniq)
     onp.run_frame(frames[0], calib, gat_sd, prm, mlp_sd, mode=args.mode)       # warm up
+    res = []
     t0 = time.perf_counter()
     for i in range(n):
-        onp.run_frame(frames[i], calib, gat_sd, prm, mlp_sd, mode=args.mode)
+        res.append(onp.run_frame(frames[i], calib, gat_sd, prm, mlp_sd, mode=args.mode))
     dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    base = {'value': n / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': '%d frames of the same batch, per-frame loop as in the reference (torch-CPU GEMMs)' % n}
+    # the HIP side of the same frames (one more pass outside any timed region)
+    scores, persons, n_persons = eng.match(db)
+    if args.mode == 'mlp':
+        poses = eng.mlp3d(db, persons, n_persons)[0]
+    else:
+        poses = eng.triangulate(db, persons, n_persons)[0]
+    persons, n_persons, poses = persons.cpu().numpy(), n_persons.cpu().numpy(), poses.cpu().numpy()
+    scores = scores.cpu().numpy()
+    used = list(calib.params.used_joints)
+    V = eng.V
+    exact, max_abs, dscore = 0, 0.0, 0.0
+    e_gpu, e_cpu = [], []
+
+    def mpjpe(pred, gt_people):
+        return min(float(np.mean([np.linalg.norm(pred[j] - g[j]) for j in used])) for g in gt_people)
+    for f in range(n):
+        r = res[f]
+        if r is None:
+            exact += int(n_persons[f] == 0)
+            continue
+        h0, H, e0, M = db.host.frame_counts(f)
+        dscore = max(dscore, float(np.abs(scores[e0:e0 + M] - r['scores']).max()))
+        want = np.array(r['persons'], np.int32).reshape(-1, V)
+        if n_persons[f] != len(want) or not np.array_equal(persons[f, :len(want)], want):
+            continue
+        exact += 1
+        if args.mode == 'mlp':
+            ref = r['poses']
+        else:
+            ref = np.stack([np.stack([t.get(j, np.zeros(3)) for j in range(eng.J)]) for t in r['tri']]) if r['tri'] else np.zeros((0, eng.J, 3))
+        if len(want):
+            max_abs = max(max_abs, float(np.abs(poses[f, :len(want)] - ref).max()))
+            for k in range(len(want)):
+                e_gpu.append(mpjpe(poses[f, k], gts[f]))
+                e_cpu.append(mpjpe(ref[k], gts[f]))
+    parity = {'sample_frames': n, 'clusters_exact_frac': exact / n, 'max_abs_mm': max_abs * 1e3,
+              'delta_mpjpe_mm': (abs(float(np.mean(e_gpu)) - float(np.mean(e_cpu))) * 1e3) if e_gpu else None,
+              'max_abs_score_diff': dscore,
+              'against': 'CPU oracle (oracle/oracle_np.py) on the same frames; north star: clusters exact, 3D within 1e-3 mm, '
+                         'MPJPE within 0.01 mm.  Measured floor of the 3D figure: the reference\'s own torch-CPU MLP is '
+                         '~4e-3 mm from the exactly evaluated network (tests/test_gpu_stages.py::test_mlp_error_budget_every_golden_row)'}
+    return base, parity
+
+
+def dry_run(args, dist, dmod, world, rank, B, cap, total, strong):
+    """Launch / rendezvous / sharding / all-gather without a GPU: stand-in results that encode
+    the global frame index, checked after the gather on every rank."""
+    import torch
+    lo = rank * cap if strong else rank * B
+    ok = True
+    for _ in range(max(1, args.steps)):
+        poses = torch.arange(lo, lo + B, dtype=torch.float32).view(-1, 1, 1, 1).expand(-1, 2, 18, 3).contiguous()
+        n_p = (torch.arange(lo, lo + B, dtype=torch.int32) % 3)
+        if world > 1:
+            gp, gn = dmod.all_gather_results(dmod.pad_to(poses, cap), dmod.pad_to(n_p, cap), cap * world)
+            for r in range(world):
+                r_lo, r_hi, _ = dmod.shard_range(total, r, world) if strong else (r * B, (r + 1) * B, B)
+                seg = gp[r * cap: r * cap + (r_hi - r_lo), 0, 0, 0]
+                ok = ok and bool(torch.equal(seg, torch.arange(r_lo, r_hi, dtype=torch.float32)))
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'value': None, 'n_gpus': world, 'world_size_seen': dist.get_world_size() if world > 1 else 1,
+                          'scaling': 'strong' if strong else 'weak', 'frames_per_step_total': total,
+                          'frames_this_rank': B, 'gather_ok': ok,
+                          'launcher': 'bench.py spawn' if os.environ.get('MPE_BENCH_SPAWNED') else 'external'}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

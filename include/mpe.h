@@ -175,6 +175,35 @@ int mpe_head_features(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_f
  * the last layer at head nodes; unused downstream). */
 int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float *d_feats, int32_t ld_feats,
                     float *d_scores_en, float *d_scores_heads);
+/* Activation of the last GAT layer: 1 = sigmoid (final_activation = nn.Sigmoid(), the deployed
+ * model, train_skeleton_matching.py:34), 2 = identity (final_activation = None, gat2.py:146-148). */
+int mpe_set_gat_output(mpe_ctx *ctx, int32_t mode);
+
+/* One GraphAttention2 layer (gat2.py:50-76) plus the activation GAT2.forward applies to its
+ * flattened output (:141-147).  d_in [n_nodes][ld_in] holds the layer's input rows in node order
+ * (frame by frame: heads, then edge-nodes; in_dim columns used), d_out [n_nodes][ld_out] receives
+ * heads*out_dim columns.  activation: 0 = LeakyReLU(hidden slope), 1 = sigmoid, 2 = none.
+ * Layer 0 takes dense F-wide rows (no de-duplication of the constant edge-node rows). */
+int mpe_gat_layer(mpe_ctx *ctx, void *stream, const mpe_batch *b, int32_t layer, const float *d_in, int32_t ld_in,
+                  float *d_out, int32_t ld_out, int32_t activation);
+
+/* The graph half of a layer only -- what the reference delegates to DGL (gat2.py:57-66, 78-88):
+ * a1/a2 = <ft2, attn_l/r> (the two torch.bmm), apply_edges(LeakyReLU(a1[src] + a2[dst])),
+ * edge_softmax over the in-edges of every destination, update_all(u_mul_e, sum).
+ * d_ft2 [n_nodes][ld_ft2] = fc2 output (heads*out_dim columns) -> d_out [n_nodes][ld_out], no
+ * activation.  Uses attn_l / attn_r of `layer`. */
+int mpe_edge_softmax_aggregate(mpe_ctx *ctx, void *stream, const mpe_batch *b, int32_t layer, const float *d_ft2,
+                               int32_t ld_ft2, float *d_out, int32_t ld_out);
+
+/* Per-frame capacity.  The host side of this ABI sees batch totals only; a frame that holds
+ * more than mpe_config.max_heads_per_frame skeletons (and therefore possibly more edge-nodes
+ * than the per-frame LDS / scratch budget) is detected on the device: its scores come back as
+ * zeros, it yields n_persons = 0, and a sticky status bit is raised.  mpe_sync_status
+ * synchronises `stream`, returns MPE_ERR_CAPACITY if any batch since the last call contained
+ * such a frame (MPE_OK otherwise) and clears the bit.  Limits that mpe_create enforces:
+ * max_heads_per_frame < 32768, n_cameras <= 32, n_joints <= 32, attention heads <= 16. */
+int mpe_sync_status(mpe_ctx *ctx, void *stream);
+
 /* CLASSIFICATION_THRESHOLD of get_person_proposal_from_network_output (default from mpe_config) */
 int mpe_set_threshold(mpe_ctx *ctx, float threshold);
 

@@ -486,6 +486,20 @@ def mlp_forward(sd, x, slope=0.1):
     return h
 
 
+def mlp_exact(sd, x, slope=0.1):
+    """The same network evaluated in f64 with the activations rounded to fp32 between layers:
+    what every fp32 implementation of utils/mlp.py approximates.  Tests use it to split
+    |gpu - reference| into the two sides' own rounding noise (no reference counterpart)."""
+    h = _t(x).double()
+    keys = sorted({int(k.split('.')[1]) for k in sd})
+    for n, k in enumerate(keys):
+        h = h @ _t(sd['layers.%d.weight' % k]).double().T + _t(sd['layers.%d.bias' % k]).double()
+        if n != len(keys) - 1:
+            h = torch.nn.functional.leaky_relu(h, slope)
+        h = h.float().double()
+    return h
+
+
 def decode_pose(out_row, n_joints):
     """results*10, joint k = (r[3k], r[3k+1], r[3k+2]) (metrics_from_model.py:281-294)."""
     r = (_t(out_row) * 10.).numpy()

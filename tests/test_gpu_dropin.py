@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CASES, ROOT, load_case
+from conftest import CASES, ROOT, load_case, oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def dropin(gat_weights, mlp_weights):
 
 
 @pytest.mark.parametrize('name', CASES)
-def test_reference_loop_on_dropin(dropin, name):
+def test_reference_loop_on_dropin(dropin, name, mlp_weights):
     d = dropin
     parameters = d['parameters']
     device = torch.device('cuda')
@@ -91,7 +91,14 @@ def test_reference_loop_on_dropin(dropin, name):
             input_all = torch.cat(batched_input, dim=0)
             np.testing.assert_allclose(input_all.cpu().numpy(), arr[p + 'mlp_in'], rtol=0, atol=3e-7)
             output_all = d['mlp'](input_all.to(device))
-            np.testing.assert_allclose(output_all.cpu().numpy(), arr[p + 'mlp_out'], rtol=0, atol=1.2e-6)
+            # same rule as test_mlp_error_budget_every_golden_row, on the mirror's own rows
+            onp = oracle()
+            ex = onp.mlp_exact(mlp_weights, input_all.cpu()).numpy()
+            y_cpu = onp.mlp_forward(mlp_weights, input_all.cpu()).numpy()
+            e_gpu, e_cpu = np.abs(output_all.cpu().numpy() - ex).max(), np.abs(y_cpu - ex).max()
+            assert e_gpu <= e_cpu, (e_gpu, e_cpu)
+            drift = np.abs(y_cpu - arr[p + 'mlp_out']).max()       # rows differ by <= 3e-7 from the reference's
+            assert np.abs(output_all.cpu().numpy() - arr[p + 'mlp_out']).max() <= e_gpu + e_cpu + drift
         # 3D stage B
         has_id = any('ID' in sk for cam in input_element for sk in json.loads(input_element[cam][0]))
         if has_id:
@@ -134,3 +141,25 @@ def test_gat2_honours_caller_features(dropin, calib):
     eng = d['model']._engine
     sc, sh = eng.gat_scores(g.device_batch(eng), heads=True, feats=own.cuda())
     np.testing.assert_allclose(torch.cat([sh, sc]).cpu().numpy(), arr['f0_scores'], rtol=0, atol=2e-5)
+
+
+def test_gat2_without_final_activation_returns_logits(dropin):
+    """final_activation=None (gat2.py:146-148 skips the activation): raw logits from the device,
+    not logit(sigmoid(x)), which turns into +/-inf where the fp32 sigmoid saturates."""
+    d = dropin
+    arr, frames = load_case('c2_5x4_clean')
+    frame = frames[0]
+    pi = {c: [frame[c][0], 0] for c in frame if json.loads(frame[c][0])}
+    scenario = d['MergedMultipleHumansDataset'](pi, mode='test', limit=10000, debug=True, alt='3', verbose=False)
+    g = scenario.graphs[0]
+    model = d['model']
+    keep = model.final_activation
+    try:
+        model.final_activation = None
+        logits = torch.squeeze(model(g.ndata['h'].cuda(), g)).cpu().double()
+    finally:
+        model.final_activation = keep
+    assert torch.isfinite(logits).all() and logits.min() < 0 < logits.max()
+    probs = torch.squeeze(model(g.ndata['h'].cuda(), g)).cpu().numpy()
+    np.testing.assert_allclose(probs, arr['f0_scores'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(torch.sigmoid(logits).numpy(), arr['f0_scores'], rtol=0, atol=2e-5)

@@ -253,17 +253,35 @@ def test_match_and_3d_vs_golden(variant, name):
         rows, valid = engine.mlp_input_rows(db, persons, n_persons)
         np.testing.assert_allclose(rows[0, :len(want)].cpu().numpy(), arr[p + 'mlp_in'], rtol=0, atol=3e-7)
         assert valid[0, :len(want)].all()
-        y = engine.mlp_forward(torch.from_numpy(arr[p + 'mlp_in']).cuda()).cpu().numpy()
-        # |gpu - torch-CPU| is bounded by the two sides' distances to the exactly evaluated
-        # network; the reference's own distance (e_cpu) is the floor nobody can beat
-        exact = _exact_mlp(torch.from_numpy(arr[p + 'mlp_in']), env(variant).mlp).numpy()
+        # MLP on IDENTICAL rows (the reference's): |gpu - ref| is bounded by the two sides' distances
+        # to the exactly evaluated network, and the HIP side is the closer one.  No additive slack.
+        onp = oracle()
+        mlp_sd = env(variant).mlp
+        x_ref = torch.from_numpy(arr[p + 'mlp_in'])
+        y = engine.mlp_forward(x_ref.cuda()).cpu().numpy()
+        exact = onp.mlp_exact(mlp_sd, x_ref).numpy()
         e_cpu = np.abs(arr[p + 'mlp_out'] - exact).max()
         e_gpu = np.abs(y - exact).max()
-        assert e_gpu <= max(e_cpu, 2.5e-7), (e_gpu, e_cpu)
-        assert np.abs(y - arr[p + 'mlp_out']).max() <= e_cpu + e_gpu + 1e-8
+        assert e_gpu <= e_cpu, (e_gpu, e_cpu)
+        assert np.abs(y - arr[p + 'mlp_out']).max() <= e_cpu + e_gpu
+        # end to end the HIP path feeds its OWN rows (<= 3e-7 from the reference's, above).  Same
+        # rule on those rows with torch-CPU (= the reference's MLP arithmetic) as the other side;
+        # the batched path must give the bits of the stage call and the x10 decode must be exact fp32.
+        x_gpu = rows[0, :len(want)]
+        y_gpu_own = engine.mlp_forward(x_gpu.contiguous()).cpu().numpy()
+        y_cpu_own = onp.mlp_forward(mlp_sd, x_gpu.cpu()).numpy()
+        ex_own = onp.mlp_exact(mlp_sd, x_gpu.cpu()).numpy()
+        e_gpu_own, e_cpu_own = np.abs(y_gpu_own - ex_own).max(), np.abs(y_cpu_own - ex_own).max()
+        assert e_gpu_own <= e_cpu_own, (e_gpu_own, e_cpu_own)
         poses, pv = engine.mlp3d(db, persons, n_persons)
-        d = np.abs(poses[0, :len(want)].cpu().numpy() - arr[p + 'poses']).max()
-        assert d < 10 * (e_cpu + e_gpu) + 2e-6, d      # metres (x10 of the MLP output)
+        got_pose = poses[0, :len(want)].cpu().numpy()
+        assert np.array_equal(got_pose.reshape(len(want), -1), y_gpu_own * np.float32(10.0))
+        # distance to the reference's poses = MLP budget + what the reference network itself makes of
+        # the row difference (torch-CPU on both sets of rows) + one fp32 quantum of the decode
+        drift = 10 * np.abs(y_cpu_own - arr[p + 'mlp_out']).max()
+        q = float(np.spacing(np.float32(np.abs(arr[p + 'poses']).max())))
+        d = np.abs(got_pose - arr[p + 'poses']).max()
+        assert d <= 10 * (e_gpu_own + e_cpu_own) + drift + q, (d, e_gpu_own, e_cpu_own, drift)
         tri, jv = engine.triangulate(db, persons, n_persons)
         tv = arr[p + 'tri_valid'].astype(bool)
         has_id = any('ID' in sk for cam in frame for sk in json.loads(frame[cam][0]))
@@ -271,6 +289,26 @@ def test_match_and_3d_vs_golden(variant, name):
             assert np.array_equal(jv[0, :len(want)].cpu().numpy().astype(bool), tv)
             got = tri[0, :len(want)].cpu().numpy()
             np.testing.assert_allclose(got[tv], arr[p + 'tri'][tv], rtol=1e-9, atol=1e-9)
+
+
+def _first_divergence(s_gpu, s_ref, thr=0.5):
+    """Both score vectors drive the same integer logic (stable sort by descending score of the
+    matchings above the threshold, then sequential rules), so two runs can only differ from the
+    first position where the sorted sequences differ.  Returns (gap, allowed): the oracle-score gap
+    that decided that position and the largest gap the measured score deviation can explain."""
+    dev = float(np.abs(s_gpu - s_ref).max())
+    og = [m for m in np.argsort(-s_gpu, kind='stable') if s_gpu[m] > thr]
+    orf = [m for m in np.argsort(-s_ref, kind='stable') if s_ref[m] > thr]
+    for k in range(max(len(og), len(orf))):
+        a = og[k] if k < len(og) else None
+        b = orf[k] if k < len(orf) else None
+        if a == b:
+            continue
+        if a is None or b is None:                 # one list ended: a score crossed the threshold
+            m = b if a is None else a
+            return abs(float(s_ref[m]) - thr), dev
+        return abs(float(s_ref[a]) - float(s_ref[b])), 2.0 * dev
+    return None, dev
 
 
 def _exact_mlp(x, weights):
@@ -328,6 +366,7 @@ def test_batch_vs_oracle(engine, calib, gat_weights, mlp_weights):
     sm = list(calib.params.used_cameras_skeleton_matching)
     exact, flagged = 0, 0
     worst_pose = 0.0
+    gaps = []
     for f, frame in enumerate(frames):
         h0, H, e0, M = db.host.frame_counts(f)
         res = onp.run_frame(frame, calib, sd, prm, mlp_weights, mode='mlp')
@@ -354,10 +393,17 @@ def test_batch_vs_oracle(engine, calib, gat_weights, mlp_weights):
                         if j in t:
                             np.testing.assert_allclose(tri[f, k, j], t[j], rtol=1e-9, atol=1e-9)
         else:
+            # a differing frame is excused only by the score gap at the FIRST diverging decision:
+            # the two matchings that swap places there must be closer, in the oracle's scores, than
+            # twice the measured score deviation of this frame (or one of them must sit within that
+            # deviation of the threshold)
             flagged += 1
-            s = np.sort(res['scores'][res['scores'] > 0.4])
-            assert np.min(np.diff(s)) < 1e-4
+            gap, allowed = _first_divergence(scores[e0:e0 + M], res['scores'])
+            assert gap is not None and gap <= allowed, (f, gap, allowed)
+            gaps.append((f, gap, allowed))
+    print('clusters equal to the oracle in %d of %d frames; excused by first-divergence gaps %s' % (exact, len(frames), gaps))
     assert exact >= 44, (exact, flagged)
+    # end to end (HIP rows, <= 3e-7 from the oracle's rows, through a 9-layer MLP), relative to the pose magnitude
     assert worst_pose < 1.2e-5
 
 

@@ -1,0 +1,338 @@
+"""GPU parity tests of the stage-level entry points and of the evidence gaps the round-1 review
+listed: the DGL replacement in isolation (mpe_edge_softmax_aggregate), single GAT layers against
+the per-layer fixtures the reference produced (mpe_gat_layer), a full-shape 23-view x 10-person
+frame against the oracle, the reduced-precision mode against the ORACLE (not against the HIP fp32
+path), the device-side per-frame capacity check, and the MLP error budget over every golden row
+without additive slack."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ALL_CASES, ROOT, env, load_case, oracle, pkg
+
+pytestmark = pytest.mark.gpu
+
+_engines = {}
+
+
+def engine_for(variant, ppc=None):
+    key = (variant, ppc)
+    if key not in _engines:
+        e = env(variant)
+        eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=4,
+                                     max_persons_per_camera=ppc or (10 if variant == 'panoptic' else 3))
+        eng.load_gat(*e.gat)
+        eng.load_mlp(e.mlp)
+        _engines[key] = eng
+    return _engines[key]
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _close_engines():
+    yield
+    for eng in _engines.values():
+        eng.close()
+    _engines.clear()
+
+
+def _dense_features(arr, p, nf):
+    N = int(arr[p + 'N'])
+    feats = np.zeros((N, nf), np.float32)
+    rc = arr[p + 'feat_rc']
+    feats[rc[:, 0], rc[:, 1]] = arr[p + 'feat_v']
+    return feats
+
+
+def _close(a, b, tol):
+    """|a - b| <= tol * max(1, |b|): activations reach a few units; fp32 reordering noise scales
+    with the magnitude."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max()) <= tol
+
+
+@pytest.mark.parametrize('variant,name', ALL_CASES)
+def test_gat_layers_vs_reference_activations(variant, name):
+    """mpe_gat_layer, layer by layer, on the reference graph's own feature rows: the hidden
+    activations the REFERENCE computed (fixtures act{l}_head / act{l}_en, first four heads and
+    first four edge-nodes, gat2.py:137-149) and every row of the oracle's."""
+    onp = oracle()
+    e = env(variant)
+    eng = engine_for(variant)
+    sd, prm = e.gat
+    arr, frames = load_case(name, variant)
+    for n, frame in enumerate(frames):
+        p = 'f%d_' % n
+        db = eng.to_device(eng.pack([onp.processed_input(frame)]))
+        feats = _dense_features(arr, p, e.meta['num_feats'])
+        H = db.n_heads
+        _, inter = onp.gat_forward(sd, prm, feats, arr[p + 'src'], arr[p + 'dst'], keep=True)
+        x = torch.from_numpy(feats).cuda()
+        for l in range(prm['gnn_layers'] - 1):
+            # (i) chained: the layer consumes the HIP path's own previous output
+            x = eng.gat_layer(db, l, x, activation=0)
+            got = x.cpu().numpy()
+            assert _close(got[:4], arr[p + 'act%d_head' % l][:min(4, H)], 2e-5), (l, 'head rows vs reference')
+            assert _close(got[H:H + 4], arr[p + 'act%d_en' % l], 2e-5), (l, 'edge-node rows vs reference')
+            assert _close(got, inter[l].numpy(), 2e-5), (l, 'all rows vs oracle')
+            # (ii) isolated: the layer alone on the oracle's input rows
+            if l > 0:
+                alone = eng.gat_layer(db, l, inter[l - 1].cuda(), activation=0).cpu().numpy()
+                assert _close(alone, inter[l].numpy(), 1e-5), (l, 'isolated layer vs oracle')
+        # last layer through the same entry point: sigmoid scores in node order
+        sc = eng.gat_layer(db, prm['gnn_layers'] - 1, x, activation=1).cpu().numpy().reshape(-1)
+        np.testing.assert_allclose(sc, arr[p + 'scores'], rtol=0, atol=2e-5)
+        logits = eng.gat_layer(db, prm['gnn_layers'] - 1, x, activation=2).cpu().numpy().reshape(-1)
+        np.testing.assert_allclose(1.0 / (1.0 + np.exp(-logits.astype(np.float64))), arr[p + 'scores'], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('variant,name', [('panoptic', 'c2_5x4_clean'), ('panoptic', 'c2_5x4_messy'),
+                                          ('panoptic', 'c4_5x10'), ('panoptic', 'c1_2view_1person'),
+                                          ('arplab', 'arp_6x3'), ('ring23', 'ring23x3')])
+def test_edge_softmax_aggregate_vs_oracle(variant, name):
+    """The part the reference delegates to DGL (gat2.py:57-66,78-88) in isolation: identical ft2
+    rows in, a1/a2 + apply_edges + edge_softmax(norm_by='dst') + update_all(u_mul_e, sum) out.
+    The only freedom is the summation order over a destination's in-edges (<= 1 + in-degree
+    terms), so the bound is a few ulp of the row magnitude."""
+    onp = oracle()
+    e = env(variant)
+    eng = engine_for(variant)
+    sd, prm = e.gat
+    arr, frames = load_case(name, variant)
+    p = 'f0_'
+    db = eng.to_device(eng.pack([onp.processed_input(frames[0])]))
+    feats = _dense_features(arr, p, e.meta['num_feats'])
+    heads = list(prm['heads']) + [1]
+    h = torch.from_numpy(feats)
+    for l in range(prm['gnn_layers']):
+        out, aux = onp.gat_layer(sd, l, h, arr[p + 'src'], arr[p + 'dst'], prm['alpha'], heads[l])
+        ft2 = aux['ft2'].reshape(h.shape[0], -1)
+        got = eng.edge_softmax_aggregate(db, l, ft2.cuda()).cpu().numpy()
+        want = out.reshape(h.shape[0], -1).numpy()
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= 4e-6 * scale, (l, np.abs(got - want).max(), scale)
+        h = torch.nn.functional.leaky_relu(out.flatten(1), prm.get('nonlinearity', 0.01))
+
+
+def _first_divergence(s_gpu, s_ref, thr=0.5):
+    """Both score vectors drive the same integer logic (stable sort by descending score of the
+    matchings above the threshold, then sequential rules), so two runs can only differ from the
+    first position where the sorted sequences differ.  Returns (gap, allowed): the oracle-score gap
+    that decided that position and the largest gap the measured score deviation can explain."""
+    dev = float(np.abs(s_gpu - s_ref).max())
+    og = [m for m in np.argsort(-s_gpu, kind='stable') if s_gpu[m] > thr]
+    orf = [m for m in np.argsort(-s_ref, kind='stable') if s_ref[m] > thr]
+    for k in range(max(len(og), len(orf))):
+        a = og[k] if k < len(og) else None
+        b = orf[k] if k < len(orf) else None
+        if a == b:
+            continue
+        if a is None or b is None:                 # one list ended: a score crossed the threshold
+            m = b if a is None else a
+            return abs(float(s_ref[m]) - thr), dev
+        return abs(float(s_ref[a]) - float(s_ref[b])), 2.0 * dev
+    return None, dev
+
+
+def test_ring23_full_shape_frame_vs_oracle():
+    """BASELINE configs[4] at its real shape in fp32: 23 views x 10 persons (230 heads, 25 300
+    edge-nodes, head in-degree 221).  Covers k_attn_coef / the head aggregation at that in-degree,
+    the per-camera grouped layer-0 GEMM and k_cluster_block on real scores, against the oracle
+    (scores 2e-5, clusters exact, MLP input rows 3e-7)."""
+    onp = oracle()
+    syn = pkg('synthetic')
+    e = env('ring23')
+    sd, prm = e.gat
+    eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=1, max_persons_per_camera=10)
+    try:
+        eng.load_gat(sd, prm)
+        eng.load_mlp(e.mlp)
+        frame = onp.processed_input(syn.make_frame(e.calib, 77, syn.FrameSpec(persons=10, noise_px=0.5))[0])
+        db = eng.to_device(eng.pack([frame]))
+        assert db.n_heads >= 200 and db.n_edge_nodes >= 19000
+        scores, persons, n_persons = eng.match(db)
+        eng.sync_status()
+        res = onp.run_frame(frame, e.calib, sd, prm, e.mlp, mode='mlp')
+        s = scores.cpu().numpy()
+        np.testing.assert_allclose(s, res['scores'], rtol=0, atol=2e-5)
+        sm = list(e.params.used_cameras_skeleton_matching)
+        H = db.n_heads
+        head_cam = [sm.index(c) for c in res['graph']['nodes_camera'][:H]]
+        own = onp.cluster(s, res['graph']['pairs'], H, head_cam, len(sm))
+        k = min(len(own), eng.pcap)
+        assert int(n_persons[0]) == k
+        got = persons[0, :k].cpu().numpy()
+        assert np.array_equal(got, np.array(own, np.int32).reshape(-1, len(sm))[:k])
+        if own != res['persons']:
+            gap, allowed = _first_divergence(s, res['scores'])
+            assert gap is not None and gap <= allowed, (gap, allowed)
+        else:
+            rows, valid = eng.mlp_input_rows(db, persons, n_persons)
+            want = res['mlp_in'].numpy()
+            assert want.shape[0] == k
+            np.testing.assert_allclose(rows[0, :k].cpu().numpy(), want, rtol=0, atol=3e-7)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize('variant,name', [('panoptic', 'c2_5x4_clean'), ('panoptic', 'c4_5x10'),
+                                          ('ring23', 'ring23x3')])
+def test_reduced_mode_vs_oracle(variant, name):
+    """BASELINE configs[4] precision (bf16 MFMA GEMMs, fp16 ft2 rows) against the fp32 ORACLE
+    scores (reference fixtures), with a stated bound: bf16 carries 8 significant bits, five layers
+    and a logit gain of 25 in the fixture weights put the sigmoid outputs within 0.08 of fp32;
+    decisions further than 0.1 from the threshold are unchanged.  Restoring fp32 restores parity."""
+    onp = oracle()
+    eng = engine_for(variant)
+    arr, frames = load_case(name, variant)
+    db = eng.to_device(eng.pack([onp.processed_input(f) for f in frames]))
+    want = np.concatenate([arr['f%d_scores' % n][int(arr['f%d_N' % n]) - len(arr['f%d_edge_nodes_indices' % n]):]
+                           for n in range(len(frames))])
+    try:
+        eng.set_precision(gat_reduced=True)
+        s16 = eng.gat_scores(db).cpu().numpy()
+    finally:
+        eng.set_precision()
+    d = np.abs(s16 - want)
+    assert 1e-6 < d.max() < 0.08, d.max()
+    far = np.abs(want - 0.5) > 0.1
+    assert far.sum() > 0 and np.array_equal(s16[far] > 0.5, want[far] > 0.5)
+    s32 = eng.gat_scores(db).cpu().numpy()
+    np.testing.assert_allclose(s32, want, rtol=0, atol=2e-5)
+
+
+def test_reduced_mode_cluster_agreement_with_oracle(tmp_path):
+    """Cluster agreement of the reduced mode with the ORACLE's fp32 clusters over a 48-frame
+    5x4 batch, and the MPJPE shift of the bf16 MLP on those frames (reported, bounded loosely:
+    this mode carries no parity claim)."""
+    onp = oracle()
+    syn = pkg('synthetic')
+    e = env('panoptic')
+    sd, prm = e.gat
+    eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=48, max_persons_per_camera=4)
+    try:
+        eng.load_gat(sd, prm)
+        eng.load_mlp(e.mlp)
+        frames = [onp.processed_input(syn.make_frame(e.calib, 4000 + i, syn.FrameSpec(persons=4, noise_px=1.0))[0])
+                  for i in range(48)]
+        db = eng.to_device(eng.pack(frames))
+        eng.set_precision(False, False, mlp_bf16=True, gat_reduced=True)
+        scores, persons, n_persons = eng.match(db)
+        poses, _ = eng.mlp3d(db, persons, n_persons)
+        scores, persons, n_persons, poses = (t.cpu().numpy() for t in (scores, persons, n_persons, poses))
+        sm = list(e.params.used_cameras_skeleton_matching)
+        agree, dmax, pose_d = 0, 0.0, 0.0
+        for f, frame in enumerate(frames):
+            h0, H, e0, M = db.host.frame_counts(f)
+            res = onp.run_frame(frame, e.calib, sd, prm, e.mlp, mode='mlp')
+            dmax = max(dmax, float(np.abs(scores[e0:e0 + M] - res['scores']).max()))
+            want = np.array(res['persons'], np.int32).reshape(-1, len(sm))
+            if n_persons[f] == len(want) and np.array_equal(persons[f, :len(want)], want):
+                agree += 1
+                if len(want):
+                    mag = max(1.0, float(np.abs(res['poses']).max()) / 4.0)
+                    pose_d = max(pose_d, float(np.abs(poses[f, :len(want)] - res['poses']).max()) / mag)
+        frac = agree / len(frames)
+        print('reduced mode: clusters equal to the oracle in %d of %d frames, max |score - oracle| %.3g, '
+              'max |pose - oracle| %.3g m' % (agree, len(frames), dmax, pose_d))
+        assert dmax < 0.08
+        assert frac >= 0.75, frac
+        assert pose_d < 0.5            # bf16 MLP: centimetres, not the parity path
+    finally:
+        eng.close()
+
+
+def test_frame_beyond_capacity_is_flagged_on_device():
+    """mpe.h per-frame capacity contract: a frame with more skeletons than max_heads_per_frame
+    that slips past the host (here: the packed batch is uploaded without Engine.check_capacity)
+    is detected by k_topology, yields zero scores and no persons, leaves its neighbours intact,
+    and mpe_sync_status returns MPE_ERR_CAPACITY exactly once."""
+    onp = oracle()
+    syn = pkg('synthetic')
+    L = pkg('lib')
+    e = env('panoptic')
+    sd, prm = e.gat
+    big = pkg('pipeline').Engine(e.params, e.calib, max_frames=3, max_persons_per_camera=4)
+    small = pkg('pipeline').Engine(e.params, e.calib, max_frames=4, max_heads_per_frame=14)
+    try:
+        for eng in (big, small):
+            eng.load_gat(sd, prm)
+        ok = onp.processed_input(syn.make_frame(e.calib, 31, syn.FrameSpec(persons=2))[0])       # 10 heads
+        over = onp.processed_input(syn.make_frame(e.calib, 32, syn.FrameSpec(persons=4))[0])     # 20 heads > 14
+        pb = big.pack([ok, over, ok])
+        want_s, want_p, want_n = big.match(big.to_device(pb))
+        big.sync_status()
+        with pytest.raises(ValueError):
+            small.to_device(pb)                                     # the Python engine refuses on the host
+        db = pb.to(small.device)                                    # the C ABI alone: device-side detection
+        assert pb.n_heads <= small.max_frames * small.hpf
+        s, p, n = small.match(db)
+        with pytest.raises(L.MpeError) as ei:
+            small.sync_status()
+        assert ei.value.code == -2
+        small.sync_status()                                         # sticky bit was cleared
+        s, n, p = s.cpu().numpy(), n.cpu().numpy(), p.cpu().numpy()
+        e_off = pb.frame_en_off
+        assert n[1] == 0 and not s[e_off[1]:e_off[2]].any()
+        ws, wn, wp = want_s.cpu().numpy(), want_n.cpu().numpy(), want_p.cpu().numpy()
+        for f in (0, 2):
+            assert np.array_equal(s[e_off[f]:e_off[f + 1]], ws[e_off[f]:e_off[f + 1]])
+            assert n[f] == wn[f] and np.array_equal(p[f, :n[f], :], wp[f, :n[f], :])
+    finally:
+        big.close()
+        small.close()
+
+
+def _exact_mlp(x, weights):
+    keys = sorted({int(k.split('.')[1]) for k in weights})
+    h = x.double()
+    for n, k in enumerate(keys):
+        W = torch.from_numpy(weights['layers.%d.weight' % k]).double()
+        b = torch.from_numpy(weights['layers.%d.bias' % k]).double()
+        h = h @ W.T + b
+        if n != len(keys) - 1:
+            h = torch.nn.functional.leaky_relu(h, 0.1)
+        h = h.float().double()
+    return h
+
+
+def test_mlp_error_budget_every_golden_row():
+    """3D tolerance, pinned without slack (north star: 1e-3 mm vs the reference).  For EVERY MLP
+    input row the reference produced (all fixture variants): with `exact` = the network evaluated
+    in f64 with fp32 rounding between layers,
+        |gpu - exact| <= |ref - exact|            (the HIP path is at least as accurate as torch-CPU)
+        |gpu - ref|   <= |gpu - exact| + |ref - exact|   (triangle inequality, no additive constant)
+    per variant, on the maxima over its rows; the measured figures are written to
+    gpurun_out/mlp_error_budget.json (millimetres after the x10 decode)."""
+    report = {}
+    for variant in ('panoptic', 'arplab', 'ring23'):
+        e = env(variant)
+        eng = engine_for(variant)
+        xs, refs = [], []
+        for v, name in ALL_CASES:
+            if v != variant:
+                continue
+            arr, frames = load_case(name, variant)
+            for n in range(len(frames)):
+                if 'f%d_mlp_in' % n in arr:
+                    xs.append(arr['f%d_mlp_in' % n])
+                    refs.append(arr['f%d_mlp_out' % n])
+        x = torch.from_numpy(np.concatenate(xs))
+        ref = torch.from_numpy(np.concatenate(refs)).double()
+        exact = _exact_mlp(x, e.mlp)
+        gpu = eng.mlp_forward(x.cuda()).cpu().double()
+        e_ref = (ref - exact).abs().max().item()
+        e_gpu = (gpu - exact).abs().max().item()
+        d = (gpu - ref).abs().max().item()
+        # metres = MLP units x 10 (metrics_from_model.py:281); mm = x 1e4
+        report[variant] = {'rows': int(x.shape[0]), 'gpu_vs_exact_mm': e_gpu * 1e4, 'ref_vs_exact_mm': e_ref * 1e4,
+                           'gpu_vs_ref_mm': d * 1e4, 'output_scale': float(ref.abs().max())}
+        assert e_gpu <= e_ref, (variant, e_gpu, e_ref)
+        assert d <= e_gpu + e_ref, (variant, d, e_gpu, e_ref)
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'mlp_error_budget.json'), 'w') as fh:
+        json.dump(report, fh, indent=1)
+    print(json.dumps(report))

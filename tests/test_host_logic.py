@@ -190,3 +190,84 @@ def test_native_json_packer_numbers_are_python_floats(calib):
     text = json.dumps([{'trackera': [json.dumps(sks[i:i + 10]), 0]} for i in range(0, len(sks), 10)])
     pb = packing.pack_json(text, calib.params)
     assert np.array_equal(pb.xy, np.array(vals).reshape(-1, 18, 2))
+
+
+def test_native_json_packer_never_reads_past_len(tmp_path, calib):
+    """The C entry point takes (json, len): no NUL terminator may be assumed.  CPU build of
+    packer.cpp under AddressSanitizer, fed every prefix of a list document and of a single-frame
+    document from exactly sized heap buffers (tests/native/packer_prefix_driver.cpp)."""
+    import json
+    import shutil
+    import subprocess
+    if not shutil.which('g++'):
+        pytest.skip('no g++')
+    exe = str(tmp_path / 'packer_asan')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address', '-fno-omit-frame-pointer',
+                           os.path.join(ROOT, '3d_multi_pose_estimator_amd', 'csrc', 'packer.cpp'),
+                           os.path.join(ROOT, 'tests', 'native', 'packer_prefix_driver.cpp'), '-lpthread', '-o', exe])
+    _, frames = load_case('c1_2view_1person')
+    cams = list(calib.params.used_cameras_skeleton_matching)
+    docs = {'list': json.dumps(frames), 'single': json.dumps(frames[0]),
+            'numbers': json.dumps([{cams[0]: [json.dumps([{'3': [3, 1e-320, 1234567890.12345678901, 1, 0.1234567890123456789]}]), 0]}])}
+    for name, text in docs.items():
+        path = tmp_path / (name + '.json')
+        path.write_text(text)
+        res = subprocess.run([exe, str(path), '18'] + cams, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and 'AddressSanitizer' not in res.stderr, res.stderr[-2000:]
+        full, accepted = (int(x) for x in res.stdout.split())
+        assert full == (len(frames) if name == 'list' else 1) and accepted >= 1
+
+
+def test_batch_arena_layout_roundtrip(calib):
+    """One contiguous buffer per batch (single H2D copy): every array lands 256-byte aligned and
+    reads back bit-identically."""
+    packing = pkg('packing')
+    _, frames = load_case('c2_5x4_messy')
+    pb = packing.pack_frames(frames, calib.params)
+    arena = packing.BatchArena(pb, 'host').fill(pb)
+    raw = arena.buf.numpy()
+    for name, (off, n, dt) in arena.offsets.items():
+        assert off % 256 == 0
+        got = raw[off: off + n * np.dtype(dt).itemsize].view(dt)
+        assert np.array_equal(got, np.asarray(getattr(pb, name)).reshape(-1).view(dt)), name
+    assert arena.nbytes < 1.1 * sum(np.asarray(getattr(pb, n)).nbytes for n, _ in packing.ARRAYS) + 9 * 256
+
+
+@pytest.mark.parametrize('extra,total,scaling', [(['--frames', '7'], 14, 'weak'), (['--total-frames', '11'], 11, 'strong')])
+def test_bench_gpus_flag_spawns_ranks(extra, total, scaling):
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must itself start two ranks: the
+    parent spawns them before any GPU call, rank 0 reports n_gpus = 2 and the world size the
+    process group saw.  --dry-run keeps the launch, rendezvous (gloo), sharding and all-gather and
+    drops the GPU work, so this runs on the CPU box."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '2'] + extra,
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, res.stdout
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['world_size_seen'] == 2 and out['launcher'] == 'bench.py spawn'
+    assert out['gather_ok'] and out['scaling'] == scaling and out['frames_per_step_total'] == total
+
+
+def test_bench_under_external_launcher_uses_its_world():
+    """Under torchrun-style env (RANK/WORLD_SIZE set) bench.py must NOT spawn again."""
+    import json
+    import subprocess
+    import sys
+    port = 29700 + os.getpid() % 200
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.pop('MPE_BENCH_SPAWNED', None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '1',
+                                       '--frames', '5'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['launcher'] == 'external' and out['gather_ok']
+    assert not [l for l in outs[1][0].splitlines() if l.startswith('{')]      # only rank 0 prints
