@@ -271,3 +271,50 @@ def make_frames(calib, n, spec=None, seed=1234, start=0):
         frames.append(f)
         gts.append(g)
     return frames, gts
+
+
+def decoder_mlp_state_dict(n_cameras, n_joints=18, npj=14, noise_seed=None, noise_bound=0.0, mean_of=range(5, 18)):
+    """Hand-built PoseEstimatorMLP weights (reference utils/mlp.py:8-28 shapes and key names) that
+    make the network a DECODER of its own input row: output joint j = the triangulated point the
+    row carries for joint j in camera block 0 (columns 11..13 = XYZ/10 where the flag in column 10
+    is set, reference pose_estimator_dataset_from_json.py:280-285); joint 0, which is never
+    triangulated (:75), gets the mean of the joints in `mean_of`.  A value x travels through the
+    LeakyReLU(0.1) layers as the pair (x, -x): leaky(x) - leaky(-x) = 1.1 x.  With these weights the
+    harness' MPJPE / AP figures are meaningful (millimetres) without a trained checkpoint, which
+    does not exist offline.  `noise_bound` > 0 adds dense hash noise to every weight so that the
+    GEMMs are not sparse copies."""
+    dims = mlp_layer_dims(n_cameras * n_joints * npj, n_joints * 3)
+    n_val = n_joints * 3
+    sd = {}
+    inv = np.float32(1.0 / 1.1)
+    for i, (din, dout) in enumerate(dims):
+        key = 2 * i + 1
+        W = np.zeros((dout, din), np.float32)
+        first, last = i == 0, i == len(dims) - 1
+        for v in range(n_val):
+            j, k = divmod(v, 3)
+            if first:
+                src = {}
+                if j == 0:
+                    for jj in mean_of:
+                        src[jj * npj + 11 + k] = 1.0 / len(list(mean_of))
+                else:
+                    src[j * npj + 11 + k] = 1.0
+                for col, w in src.items():
+                    W[2 * v, col] = w
+                    W[2 * v + 1, col] = -w
+            elif last:
+                W[v, 2 * v] = inv
+                W[v, 2 * v + 1] = -inv
+            else:
+                W[2 * v, 2 * v] = inv
+                W[2 * v, 2 * v + 1] = -inv
+                W[2 * v + 1, 2 * v] = -inv
+                W[2 * v + 1, 2 * v + 1] = inv
+        b = np.zeros((dout,), np.float32)
+        if noise_bound > 0 and noise_seed is not None:
+            W = W + hash_symmetric(noise_seed, 70000 + 10 * i, (dout, din), noise_bound / np.sqrt(din))
+            b = b + hash_symmetric(noise_seed, 70001 + 10 * i, (dout,), noise_bound)
+        sd['layers.%d.weight' % key] = W.astype(np.float32)
+        sd['layers.%d.bias' % key] = b.astype(np.float32)
+    return sd

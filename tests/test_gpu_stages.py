@@ -74,8 +74,10 @@ def test_gat_layers_vs_reference_activations(variant, name):
             # (i) chained: the layer consumes the HIP path's own previous output
             x = eng.gat_layer(db, l, x, activation=0)
             got = x.cpu().numpy()
-            assert _close(got[:4], arr[p + 'act%d_head' % l][:min(4, H)], 2e-5), (l, 'head rows vs reference')
-            assert _close(got[H:H + 4], arr[p + 'act%d_en' % l], 2e-5), (l, 'edge-node rows vs reference')
+            nh = min(4, H)                         # the fixture holds rows [0:4] and [H:H+4] of the N x HD matrix
+            assert _close(got[:nh], arr[p + 'act%d_head' % l][:nh], 2e-5), (l, 'head rows vs reference')
+            want_en = arr[p + 'act%d_en' % l]
+            assert _close(got[H:H + len(want_en)], want_en, 2e-5), (l, 'edge-node rows vs reference')
             assert _close(got, inter[l].numpy(), 2e-5), (l, 'all rows vs oracle')
             # (ii) isolated: the layer alone on the oracle's input rows
             if l > 0:
