@@ -106,6 +106,12 @@ def ground_truth(frame, T_dataset_cam1, T_i_cam1):
 
 
 class Metrics:
+    """Bookkeeping of the two reference callers (metrics_from_model.py:303-390,
+    metrics_from_triangulation.py:281-372), statement for statement.  The scripts differ in one
+    place: the triangulation script marks a detection invalid when a used joint of the ground
+    truth is missing from it (:297-298) and then books it as a false positive at every threshold
+    (:333), while its MPJPE sum still counts it (:323-327)."""
+
     def __init__(self):
         self.acc_err = 0.0
         self.n_matching = 0
@@ -114,41 +120,46 @@ class Metrics:
         self.TP = [[] for _ in THRESHOLDS_MM]
         self.FP = [[] for _ in THRESHOLDS_MM]
 
-    def add_frame(self, gts, valid_gt, results, result_valid=None):
-        """results: list of {joint idx: (3,)}; error table + exhaustive assignment."""
+    def add_frame(self, gts, valid_gt, results, triangulation=False):
+        """gts: list of {joint str or int: (3,)}; results: list of {joint idx: (3,)} in the order
+        the 3D stage produced them."""
         G, R = len(gts), len(results)
         table = np.zeros((G, R))
+        valid_detection = [True] * R
         for i, gt in enumerate(gts):
             for r, res in enumerate(results):
                 tot, n = 0.0, 0
                 for j, g in gt.items():
-                    if j in parameters.used_joints:
-                        if j in res:
-                            tot += np.linalg.norm(np.asarray(res[j]) - g)
+                    idx = int(j)
+                    if idx in parameters.used_joints:
+                        if idx in res:
+                            tot += np.linalg.norm(np.asarray(res[idx]) - g)
                             n += 1
-                        elif result_valid is not None:
-                            result_valid[r] = False
-                if n:
+                        else:
+                            valid_detection[r] = False
+                if n > 0:
                     table[i, r] = tot / n
         perms = itertools.permutations(range(R), G) if G <= R else itertools.permutations(range(G), G)
         best, best_p = 10000., None
         for p in perms:
-            acc = sum(table[i, r] for i, r in enumerate(p) if r < R)
+            acc = 0
+            for i, r in enumerate(p):
+                if r < R:
+                    acc += table[i, r]
             if acc < best:
                 best, best_p = acc, p
         self.n_poses += R
         self.n_gt += G
         for r in range(R):
-            matched = best_p is not None and r in best_p
-            if matched:
+            if r in best_p:
                 i = best_p.index(r)
-                if valid_gt[i] and (result_valid is None or result_valid[r]):
+                if valid_gt[i]:
                     self.n_matching += 1
                     self.acc_err += table[i, r]
-                elif not valid_gt[i]:
+                else:
                     self.n_gt -= 1
             for k, th in enumerate(THRESHOLDS_MM):
-                if matched:
+                if r in best_p and (valid_detection[r] or not triangulation):
                     i = best_p.index(r)
                     if not valid_gt[i]:
                         continue
@@ -160,21 +171,19 @@ class Metrics:
                     self.FP[k].append(1)
 
     def report(self):
-        out = {}
+        out = {'ap': {}}
         for k, th in enumerate(THRESHOLDS_MM):
             tp, fp = np.cumsum(np.array(self.TP[k])), np.cumsum(np.array(self.FP[k]))
-            if len(tp) == 0:
-                continue
             recall = tp / (self.n_gt + 1e-5)
             precise = tp / (tp + fp + 1e-5)
-            for n in range(len(tp) - 2, -1, -1):
+            for n in range(len(self.TP[k]) - 2, -1, -1):
                 precise[n] = max(precise[n], precise[n + 1])
             precise = np.concatenate(([0], precise, [0]))
             recall = np.concatenate(([0], recall, [1]))
             idx = np.where(recall[1:] != recall[:-1])[0]
             ap = np.sum((recall[idx + 1] - recall[idx]) * precise[idx + 1])
             print('AP, precise and recall for', th, ':', ap, precise[-2], recall[-2])
-            out[int(th)] = (float(ap), float(precise[-2]), float(recall[-2]))
+            out['ap'][str(int(th))] = [float(ap), float(precise[-2]), float(recall[-2])]
         if self.n_matching > 0:
             print('MEAN ERR (mm)', self.acc_err * 1000. / self.n_matching)
             out['mpjpe_mm'] = self.acc_err * 1000. / self.n_matching
@@ -202,37 +211,38 @@ def teacher_scores(db, owners):
     return torch.from_numpy(sc)
 
 
-def run(args, mode):
-    calib = Calibration(parameters)
-    eng = Engine(parameters, calib, max_frames=args.batch, max_persons_per_camera=max(4, args.persons + 1))
-    load_models(eng, args, need_mlp=(mode == 'mlp'))
-    tm_dir = args.tmdir[0]
-    T_i1 = torch.from_numpy(calib.T_i32[1])
-    work = []          # (frame, T_dataset_cam1, owners or None)
+def collect_work(args, calib):
+    """[(frame, T_dataset_cam1, owners or None)] honouring --datastep across files (the counter
+    runs over all files, metrics_from_model.py:102-124)."""
+    work = []
     if args.synthetic:
         spec = synthetic.FrameSpec(persons=args.persons, noise_px=args.noise_px)
         for i in range(args.synthetic):
             f, gt = synthetic.make_frame(calib, i, spec)
             work.append((f, torch.from_numpy(calib.T_d[1]).type(torch.float32), gt['owner']))
-        datastep = 1
-    else:
-        datastep = args.datastep
-        n_input = 0
-        for file in args.testfiles:
-            print(file)
-            T_d1 = torch.from_numpy(dataset_transform(tm_dir, file).get_transform('root', parameters.camera_names[1])).type(torch.float32)
-            for frame in json.load(open(file, 'rb')):
-                n_input += 1
-                if (n_input - 1) % datastep == 0:
-                    work.append((frame, T_d1, None))
+        return work
+    tm_dir = args.tmdir[0]
+    n_input = 0
+    for file in args.testfiles:
+        print(file)
+        T_d1 = torch.from_numpy(dataset_transform(tm_dir, file).get_transform('root', parameters.camera_names[1])).type(torch.float32)
+        for frame in json.load(open(file, 'rb')):
+            n_input += 1
+            if (n_input - 1) % args.datastep == 0:
+                work.append((frame, T_d1, None))
+    return work
+
+
+def evaluate(work, infer, mode, T_i1, batch=256):
+    """The callers' loop around the inference path.  `infer(frames, owners)` receives the
+    pre-processed frames of one batch (cameras with an empty skeleton list dropped, :182-191) and
+    returns, per frame, None when the frame has no cross-camera pair (no graph, :195-196) or the
+    list of 3D results {joint idx: (3,)} in production order.  Returns (Metrics, n_data, n_results)."""
     metrics = Metrics()
-    t_match = t_3d = 0.0
-    n_data = n_persons_total = 0
-    J = eng.J
-    for start in range(0, len(work), args.batch):
-        chunk = work[start:start + args.batch]
+    n_data = n_results = 0
+    for start in range(0, len(work), batch):
         keep, gts = [], []
-        for frame, T_d1, owners in chunk:
+        for frame, T_d1, owners in work[start:start + batch]:
             gt = ground_truth(frame, T_d1, T_i1)
             if gt is None:
                 continue
@@ -240,14 +250,32 @@ def run(args, mode):
             gts.append(gt)
         if not keep:
             continue
-        frames = []
-        for frame, _ in keep:     # callers drop cameras with an empty skeleton list (:182-191)
-            frames.append({c: [frame[c][0], frame[c][1]] for c in frame if json.loads(frame[c][0])})
+        frames = [{c: [frame[c][0], frame[c][1]] for c in frame if json.loads(frame[c][0])} for frame, _ in keep]
+        per_frame = infer(frames, [o for _, o in keep])
+        for f, results in enumerate(per_frame):
+            if results is None:
+                continue
+            n_data += 1
+            n_results += len(results)
+            metrics.add_frame(gts[f][0], gts[f][1], results, triangulation=(mode != 'mlp'))
+    return metrics, n_data, n_results
+
+
+def run(args, mode):
+    calib = Calibration(parameters)
+    eng = Engine(parameters, calib, max_frames=args.batch, max_persons_per_camera=max(4, args.persons + 1))
+    load_models(eng, args, need_mlp=(mode == 'mlp'))
+    T_i1 = torch.from_numpy(calib.T_i32[1])
+    work = collect_work(args, calib)
+    J = eng.J
+    t = {'match': 0.0, '3d': 0.0}
+
+    def infer(frames, owners):
         db = eng.to_device(eng.pack(frames))
         torch.cuda.synchronize()
         t0 = time.time()
-        if args.teacher_scores and keep[0][1] is not None:
-            persons, n_persons = eng.cluster(db, teacher_scores(db, [o for _, o in keep]))
+        if args.teacher_scores and owners[0] is not None:
+            persons, n_persons = eng.cluster(db, teacher_scores(db, owners))
         else:
             _, persons, n_persons = eng.match(db, want_scores=False)
         torch.cuda.synchronize()
@@ -257,37 +285,35 @@ def run(args, mode):
         else:
             poses, jvalid = eng.triangulate(db, persons, n_persons)
         torch.cuda.synchronize()
-        t2 = time.time()
-        t_match += t1 - t0
-        t_3d += t2 - t1
-        n_np = n_persons.cpu().numpy()
-        poses = poses.cpu().numpy()
-        if mode == 'mlp':
-            valid = valid.cpu().numpy()
-        else:
-            jvalid = jvalid.cpu().numpy()
-        for f in range(len(keep)):
+        t['match'] += t1 - t0
+        t['3d'] += time.time() - t1
+        eng.sync_status()
+        n_np, poses = n_persons.cpu().numpy(), poses.cpu().numpy()
+        flags = (valid if mode == 'mlp' else jvalid).cpu().numpy()
+        out = []
+        for f in range(len(frames)):
             h0, H, e0, M = db.host.frame_counts(f)
             if M == 0:
+                out.append(None)
                 continue
-            n_data += 1
-            results, rvalid = [], None
+            results = []
             for p in range(int(n_np[f])):
                 if mode == 'mlp':
-                    if valid[f, p]:
+                    if flags[f, p]:
                         results.append({j: poses[f, p, j] for j in range(J)})
                 else:
-                    results.append({j: poses[f, p, j] for j in range(J) if jvalid[f, p, j]})
-            if mode != 'mlp':
-                rvalid = [True] * len(results)
-            n_persons_total += len(results)
-            metrics.add_frame(gts[f][0], gts[f][1], results, rvalid)
+                    results.append({j: poses[f, p, j] for j in range(J) if flags[f, p, j]})
+            out.append(results)
+        return out
+
+    metrics, n_data, n_results = evaluate(work, infer, mode, T_i1, args.batch)
     out = metrics.report()
     if n_data > 0:
-        print('Mean time for graph matching', t_match / n_data)
-        print('Mean time for graph matching (per person)', t_match / max(1, n_persons_total))
-        print('Mean time for 3D', t_3d / n_data)
-        print('Mean time for 3D (per person)', t_3d / max(1, n_persons_total))
-        print('Frames per second', n_data / max(1e-9, t_match + t_3d))
+        print('Mean time for graph matching', t['match'] / n_data)
+        print('Mean time for graph matching (per person)', t['match'] / max(1, n_results))
+        print('Mean time for 3D', t['3d'] / n_data)
+        print('Mean time for 3D (per person)', t['3d'] / max(1, n_results))
+        print('Frames per second', n_data / max(1e-9, t['match'] + t['3d']))
+    out['n_data'] = n_data
     eng.close()
     return out

@@ -182,7 +182,7 @@ class FrameSpec:
 
     def __init__(self, persons=4, cameras=None, noise_px=0.0, joint_drop=0.0,
                  permute=True, add_id_key=False, spurious=0, empty_cameras=(),
-                 float_conf=True):
+                 float_conf=True, identity_prob=False):
         self.persons = persons
         self.cameras = cameras            # list of camera names present (dict order); None = all
         self.noise_px = noise_px
@@ -192,6 +192,10 @@ class FrameSpec:
         self.spurious = spurious
         self.empty_cameras = tuple(empty_cameras)
         self.float_conf = float_conf
+        # person p's detections carry prob = 0.3 + 0.1 p in every view: an appearance cue that the
+        # hand-built matcher network (matcher_gat_state_dict) reads, standing in for what a trained
+        # checkpoint (not available offline) infers from geometry
+        self.identity_prob = identity_prob
 
 
 def _normal(u1, u2):
@@ -241,6 +245,8 @@ def make_frame(calib, frame_index, spec=None, seed=1234):
                         prob = float(np.float32(0.30 + 0.70 * conf_u[p, j, 1]))
                     else:
                         valid, prob = 1, 1
+                    if spec.identity_prob:
+                        prob = float(np.float32(0.3 + 0.1 * p))
                     sk[str(j)] = [j, x, y, valid, prob]
                 if spec.add_id_key and sk:
                     sk['ID'] = p
@@ -317,4 +323,100 @@ def decoder_mlp_state_dict(n_cameras, n_joints=18, npj=14, noise_seed=None, nois
             b = b + hash_symmetric(noise_seed, 70001 + 10 * i, (dout,), noise_bound)
         sd['layers.%d.weight' % key] = W.astype(np.float32)
         sd['layers.%d.bias' % key] = b.astype(np.float32)
+    return sd
+
+
+class _NetBuilder:
+    """fc1 -> LeakyReLU(alpha) -> fc2 as a list of exact ReLU units: relu(y) is assembled from the
+    pair (leaky(y), leaky(-y)) since leaky(y) = alpha*y + (1-alpha)*relu(y)."""
+
+    def __init__(self, din, dout, alpha):
+        self.W1 = np.zeros((din, din), np.float64)
+        self.b1 = np.zeros(din, np.float64)
+        self.W2 = np.zeros((dout, din), np.float64)
+        self.b2 = np.zeros(dout, np.float64)
+        self.alpha = alpha
+        self.n = 0
+
+    def relu(self, weights, bias):
+        """New unit relu(sum_c weights[c]*x[c] + bias) -> handle (pair of hidden rows)."""
+        u = self.n
+        self.n += 2
+        for c, w in weights.items():
+            self.W1[u, c] += w
+            self.W1[u + 1, c] -= w
+        self.b1[u] += bias
+        self.b1[u + 1] -= bias
+        return u
+
+    def out(self, channel, unit, w):
+        """output[channel] += w * relu-unit."""
+        a = self.alpha
+        # relu(y) = (leaky(y) - a*y)/(1-a), y = (leaky(y) - leaky(-y))/(1+a)
+        k = a / (1.0 + a)
+        self.W2[channel, unit] += w * (1.0 - k) / (1.0 - a)
+        self.W2[channel, unit + 1] += w * k / (1.0 - a)
+
+
+def matcher_gat_state_dict(num_feats, n_cameras, n_joints=18, levels=8, key_joint=8, gain=12.0, noise_seed=None,
+                           noise_bound=0.0):
+    """Hand-built GAT2 weights (reference gat2.py shapes and state-dict names, deployed layer
+    sizes) that make the network a correct matcher on frames generated with
+    FrameSpec(identity_prob=True): an edge-node scores ~0.88 when its two skeletons carry the same
+    `prob` level on `key_joint` and ~0.12 otherwise.
+
+    How: attn_l = attn_r = 0, so every edge softmax is uniform and a layer's graph half is the mean
+    over in-edges.  Layer 0 turns the key joint's prob of a head row into a one-hot over `levels`
+    (piecewise-linear hats) plus a node-type flag read from column 0; the edge-node rows (one-hot at
+    column 1) produce zeros.  After the mean an edge-node holds (onehot(h1) + onehot(h2))/3, so a
+    component reaches 2/3 exactly when the two heads agree; layer 1 thresholds that at 1/2.  Layers
+    2..4 carry the decision, re-deriving in every layer which rows are edge-nodes from the type
+    channel (its value after the mean is a known constant at edge-nodes and lies on one side of it
+    at heads) so that head rows contribute zeros to the next mean.  The last layer emits
+    gain*(decision - 1/2) at edge-nodes and 0 at heads.
+    With noise_bound > 0 dense hash noise is added to every weight (thresholds have margins of 1/6)."""
+    dims = gat_layer_dims(num_feats)
+    alpha = GAT_ALPHA
+    sd = {}
+    blk = n_joints * 10
+    third = float(np.float32(1.0 / 3.0))
+    two_thirds = float(np.float32(third) + np.float32(third))
+    for l, (din, nh, dout) in enumerate(dims):
+        nb = _NetBuilder(din, nh * dout, alpha)
+        if l == 0:
+            s_cols = {2 + c * blk + key_joint * 10 + 3: 1.0 for c in range(n_cameras)}    # prob of key_joint, any camera block
+            w = 0.05
+            for k in range(levels):
+                ck = float(np.float32(0.3 + 0.1 * k))
+                for t, coef in ((ck - w, 1.0 / w), (ck, -2.0 / w), (ck + w, 1.0 / w)):
+                    col = dict(s_cols)
+                    col[0] = -t                         # threshold through the head flag: edge-node rows give 0
+                    nb.out(k, nb.relu(col, 0.0), coef)
+            nb.out(levels, nb.relu({0: 1.0}, 0.0), 1.0)  # type flag F: 1 at heads, 0 at edge-nodes
+        elif l == 1:
+            c = 12.0
+            for k in range(levels):
+                u = nb.relu({k: 1.0, levels: c}, -0.5 - c * two_thirds)
+                nb.out(0, u, 6.0)                        # decision v in {0, 1}
+            nb.out(1, nb.relu({levels: c}, 1.0 - c * two_thirds), 1.0)     # type t: 1 at edge-nodes
+        else:
+            c = 24.0
+            a = nb.relu({0: 3.0, 1: -c}, c * third)      # v at edge-nodes (type channel == 1/3), 0 at heads
+            t = nb.relu({1: -c}, 1.0 + c * third)        # 1 at edge-nodes, 0 at heads
+            if l < len(dims) - 1:
+                nb.out(0, a, 1.0)
+                nb.out(1, t, 1.0)
+            else:
+                nb.out(0, a, 3.0 * gain)
+                nb.out(0, t, -1.5 * gain)
+        W1, b1, W2, b2 = nb.W1, nb.b1, nb.W2, nb.b2
+        if noise_bound > 0 and noise_seed is not None:
+            W1 = W1 + hash_symmetric(noise_seed, 90000 + 10 * l, W1.shape, noise_bound / np.sqrt(din))
+            W2 = W2 + hash_symmetric(noise_seed, 90001 + 10 * l, W2.shape, noise_bound / np.sqrt(din))
+        sd['layers.%d.attn_l' % l] = np.zeros((nh, dout, 1), np.float32)
+        sd['layers.%d.attn_r' % l] = np.zeros((nh, dout, 1), np.float32)
+        sd['layers.%d.fc1.weight' % l] = W1.astype(np.float32)
+        sd['layers.%d.fc1.bias' % l] = b1.astype(np.float32)
+        sd['layers.%d.fc2.weight' % l] = W2.astype(np.float32)
+        sd['layers.%d.fc2.bias' % l] = b2.astype(np.float32)
     return sd

@@ -39,7 +39,7 @@ SHIMS = os.path.join(ROOT, 'oracle', 'shims')
 OUT = os.path.join(ROOT, 'tests', 'golden', 'harness')
 PKG = '3d_multi_pose_estimator_amd'
 
-GAT_SEED, GAT_SHIFT, GAT_GAIN = 7, 0.698 + 0.25, 25.0
+GAT_NOISE_SEED, GAT_NOISE = 5, 1e-4
 MLP_NOISE_SEED, MLP_NOISE = 3, 2e-4
 DATASTEP = 3
 TEST_NAME = 'syn_pinning_test.json'
@@ -59,20 +59,21 @@ def rigid_offset():
 def build_frames(calib, syn):
     """48 frames; with --datastep 3 the scripts read frames 0, 3, 6, ...: those carry the cases,
     the frames between them are different fillers (a wrong stride changes every number)."""
-    F = syn.FrameSpec
-    cases = [F(persons=1, noise_px=1.0), F(persons=1, noise_px=2.0, joint_drop=0.1), F(persons=2, noise_px=1.0),
-             F(persons=1, noise_px=0.5), F(persons=3, noise_px=1.0), F(persons=1, noise_px=1.5, add_id_key=False),
-             F(persons=1, cameras=['trackerb', 'trackerd', 'trackere'], noise_px=1.0),
-             F(persons=2, noise_px=0.5, joint_drop=0.2), F(persons=1, noise_px=3.0),
-             F(persons=1, cameras=['trackerc']),                      # one camera: no graph -> skipped (:195-196)
-             F(persons=1, noise_px=1.0, spurious=1), F(persons=1, noise_px=1.0),
-             F(persons=4, noise_px=1.0), F(persons=1, noise_px=2.5), F(persons=1, noise_px=1.0, empty_cameras=('trackera',)),
-             F(persons=1, noise_px=1.0)]
+    def F(**kw):
+        return syn.FrameSpec(identity_prob=True, **kw)
+    cases = [F(persons=4, noise_px=1.0), F(persons=1, noise_px=2.0, joint_drop=0.1), F(persons=2, noise_px=1.0),
+             F(persons=3, noise_px=0.5), F(persons=3, noise_px=1.0, spurious=1), F(persons=5, noise_px=1.5),
+             F(persons=2, cameras=['trackerb', 'trackerd', 'trackere'], noise_px=1.0),
+             F(persons=4, noise_px=0.5, joint_drop=0.2), F(persons=1, noise_px=3.0),
+             F(persons=2, cameras=['trackerc']),                      # one camera: no graph -> skipped (:195-196)
+             F(persons=4, noise_px=6.0), F(persons=2, noise_px=1.0),
+             F(persons=4, noise_px=1.0), F(persons=3, noise_px=12.0), F(persons=2, noise_px=1.0, empty_cameras=('trackera',)),
+             F(persons=6, noise_px=1.0)]
     R = rigid_offset()
     Rinv = np.linalg.inv(R)
     frames = []
     for i in range(48):
-        spec = cases[i // DATASTEP] if i % DATASTEP == 0 else F(persons=2 + i % 2, noise_px=4.0)
+        spec = cases[i // DATASTEP] if i % DATASTEP == 0 else F(persons=2 + i % 2, noise_px=40.0)
         frame, _ = syn.make_frame(calib, 7000 + i, spec)
         for cam in frame:
             bodies = frame[cam][3]
@@ -100,7 +101,7 @@ def save_models(mdir, syn, V, J):
     prm = dict(prm, nonlinearity=torch.nn.LeakyReLU(), final_activation=torch.nn.Sigmoid())
     with open(os.path.join(mdir, 'skeleton_matching.prms'), 'wb') as fh:
         pickle.dump(prm, fh)
-    gat = syn.gat_state_dict(GAT_SEED, nf, logit_gain=GAT_GAIN, logit_shift=GAT_SHIFT)
+    gat = syn.matcher_gat_state_dict(nf, V, J, noise_seed=GAT_NOISE_SEED, noise_bound=GAT_NOISE)
     torch.save({k: torch.from_numpy(v) for k, v in gat.items()}, os.path.join(mdir, 'skeleton_matching.tch'))
     mlp = syn.decoder_mlp_state_dict(V, J, 14, noise_seed=MLP_NOISE_SEED, noise_bound=MLP_NOISE)
     torch.save({'model_state_dict': {k: torch.from_numpy(v) for k, v in mlp.items()}},
@@ -162,7 +163,7 @@ def main():
             report[key] = parse_report(text)
             assert 'mpjpe_mm' in report[key] and len(report[key]['ap']) == 6, text
     report['inputs'] = {'testfile': TEST_NAME, 'tm': 'tm_syn_pinning.pickle', 'datastep': DATASTEP,
-                        'gat': {'seed': GAT_SEED, 'logit_gain': GAT_GAIN, 'logit_shift': GAT_SHIFT},
+                        'gat': {'kind': 'matcher', 'noise_seed': GAT_NOISE_SEED, 'noise_bound': GAT_NOISE},
                         'mlp': {'kind': 'decoder', 'noise_seed': MLP_NOISE_SEED, 'noise_bound': MLP_NOISE}}
     with open(os.path.join(OUT, 'harness_expected.json'), 'w') as fh:
         json.dump(report, fh, indent=1)

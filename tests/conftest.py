@@ -109,3 +109,29 @@ def load_case(name, variant='panoptic'):
     with open(os.path.join(d, name + '.frames.json')) as fh:
         frames = json.load(fh)
     return arr, frames
+
+
+def harness_model_files(out_dir, inputs):
+    """The model files of the harness pinning test in the reference's three formats
+    (skeleton_matching.prms / .tch, pose_estimator.pytorch), rebuilt from the deterministic
+    generators named in harness_expected.json (the files themselves are 116 MB)."""
+    import pickle
+
+    import torch
+    syn = pkg('synthetic')
+    par = pkg('parameters').parameters
+    V, J = len(par.camera_names), len(par.joint_list)
+    nf = 2 + V * J * 10
+    mdir = os.path.join(out_dir, 'models')
+    os.makedirs(mdir, exist_ok=True)
+    prm = dict(syn.gat_params(nf), nonlinearity=torch.nn.LeakyReLU(), final_activation=torch.nn.Sigmoid())
+    with open(os.path.join(mdir, 'skeleton_matching.prms'), 'wb') as fh:
+        pickle.dump(prm, fh)
+    g, m = inputs['gat'], inputs['mlp']
+    assert g['kind'] == 'matcher' and m['kind'] == 'decoder'
+    gat = syn.matcher_gat_state_dict(nf, V, J, noise_seed=g['noise_seed'], noise_bound=g['noise_bound'])
+    torch.save({k: torch.from_numpy(v) for k, v in gat.items()}, os.path.join(mdir, 'skeleton_matching.tch'))
+    mlp = syn.decoder_mlp_state_dict(V, J, par.numbers_per_joint, noise_seed=m['noise_seed'], noise_bound=m['noise_bound'])
+    torch.save({'model_state_dict': {k: torch.from_numpy(v) for k, v in mlp.items()}},
+               os.path.join(mdir, 'pose_estimator.pytorch'))
+    return mdir

@@ -1,9 +1,34 @@
-"""GPU: the evaluation harness end to end on synthetic frames."""
+"""GPU: the evaluation harness end to end -- on synthetic frames, and on the committed test file
+against the numbers the REFERENCE'S OWN scripts printed for it (tests/golden/harness/)."""
 import importlib
+import json
+import os
 
 import pytest
 
+from conftest import GOLDEN, harness_model_files
+
 pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('script,key', [('metrics_from_model', 'model'), ('metrics_from_triangulation', 'triangulation')])
+def test_harness_reproduces_the_reference_scripts_report(script, key, tmp_path):
+    """the build's harness, driven exactly like the reference script
+    (--testfiles --tmdir --modelsdir --datastep; weights read from skeleton_matching.prms/.tch and
+    pose_estimator.pytorch, calibration from tm_<a>_<b>.pickle), prints what
+    /root/reference/test/<script>.py printed for the same files (oracle/gen_harness_golden.py):
+    AP / precision / recall at every threshold exactly, MPJPE within 0.01 mm."""
+    hd = os.path.join(GOLDEN, 'harness')
+    with open(os.path.join(hd, 'harness_expected.json')) as fh:
+        exp = json.load(fh)
+    mdir = harness_model_files(str(tmp_path), exp['inputs'])
+    m = importlib.import_module('3d_multi_pose_estimator_amd.harness.' + script)
+    out = m.main(['--testfiles', os.path.join(hd, exp['inputs']['testfile']), '--tmdir', hd, '--modelsdir', mdir,
+                  '--datastep', str(exp['inputs']['datastep']), '--batch', '7'])
+    want = exp[key]
+    assert abs(out['mpjpe_mm'] - want['mpjpe_mm']) < 0.01, (out['mpjpe_mm'], want['mpjpe_mm'])
+    for th, triple in want['ap'].items():
+        assert out['ap'][th] == pytest.approx(triple, rel=1e-12, abs=1e-12), (th, out['ap'][th], triple)
 
 
 def test_triangulation_harness_recovers_ground_truth():
@@ -13,13 +38,13 @@ def test_triangulation_harness_recovers_ground_truth():
     m = importlib.import_module('3d_multi_pose_estimator_amd.harness.metrics_from_triangulation')
     out = m.main(['--synthetic', '40', '--random-weights', '--teacher-scores', '--batch', '16'])
     assert out['mpjpe_mm'] < 0.5
-    assert out[25][2] > 0.95          # recall at 25 mm
+    assert out['ap']['25'][2] > 0.95          # recall at 25 mm
 
 
 def test_model_harness_runs():
     m = importlib.import_module('3d_multi_pose_estimator_amd.harness.metrics_from_model')
     out = m.main(['--synthetic', '24', '--random-weights', '--batch', '16'])
-    assert 25 in out
+    assert '25' in out['ap']
 
 
 def test_sm_metrics_harness():

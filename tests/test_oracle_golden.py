@@ -1,5 +1,7 @@
 """CPU: the oracle restatement (oracle/oracle_np.py) against the fixtures produced by the
 reference's own files (oracle/gen_golden.py).  This is what pins the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -123,3 +125,50 @@ def test_stage3d(variant, name):
         np.testing.assert_allclose(out.numpy(), arr[p + 'mlp_out'], rtol=1e-5, atol=1e-6)
         poses = np.stack([onp.decode_pose(out[i], 18) for i in range(out.shape[0])])
         np.testing.assert_allclose(poses, arr[p + 'poses'], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('mode,key', [('mlp', 'model'), ('tri', 'triangulation')])
+def test_harness_bookkeeping_reproduces_reference_report(mode, key, tmp_path):
+    """CPU half of the a14/a15 pin: the harness' own file handling (--datastep stride over the
+    file, tm_<a>_<b>.pickle lookup, GT to world through the dataset calibration, skip rules) and
+    its Metrics bookkeeping, with the ORACLE as the inference side, must print what the
+    reference's scripts printed (tests/golden/harness/harness_expected.json)."""
+    import argparse
+    import json
+    import pickle
+    import torch
+    from conftest import GOLDEN, harness_model_files
+    onp = oracle()
+    common = pkg('harness.common')
+    calib = env().calib
+    hd = os.path.join(GOLDEN, 'harness')
+    exp = json.load(open(os.path.join(hd, 'harness_expected.json')))
+    mdir = harness_model_files(str(tmp_path), exp['inputs'])
+    prm = pickle.load(open(os.path.join(mdir, 'skeleton_matching.prms'), 'rb'))
+    prm = dict(prm, nonlinearity=prm['nonlinearity'].negative_slope)
+    gat_sd = {k: v.numpy() for k, v in torch.load(os.path.join(mdir, 'skeleton_matching.tch')).items()}
+    mlp_sd = {k: v.numpy() for k, v in torch.load(os.path.join(mdir, 'pose_estimator.pytorch'))['model_state_dict'].items()}
+    args = argparse.Namespace(synthetic=0, tmdir=[hd], testfiles=[os.path.join(hd, exp['inputs']['testfile'])],
+                              datastep=exp['inputs']['datastep'])
+    work = common.collect_work(args, calib)
+    assert len(work) == 16
+    J = len(calib.params.joint_list)
+
+    def infer(frames, owners):
+        out = []
+        for frame in frames:
+            res = onp.run_frame(frame, calib, gat_sd, prm, mlp_sd, mode=mode)
+            if res is None:
+                out.append(None)
+            elif mode == 'mlp':
+                out.append([{j: p[j] for j in range(J)} for p in res['poses']])
+            else:
+                out.append(res['tri'])
+        return out
+    metrics, n_data, _ = common.evaluate(work, infer, mode, torch.from_numpy(calib.T_i32[1]), batch=5)
+    got = metrics.report()
+    want = exp[key]
+    assert n_data == 14                       # 16 strided frames - one without GT bodies - one without a graph
+    assert abs(got['mpjpe_mm'] - want['mpjpe_mm']) < 1e-6
+    for th, triple in want['ap'].items():
+        assert got['ap'][th] == pytest.approx(triple, rel=1e-12, abs=1e-12), th
