@@ -241,14 +241,25 @@ __device__ __forceinline__ int dma_swz(int row) { return ((row >> 1) & 1) | (((r
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <bool LEAKY, bool ACC64, int NTT>
+// A12 (fc2 of a graph-attention layer with 40-wide attention heads, 80-wide feature tiles): the
+// epilogue also emits the attention coefficients of gat2.py:57-58,
+//   a1[row][head] = <ft2[row, head, :], attn_l[head]>,  a2 with attn_r,
+// from the result values the lanes already hold (a tile covers exactly two heads), so the
+// attention stage does not have to read ft2 a second time.  Summation order (the canonical order,
+// mirrored by coef40() in gat.hip for the paths that compute the coefficients elsewhere): lane
+// group q = 0..3 of the MFMA layout runs one fma chain over the features it owns in ascending
+// order, then (s_q + s_q^1) + (s_q^2 + s_q^3).
+template <bool LEAKY, bool ACC64, int NTT, bool A12 = false>
 __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
                                                        const float *__restrict__ W, int ldw,
                                                        const float *__restrict__ bias, float *__restrict__ C,
                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
                                                        int k_pad, float slope, int ntn, int n_major,
                                                        const int32_t *__restrict__ a_rows,
-                                                       const int32_t *__restrict__ c_rows) {
+                                                       const int32_t *__restrict__ c_rows,
+                                                       const float *__restrict__ attn_l = nullptr,
+                                                       const float *__restrict__ attn_r = nullptr,
+                                                       float *__restrict__ a12 = nullptr) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];   // 2 stages of (128 + 16 NTT) rows x 128 B
     constexpr int ROWF = 32;                   // floats per tile row (dense)
     constexpr int W_OFF = GEMM_BM * ROWF;      // weight rows follow the activation rows
@@ -377,14 +388,25 @@ __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_
         }
     }
 
+    float pl[2][MT], pr[2][MT];          // A12: per (head of the tile, row tile) partial dot products
+    if (A12) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) pl[h][mt] = pr[h][mt] = 0.f;
+    }
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) {
         const int nb = n0 + nt * 16 + fq * 4;
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+        f32x4 al = {0.f, 0.f, 0.f, 0.f}, ar = {0.f, 0.f, 0.f, 0.f};
+        if (A12 && nb + 3 < n) {
+            al = *reinterpret_cast<const f32x4 *>(attn_l + nb);
+            ar = *reinterpret_cast<const f32x4 *>(attn_r + nb);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = m0 + wave * 32 + mt * 16 + fr;
-            if (m >= M) continue;
             f32x4 v;
             if (ACC64) {
 #pragma unroll
@@ -396,6 +418,17 @@ __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
             }
+            if (A12) {
+                // a 4-feature group never straddles the 40-feature head boundary of the tile
+                const int hp = (nt * 16 + fq * 4) >= 40 ? 1 : 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float l1 = __builtin_fmaf(v[i], al[i], hp ? pl[1][mt] : pl[0][mt]);
+                    const float r1 = __builtin_fmaf(v[i], ar[i], hp ? pr[1][mt] : pr[0][mt]);
+                    if (hp) { pl[1][mt] = l1; pr[1][mt] = r1; } else { pl[0][mt] = l1; pr[0][mt] = r1; }
+                }
+            }
+            if (m >= M) continue;
             const int mo = c_rows ? c_rows[m] : m;
             float *dst = C + (size_t)mo * ldc + nb;
             if (nb + 3 < n) {
@@ -406,6 +439,25 @@ __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_
                     if (nb + i < n) dst[i] = v[i];
             }
         }
+    }
+    if (A12) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float x = pl[h][mt], y = pr[h][mt];
+                x = x + __shfl_xor(x, 16);
+                y = y + __shfl_xor(y, 16);
+                x = x + __shfl_xor(x, 32);
+                y = y + __shfl_xor(y, 32);
+                const int m = m0 + wave * 32 + mt * 16 + fr;
+                const int head = (n0 / 40) + h;
+                if (fq == 0 && m < M && head * 40 < n) {
+                    const int mo = c_rows ? c_rows[m] : m;
+                    a12[(size_t)mo * 32 + head] = x;
+                    a12[(size_t)mo * 32 + 16 + head] = y;
+                }
+            }
     }
 }
 

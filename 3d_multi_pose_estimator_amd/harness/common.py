@@ -261,12 +261,23 @@ def evaluate(work, infer, mode, T_i1, batch=256):
     return metrics, n_data, n_results
 
 
+def max_skeletons_per_camera(work):
+    """Largest skeleton list of any camera in the selected frames: sizes the engine's per-frame
+    capacity (the reference has no such limit; its graphs simply grow)."""
+    m = 1
+    for frame, _, _ in work:
+        for cam in frame:
+            m = max(m, frame[cam][0].count('{'))       # one '{' per skeleton dict in the JSON text
+    return m
+
+
 def run(args, mode):
     calib = Calibration(parameters)
-    eng = Engine(parameters, calib, max_frames=args.batch, max_persons_per_camera=max(4, args.persons + 1))
+    work = collect_work(args, calib)
+    eng = Engine(parameters, calib, max_frames=args.batch,
+                 max_persons_per_camera=max(4, args.persons + 1, max_skeletons_per_camera(work)))
     load_models(eng, args, need_mlp=(mode == 'mlp'))
     T_i1 = torch.from_numpy(calib.T_i32[1])
-    work = collect_work(args, calib)
     J = eng.J
     t = {'match': 0.0, '3d': 0.0}
 
