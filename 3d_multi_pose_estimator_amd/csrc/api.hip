@@ -139,14 +139,16 @@ struct GemmProf {
 
 int linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, const Linear &L, float *C, int ldc, int m,
            const int32_t *d_m, bool leaky, float slope, bool acc64 = false, const int32_t *a_rows = nullptr,
-           const int32_t *c_rows = nullptr, double flop_override = -1.0) {
+           const int32_t *c_rows = nullptr, double flop_override = -1.0, const AttnCoef *coef = nullptr,
+           bool *coef_done = nullptr) {
+    if (coef_done) *coef_done = false;
     if (m <= 0) return MPE_OK;
     if (lda < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", lda, L.ldw);
     const bool host_m = !d_m || flop_override >= 0.0;
     GemmProf gp(ctx, s, flop_override >= 0.0 ? flop_override : (d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim),
                 host_m ? 0 : L.out_dim, host_m ? 0 : L.in_dim);
     HIPCHK(ctx, launch_linear(s, A, lda, L.w, L.ldw, L.b, C, ldc, m, d_m, L.out_dim, L.ldw, leaky, slope, acc64, a_rows,
-                              c_rows));
+                              c_rows, coef, coef_done));
     return MPE_OK;
 }
 
@@ -157,9 +159,12 @@ int ensure_bf16_weights(mpe_ctx *ctx, Linear *L);
 // optional fp16 result (`out_half`: C is the same buffer seen as fp16 rows, ldc in halves)
 int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, float *C, int ldc, int m,
                const int32_t *d_m, bool leaky, float slope, bool out_half, const int32_t *a_rows = nullptr,
-               const int32_t *c_rows = nullptr, double flop_override = -1.0) {
+               const int32_t *c_rows = nullptr, double flop_override = -1.0, const AttnCoef *coef = nullptr,
+               bool *coef_done = nullptr) {
+    if (coef_done) *coef_done = false;
     if (!ctx->gat_reduced)
-        return linear(ctx, s, A, lda, L, C, ldc, m, d_m, leaky, slope, ctx->gat_acc64, a_rows, c_rows, flop_override);
+        return linear(ctx, s, A, lda, L, C, ldc, m, d_m, leaky, slope, ctx->gat_acc64, a_rows, c_rows, flop_override, coef,
+                      coef_done);
     if (m <= 0) return MPE_OK;
     int rc = ensure_bf16_weights(ctx, &L);
     if (rc) return rc;
@@ -336,12 +341,17 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
     const bool red = ctx->gat_reduced;
     const int ld_ft = red ? 2 * ctx->act_ld : ctx->act_ld;   // fp16 rows keep the byte stride of the fp32 rows
     int rc;
+    // fc2 also emits the attention coefficients a1|a2 from its epilogue when the layer's shape allows
+    const AttnCoef coef{g.attn_l, g.attn_r, ctx->a12, g.heads, g.out_dim};
+    const bool no_epi = getenv("MPE_NO_COEF_EPILOGUE") != nullptr;           // read per call: tests toggle it
+    const AttnCoef *cp = no_epi ? nullptr : &coef;
+    bool done = false;
     if (in == GAT_IN_DENSE0) {
         if ((rc = gat_linear(ctx, s, ctx->xdense, ctx->feat_ld, g.fc1, ctx->hdense, ctx->feat_ld, n_nodes, nullptr,
                              true, ctx->gat_alpha, false)))
             return rc;
         if ((rc = gat_linear(ctx, s, ctx->hdense, ctx->feat_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
-                             0.f, red)))
+                             0.f, red, nullptr, nullptr, -1.0, cp, &done)))
             return rc;
         a->ft2 = ctx->act[2];
         *n_rows_ft2 = n_nodes;
@@ -361,7 +371,7 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
                                     true, ctx->gat_alpha, false)))
             return rc;
         if ((rc = gat_linear(ctx, s, ctx->h0, ctx->feat_ld, g.fc2, ctx->act[1], ld_ft, b->n_heads, nullptr, false,
-                             0.f, red)))
+                             0.f, red, nullptr, nullptr, -1.0, cp, &done)))
             return rc;
         a->ft2 = ctx->act[1];
         *n_rows_ft2 = b->n_heads;
@@ -372,11 +382,12 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
                              true, ctx->gat_alpha, false)))
             return rc;
         if ((rc = gat_linear(ctx, s, ctx->act[1], ctx->act_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
-                             0.f, red)))
+                             0.f, red, nullptr, nullptr, -1.0, cp, &done)))
             return rc;
         a->ft2 = ctx->act[2];
         *n_rows_ft2 = n_nodes;
     }
+    a->a12_ready = done ? 1 : 0;
     return MPE_OK;
 }
 

@@ -194,7 +194,51 @@ __device__ __forceinline__ void ld_ftv<1>(const float *base, size_t idx, int hal
 
 // ---------------------------------------------------------------------------------------
 // attention coefficients a1 = <ft2[n,h,:], attn_l[h,:]>, a2 with attn_r  (gat2.py:57-58)
+//
+// Canonical summation order for 40-wide heads = the order of the fc2 GEMM epilogue
+// (k_linear_dma<.., A12>, gemm.hip), so that a coefficient has the same bits whichever kernel
+// produced it: four fma chains s_0..s_3 over the features that lane group q of the MFMA layout
+// owns inside an 80-wide tile (two heads per tile, hence the head's parity), then
+// (s_0 + s_1) + (s_2 + s_3).  Other head widths: one fma chain over d.
 // ---------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ void coef40(F ft, const float *__restrict__ al, const float *__restrict__ ar, int parity,
+                                       float &o1, float &o2) {
+    float s1[4], s2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x1 = 0.f, x2 = 0.f;
+        auto step = [&](int d) {
+            const float v = ft(d);
+            x1 = __builtin_fmaf(v, al[d], x1);
+            x2 = __builtin_fmaf(v, ar[d], x2);
+        };
+        if (parity == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) step(16 * t + 4 * q + i);
+            if (q < 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) step(32 + 4 * q + i);
+            }
+        } else {
+            if (q >= 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) step(4 * q - 8 + i);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) step(8 + 4 * q + i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) step(24 + 4 * q + i);
+        }
+        s1[q] = x1;
+        s2[q] = x2;
+    }
+    o1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+    o2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+}
+
 constexpr int COEF_ROWS = 8;
 
 __global__ __launch_bounds__(256) void k_attn_coef(const float *__restrict__ ft2, int ld, int n_rows, int heads,
@@ -210,14 +254,21 @@ __global__ __launch_bounds__(256) void k_attn_coef(const float *__restrict__ ft2
         s_ft[r * hd + c] = ld_ft(ft2, (size_t)(r0 + r) * ld + c, ft_half);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nr * heads * 2; i += blockDim.x) {
-        const int r = i / (heads * 2), rem = i - r * heads * 2;
-        const int which = rem / heads, h = rem - which * heads;
-        const float *av = (which ? attn_r : attn_l) + h * out_dim;
+    for (int i = threadIdx.x; i < nr * heads; i += blockDim.x) {
+        const int r = i / heads, h = i - r * heads;
         const float *fv = s_ft + r * hd + h * out_dim;
-        float acc = 0.f;
-        for (int d = 0; d < out_dim; ++d) acc = __builtin_fmaf(fv[d], av[d], acc);
-        a12[(size_t)(r0 + r) * 32 + which * 16 + h] = acc;
+        float x1 = 0.f, x2 = 0.f;
+        if (out_dim == 40) {
+            coef40([&](int d) { return fv[d]; }, attn_l + h * 40, attn_r + h * 40, h & 1, x1, x2);
+        } else {
+            const float *al = attn_l + h * out_dim, *ar = attn_r + h * out_dim;
+            for (int d = 0; d < out_dim; ++d) {
+                x1 = __builtin_fmaf(fv[d], al[d], x1);
+                x2 = __builtin_fmaf(fv[d], ar[d], x2);
+            }
+        }
+        a12[(size_t)(r0 + r) * 32 + h] = x1;
+        a12[(size_t)(r0 + r) * 32 + 16 + h] = x2;
     }
 }
 
@@ -235,15 +286,93 @@ hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows,
 // edge attention + softmax over in-edges + weighted sum + activation
 // (gat2.py:61-66,78-88 and the activation of GAT2.forward :141-147)
 //
-// Two kernels: edge-node destinations (89 % of the rows at 5x4) have exactly three in-edges
-// (h1, h2, self), so every lane recomputes its head's 3-way softmax in registers and streams
-// its columns -- no LDS, no barrier.  Head destinations (in-degree 1 + heads of the other
-// cameras) use the general LDS path.
+// Edge-node destinations (89 % of the rows at 5x4) have exactly three in-edges (h1, h2, self):
+// every lane recomputes its head's 3-way softmax in registers.  Head destinations (in-degree
+// 1 + heads of the other cameras, 221 at 23x10) use a WAVE per (destination, attention head):
+//   * the source of in-edge e is arithmetic, no list is built: e = 0 is the self loop, e >= 1 is
+//     the (e-1)-th head of the other cameras in head order, and the edge-node that joins them
+//     follows from the per-frame table of pair bases -- ascending e is ascending edge id, the
+//     reference's edge creation order (graph_generator.py:632-651);
+//   * max, exp and sum are wave reductions of fixed shape: lane j accumulates the in-edges
+//     e = j, j+64, ... in ascending order, then an xor butterfly (32,16,8,4,2,1).  The reference
+//     delegates this sum to DGL's edge_softmax, whose order is not pinned by anything in the
+//     reference; the tree differs from a sequential sum by a few ulp (parity bound 2e-5).
+//   * the weighted sum of the source rows stays sequential in edge order per output column.
+// The fused kernel (frames whose slice fits in LDS) and the general kernels share these orders,
+// so a frame gives the same bits on either path (tested).
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float agg_activate(float x, int mode, float slope) {
     if (mode == 0) return x > 0.f ? x : x * slope;
     if (mode == 1) return 1.f / (1.f + expf(-x));
     return x;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+    x = x + __shfl_xor(x, 32);
+    x = x + __shfl_xor(x, 16);
+    x = x + __shfl_xor(x, 8);
+    x = x + __shfl_xor(x, 4);
+    x = x + __shfl_xor(x, 2);
+    x = x + __shfl_xor(x, 1);
+    return x;
+}
+
+__device__ __forceinline__ float wave_max(float x) {
+    x = fmaxf(x, __shfl_xor(x, 32));
+    x = fmaxf(x, __shfl_xor(x, 16));
+    x = fmaxf(x, __shfl_xor(x, 8));
+    x = fmaxf(x, __shfl_xor(x, 4));
+    x = fmaxf(x, __shfl_xor(x, 2));
+    x = fmaxf(x, __shfl_xor(x, 1));
+    return x;
+}
+
+// Per-frame topology scalars in LDS: slot prefix sums and the first edge-node id of every
+// camera-slot pair (p < q), lexicographic = creation order (graph_generator.py:854-864).
+struct FrameTopo {
+    int *start;   // [V + 1] first head of slot s
+    int *base;    // [V * V] frame-local node id of the first edge-node of pair (p, q), p < q
+};
+
+__device__ __forceinline__ void build_topo(FrameTopo tp, const int32_t *__restrict__ sn, int V, int H, int t, int nthreads) {
+    if (t == 0) {
+        int acc = 0;
+        for (int s = 0; s < V; ++s) {
+            tp.start[s] = acc;
+            acc += sn[s];
+        }
+        tp.start[V] = acc;
+    }
+    for (int pq = t; pq < V * V; pq += nthreads) {
+        const int p = pq / V, q = pq - p * V;
+        if (p >= q) continue;
+        int b = H;
+        for (int a = 0; a <= p; ++a) {
+            const int na = sn[a];
+            const int qe = a == p ? q : V;
+            for (int c = a + 1; c < qe; ++c) b += na * sn[c];
+        }
+        tp.base[pq] = b;
+    }
+}
+
+// source node (frame-local id) of in-edge e of head v
+__device__ __forceinline__ int head_in_edge(const FrameTopo &tp, const int32_t *__restrict__ sn, int V, int v, int s,
+                                            int e) {
+    if (e == 0) return v;
+    const int st = tp.start[s], ns = sn[s], i = v - st;
+    int u = e - 1;
+    if (u >= st) u += ns;                       // the (e-1)-th head that is not in slot s
+    int p = 0;
+    while (p + 1 < V && u >= tp.start[p + 1]) ++p;
+    const int k = u - tp.start[p];
+    return p < s ? tp.base[p * V + s] + k * ns + i : tp.base[s * V + p] + i * sn[p] + k;
+}
+
+__device__ __forceinline__ int slot_of_head(const FrameTopo &tp, int V, int v) {
+    int s = 0;
+    while (s + 1 < V && v >= tp.start[s + 1]) ++s;
+    return s;
 }
 
 constexpr int EN_ROWS = 16;     // edge-node rows per workgroup
@@ -310,6 +439,10 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
     }
 }
 
+// Head destinations, general path: AGG_ROWS head rows per workgroup, one WAVE per row for the
+// topology scalars, the in-edge sources and the softmax weights (all attention heads of the row,
+// wave reductions), then all threads accumulate the weighted source rows column by column in
+// edge order.
 constexpr int AGG_ROWS = 4;
 
 template <int VEC>
@@ -319,90 +452,73 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
     const int32_t *__restrict__ head_frame, AggArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ float s_dyn[];
-    // layout: alpha [AGG_ROWS][max_deg][heads] | src [AGG_ROWS][max_deg] (int)
-    float *s_alpha = s_dyn;
-    int *s_src = reinterpret_cast<int *>(s_dyn + (size_t)AGG_ROWS * max_deg * a.heads);
+    const int heads = a.heads, hd = a.heads * a.out_dim;
+    float *s_w = s_dyn;                                                          // [AGG_ROWS][heads][max_deg]
+    int *s_src = reinterpret_cast<int *>(s_w + (size_t)AGG_ROWS * heads * max_deg);   // [AGG_ROWS][max_deg]
+    int *s_topo = s_src + AGG_ROWS * max_deg;                                    // [AGG_ROWS][V + 1 + V * V]
     __shared__ int s_deg[AGG_ROWS], s_f[AGG_ROWS], s_v[AGG_ROWS], s_H[AGG_ROWS];
 
-    const int row0 = blockIdx.x * AGG_ROWS;
-    const int t = threadIdx.x;
-    const int heads = a.heads, hd = a.heads * a.out_dim;
-
-    // phase A: in-edge list of head v: (v,v), then the adjacent edge-nodes in ascending id
-    if (t < AGG_ROWS) {
-        const int gh = row0 + t;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool l0 = a.en_const_ft2 != nullptr;
+    {
+        // one wave per row
+        const int gh = blockIdx.x * AGG_ROWS + wave;
         int deg = 0;
-        // heads of a frame beyond max_heads_per_frame are skipped (their list would not fit)
-        if (gh < n_heads && head_off[head_frame[gh] + 1] - head_off[head_frame[gh]] <= max_deg - 1) {
+        if (gh < n_heads) {
             const int f = head_frame[gh];
-            const int v = gh - head_off[f];
-            const int H = head_off[f + 1] - head_off[f];
-            s_f[t] = f;
-            s_v[t] = v;
-            s_H[t] = H;
-            int *src = s_src + t * max_deg;
-            const int32_t *sn = slot_n + (size_t)f * V;
-            int s = 0, start = 0;
-            while (s < V && v >= start + sn[s]) { start += sn[s]; ++s; }
-            const int i = v - start, ns = sn[s];
-            src[deg++] = v;
-            int base = H;
-            for (int p = 0; p < V; ++p)
-                for (int q = p + 1; q < V; ++q) {
-                    const int np_ = sn[p], nq = sn[q];
-                    if (q == s) {
-                        for (int k = 0; k < np_; ++k) src[deg++] = base + k * ns + i;
-                    } else if (p == s) {
-                        for (int k = 0; k < nq; ++k) src[deg++] = base + i * nq + k;
-                    }
-                    base += np_ * nq;
+            const int hb = head_off[f], H = head_off[f + 1] - hb;
+            if (H <= max_deg - 1) {                 // frames beyond max_heads_per_frame are skipped (flagged by k_topology)
+                const int v = gh - hb;
+                const int32_t nb = node_off[f];
+                const int32_t *sn = slot_n + (size_t)f * V;
+                FrameTopo tp;
+                tp.start = s_topo + wave * (V + 1 + V * V);
+                tp.base = tp.start + V + 1;
+                build_topo(tp, sn, V, H, lane, 64);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int s = slot_of_head(tp, V, v);
+                deg = 1 + H - sn[s];
+                int *src = s_src + wave * max_deg;
+                for (int e = lane; e < deg; e += 64) src[e] = head_in_edge(tp, sn, V, v, s, e);
+                if (lane == 0) {
+                    s_f[wave] = f;
+                    s_v[wave] = v;
+                    s_H[wave] = H;
                 }
+                const float *a_dst = l0 ? a.a12 + (size_t)(hb + v) * 32 : a.a12 + (size_t)(nb + v) * 32;
+                for (int hh = 0; hh < heads; ++hh) {
+                    const float a2v = a_dst[16 + hh];
+                    float *w = s_w + ((size_t)wave * heads + hh) * max_deg;
+                    float mx = -INFINITY;
+                    for (int e = lane; e < deg; e += 64) {
+                        const int u = src[e];       // written by this lane above
+                        const float *a_src;
+                        if (l0) a_src = u >= H ? a.en_const_a : a.a12 + (size_t)(hb + u) * 32;
+                        else a_src = a.a12 + (size_t)(nb + u) * 32;
+                        float x = a_src[hh] + a2v;
+                        x = x > 0.f ? x : x * a.alpha;
+                        w[e] = x;
+                        mx = fmaxf(mx, x);
+                    }
+                    mx = wave_max(mx);
+                    float sum = 0.f;
+                    for (int e = lane; e < deg; e += 64) {
+                        const float ex = expf(w[e] - mx);
+                        w[e] = ex;
+                        sum = sum + ex;
+                    }
+                    sum = wave_sum(sum);
+                    for (int e = lane; e < deg; e += 64) w[e] = w[e] / sum;
+                }
+            }
         }
-        s_deg[t] = deg;
+        if (lane == 0) s_deg[wave] = deg;
     }
     __syncthreads();
 
-    // phase B: logits e = LeakyReLU_alpha(a1[src] + a2[dst])
-    for (int r = 0; r < AGG_ROWS; ++r) {
-        const int deg = s_deg[r];
-        if (deg == 0) continue;
-        const int f = s_f[r], v = s_v[r], H = s_H[r];
-        const int32_t nb = node_off[f], hb = head_off[f];
-        const bool l0 = a.en_const_ft2 != nullptr;
-        const float *a_dst = l0 ? a.a12 + (size_t)(hb + v) * 32 : a.a12 + (size_t)(nb + v) * 32;
-        for (int i = t; i < deg * heads; i += blockDim.x) {
-            const int e = i / heads, hh = i - e * heads;
-            const int u = s_src[r * max_deg + e];
-            const float *a_src;
-            if (l0) a_src = u >= H ? a.en_const_a : a.a12 + (size_t)(hb + u) * 32;
-            else a_src = a.a12 + (size_t)(nb + u) * 32;
-            float x = a_src[hh] + a_dst[16 + hh];
-            x = x > 0.f ? x : x * a.alpha;
-            s_alpha[((size_t)r * max_deg + e) * heads + hh] = x;
-        }
-    }
-    __syncthreads();
-
-    // phase C: softmax over the in-edges of each (row, head): max, exp, sum in edge order, div
-    for (int i = t; i < AGG_ROWS * heads; i += blockDim.x) {
-        const int r = i / heads, hh = i - r * heads;
-        const int deg = s_deg[r];
-        if (deg == 0) continue;
-        float *al = s_alpha + (size_t)r * max_deg * heads + hh;
-        float mx = -INFINITY;
-        for (int e = 0; e < deg; ++e) mx = fmaxf(mx, al[e * heads]);
-        float sum = 0.f;
-        for (int e = 0; e < deg; ++e) {
-            const float ex = expf(al[e * heads] - mx);
-            al[e * heads] = ex;
-            sum = sum + ex;
-        }
-        for (int e = 0; e < deg; ++e) al[e * heads] = al[e * heads] / sum;
-    }
-    __syncthreads();
-
-    // phase D: out[v][c] = sum_e round(alpha[e][h(c)] * ft2[src_e][c]), then activation;
-    // VEC consecutive columns (of one attention head) per thread, each summed in edge order
+    // out[v][c] = sum_e round(w[e][h(c)] * ft2[src_e][c]) in edge order, then activation;
+    // VEC consecutive columns (of one attention head) per thread
     const int per_row = hd / VEC;
     for (int i = t; i < AGG_ROWS * per_row; i += blockDim.x) {
         const int r = i / per_row, c = (i - r * per_row) * VEC;
@@ -411,19 +527,20 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
         const int f = s_f[r], v = s_v[r], H = s_H[r];
         const int hh = c / a.out_dim;
         const int32_t nb = node_off[f], hb = head_off[f];
-        const bool l0 = a.en_const_ft2 != nullptr;
+        const float *w = s_w + ((size_t)r * heads + hh) * max_deg;
+        const int *src = s_src + r * max_deg;
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
         for (int e = 0; e < deg; ++e) {
-            const int u = s_src[r * max_deg + e];
+            const int u = src[e];
             float fv[VEC];
             if (l0 && u >= H) ld_ftv<VEC>(a.en_const_ft2, (size_t)c, 0, fv);
             else ld_ftv<VEC>(a.ft2, (size_t)((l0 ? hb : nb) + u) * a.ld + c, a.ft_half, fv);
-            const float w = s_alpha[((size_t)r * max_deg + e) * heads + hh];
+            const float we = w[e];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float m = fv[k] * w;
+                const float m = fv[k] * we;
                 acc[k] = acc[k] + m;
             }
         }
@@ -439,17 +556,12 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
     }
 }
 
-hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
-                            const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
-                            const int32_t *en_pair, const AggArgs &a);
-
 // ---------------------------------------------------------------------------------------
 // Fused attention stage for frames whose head slice fits in LDS: one workgroup per
-// (frame, attention head).  It loads ft2[:, head, :] of the frame once (N x D' floats),
-// computes a1/a2 (the two bmm of gat2.py:57-58), the edge softmax and the weighted sums, and
-// writes the activated output slice -- ft2 is read once and nothing else touches HBM.
-// Same operation order as k_attn_coef / k_aggregate_en / k_aggregate_heads, so the results
-// are bit-identical to the unfused path (which remains for large frames).
+// (frame, attention head).  It loads ft2[:, head, :] of the frame once (N x D' floats, dense
+// 16-byte chunks: every LDS access of the hot loops is a ds_read/write_b128), takes a1/a2 from the
+// fc2 epilogue (or computes them in the canonical order when the GEMM did not), and writes the
+// activated output slice -- ft2 is read once and nothing else touches HBM.
 // ---------------------------------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap, int m_cap,
@@ -462,14 +574,14 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
                                                    const float *__restrict__ attn_r, AggArgs a) {
 #pragma clang fp contract(off)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
-    extern __shared__ float s_dyn[];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     // XCD-aware order: workgroups with equal (id % 8) share an L2; the attention heads of one
     // frame read neighbouring 160-byte pieces of the same rows, so they go to the same XCD
     const int bid = blockIdx.x, nwg = gridDim.x;
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
     const int vid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int f = vid / a.heads, hh = vid - f * a.heads;
-    const int D = a.out_dim, Dp = D | 1;           // odd row stride: conflict-free column walks
+    const int D = a.out_dim;
     const int hb = head_off[f], H = head_off[f + 1] - hb;
     const int eb = en_off[f], M = en_off[f + 1] - eb;
     const int N = H + M, nb = node_off[f];
@@ -480,141 +592,123 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
             for (int m = threadIdx.x; m < M; m += blockDim.x) a.out[(size_t)eb + m] = 0.f;
         return;
     }
+    const int Dp = (D + 3) & ~3;                    // row stride: whole 16-byte chunks
     float *s_ft = s_dyn;                            // [n_cap][Dp]
     float *s_a1 = s_ft + (size_t)n_cap * Dp;        // [n_cap]
     float *s_a2 = s_a1 + n_cap;                     // [n_cap]
-    float *s_wen = s_a2 + n_cap;                    // [m_cap][3] softmax weights of edge-nodes
-    float *s_wh = s_wen + (size_t)m_cap * 3;        // [hmax][max_deg] softmax weights of heads
+    float *s_wh = s_a2 + n_cap;                     // [hmax][max_deg] softmax weights of heads
     int *s_src = reinterpret_cast<int *>(s_wh + (size_t)(max_deg - 1) * max_deg);   // [hmax][max_deg]
-    int *s_deg = s_src + (size_t)(max_deg - 1) * max_deg;                           // [hmax]
-    int *s_pair = s_deg + (max_deg - 1);                                            // [m_cap] h1 << 16 | h2
-    float *s_hred = reinterpret_cast<float *>(s_pair + m_cap);                      // [hmax] per-head max / sum
-    const int t = threadIdx.x;
+    int *s_pair = s_src + (size_t)(max_deg - 1) * max_deg;                          // [m_cap] h1 << 16 | h2
+    FrameTopo tp;
+    tp.start = s_pair + m_cap;                      // [V + 1]
+    tp.base = tp.start + V + 1;                     // [V * V]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool l0 = a.en_const_ft2 != nullptr;
     const int c0 = hh * D;
     const int DV = D / VEC;
+    const int32_t *sn = slot_n + (size_t)f * V;
 
-    // phase 1: feature slice -> LDS (layer 0: ft2 holds head rows only, edge-nodes share one row)
+    // phase 1: feature slice -> LDS (layer 0: ft2 holds head rows only, edge-nodes share one row),
+    // coefficients of this attention head, pair table, topology scalars
     for (int i = t; i < N * DV; i += blockDim.x) {
         const int node = i / DV, d = (i - node * DV) * VEC;
         float v[VEC];
         if (l0 && node >= H) ld_ftv<VEC>(a.en_const_ft2, (size_t)(c0 + d), 0, v);
         else ld_ftv<VEC>(a.ft2, (size_t)((l0 ? hb : nb) + node) * a.ld + c0 + d, a.ft_half, v);
+        vecf o;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) s_ft[node * Dp + d + k] = v[k];
+        for (int k = 0; k < VEC; ++k) o[k] = v[k];
+        *reinterpret_cast<vecf *>(s_ft + node * Dp + d) = o;
+    }
+    if (a.a12_ready) {
+        for (int node = t; node < N; node += blockDim.x) {
+            const float *r = (l0 && node >= H) ? a.en_const_a : a.a12 + (size_t)((l0 ? hb : nb) + node) * 32;
+            s_a1[node] = r[hh];
+            s_a2[node] = r[16 + hh];
+        }
     }
     for (int m = t; m < M; m += blockDim.x)
         s_pair[m] = (en_pair[2 * (size_t)(eb + m)] << 16) | en_pair[2 * (size_t)(eb + m) + 1];
-    // in-edge lists of the heads (ascending edge id), one thread per head
-    for (int hd_ = t; hd_ < H; hd_ += blockDim.x) {
-        const int32_t *sn = slot_n + (size_t)f * V;
-        int s = 0, start = 0;
-        while (s < V && hd_ >= start + sn[s]) { start += sn[s]; ++s; }
-        const int i = hd_ - start, ns = sn[s];
-        int *src = s_src + hd_ * max_deg;
-        int deg = 0;
-        src[deg++] = hd_;
-        int base = H;
-        for (int p = 0; p < V; ++p)
-            for (int q = p + 1; q < V; ++q) {
-                const int np_ = sn[p], nq = sn[q];
-                if (q == s) {
-                    for (int k = 0; k < np_; ++k) src[deg++] = base + k * ns + i;
-                } else if (p == s) {
-                    for (int k = 0; k < nq; ++k) src[deg++] = base + i * nq + k;
+    build_topo(tp, sn, V, H, t, blockDim.x);
+    __syncthreads();
+    if (!a.a12_ready) {
+        // a1 = <ft, attn_l[head]>, a2 = <ft, attn_r[head]> (the GEMM epilogue did not provide them)
+        for (int node = t; node < N; node += blockDim.x) {
+            const float *fv = s_ft + node * Dp;
+            float x1 = 0.f, x2 = 0.f;
+            if (D == 40) {
+                coef40([&](int d) { return fv[d]; }, attn_l + c0, attn_r + c0, hh & 1, x1, x2);
+            } else {
+                for (int d = 0; d < D; ++d) {
+                    x1 = __builtin_fmaf(fv[d], attn_l[c0 + d], x1);
+                    x2 = __builtin_fmaf(fv[d], attn_r[c0 + d], x2);
                 }
-                base += np_ * nq;
             }
-        s_deg[hd_] = deg;
-    }
-    __syncthreads();
-    // phase 2: a1 = <ft, attn_l[head]>, a2 = <ft, attn_r[head]>
-    for (int node = t; node < N; node += blockDim.x) {
-        const float *fv = s_ft + node * Dp;
-        float x1 = 0.f, x2 = 0.f;
-        // the attention vectors are uniform: read through the scalar cache, not LDS
-        for (int d = 0; d < D; ++d) {
-            x1 = __builtin_fmaf(fv[d], attn_l[c0 + d], x1);
-            x2 = __builtin_fmaf(fv[d], attn_r[c0 + d], x2);
+            s_a1[node] = x1;
+            s_a2[node] = x2;
         }
-        s_a1[node] = x1;
-        s_a2[node] = x2;
+        __syncthreads();
     }
-    __syncthreads();
-    // phase 3: softmax weights.  Edge-node X: in-edges (h1, h2, X); head h: its list.
-    for (int m = t; m < M; m += blockDim.x) {
-        const int pr = s_pair[m];
-        const int h1 = pr >> 16, h2 = pr & 0xFFFF, x = H + m;
-        const float a2v = s_a2[x];
-        float e1 = s_a1[h1] + a2v, e2 = s_a1[h2] + a2v, e3 = s_a1[x] + a2v;
-        e1 = e1 > 0.f ? e1 : e1 * a.alpha;
-        e2 = e2 > 0.f ? e2 : e2 * a.alpha;
-        e3 = e3 > 0.f ? e3 : e3 * a.alpha;
-        const float mx = fmaxf(fmaxf(e1, e2), e3);
-        const float x1 = expf(e1 - mx), x2 = expf(e2 - mx), x3 = expf(e3 - mx);
-        const float sum = (x1 + x2) + x3;
-        s_wen[m * 3 + 0] = x1 / sum;
-        s_wen[m * 3 + 1] = x2 / sum;
-        s_wen[m * 3 + 2] = x3 / sum;
-    }
+    // phase 2: softmax weights of the head destinations, one wave per head (fixed-shape reductions)
     if (!a.score_mode || a.out_heads) {
-        // heads: one (head, in-edge) pair per thread for the logits, exponentials and divisions;
-        // only the max and the edge-ordered sum walk a head's list serially
-        const int n_pairs = H * max_deg;
-        for (int i = t; i < n_pairs; i += blockDim.x) {
-            const int h = i / max_deg, e = i - h * max_deg;
-            if (e < s_deg[h]) {
-                float x = s_a1[s_src[i]] + s_a2[h];
-                s_wh[i] = x > 0.f ? x : x * a.alpha;
-            }
-        }
-        __syncthreads();
-        for (int h = t; h < H; h += blockDim.x) {
-            const int deg = s_deg[h];
-            const float *w = s_wh + h * max_deg;
+        for (int h = wave; h < H; h += 4) {
+            const int s = slot_of_head(tp, V, h);
+            const int deg = 1 + H - sn[s];
+            float *w = s_wh + h * max_deg;
+            int *src = s_src + h * max_deg;
+            const float a2v = s_a2[h];
             float mx = -INFINITY;
-            for (int e = 0; e < deg; ++e) mx = fmaxf(mx, w[e]);
-            s_hred[h] = mx;
-        }
-        __syncthreads();
-        for (int i = t; i < n_pairs; i += blockDim.x) {
-            const int h = i / max_deg, e = i - h * max_deg;
-            if (e < s_deg[h]) s_wh[i] = expf(s_wh[i] - s_hred[h]);
-        }
-        __syncthreads();
-        for (int h = t; h < H; h += blockDim.x) {
-            const int deg = s_deg[h];
-            const float *w = s_wh + h * max_deg;
+            for (int e = lane; e < deg; e += 64) {
+                const int u = head_in_edge(tp, sn, V, h, s, e);
+                src[e] = u;
+                float x = s_a1[u] + a2v;
+                x = x > 0.f ? x : x * a.alpha;
+                w[e] = x;
+                mx = fmaxf(mx, x);
+            }
+            mx = wave_max(mx);
             float sum = 0.f;
-            for (int e = 0; e < deg; ++e) sum = sum + w[e];
-            s_hred[h] = sum;
+            for (int e = lane; e < deg; e += 64) {
+                const float ex = expf(w[e] - mx);
+                w[e] = ex;
+                sum = sum + ex;
+            }
+            sum = wave_sum(sum);
+            for (int e = lane; e < deg; e += 64) w[e] = w[e] / sum;
         }
         __syncthreads();
-        for (int i = t; i < n_pairs; i += blockDim.x) {
-            const int h = i / max_deg, e = i - h * max_deg;
-            if (e < s_deg[h]) s_wh[i] = s_wh[i] / s_hred[h];
-        }
     }
-    __syncthreads();
-    // phase 4: weighted sums in edge order, activation, store
+    // phase 3: weighted sums in edge order, activation, store.  Edge-node X: in-edges (h1, h2, X),
+    // its 3-way softmax recomputed per lane.
     const int first = (a.score_mode && !a.out_heads) ? H : 0;
     for (int i = first * DV + t; i < N * DV; i += blockDim.x) {
         const int node = i / DV, d = (i - node * DV) * VEC;
         vecf o;
         if (node >= H) {
-            const int m = node - H;
-            const int pr = s_pair[m];
+            const int pr = s_pair[node - H];
             const int h1 = pr >> 16, h2 = pr & 0xFFFF;
-            const float w1 = s_wen[m * 3 + 0], w2 = s_wen[m * 3 + 1], w3 = s_wen[m * 3 + 2];
+            const float a2v = s_a2[node];
+            float e1 = s_a1[h1] + a2v, e2 = s_a1[h2] + a2v, e3 = s_a1[node] + a2v;
+            e1 = e1 > 0.f ? e1 : e1 * a.alpha;
+            e2 = e2 > 0.f ? e2 : e2 * a.alpha;
+            e3 = e3 > 0.f ? e3 : e3 * a.alpha;
+            const float mx = fmaxf(fmaxf(e1, e2), e3);
+            const float x1 = expf(e1 - mx), x2 = expf(e2 - mx), x3 = expf(e3 - mx);
+            const float sum = (x1 + x2) + x3;
+            const float w1 = x1 / sum, w2 = x2 / sum, w3 = x3 / sum;
+            const vecf f1 = *reinterpret_cast<const vecf *>(s_ft + h1 * Dp + d);
+            const vecf f2 = *reinterpret_cast<const vecf *>(s_ft + h2 * Dp + d);
+            const vecf f3 = *reinterpret_cast<const vecf *>(s_ft + node * Dp + d);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                float acc = s_ft[h1 * Dp + d + k] * w1;
-                acc = acc + s_ft[h2 * Dp + d + k] * w2;
-                acc = acc + s_ft[node * Dp + d + k] * w3;
+                float acc = f1[k] * w1;
+                acc = acc + f2[k] * w2;
+                acc = acc + f3[k] * w3;
                 o[k] = agg_activate(acc, a.out_mode, a.out_slope);
             }
         } else {
-            const int deg = s_deg[node];
+            const int s = slot_of_head(tp, V, node);
+            const int deg = 1 + H - sn[s];
             const int *src = s_src + node * max_deg;
             const float *w = s_wh + node * max_deg;
             float acc[VEC];
@@ -622,7 +716,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
             for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
             for (int e = 0; e < deg; ++e) {
                 const float we = w[e];
-                const float *fv = s_ft + src[e] * Dp + d;
+                const vecf fv = *reinterpret_cast<const vecf *>(s_ft + src[e] * Dp + d);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     const float mm = fv[k] * we;
@@ -641,18 +735,32 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     }
 }
 
-// LDS bytes of k_gat_fused for frames of up to `hmax` heads (0 = does not fit)
+// LDS bytes of k_gat_fused for frames of up to `hmax` heads
 static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_cap) {
     const int mc = hmax * hmax * (V - 1) / (2 * V) + 1;
     const int nc = hmax + mc;
-    const int Dp = out_dim | 1;
+    const int Dp = (out_dim + 3) & ~3;
     const size_t deg = (size_t)hmax + 1;
-    const size_t bytes = ((size_t)nc * Dp + 2 * (size_t)nc + (size_t)mc * 3 + (size_t)hmax * deg + 2 * (size_t)out_dim + hmax) * sizeof(float) +
-                         ((size_t)hmax * deg + hmax + mc) * sizeof(int);
+    const size_t bytes = ((size_t)nc * Dp + 2 * (size_t)nc + (size_t)hmax * deg) * sizeof(float) +
+                         ((size_t)hmax * deg + mc + (V + 1) + (size_t)V * V) * sizeof(int);
     *n_cap = nc;
     *m_cap = mc;
-    return bytes;
+    return (bytes + 15) & ~(size_t)15;
 }
+
+hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
+                            const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
+                            const int32_t *en_pair, const AggArgs &a);
+
+static int agg_vec(const AggArgs &a) {
+    if (!a.score_mode && a.ld % 4 == 0 && a.ld_out % 4 == 0) {
+        if (a.out_dim % 4 == 0) return 4;
+        if (a.out_dim % 2 == 0) return 2;
+    }
+    return 1;
+}
+
+constexpr size_t FUSED_LDS_LIMIT = 160 * 1024;      // all of a CU's LDS (one workgroup per CU at the limit)
 
 hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                                 const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
@@ -660,12 +768,20 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
                                 const AggArgs &a, int n_rows_ft2) {
     int n_cap, m_cap;
     const size_t shm = fused_lds_bytes(max_heads_per_frame, V, a.out_dim, &n_cap, &m_cap);
-    static const bool no_fuse = getenv("MPE_NO_FUSED_ATTENTION") != nullptr;
-    if (shm <= 64 * 1024 && !no_fuse && b.n_frames > 0) {
-        int vec = 1;
-        if (!a.score_mode && a.ld % 4 == 0 && a.ld_out % 4 == 0) {
-            if (a.out_dim % 4 == 0) vec = 4;
-            else if (a.out_dim % 2 == 0) vec = 2;
+    const bool no_fuse = getenv("MPE_NO_FUSED_ATTENTION") != nullptr;       // read per call: tests toggle it
+    if (shm <= FUSED_LDS_LIMIT && !no_fuse && b.n_frames > 0) {
+        const int vec = agg_vec(a);
+        if (shm > 64 * 1024) {                       // opt in to more than 64 KB of dynamic LDS (per device)
+            static PerDeviceFlag attr;
+            if (!attr.test()) {
+                hipError_t e = hipSuccess;
+                const void *fns[3] = {reinterpret_cast<const void *>(k_gat_fused<4>), reinterpret_cast<const void *>(k_gat_fused<2>),
+                                      reinterpret_cast<const void *>(k_gat_fused<1>)};
+                for (const void *fn : fns)
+                    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_LIMIT);
+                if (e != hipSuccess) return e;
+                attr.set();
+            }
         }
 #define MPE_FUSED(V_)                                                                                       \
     hipLaunchKernelGGL(k_gat_fused<V_>, dim3(b.n_frames * a.heads), dim3(256), shm, s, V, max_heads_per_frame + 1, \
@@ -677,23 +793,20 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
 #undef MPE_FUSED
         return hipGetLastError();
     }
-    hipError_t e = launch_attn_coef(s, a.ft2, a.ld, n_rows_ft2, a.heads, a.out_dim, attn_l, attn_r, a12, a.ft_half);
-    if (e != hipSuccess) return e;
     AggArgs a2 = a;
     a2.a12 = a12;
+    if (!a.a12_ready) {
+        hipError_t e = launch_attn_coef(s, a.ft2, a.ld, n_rows_ft2, a.heads, a.out_dim, attn_l, attn_r, a12, a.ft_half);
+        if (e != hipSuccess) return e;
+    }
     return launch_aggregate(s, b, V, max_heads_per_frame, node_off, head_frame, en_frame, en_pair, a2);
 }
 
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                             const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
                             const int32_t *en_pair, const AggArgs &a) {
-    const int hd = a.heads * a.out_dim;
+    const int vec = agg_vec(a);
     if (b.n_edge_nodes > 0) {
-        int vec = 1;
-        if (!a.score_mode && a.ld % 4 == 0 && a.ld_out % 4 == 0) {
-            if (a.out_dim % 4 == 0) vec = 4;
-            else if (a.out_dim % 2 == 0) vec = 2;
-        }
         const unsigned blocks = (unsigned)((b.n_edge_nodes + EN_ROWS - 1) / EN_ROWS);
 #define MPE_EN(V_)                                                                                      \
     hipLaunchKernelGGL(k_aggregate_en<V_>, dim3(blocks), dim3(256), 0, s, b.n_edge_nodes, b.d_frame_head_off, \
@@ -709,13 +822,20 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
     if (b.n_heads > 0 && (!a.score_mode || a.out_heads)) {
         int max_deg = max_heads_per_frame + 1;
         if (max_deg < 3) max_deg = 3;
-        const size_t shm = (size_t)AGG_ROWS * max_deg * (a.heads * sizeof(float) + sizeof(int));
-        const int grid = (b.n_heads + AGG_ROWS - 1) / AGG_ROWS;
-        int vec = 1;
-        if (!a.score_mode && a.ld % 4 == 0 && a.ld_out % 4 == 0) {
-            if (a.out_dim % 4 == 0) vec = 4;
-            else if (a.out_dim % 2 == 0) vec = 2;
+        const size_t shm = (size_t)AGG_ROWS * ((size_t)a.heads * max_deg + max_deg + (V + 1) + (size_t)V * V) * sizeof(float);
+        if (shm > 64 * 1024) {
+            static PerDeviceFlag attr;
+            if (!attr.test()) {
+                hipError_t e = hipSuccess;
+                const void *fns[4] = {reinterpret_cast<const void *>(k_aggregate_heads<8>), reinterpret_cast<const void *>(k_aggregate_heads<4>),
+                                      reinterpret_cast<const void *>(k_aggregate_heads<2>), reinterpret_cast<const void *>(k_aggregate_heads<1>)};
+                for (const void *fn : fns)
+                    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_LIMIT);
+                if (e != hipSuccess) return e;
+                attr.set();
+            }
         }
+        const int grid = (b.n_heads + AGG_ROWS - 1) / AGG_ROWS;
 #define MPE_HEADS(V_)                                                                                   \
     hipLaunchKernelGGL(k_aggregate_heads<V_>, dim3(grid), dim3(256), shm, s, b.n_heads, V, max_deg,         \
                        b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a)

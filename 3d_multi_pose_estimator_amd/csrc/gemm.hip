@@ -858,7 +858,9 @@ static bool dma_set_lds_attributes() {
 
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
-                         float slope, bool acc64, const int32_t *a_rows, const int32_t *c_rows) {
+                         float slope, bool acc64, const int32_t *a_rows, const int32_t *c_rows,
+                         const AttnCoef *coef, bool *coef_done) {
+    if (coef_done) *coef_done = false;
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
     const int ntn = (n + GEMM_BN - 1) / GEMM_BN;
@@ -933,6 +935,15 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
                 best_cost = cost;
                 best = i;
             }
+        }
+        // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile)
+        if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !acc64 && !force_bn) {
+            const int ntn_ = (n + 79) / 80;
+            hipLaunchKernelGGL((k_linear_dma<false, false, 5, true>), dim3(ntm * ntn_), block, dma_lds_bytes(5), s, A, lda, W,
+                               ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows, coef->attn_l,
+                               coef->attn_r, coef->a12);
+            if (coef_done) *coef_done = true;
+            return hipGetLastError();
         }
         const int ntn_ = (n + widths[best] - 1) / widths[best];
 #define MPE_DMA_WIDTH(N_)                                    \

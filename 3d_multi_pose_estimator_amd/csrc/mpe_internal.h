@@ -135,9 +135,15 @@ struct mpe_ctx {
 namespace mpe {
 
 // gemm.hip
+struct AttnCoef {              // fc2 of a graph-attention layer: also emit a1|a2 (gat2.py:57-58) from the epilogue
+    const float *attn_l, *attn_r;   // [heads*out_dim]
+    float *a12;                     // [rows][32]: a1[0..15] | a2[0..15]
+    int heads, out_dim;
+};
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
-                         float slope, bool acc64, const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr);
+                         float slope, bool acc64, const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr,
+                         const AttnCoef *coef = nullptr, bool *coef_done = nullptr);
 hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *head_cam, int32_t *cam_count,
                               int32_t *cam_list, int list_stride);
 
@@ -158,6 +164,7 @@ struct AggArgs {
     int ld;                    // row stride in elements of that type
     int ft_half;
     const float *a12;          // [rows][32]: a1[0..15] | a2[0..15]
+    int a12_ready;             // a12 already holds this layer's coefficients (fc2 epilogue)
     int heads, out_dim;
     float alpha, out_slope;    // attention LeakyReLU slope; activation applied to the output
     int out_mode;              // 0 = LeakyReLU(out_slope), 1 = sigmoid, 2 = identity

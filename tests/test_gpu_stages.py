@@ -343,3 +343,39 @@ def test_mlp_error_budget_every_golden_row():
     with open(os.path.join(out, 'mlp_error_budget.json'), 'w') as fh:
         json.dump(report, fh, indent=1)
     print(json.dumps(report))
+
+
+def test_attention_paths_give_identical_bits(monkeypatch):
+    """The attention stage has two kernels (k_gat_fused for frames whose slice fits in LDS, the
+    general k_aggregate_en / k_aggregate_heads pair otherwise) and two sources of the coefficients
+    a1/a2 (fc2 GEMM epilogue, or k_attn_coef / the fused kernel itself).  All of them use the same
+    summation orders, so every combination must give bit-identical scores and hidden rows."""
+    onp = oracle()
+    syn = pkg('synthetic')
+    e = env('panoptic')
+    sd, prm = e.gat
+    eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=96, max_persons_per_camera=5)
+    try:
+        eng.load_gat(sd, prm)
+        specs = [syn.FrameSpec(persons=4), syn.FrameSpec(persons=5, joint_drop=0.2), syn.FrameSpec(persons=2, empty_cameras=('trackerb',)),
+                 syn.FrameSpec(persons=3, cameras=['trackerd', 'trackera', 'trackere'])]
+        frames = [onp.processed_input(syn.make_frame(e.calib, 6000 + i, specs[i % 4])[0]) for i in range(96)]
+        db = eng.to_device(eng.pack(frames))
+        res = {}
+        for fused in (True, False):
+            for epi in (True, False):
+                if fused:
+                    monkeypatch.delenv('MPE_NO_FUSED_ATTENTION', raising=False)
+                else:
+                    monkeypatch.setenv('MPE_NO_FUSED_ATTENTION', '1')
+                if epi:
+                    monkeypatch.delenv('MPE_NO_COEF_EPILOGUE', raising=False)
+                else:
+                    monkeypatch.setenv('MPE_NO_COEF_EPILOGUE', '1')
+                sc, sh = eng.gat_scores(db, heads=True)
+                res[(fused, epi)] = (sc.cpu().numpy(), sh.cpu().numpy())
+        ref = res[(True, True)]
+        for key, (sc, sh) in res.items():
+            assert np.array_equal(sc, ref[0]) and np.array_equal(sh, ref[1]), key
+    finally:
+        eng.close()
