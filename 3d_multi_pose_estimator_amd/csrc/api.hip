@@ -187,7 +187,13 @@ void drop_gat_workspace(mpe_ctx *ctx) {
     dev_free(ctx, ctx->cam_count);
     dev_free(ctx, ctx->cam_list);
     ctx->cam_count = ctx->cam_list = nullptr;
-    for (int c = 0; c < MPE_MAX_CAMERAS; ++c) free_linear(ctx, &ctx->l0_fc1[c]);
+    for (int c = 0; c < MPE_MAX_CAMERAS; ++c) {
+        dev_free(ctx, ctx->l0_fc1[c].w16);          // w / b are views into l0_w / l0_b
+        ctx->l0_fc1[c] = Linear();
+    }
+    dev_free(ctx, ctx->l0_w);
+    dev_free(ctx, ctx->l0_b);
+    ctx->l0_w = ctx->l0_b = nullptr;
     ctx->en0_ready = false;
     ctx->gat_ws_ready = false;
 }
@@ -256,16 +262,30 @@ int ensure_gat_workspace(mpe_ctx *ctx) {
         if ((rc = dev_alloc(ctx, &ctx->xc, (size_t)ctx->cfg.max_heads * ctx->l0_ld))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->cam_count, (size_t)V))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->cam_list, (size_t)V * ctx->cfg.max_heads))) return rc;
+        // the V per-camera matrices live in ONE allocation at a constant stride so that a single
+        // grouped launch can address them (launch_linear_grouped); l0_fc1[c] are views into it
+        const int rows = weight_rows(g0.in_dim);
+        const size_t per = (size_t)rows * ctx->l0_ld;
+        if ((rc = dev_alloc(ctx, &ctx->l0_w, per * V))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->l0_b, (size_t)rows))) return rc;
         std::vector<float> wc((size_t)g0.in_dim * blk), bc(g0.in_dim);
         for (int n = 0; n < g0.in_dim; ++n) bc[n] = b1[n] + w1[(size_t)n * g0.fc1.ldw + 0];
+        HIPCHK(ctx, hipMemcpy(ctx->l0_b, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice));
         for (int c = 0; c < V; ++c) {
             for (int n = 0; n < g0.in_dim; ++n)
                 memcpy(&wc[(size_t)n * blk], &w1[(size_t)n * g0.fc1.ldw + 2 + c * blk], blk * sizeof(float));
-            if ((rc = upload_linear(ctx, wc.data(), bc.data(), g0.in_dim, blk, &ctx->l0_fc1[c]))) return rc;
+            Linear &L = ctx->l0_fc1[c];
+            L = Linear();
+            L.w = ctx->l0_w + per * c;
+            L.b = ctx->l0_b;
+            L.in_dim = blk;
+            L.out_dim = g0.in_dim;
+            L.ldw = ctx->l0_ld;
+            HIPCHK(ctx, hipMemcpy2D(L.w, (size_t)L.ldw * sizeof(float), wc.data(), (size_t)blk * sizeof(float),
+                                    (size_t)blk * sizeof(float), g0.in_dim, hipMemcpyHostToDevice));
         }
-        // pays when the camera block is a small part of the row (K shrinks V-fold); at V = 5 the
-        // five short launches cost as much as the one dense GEMM they replace (measured)
-        ctx->l0_grouped = V >= 8;
+        // K shrinks from F to J*10 (exact: the skipped products are zeros), one launch for all cameras
+        ctx->l0_grouped = true;
         if (const char *e = getenv("MPE_L0_GROUPED")) ctx->l0_grouped = atoi(e) != 0;
     }
     ctx->gat_ws_ready = true;              // last step: a failure above leaves the flag false and is retried
@@ -357,9 +377,16 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
         *n_rows_ft2 = n_nodes;
     } else if (in == GAT_IN_IMPLICIT) {
         // heads only: edge-node rows are the layer-0 constants
-        if (ctx->l0_grouped) {
-            // one launch per camera over that camera's heads (device-side count), rows gathered
-            // from the compact features and scattered back to head order
+        if (ctx->l0_grouped && !red && linear_uses_tile_kernel(b->n_heads, g.in_dim)) {
+            // ONE grouped launch: camera c's heads (device-side count, rows gathered from the compact
+            // features and scattered back to head order) x camera c's J*10-column block of fc1
+            GemmProf gp(ctx, s, 2.0 * b->n_heads * (double)g.in_dim * (J * 10), 0, 0);
+            HIPCHK(ctx, launch_linear_grouped(s, ctx->xc, ctx->l0_ld, ctx->l0_w, ctx->l0_ld,
+                                              (long)weight_rows(g.in_dim) * ctx->l0_ld, ctx->l0_b, ctx->h0, ctx->feat_ld,
+                                              b->n_heads, ctx->cam_count, V, ctx->cam_list, ctx->cfg.max_heads, g.in_dim,
+                                              ctx->l0_ld, true, ctx->gat_alpha));
+        } else if (ctx->l0_grouped) {
+            // small batches / reduced precision: one launch per camera over that camera's heads
             const double flop_each = 2.0 * b->n_heads * (double)g.in_dim * (J * 10) / V;
             for (int c = 0; c < V; ++c)
                 if ((rc = gat_linear(ctx, s, ctx->xc, ctx->l0_ld, ctx->l0_fc1[c], ctx->h0, ctx->feat_ld, b->n_heads,

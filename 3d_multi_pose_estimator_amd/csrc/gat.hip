@@ -307,9 +307,13 @@ __device__ __forceinline__ float agg_activate(float x, int mode, float slope) {
     return x;
 }
 
-__device__ __forceinline__ float wave_sum(float x) {
-    x = x + __shfl_xor(x, 32);
-    x = x + __shfl_xor(x, 16);
+// Butterfly over a lane group of G = 64, 32 or 16 lanes.  The canonical shape is the 64-lane one;
+// a smaller group is used only when every in-degree of the launch fits in it (deg <= G), and then
+// gives the same bits: the lanes it leaves out would hold 0 (sum) / -inf (max).
+template <int G>
+__device__ __forceinline__ float group_sum(float x) {
+    if (G > 32) x = x + __shfl_xor(x, 32);
+    if (G > 16) x = x + __shfl_xor(x, 16);
     x = x + __shfl_xor(x, 8);
     x = x + __shfl_xor(x, 4);
     x = x + __shfl_xor(x, 2);
@@ -317,15 +321,19 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
-__device__ __forceinline__ float wave_max(float x) {
-    x = fmaxf(x, __shfl_xor(x, 32));
-    x = fmaxf(x, __shfl_xor(x, 16));
+template <int G>
+__device__ __forceinline__ float group_max(float x) {
+    if (G > 32) x = fmaxf(x, __shfl_xor(x, 32));
+    if (G > 16) x = fmaxf(x, __shfl_xor(x, 16));
     x = fmaxf(x, __shfl_xor(x, 8));
     x = fmaxf(x, __shfl_xor(x, 4));
     x = fmaxf(x, __shfl_xor(x, 2));
     x = fmaxf(x, __shfl_xor(x, 1));
     return x;
 }
+
+__device__ __forceinline__ float wave_sum(float x) { return group_sum<64>(x); }
+__device__ __forceinline__ float wave_max(float x) { return group_max<64>(x); }
 
 // Per-frame topology scalars in LDS: slot prefix sums and the first edge-node id of every
 // camera-slot pair (p < q), lexicographic = creation order (graph_generator.py:854-864).
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
 // fc2 epilogue (or computes them in the canonical order when the GEMM did not), and writes the
 // activated output slice -- ft2 is read once and nothing else touches HBM.
 // ---------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, int G>
 __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap, int m_cap,
                                                    const int32_t *__restrict__ head_off,
                                                    const int32_t *__restrict__ en_off,
@@ -599,8 +607,9 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     float *s_wh = s_a2 + n_cap;                     // [hmax][max_deg] softmax weights of heads
     int *s_src = reinterpret_cast<int *>(s_wh + (size_t)(max_deg - 1) * max_deg);   // [hmax][max_deg]
     int *s_pair = s_src + (size_t)(max_deg - 1) * max_deg;                          // [m_cap] h1 << 16 | h2
+    float *s_wen = reinterpret_cast<float *>(s_pair + m_cap);                       // [m_cap][3] softmax weights of edge-nodes
     FrameTopo tp;
-    tp.start = s_pair + m_cap;                      // [V + 1]
+    tp.start = reinterpret_cast<int *>(s_wen + (size_t)m_cap * 3);                  // [V + 1]
     tp.base = tp.start + V + 1;                     // [V * V]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool l0 = a.en_const_ft2 != nullptr;
@@ -649,16 +658,33 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
         }
         __syncthreads();
     }
-    // phase 2: softmax weights of the head destinations, one wave per head (fixed-shape reductions)
+    // phase 2: softmax weights.  Edge-node X: in-edges (h1, h2, X), one thread each.  Head h: one
+    // lane group per head, fixed-shape reductions.
+    for (int m = t; m < M; m += blockDim.x) {
+        const int pr = s_pair[m];
+        const int h1 = pr >> 16, h2 = pr & 0xFFFF, x = H + m;
+        const float a2v = s_a2[x];
+        float e1 = s_a1[h1] + a2v, e2 = s_a1[h2] + a2v, e3 = s_a1[x] + a2v;
+        e1 = e1 > 0.f ? e1 : e1 * a.alpha;
+        e2 = e2 > 0.f ? e2 : e2 * a.alpha;
+        e3 = e3 > 0.f ? e3 : e3 * a.alpha;
+        const float mx = fmaxf(fmaxf(e1, e2), e3);
+        const float x1 = expf(e1 - mx), x2 = expf(e2 - mx), x3 = expf(e3 - mx);
+        const float sum = (x1 + x2) + x3;
+        s_wen[m * 3 + 0] = x1 / sum;
+        s_wen[m * 3 + 1] = x2 / sum;
+        s_wen[m * 3 + 2] = x3 / sum;
+    }
     if (!a.score_mode || a.out_heads) {
-        for (int h = wave; h < H; h += 4) {
+        const int gl = t & (G - 1);
+        for (int h = t / G; h < H; h += 256 / G) {
             const int s = slot_of_head(tp, V, h);
             const int deg = 1 + H - sn[s];
             float *w = s_wh + h * max_deg;
             int *src = s_src + h * max_deg;
             const float a2v = s_a2[h];
             float mx = -INFINITY;
-            for (int e = lane; e < deg; e += 64) {
+            for (int e = gl; e < deg; e += G) {
                 const int u = head_in_edge(tp, sn, V, h, s, e);
                 src[e] = u;
                 float x = s_a1[u] + a2v;
@@ -666,36 +692,28 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
                 w[e] = x;
                 mx = fmaxf(mx, x);
             }
-            mx = wave_max(mx);
+            mx = group_max<G>(mx);
             float sum = 0.f;
-            for (int e = lane; e < deg; e += 64) {
+            for (int e = gl; e < deg; e += G) {
                 const float ex = expf(w[e] - mx);
                 w[e] = ex;
                 sum = sum + ex;
             }
-            sum = wave_sum(sum);
-            for (int e = lane; e < deg; e += 64) w[e] = w[e] / sum;
+            sum = group_sum<G>(sum);
+            for (int e = gl; e < deg; e += G) w[e] = w[e] / sum;
         }
-        __syncthreads();
     }
-    // phase 3: weighted sums in edge order, activation, store.  Edge-node X: in-edges (h1, h2, X),
-    // its 3-way softmax recomputed per lane.
+    __syncthreads();
+    // phase 3: weighted sums in edge order, activation, store
     const int first = (a.score_mode && !a.out_heads) ? H : 0;
     for (int i = first * DV + t; i < N * DV; i += blockDim.x) {
         const int node = i / DV, d = (i - node * DV) * VEC;
         vecf o;
         if (node >= H) {
-            const int pr = s_pair[node - H];
+            const int m = node - H;
+            const int pr = s_pair[m];
             const int h1 = pr >> 16, h2 = pr & 0xFFFF;
-            const float a2v = s_a2[node];
-            float e1 = s_a1[h1] + a2v, e2 = s_a1[h2] + a2v, e3 = s_a1[node] + a2v;
-            e1 = e1 > 0.f ? e1 : e1 * a.alpha;
-            e2 = e2 > 0.f ? e2 : e2 * a.alpha;
-            e3 = e3 > 0.f ? e3 : e3 * a.alpha;
-            const float mx = fmaxf(fmaxf(e1, e2), e3);
-            const float x1 = expf(e1 - mx), x2 = expf(e2 - mx), x3 = expf(e3 - mx);
-            const float sum = (x1 + x2) + x3;
-            const float w1 = x1 / sum, w2 = x2 / sum, w3 = x3 / sum;
+            const float w1 = s_wen[m * 3 + 0], w2 = s_wen[m * 3 + 1], w3 = s_wen[m * 3 + 2];
             const vecf f1 = *reinterpret_cast<const vecf *>(s_ft + h1 * Dp + d);
             const vecf f2 = *reinterpret_cast<const vecf *>(s_ft + h2 * Dp + d);
             const vecf f3 = *reinterpret_cast<const vecf *>(s_ft + node * Dp + d);
@@ -741,7 +759,7 @@ static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_c
     const int nc = hmax + mc;
     const int Dp = (out_dim + 3) & ~3;
     const size_t deg = (size_t)hmax + 1;
-    const size_t bytes = ((size_t)nc * Dp + 2 * (size_t)nc + (size_t)hmax * deg) * sizeof(float) +
+    const size_t bytes = ((size_t)nc * Dp + 2 * (size_t)nc + (size_t)hmax * deg + (size_t)mc * 3) * sizeof(float) +
                          ((size_t)hmax * deg + mc + (V + 1) + (size_t)V * V) * sizeof(int);
     *n_cap = nc;
     *m_cap = mc;
@@ -771,25 +789,30 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
     const bool no_fuse = getenv("MPE_NO_FUSED_ATTENTION") != nullptr;       // read per call: tests toggle it
     if (shm <= FUSED_LDS_LIMIT && !no_fuse && b.n_frames > 0) {
         const int vec = agg_vec(a);
-        if (shm > 64 * 1024) {                       // opt in to more than 64 KB of dynamic LDS (per device)
-            static PerDeviceFlag attr;
-            if (!attr.test()) {
-                hipError_t e = hipSuccess;
-                const void *fns[3] = {reinterpret_cast<const void *>(k_gat_fused<4>), reinterpret_cast<const void *>(k_gat_fused<2>),
-                                      reinterpret_cast<const void *>(k_gat_fused<1>)};
-                for (const void *fn : fns)
-                    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_LIMIT);
-                if (e != hipSuccess) return e;
-                attr.set();
-            }
-        }
-#define MPE_FUSED(V_)                                                                                       \
-    hipLaunchKernelGGL(k_gat_fused<V_>, dim3(b.n_frames * a.heads), dim3(256), shm, s, V, max_heads_per_frame + 1, \
-                       n_cap, m_cap, b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, en_pair, attn_l,   \
-                       attn_r, a)
-        if (vec == 4) MPE_FUSED(4);
-        else if (vec == 2) MPE_FUSED(2);
-        else MPE_FUSED(1);
+        // lane-group width of the head softmax: the in-degree of a head is at most max_heads_per_frame
+        const int grp = max_heads_per_frame + 1 <= 16 ? 16 : max_heads_per_frame + 1 <= 32 ? 32 : 64;
+        const void *fn = nullptr;
+#define MPE_FUSED(V_, G_)                                                                                     \
+    do {                                                                                                      \
+        fn = reinterpret_cast<const void *>(k_gat_fused<V_, G_>);                                             \
+        if (shm > 64 * 1024) {                                                                                \
+            hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_LIMIT); \
+            if (e_ != hipSuccess) return e_;                                                                  \
+        }                                                                                                     \
+        hipLaunchKernelGGL((k_gat_fused<V_, G_>), dim3(b.n_frames * a.heads), dim3(256), shm, s, V,            \
+                           max_heads_per_frame + 1, n_cap, m_cap, b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, \
+                           node_off, en_pair, attn_l, attn_r, a);                                             \
+    } while (0)
+#define MPE_FUSED_G(V_)                     \
+    do {                                    \
+        if (grp == 16) MPE_FUSED(V_, 16);   \
+        else if (grp == 32) MPE_FUSED(V_, 32); \
+        else MPE_FUSED(V_, 64);             \
+    } while (0)
+        if (vec == 4) MPE_FUSED_G(4);
+        else if (vec == 2) MPE_FUSED_G(2);
+        else MPE_FUSED_G(1);
+#undef MPE_FUSED_G
 #undef MPE_FUSED
         return hipGetLastError();
     }

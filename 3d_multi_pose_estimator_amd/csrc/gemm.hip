@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_
                                                        const int32_t *__restrict__ c_rows,
                                                        const float *__restrict__ attn_l = nullptr,
                                                        const float *__restrict__ attn_r = nullptr,
-                                                       float *__restrict__ a12 = nullptr) {
+                                                       float *__restrict__ a12 = nullptr,
+                                                       const int32_t *__restrict__ grp_count = nullptr, int n_grp = 0,
+                                                       int grp_stride = 0, long w_grp_stride = 0) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];   // 2 stages of (128 + 16 NTT) rows x 128 B
     constexpr int ROWF = 32;                   // floats per tile row (dense)
     constexpr int W_OFF = GEMM_BM * ROWF;      // weight rows follow the activation rows
@@ -270,7 +272,13 @@ __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_
         int dm = *d_m;
         M = dm < m_cap ? dm : m_cap;
     }
-    const int ntm = (M + GEMM_BM - 1) / GEMM_BM;
+    int ntm = (M + GEMM_BM - 1) / GEMM_BM;
+    if (grp_count) {
+        // grouped GEMM: group g multiplies its own rows (row list g) with its own weight matrix;
+        // every 128-row tile belongs to one group, the device-side counts give the tile ranges
+        ntm = 0;
+        for (int g = 0; g < n_grp; ++g) ntm += (grp_count[g] + GEMM_BM - 1) / GEMM_BM;
+    }
     const int bid = blockIdx.x, nwg = ntm * ntn;
     if (bid >= nwg) return;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -290,6 +298,20 @@ __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_
         tn = swz - tm * ntn;
     }
     constexpr int BN = NTT * 16;
+    if (grp_count) {
+        int g = 0, t0 = 0;
+        for (;;) {
+            const int nt_g = (grp_count[g] + GEMM_BM - 1) / GEMM_BM;
+            if (tm < t0 + nt_g || g == n_grp - 1) break;
+            t0 += nt_g;
+            ++g;
+        }
+        tm -= t0;
+        M = grp_count[g];
+        a_rows += (size_t)g * grp_stride;
+        c_rows += (size_t)g * grp_stride;
+        W += (size_t)g * w_grp_stride;
+    }
     const int m0 = tm * GEMM_BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -856,6 +878,30 @@ static bool dma_set_lds_attributes() {
     return true;
 }
 
+bool linear_uses_tile_kernel(int m_cap, int n) {
+    static const int skinny_waves = getenv("MPE_SKINNY_WAVES") ? atoi(getenv("MPE_SKINNY_WAVES")) : 1024;
+    return (long)((m_cap + 15) / 16) * ((n + 15) / 16) > skinny_waves;
+}
+
+hipError_t launch_linear_grouped(hipStream_t s, const float *A, int lda, const float *W, int ldw, long w_grp_stride,
+                                 const float *bias, float *C, int ldc, int m_cap, const int32_t *grp_count, int n_grp,
+                                 const int32_t *row_lists, int grp_stride, int n, int k_pad, bool leaky, float slope) {
+    if (m_cap <= 0 || n <= 0 || n_grp <= 0) return hipSuccess;
+    const int ntm_cap = (m_cap + GEMM_BM - 1) / GEMM_BM + n_grp;       // sum of per-group ceilings
+    const int ntn_ = (n + 79) / 80;
+    const int n_major = 0;
+    dim3 grid(ntm_cap * ntn_), block(256);
+    if (leaky)
+        hipLaunchKernelGGL((k_linear_dma<true, false, 5>), grid, block, (size_t)2 * (GEMM_BM + 80) * 32 * sizeof(float), s, A, lda,
+                           W, ldw, bias, C, ldc, m_cap, nullptr, n, k_pad, slope, ntn_, n_major, row_lists, row_lists, nullptr,
+                           nullptr, nullptr, grp_count, n_grp, grp_stride, w_grp_stride);
+    else
+        hipLaunchKernelGGL((k_linear_dma<false, false, 5>), grid, block, (size_t)2 * (GEMM_BM + 80) * 32 * sizeof(float), s, A,
+                           lda, W, ldw, bias, C, ldc, m_cap, nullptr, n, k_pad, slope, ntn_, n_major, row_lists, row_lists,
+                           nullptr, nullptr, nullptr, grp_count, n_grp, grp_stride, w_grp_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64, const int32_t *a_rows, const int32_t *c_rows,
@@ -937,11 +983,16 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
             }
         }
         // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile)
-        if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !acc64 && !force_bn) {
+        if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !force_bn) {
             const int ntn_ = (n + 79) / 80;
-            hipLaunchKernelGGL((k_linear_dma<false, false, 5, true>), dim3(ntm * ntn_), block, dma_lds_bytes(5), s, A, lda, W,
-                               ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows, coef->attn_l,
-                               coef->attn_r, coef->a12);
+            if (acc64)
+                hipLaunchKernelGGL((k_linear_dma<false, true, 5, true>), dim3(ntm * ntn_), block, dma_lds_bytes(5), s, A, lda, W,
+                                   ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows, coef->attn_l,
+                                   coef->attn_r, coef->a12);
+            else
+                hipLaunchKernelGGL((k_linear_dma<false, false, 5, true>), dim3(ntm * ntn_), block, dma_lds_bytes(5), s, A, lda, W,
+                                   ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows, coef->attn_l,
+                                   coef->attn_r, coef->a12);
             if (coef_done) *coef_done = true;
             return hipGetLastError();
         }

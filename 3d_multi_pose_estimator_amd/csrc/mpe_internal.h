@@ -103,7 +103,9 @@ struct mpe_ctx {
     // layer 0 grouped by camera: only the own-camera block of a head row is non-zero
     float *xc = nullptr;           // [max_heads][l0_ld] compact J*10 features
     int l0_ld = 0;
-    mpe::Linear l0_fc1[MPE_MAX_CAMERAS];   // fc1 restricted to the camera's column block, bias + W[:,0]
+    mpe::Linear l0_fc1[MPE_MAX_CAMERAS];   // fc1 restricted to the camera's column block, bias + W[:,0] (views into l0_w)
+    float *l0_w = nullptr;         // [V][weight_rows(in_dim)][l0_ld] the per-camera matrices, contiguous (grouped launch)
+    float *l0_b = nullptr;         // [weight_rows(in_dim)] their common bias
     int32_t *cam_count = nullptr;  // [V]
     int32_t *cam_list = nullptr;   // [V][max_heads] head indices of each camera
     bool l0_grouped = true;
@@ -144,6 +146,12 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64, const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr,
                          const AttnCoef *coef = nullptr, bool *coef_done = nullptr);
+// one launch for `n_grp` GEMMs that share the activation / result buffers: group g takes the rows
+// row_lists[g * grp_stride + 0 .. grp_count[g]) (device-side counts) and the weights W + g * w_grp_stride
+hipError_t launch_linear_grouped(hipStream_t s, const float *A, int lda, const float *W, int ldw, long w_grp_stride,
+                                 const float *bias, float *C, int ldc, int m_cap, const int32_t *grp_count, int n_grp,
+                                 const int32_t *row_lists, int grp_stride, int n, int k_pad, bool leaky, float slope);
+bool linear_uses_tile_kernel(int m_cap, int n);
 hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *head_cam, int32_t *cam_count,
                               int32_t *cam_list, int list_stride);
 

@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument('--mode', choices=['mlp', 'tri'], default='mlp')
     ap.add_argument('--cpu-sample', type=int, default=40, help='frames of the CPU baseline / parity sample (0 = skip)')
     ap.add_argument('--fast-mlp', action='store_true', help='plain fp32 accumulation in the MLP GEMMs')
+    ap.add_argument('--gat-acc', choices=['default', 'f32', 'f64'], default='default',
+                    help='accumulation of the GAT GEMMs: one fp32 MFMA chain, or f64 running sums per 32-deep K stage')
     ap.add_argument('--bf16-mlp', action='store_true',
                     help='reduced precision (NOT the parity path): bf16 MFMA for the MLP GEMMs, configs[4] style')
     ap.add_argument('--reduced', action='store_true',
@@ -200,8 +202,10 @@ def run_rank(args):
     eng = pipeline.Engine(params, calib, max_frames=max(cap, 1), max_persons_per_camera=args.persons, device=str(device))
     eng.load_gat(gat_sd, prm)
     eng.load_mlp(mlp_sd)
+    if args.gat_acc != 'default':
+        eng.set_precision(args.gat_acc == 'f64', True)
     if args.fast_mlp:
-        eng.set_precision(False, False)
+        eng.set_precision(args.gat_acc == 'f64', False)
     if args.bf16_mlp:
         eng.set_precision(False, False, mlp_bf16=True)
     if args.reduced:
