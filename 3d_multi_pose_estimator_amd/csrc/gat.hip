@@ -147,21 +147,33 @@ hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batc
     return hipGetLastError();
 }
 
-// heads of every camera (order inside a camera is irrelevant: rows are independent)
-__global__ void k_group_heads(int n_heads, const int32_t *__restrict__ head_cam, int32_t *__restrict__ cam_count,
-                              int32_t *__restrict__ cam_list, int list_stride) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= n_heads) return;
-    const int c = head_cam[h];
-    const int pos = atomicAdd(&cam_count[c], 1);
-    cam_list[(size_t)c * list_stride + pos] = h;
+// heads of every camera (order inside a camera is irrelevant: rows are independent).  A
+// workgroup counts its 1024 heads per camera in LDS and reserves one range per camera with a
+// single global atomic (20 000 heads on 5 cameras would otherwise serialise on 5 addresses).
+__global__ __launch_bounds__(1024) void k_group_heads(int n_heads, const int32_t *__restrict__ head_cam,
+                                                      int32_t *__restrict__ cam_count, int32_t *__restrict__ cam_list,
+                                                      int list_stride) {
+    __shared__ int s_cnt[MPE_MAX_CAMERAS], s_base[MPE_MAX_CAMERAS];
+    const int t = threadIdx.x;
+    if (t < MPE_MAX_CAMERAS) s_cnt[t] = 0;
+    __syncthreads();
+    const int h = blockIdx.x * blockDim.x + t;
+    int c = -1, pos = 0;
+    if (h < n_heads) {
+        c = head_cam[h];
+        pos = atomicAdd(&s_cnt[c], 1);
+    }
+    __syncthreads();
+    if (t < MPE_MAX_CAMERAS && s_cnt[t] > 0) s_base[t] = atomicAdd(&cam_count[t], s_cnt[t]);
+    __syncthreads();
+    if (c >= 0) cam_list[(size_t)c * list_stride + s_base[c] + pos] = h;
 }
 
 hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *head_cam, int32_t *cam_count,
                               int32_t *cam_list, int list_stride) {
     hipError_t e = hipMemsetAsync(cam_count, 0, (size_t)V * sizeof(int32_t), s);
     if (e != hipSuccess || n_heads <= 0) return e;
-    hipLaunchKernelGGL(k_group_heads, dim3((n_heads + 255) / 256), dim3(256), 0, s, n_heads, head_cam, cam_count,
+    hipLaunchKernelGGL(k_group_heads, dim3((n_heads + 1023) / 1024), dim3(1024), 0, s, n_heads, head_cam, cam_count,
                        cam_list, list_stride);
     return hipGetLastError();
 }
@@ -571,6 +583,13 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
 // fc2 epilogue (or computes them in the canonical order when the GEMM did not), and writes the
 // activated output slice -- ft2 is read once and nothing else touches HBM.
 // ---------------------------------------------------------------------------------------
+// floats of the small LDS tables of k_gat_fused, rounded up to 1 KiB (the feature image follows)
+__host__ __device__ inline size_t fused_tables_floats(int hmax, int V, int n_cap, int m_cap) {
+    const size_t deg = (size_t)hmax + 1;
+    const size_t n = 2 * (size_t)n_cap + 2 * hmax * deg + (size_t)m_cap * 4 + (V + 1) + (size_t)V * V;
+    return (n + 255) & ~(size_t)255;
+}
+
 template <int VEC, int G>
 __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap, int m_cap,
                                                    const int32_t *__restrict__ head_off,
@@ -582,7 +601,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
                                                    const float *__restrict__ attn_r, AggArgs a) {
 #pragma clang fp contract(off)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    extern __shared__ __attribute__((aligned(1024))) float s_dyn[];
     // XCD-aware order: workgroups with equal (id % 8) share an L2; the attention heads of one
     // frame read neighbouring 160-byte pieces of the same rows, so they go to the same XCD
     const int bid = blockIdx.x, nwg = gridDim.x;
@@ -601,8 +620,9 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
         return;
     }
     const int Dp = (D + 3) & ~3;                    // row stride: whole 16-byte chunks
-    float *s_ft = s_dyn;                            // [n_cap][Dp]
-    float *s_a1 = s_ft + (size_t)n_cap * Dp;        // [n_cap]
+    // LDS: the small tables first, the feature image last (1 KiB aligned, 1 KiB of slack behind it:
+    // the last DMA piece of the image may run past its end)
+    float *s_a1 = s_dyn;                            // [n_cap]
     float *s_a2 = s_a1 + n_cap;                     // [n_cap]
     float *s_wh = s_a2 + n_cap;                     // [hmax][max_deg] softmax weights of heads
     int *s_src = reinterpret_cast<int *>(s_wh + (size_t)(max_deg - 1) * max_deg);   // [hmax][max_deg]
@@ -611,6 +631,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     FrameTopo tp;
     tp.start = reinterpret_cast<int *>(s_wen + (size_t)m_cap * 3);                  // [V + 1]
     tp.base = tp.start + V + 1;                     // [V * V]
+    float *s_ft = s_dyn + fused_tables_floats(max_deg - 1, V, n_cap, m_cap);         // [n_cap][Dp]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool l0 = a.en_const_ft2 != nullptr;
     const int c0 = hh * D;
@@ -618,16 +639,46 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     const int32_t *sn = slot_n + (size_t)f * V;
 
     // phase 1: feature slice -> LDS (layer 0: ft2 holds head rows only, edge-nodes share one row),
-    // coefficients of this attention head, pair table, topology scalars
-    for (int i = t; i < N * DV; i += blockDim.x) {
-        const int node = i / DV, d = (i - node * DV) * VEC;
-        float v[VEC];
-        if (l0 && node >= H) ld_ftv<VEC>(a.en_const_ft2, (size_t)(c0 + d), 0, v);
-        else ld_ftv<VEC>(a.ft2, (size_t)((l0 ? hb : nb) + node) * a.ld + c0 + d, a.ft_half, v);
-        vecf o;
+    // coefficients of this attention head, pair table, topology scalars.  fp32 rows of whole 16-byte
+    // chunks go straight into LDS (global_load_lds_dwordx4: a wave-instruction fills 1 KiB = 64
+    // consecutive chunks of the dense image, every lane with its own source address), so all of a
+    // thread's requests are in flight at once; other shapes are staged through registers, four
+    // requests at a time.
+    if (VEC == 4 && !a.ft_half) {
+        const int total = N * DV;
+        for (int c0_ = wave * 64; c0_ < total; c0_ += 256) {
+            int c = c0_ + lane;
+            c = c < total ? c : total - 1;                   // tail lanes repeat the last chunk (same bytes, same slot)
+            const int node = c / DV, d = (c - node * DV) * 4;
+            const float *src = (l0 && node >= H) ? a.en_const_ft2 + (c0 + d)
+                                                  : a.ft2 + (size_t)((l0 ? hb : nb) + node) * a.ld + c0 + d;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(s_ft + (size_t)c0_ * 4), 16, 0, 0);
+        }
+    } else {
+        const int total = N * DV;
+        for (int i0 = t; i0 < total; i0 += 4 * blockDim.x) {
+            float v[4][VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) o[k] = v[k];
-        *reinterpret_cast<vecf *>(s_ft + node * Dp + d) = o;
+            for (int u = 0; u < 4; ++u) {
+                int i = i0 + u * blockDim.x;
+                i = i < total ? i : total - 1;
+                const int node = i / DV, d = (i - node * DV) * VEC;
+                if (l0 && node >= H) ld_ftv<VEC>(a.en_const_ft2, (size_t)(c0 + d), 0, v[u]);
+                else ld_ftv<VEC>(a.ft2, (size_t)((l0 ? hb : nb) + node) * a.ld + c0 + d, a.ft_half, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * blockDim.x;
+                if (i < total) {
+                    const int node = i / DV, d = (i - node * DV) * VEC;
+                    vecf o;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) o[k] = v[u][k];
+                    *reinterpret_cast<vecf *>(s_ft + node * Dp + d) = o;
+                }
+            }
+        }
     }
     if (a.a12_ready) {
         for (int node = t; node < N; node += blockDim.x) {
@@ -758,12 +809,10 @@ static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_c
     const int mc = hmax * hmax * (V - 1) / (2 * V) + 1;
     const int nc = hmax + mc;
     const int Dp = (out_dim + 3) & ~3;
-    const size_t deg = (size_t)hmax + 1;
-    const size_t bytes = ((size_t)nc * Dp + 2 * (size_t)nc + (size_t)hmax * deg + (size_t)mc * 3) * sizeof(float) +
-                         ((size_t)hmax * deg + mc + (V + 1) + (size_t)V * V) * sizeof(int);
+    const size_t bytes = (fused_tables_floats(hmax, V, nc, mc) + (size_t)nc * Dp + 256) * sizeof(float);
     *n_cap = nc;
     *m_cap = mc;
-    return (bytes + 15) & ~(size_t)15;
+    return bytes;
 }
 
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
