@@ -395,6 +395,53 @@ __device__ __forceinline__ int slot_of_head(const FrameTopo &tp, int V, int v) {
     return s;
 }
 
+// Weighted sum over the in-edges of a head destination, canonical order: eight accumulators, the
+// j-th over the in-edges e = j, j+8, ... in ascending order, combined as
+// ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)).  Eight independent chains keep eight row loads in flight
+// (a head of the 23 x 10 rig has 221 in-edges); for the three in-edges of an edge-node the same
+// rule reads (v1*w1 + v2*w2) + v3*w3.  `row(e, out)` fetches VEC columns of the e-th source row,
+// `wt(e)` its softmax weight.
+template <int VEC, typename RowFn, typename WFn>
+__device__ __forceinline__ void weighted_sum8(int deg, RowFn row, WFn wt, float *out) {
+#pragma clang fp contract(off)
+    float acc[8][VEC];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[j][k] = 0.f;
+    int e = 0;
+    for (; e + 8 <= deg; e += 8) {
+        float fv[8][VEC], w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            row(e + j, fv[j]);
+            w[j] = wt(e + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float m = fv[j][k] * w[j];
+                acc[j][k] = acc[j][k] + m;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (e + j < deg) {
+            float fv[VEC];
+            row(e + j, fv);
+            const float w = wt(e + j);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float m = fv[k] * w;
+                acc[j][k] = acc[j][k] + m;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        out[k] = ((acc[0][k] + acc[1][k]) + (acc[2][k] + acc[3][k])) + ((acc[4][k] + acc[5][k]) + (acc[6][k] + acc[7][k]));
+}
+
 constexpr int EN_ROWS = 16;     // edge-node rows per workgroup
 
 template <int VEC>
@@ -459,11 +506,11 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
     }
 }
 
-// Head destinations, general path: AGG_ROWS head rows per workgroup, one WAVE per row for the
-// topology scalars, the in-edge sources and the softmax weights (all attention heads of the row,
-// wave reductions), then all threads accumulate the weighted source rows column by column in
-// edge order.
-constexpr int AGG_ROWS = 4;
+// Head destinations, general path: AGG_ROWS head rows per workgroup, two waves per row for the
+// topology scalars, the in-edge sources and the softmax weights (wave reductions; the two waves
+// split the attention heads), then all threads accumulate the weighted source rows column by
+// column (weighted_sum8).
+constexpr int AGG_ROWS = 2;
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_aggregate_heads(
@@ -480,98 +527,101 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool l0 = a.en_const_ft2 != nullptr;
-    {
-        // one wave per row
-        const int gh = blockIdx.x * AGG_ROWS + wave;
-        int deg = 0;
-        if (gh < n_heads) {
-            const int f = head_frame[gh];
-            const int hb = head_off[f], H = head_off[f + 1] - hb;
-            if (H <= max_deg - 1) {                 // frames beyond max_heads_per_frame are skipped (flagged by k_topology)
-                const int v = gh - hb;
-                const int32_t nb = node_off[f];
-                const int32_t *sn = slot_n + (size_t)f * V;
-                FrameTopo tp;
-                tp.start = s_topo + wave * (V + 1 + V * V);
-                tp.base = tp.start + V + 1;
-                build_topo(tp, sn, V, H, lane, 64);
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int s = slot_of_head(tp, V, v);
-                deg = 1 + H - sn[s];
-                int *src = s_src + wave * max_deg;
-                for (int e = lane; e < deg; e += 64) src[e] = head_in_edge(tp, sn, V, v, s, e);
-                if (lane == 0) {
-                    s_f[wave] = f;
-                    s_v[wave] = v;
-                    s_H[wave] = H;
-                }
-                const float *a_dst = l0 ? a.a12 + (size_t)(hb + v) * 32 : a.a12 + (size_t)(nb + v) * 32;
-                for (int hh = 0; hh < heads; ++hh) {
-                    const float a2v = a_dst[16 + hh];
-                    float *w = s_w + ((size_t)wave * heads + hh) * max_deg;
-                    float mx = -INFINITY;
-                    for (int e = lane; e < deg; e += 64) {
-                        const int u = src[e];       // written by this lane above
-                        const float *a_src;
-                        if (l0) a_src = u >= H ? a.en_const_a : a.a12 + (size_t)(hb + u) * 32;
-                        else a_src = a.a12 + (size_t)(nb + u) * 32;
-                        float x = a_src[hh] + a2v;
-                        x = x > 0.f ? x : x * a.alpha;
-                        w[e] = x;
-                        mx = fmaxf(mx, x);
-                    }
-                    mx = wave_max(mx);
-                    float sum = 0.f;
-                    for (int e = lane; e < deg; e += 64) {
-                        const float ex = expf(w[e] - mx);
-                        w[e] = ex;
-                        sum = sum + ex;
-                    }
-                    sum = wave_sum(sum);
-                    for (int e = lane; e < deg; e += 64) w[e] = w[e] / sum;
-                }
+    const int r_own = wave & (AGG_ROWS - 1), half = wave / AGG_ROWS;      // row of this wave, which half of the heads
+    const int gh = blockIdx.x * AGG_ROWS + r_own;
+    int deg = 0, f = 0, hb = 0, H = 0, v = 0;
+    int32_t nb = 0;
+    const int32_t *sn = slot_n;
+    FrameTopo tp;
+    tp.start = s_topo + r_own * (V + 1 + V * V);
+    tp.base = tp.start + V + 1;
+    bool live = false;
+    if (gh < n_heads) {
+        f = head_frame[gh];
+        hb = head_off[f];
+        H = head_off[f + 1] - hb;
+        live = H <= max_deg - 1;                // frames beyond max_heads_per_frame are skipped (flagged by k_topology)
+        v = gh - hb;
+        nb = node_off[f];
+        sn = slot_n + (size_t)f * V;
+        if (live && half == 0) build_topo(tp, sn, V, H, lane, 64);
+    }
+    __syncthreads();
+    int s = 0;
+    if (live) {
+        s = slot_of_head(tp, V, v);
+        deg = 1 + H - sn[s];
+        if (half == 0) {
+            int *src = s_src + r_own * max_deg;
+            for (int e = lane; e < deg; e += 64) src[e] = head_in_edge(tp, sn, V, v, s, e);
+            if (lane == 0) {
+                s_f[r_own] = f;
+                s_v[r_own] = v;
+                s_H[r_own] = H;
             }
         }
-        if (lane == 0) s_deg[wave] = deg;
+    }
+    if (half == 0 && lane == 0) s_deg[r_own] = deg;
+    __syncthreads();
+    if (live) {
+        const int *src = s_src + r_own * max_deg;
+        const float *a_dst = l0 ? a.a12 + (size_t)(hb + v) * 32 : a.a12 + (size_t)(nb + v) * 32;
+        for (int hh = half; hh < heads; hh += 4 / AGG_ROWS) {
+            const float a2v = a_dst[16 + hh];
+            float *w = s_w + ((size_t)r_own * heads + hh) * max_deg;
+            float mx = -INFINITY;
+            for (int e = lane; e < deg; e += 64) {
+                const int u = src[e];
+                const float *a_src;
+                if (l0) a_src = u >= H ? a.en_const_a : a.a12 + (size_t)(hb + u) * 32;
+                else a_src = a.a12 + (size_t)(nb + u) * 32;
+                float x = a_src[hh] + a2v;
+                x = x > 0.f ? x : x * a.alpha;
+                w[e] = x;
+                mx = fmaxf(mx, x);
+            }
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int e = lane; e < deg; e += 64) {
+                const float ex = expf(w[e] - mx);
+                w[e] = ex;
+                sum = sum + ex;
+            }
+            sum = wave_sum(sum);
+            for (int e = lane; e < deg; e += 64) w[e] = w[e] / sum;
+        }
     }
     __syncthreads();
 
-    // out[v][c] = sum_e round(w[e][h(c)] * ft2[src_e][c]) in edge order, then activation;
-    // VEC consecutive columns (of one attention head) per thread
+    // out[v][c] = sum_e w[e][h(c)] * ft2[src_e][c], then activation; VEC consecutive columns (of one
+    // attention head) per thread
     const int per_row = hd / VEC;
     for (int i = t; i < AGG_ROWS * per_row; i += blockDim.x) {
         const int r = i / per_row, c = (i - r * per_row) * VEC;
-        const int deg = s_deg[r];
-        if (deg == 0) continue;
-        const int f = s_f[r], v = s_v[r], H = s_H[r];
+        const int dg = s_deg[r];
+        if (dg == 0) continue;
+        const int ff = s_f[r], vv = s_v[r], HH = s_H[r];
         const int hh = c / a.out_dim;
-        const int32_t nb = node_off[f], hb = head_off[f];
+        const int32_t nbb = node_off[ff], hbb = head_off[ff];
         const float *w = s_w + ((size_t)r * heads + hh) * max_deg;
         const int *src = s_src + r * max_deg;
         float acc[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        for (int e = 0; e < deg; ++e) {
-            const int u = src[e];
-            float fv[VEC];
-            if (l0 && u >= H) ld_ftv<VEC>(a.en_const_ft2, (size_t)c, 0, fv);
-            else ld_ftv<VEC>(a.ft2, (size_t)((l0 ? hb : nb) + u) * a.ld + c, a.ft_half, fv);
-            const float we = w[e];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const float m = fv[k] * we;
-                acc[k] = acc[k] + m;
-            }
-        }
+        weighted_sum8<VEC>(
+            dg,
+            [&](int e, float *fv) {
+                const int u = src[e];
+                if (l0 && u >= HH) ld_ftv<VEC>(a.en_const_ft2, (size_t)c, 0, fv);
+                else ld_ftv<VEC>(a.ft2, (size_t)((l0 ? hbb : nbb) + u) * a.ld + c, a.ft_half, fv);
+            },
+            [&](int e) { return w[e]; }, acc);
         if (a.score_mode) {
-            a.out_heads[(size_t)hb + v] = agg_activate(acc[0], a.out_mode, a.out_slope);
+            a.out_heads[(size_t)hbb + vv] = agg_activate(acc[0], a.out_mode, a.out_slope);
         } else {
             typedef float vecf __attribute__((ext_vector_type(VEC)));
             vecf o;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) o[k] = agg_activate(acc[k], a.out_mode, a.out_slope);
-            *reinterpret_cast<vecf *>(a.out + (size_t)(nb + v) * a.ld_out + c) = o;
+            *reinterpret_cast<vecf *>(a.out + (size_t)(nbb + vv) * a.ld_out + c) = o;
         }
     }
 }
@@ -781,17 +831,14 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
             const int *src = s_src + node * max_deg;
             const float *w = s_wh + node * max_deg;
             float acc[VEC];
+            weighted_sum8<VEC>(
+                deg,
+                [&](int e, float *fv) {
+                    const vecf x = *reinterpret_cast<const vecf *>(s_ft + src[e] * Dp + d);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-            for (int e = 0; e < deg; ++e) {
-                const float we = w[e];
-                const vecf fv = *reinterpret_cast<const vecf *>(s_ft + src[e] * Dp + d);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    const float mm = fv[k] * we;
-                    acc[k] = acc[k] + mm;
-                }
-            }
+                    for (int k = 0; k < VEC; ++k) fv[k] = x[k];
+                },
+                [&](int e) { return w[e]; }, acc);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) o[k] = agg_activate(acc[k], a.out_mode, a.out_slope);
         }
