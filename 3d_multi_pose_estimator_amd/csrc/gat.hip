@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
             for (int m = threadIdx.x; m < M; m += blockDim.x) a.out[(size_t)eb + m] = 0.f;
         return;
     }
-    const int Dp = (D + 3) & ~3;                    // row stride: whole 16-byte chunks
+    const int Dp = D;                               // dense rows: 16-byte chunks when VEC = 4 (then D % 4 == 0)
     // LDS: the small tables first, the feature image last (1 KiB aligned, 1 KiB of slack behind it:
     // the last DMA piece of the image may run past its end)
     float *s_a1 = s_dyn;                            // [n_cap]
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
 static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_cap) {
     const int mc = hmax * hmax * (V - 1) / (2 * V) + 1;
     const int nc = hmax + mc;
-    const int Dp = (out_dim + 3) & ~3;
+    const int Dp = out_dim;
     const size_t bytes = (fused_tables_floats(hmax, V, nc, mc) + (size_t)nc * Dp + 256) * sizeof(float);
     *n_cap = nc;
     *m_cap = mc;
