@@ -938,7 +938,7 @@ int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const 
         return fail(ctx, MPE_ERR_INVALID, "mpe_triangulate_batch: NULL argument");
     HIPCHK(ctx, launch_triangulate(static_cast<hipStream_t>(stream), ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints,
                                    *b, d_persons, d_n_persons, ctx->cfg.max_persons_per_frame, d_poses, d_joint_valid,
-                                   (flags & 1u) ? 0xFFFFFFFFu : ctx->cfg.used_joint_mask));
+                                   (flags & 1u) ? 0xFFFFFFFFu : ctx->cfg.used_joint_mask, (flags & 2u) != 0));
     return MPE_OK;
 }
 

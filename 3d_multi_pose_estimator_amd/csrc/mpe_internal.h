@@ -208,7 +208,7 @@ hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const
                            float *rows, int ld_rows, uint8_t *valid);
 hipError_t launch_triangulate(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                               const int32_t *persons, const int32_t *n_persons, int pcap, double *poses,
-                              uint8_t *joint_valid, uint32_t out_mask);
+                              uint8_t *joint_valid, uint32_t out_mask, bool positive_ids_only = false);
 hipError_t launch_dlt_pairs(hipStream_t s, const DevCfg *cfg, const double *pts, const int32_t *cams, int n,
                             double *out);
 hipError_t launch_decode(hipStream_t s, int n_frames, int pcap, int n_out, float scale, const int32_t *n_persons,

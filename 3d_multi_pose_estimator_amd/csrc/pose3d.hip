@@ -437,7 +437,7 @@ __global__ __launch_bounds__(128) void k_triangulate(const DevCfg *__restrict__ 
 
 hipError_t launch_triangulate(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                               const int32_t *persons, const int32_t *n_persons, int pcap, double *poses,
-                              uint8_t *joint_valid, uint32_t out_mask) {
+                              uint8_t *joint_valid, uint32_t out_mask, bool positive_ids_only) {
     if (b.n_frames <= 0) return hipSuccess;
     const size_t shm = ((size_t)V * J * 2 + (size_t)J * (V * (V - 1) / 2) * 3) * sizeof(double);
     if (shm > 64 * 1024) {
@@ -446,7 +446,8 @@ hipError_t launch_triangulate(hipStream_t s, const DevCfg *cfg, int V, int J, co
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_triangulate, dim3(b.n_frames * pcap), dim3(128), shm, s, cfg, pcap, b.d_frame_head_off,
-                       b.d_joint_mask, b.d_xy, persons, n_persons, poses, joint_valid, out_mask);
+                       positive_ids_only ? b.d_tri_mask : b.d_joint_mask, b.d_xy, persons, n_persons, poses, joint_valid,
+                       out_mask);
     return hipGetLastError();
 }
 

@@ -32,55 +32,47 @@ def project(calib, cam_idx, p3d):
     return (px / px[2])[:2]
 
 
-def run(args):
-    calib = Calibration(parameters)
-    eng = Engine(parameters, calib, max_frames=args.batch, max_persons_per_camera=max(4, args.persons + 1))
-    load_models(eng, args, need_mlp=True)
-    names = list(parameters.camera_names)
+def collect_work(args, calib):
     work = []
     if args.synthetic:
         spec = synthetic.FrameSpec(persons=args.persons, noise_px=args.noise_px, float_conf=False)
         for i in range(args.synthetic):
             f, gt = synthetic.make_frame(calib, i, spec)
             work.append((f, gt['owner']))
-    else:
-        n_input = 0
-        for file in args.testfiles:
-            print(file)
-            for frame in json.load(open(file, 'rb')):
-                n_input += 1
-                if (n_input - 1) % args.datastep == 0:
-                    work.append((frame, None))
+        return work
+    n_input = 0
+    for file in args.testfiles:
+        print(file)
+        for frame in json.load(open(file, 'rb')):
+            n_input += 1
+            if (n_input - 1) % args.datastep == 0:
+                work.append((frame, None))
+    return work
+
+
+def evaluate(work, infer, calib, batch=256):
+    """`infer(frames, owners)` -> per frame a list of persons, each
+    ({camera: skeleton dict}, est pose [J,3] or None, {joint idx: (3,)} triangulated).
+    Bookkeeping of reprojection_error.py:350-420: per camera that saw the person, every used joint
+    of the estimate / every triangulated joint whose detection has valid > 0.5."""
+    names = list(parameters.camera_names)
     err = {'est': {c: [] for c in names}, 'triang': {c: [] for c in names}}
-    for start in range(0, len(work), args.batch):
-        chunk = work[start:start + args.batch]
+    for start in range(0, len(work), batch):
+        chunk = work[start:start + batch]
         frames = [{c: [f[c][0], f[c][1]] for c in f if json.loads(f[c][0])} for f, _ in chunk]
-        db = eng.to_device(eng.pack(frames, keep_json=True))
-        if args.teacher_scores and chunk[0][1] is not None:
-            persons, n_persons = eng.cluster(db, teacher_scores(db, [o for _, o in chunk]))
-        else:
-            _, persons, n_persons = eng.match(db, want_scores=False)
-        poses, valid = eng.mlp3d(db, persons, n_persons)
-        tri, jv = eng.triangulate(db, persons, n_persons, all_joints=True)
-        persons, n_persons = persons.cpu().numpy(), n_persons.cpu().numpy()
-        poses, valid, tri, jv = poses.cpu().numpy(), valid.cpu().numpy(), tri.cpu().numpy(), jv.cpu().numpy()
-        for f in range(len(chunk)):
-            heads = db.host.jsons_for_head[f]
-            for p in range(int(n_persons[f])):
-                for c, cam in enumerate(names):
-                    h = persons[f, p, c]
-                    if h < 0:
-                        continue
-                    coords = heads[int(h)]
+        for persons in infer(frames, [o for _, o in chunk]):
+            for skels, est, tri in persons or []:
+                for cam, coords in skels.items():
+                    c = names.index(cam)
                     for j in parameters.joint_list:
                         key = str(j)
                         if key not in coords or not coords[key][3] > 0.5:
                             continue
                         obs = np.array([coords[key][1], coords[key][2]])
-                        if valid[f, p] and j in parameters.used_joints:
-                            err['est'][cam].append(float(np.linalg.norm(project(calib, c, poses[f, p, j]) - obs)))
-                        if jv[f, p, j]:
-                            err['triang'][cam].append(float(np.linalg.norm(project(calib, c, tri[f, p, j]) - obs)))
+                        if est is not None and j in parameters.used_joints:
+                            err['est'][cam].append(float(np.linalg.norm(project(calib, c, est[j]) - obs)))
+                        if j in tri:
+                            err['triang'][cam].append(float(np.linalg.norm(project(calib, c, tri[j]) - obs)))
     print('**********************  REPROJECTION ERRORS (mean and median) **********************')
     out = {}
     for cam in names:
@@ -89,7 +81,43 @@ def run(args):
             if err[kind][cam]:
                 a = np.array(err[kind][cam])
                 print(kind, a.mean(), np.median(a))
-                out[(kind, cam)] = (float(a.mean()), float(np.median(a)))
+                out[(kind, cam)] = (float(a.mean()), float(np.median(a)), len(a))
+    return out
+
+
+def run(args):
+    from .common import max_skeletons_per_camera
+    calib = Calibration(parameters)
+    work = collect_work(args, calib)
+    eng = Engine(parameters, calib, max_frames=args.batch,
+                 max_persons_per_camera=max(4, args.persons + 1, max_skeletons_per_camera([(f, None, None) for f, _ in work])))
+    load_models(eng, args, need_mlp=True)
+    names = list(parameters.camera_names)
+
+    def infer(frames, owners):
+        db = eng.to_device(eng.pack(frames, keep_json=True))
+        if args.teacher_scores and owners[0] is not None:
+            persons, n_persons = eng.cluster(db, teacher_scores(db, owners))
+        else:
+            _, persons, n_persons = eng.match(db, want_scores=False)
+        poses, valid = eng.mlp3d(db, persons, n_persons)
+        # the script's own gather keeps joints whose id is > 0 (reprojection_error.py:296-300)
+        tri, jv = eng.triangulate(db, persons, n_persons, all_joints=True, positive_ids_only=True)
+        eng.sync_status()
+        persons, n_persons = persons.cpu().numpy(), n_persons.cpu().numpy()
+        poses, valid, tri, jv = poses.cpu().numpy(), valid.cpu().numpy(), tri.cpu().numpy(), jv.cpu().numpy()
+        out = []
+        for f in range(len(frames)):
+            heads = db.host.jsons_for_head[f]
+            people = []
+            for p in range(int(n_persons[f])):
+                skels = {cam: heads[int(persons[f, p, c])] for c, cam in enumerate(names) if persons[f, p, c] >= 0}
+                people.append((skels, poses[f, p] if valid[f, p] else None,
+                               {j: tri[f, p, j].astype(np.float32) for j in parameters.joint_list if jv[f, p, j]}))
+            out.append(people)
+        return out
+
+    out = evaluate(work, infer, calib, args.batch)
     eng.close()
     return out
 

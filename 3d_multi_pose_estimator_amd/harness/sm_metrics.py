@@ -52,51 +52,51 @@ def gt_labels(frame):
     return labels
 
 
-def run(args):
-    calib = Calibration(parameters)
-    eng = Engine(parameters, calib, max_frames=args.batch, max_persons_per_camera=max(4, args.persons + 1))
-    load_models(eng, args, need_mlp=False)
+def collect_work(args, calib):
     work = []
     if args.synthetic:
         spec = synthetic.FrameSpec(persons=args.persons, noise_px=args.noise_px)
         for i in range(args.synthetic):
             f, gt = synthetic.make_frame(calib, i, spec)
             work.append((f, gt['owner']))
-    else:
-        n_input = 0
-        for file in args.testfiles:
-            print(file)
-            for frame in json.load(open(file, 'rb')):
-                n_input += 1
-                if (n_input - 1) % args.datastep == 0:
-                    if len(frame[list(frame.keys())[0]]) != 4:
-                        print('There is no ground truth in the specified file')
-                        raise SystemExit
-                    work.append((frame, None))
+        return work
+    n_input = 0
+    for file in args.testfiles:
+        print(file)
+        for frame in json.load(open(file, 'rb')):
+            n_input += 1
+            if (n_input - 1) % args.datastep == 0:
+                if len(frame[list(frame.keys())[0]]) != 4:
+                    print('There is no ground truth in the specified file')
+                    raise SystemExit
+                work.append((frame, None))
+    return work
+
+
+def evaluate(work, infer, batch=256):
+    """`infer(frames, owners)` -> per frame None (no graph, reference :186-187) or
+    (H, proposals) with proposals = list of lists of head ids.  Returns the four averages."""
     tot = {'rand score': 0.0, 'homogeneity': 0.0, 'completeness': 0.0, 'v_measure': 0.0}
     n_data = 0
-    for start in range(0, len(work), args.batch):
-        chunk = [(f, o, gt_labels(f)) for f, o in work[start:start + args.batch]]
+    for start in range(0, len(work), batch):
+        chunk = [(f, o, gt_labels(f)) for f, o in work[start:start + batch]]
         chunk = [c for c in chunk if c[2] is not None]
         if not chunk:
             continue
         frames = [{c: [f[c][0], f[c][1]] for c in f if json.loads(f[c][0])} for f, _, _ in chunk]
-        db = eng.to_device(eng.pack(frames))
-        if args.teacher_scores and chunk[0][1] is not None:
-            persons, n_persons = eng.cluster(db, teacher_scores(db, [o for _, o, _ in chunk]))
-        else:
-            _, persons, n_persons = eng.match(db, want_scores=False)
-        persons, n_persons = persons.cpu().numpy(), n_persons.cpu().numpy()
-        for f, (_, _, labels) in enumerate(chunk):
-            h0, H, e0, M = db.host.frame_counts(f)
-            if M == 0 or len(labels) != H:
-                continue          # no graph (reference :186-187) / skeletons without joints
+        results = infer(frames, [o for _, o, _ in chunk])
+        for (_, _, labels), res in zip(chunk, results):
+            if res is None:
+                continue
+            H, proposals = res
+            if len(labels) != H:
+                continue          # skeletons without joints: GT list and head list no longer align
             n_data += 1
             est = []
             for h in range(H):
-                idx = int(n_persons[f])
-                for p in range(int(n_persons[f])):
-                    if h in persons[f, p]:
+                idx = len(proposals)
+                for p, members in enumerate(proposals):
+                    if h in members:
                         idx = p
                         break
                 est.append(idx)
@@ -108,6 +108,36 @@ def run(args):
     out = {k: v / max(1, n_data) for k, v in tot.items()}
     for k in ('rand score', 'homogeneity', 'completeness', 'v_measure'):
         print(k, out[k])
+    out['n_data'] = n_data
+    return out
+
+
+def run(args):
+    from .common import max_skeletons_per_camera
+    calib = Calibration(parameters)
+    work = collect_work(args, calib)
+    eng = Engine(parameters, calib, max_frames=args.batch,
+                 max_persons_per_camera=max(4, args.persons + 1, max_skeletons_per_camera([(f, None, None) for f, _ in work])))
+    load_models(eng, args, need_mlp=False)
+
+    def infer(frames, owners):
+        db = eng.to_device(eng.pack(frames))
+        if args.teacher_scores and owners[0] is not None:
+            persons, n_persons = eng.cluster(db, teacher_scores(db, owners))
+        else:
+            _, persons, n_persons = eng.match(db, want_scores=False)
+        eng.sync_status()
+        persons, n_persons = persons.cpu().numpy(), n_persons.cpu().numpy()
+        out = []
+        for f in range(len(frames)):
+            h0, H, e0, M = db.host.frame_counts(f)
+            if M == 0:
+                out.append(None)
+            else:
+                out.append((H, [[int(h) for h in persons[f, p] if h >= 0] for p in range(int(n_persons[f]))]))
+        return out
+
+    out = evaluate(work, infer, args.batch)
     eng.close()
     return out
 

@@ -247,13 +247,15 @@ class Engine:
                                            _ptr(n_persons), _ptr(poses), _ptr(valid)))
         return poses, valid
 
-    def triangulate(self, db, persons, n_persons, all_joints=False):
-        """-> (poses[B,Pcap,J,3] f64, joint_valid[B,Pcap,J] u8)."""
+    def triangulate(self, db, persons, n_persons, all_joints=False, positive_ids_only=False):
+        """-> (poses[B,Pcap,J,3] f64, joint_valid[B,Pcap,J] u8).  positive_ids_only: the gather of
+        test/reprojection_error.py:296-300 (joints with values[0] > 0 only)."""
         B = db.n_frames
         poses = torch.empty((B, self.pcap, self.J, 3), dtype=torch.float64, device=self.device)
         jv = torch.empty((B, self.pcap, self.J), dtype=torch.uint8, device=self.device)
         self._chk(self.lib.mpe_triangulate_batch(self.ctx, self._stream(), C.byref(db.struct), _ptr(persons),
-                                                 _ptr(n_persons), _ptr(poses), _ptr(jv), 1 if all_joints else 0))
+                                                 _ptr(n_persons), _ptr(poses), _ptr(jv),
+                                                 (1 if all_joints else 0) | (2 if positive_ids_only else 0)))
         return poses, jv
 
     def dlt_pairs(self, pts, cams):

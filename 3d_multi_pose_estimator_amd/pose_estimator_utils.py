@@ -1,6 +1,9 @@
 """API mirror of the reference's utils/pose_estimator_utils.py (``camera_matrix`` :17-30,
-``triangulate`` :52-75).  The undistortion, the pairwise DLT solves and the 5 cm median filter
-run in the HIP kernel k_triangulate (mpe_triangulate_batch) on a one-person batch."""
+``from_homogeneous`` / ``from_homogeneous2`` :32-36, ``get_distortion_coefficients`` :39-41,
+``apply_distortion`` :44-50, ``triangulate`` :52-75).  The undistortion, the pairwise DLT solves
+and the 5 cm median filter run in the HIP kernel k_triangulate (mpe_triangulate_batch) on a
+one-person batch; the projection helpers are the host-side tensor functions the reference's
+reprojection check uses (test/reprojection_error.py:89-107) and are not on the hot path."""
 import numpy as np
 import torch
 
@@ -18,6 +21,29 @@ def camera_matrix(cam_idx, use_cuda=True):
 
 def from_homogeneous(v):
     return (v / v[-1])[:-1]
+
+
+def from_homogeneous2(v):
+    return v / v[-1]
+
+
+def get_distortion_coefficients(cam_idx):
+    """Radial coefficients k1, k2, k3 of one camera (the tangential ones are ignored here,
+    as in the reference)."""
+    dev = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+    return torch.tensor([parameters.kd0[cam_idx], parameters.kd1[cam_idx], parameters.kd2[cam_idx]], device=dev)
+
+
+def apply_distortion(kd, v):
+    """Radial-only lens model on normalised homogeneous points v [3, n]: x,y scaled by
+    1 + k1 r^2 + k2 r^4 + k3 r^6 with r = |(x, y)|."""
+    v2 = v.clone()
+    r = torch.norm(v[:-1][:], dim=0)
+    r = r * r
+    f = 1 + kd[0] * r + kd[1] * r * r + kd[2] * r * r * r
+    v2[0][:] = v[0][:] * f
+    v2[1][:] = v[1][:] * f
+    return v2
 
 
 def _one_person_batch(points_2D, params):

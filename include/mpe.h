@@ -146,7 +146,9 @@ int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
  * pose_estimator_utils.py:52-75).
  *   d_poses [n_frames][Pcap][J][3] f64, d_joint_valid [n_frames][Pcap][J] 1 = joint emitted
  *   flags bit 0: emit every triangulated joint (what `triangulate` itself returns); otherwise
- *   joints outside parameters.used_joints come back as zeros, as the caller's copy does. */
+ *   joints outside parameters.used_joints come back as zeros, as the caller's copy does.
+ *   flags bit 1: gather only joints whose values[0] (the joint id) is > 0, as the caller in
+ *   test/reprojection_error.py:296-300 does (joint 0 is then never triangulated). */
 int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
                           const int32_t *d_persons, const int32_t *d_n_persons,
                           double *d_poses, uint8_t *d_joint_valid, uint32_t flags);

@@ -108,14 +108,47 @@ def save_models(mdir, syn, V, J):
                os.path.join(mdir, 'pose_estimator.pytorch'))
 
 
+def parse_sm(text):
+    out = {}
+    for line in text.splitlines():
+        m = re.match(r'(rand score|homogeneity|completeness|v_measure) (\S+)', line)
+        if m:
+            out[m.group(1)] = float(m.group(2))
+    return out
+
+
+def parse_reprojection(text):
+    out, cam = {}, None
+    for line in text.splitlines():
+        m = re.match(r'-+ CAMERA (\S+) -+', line)
+        if m:
+            cam = m.group(1)
+            out[cam] = {}
+        m = re.match(r'(est|triang|GT) (\S+) (\S+)', line)
+        if m and cam:
+            out[cam][m.group(1)] = [float(m.group(2)), float(m.group(3))]
+    return out
+
+
 def run_reference(script, data_file, tm_dir, models_dir):
-    """The reference script as __main__, unchanged, in its own directory."""
-    code = ('import sys, runpy; sys.dont_write_bytecode = True; sys.path.insert(0, %r); '
+    """The reference script as __main__, unchanged.  The working directory is a scratch copy of the
+    reference's LAYOUT, not of its files: <layout>/test is the cwd, <layout>/tm_panoptic.pickle a
+    symlink to the reference's calibration (parameters.transformations_path is cwd-relative), <layout>/human_pose.json likewise, and
+    <layout>/models_panoptic the model directory that test/sm_metrics.py hard-codes (:81-84); the
+    reference's own source directories are put on sys.path by absolute name."""
+    layout = os.path.dirname(models_dir.rstrip('/'))
+    os.makedirs(os.path.join(layout, 'test'), exist_ok=True)
+    for name in ('tm_panoptic.pickle', 'human_pose.json'):        # data files the scripts open relative to the cwd
+        link = os.path.join(layout, name)
+        if not os.path.exists(link):
+            os.symlink(os.path.join(REF, name), link)
+    paths = [SHIMS, os.path.join(REF, 'skeleton_matching'), os.path.join(REF, 'utils'), REF]
+    code = ('import sys, runpy; sys.dont_write_bytecode = True; sys.path[:0] = %r; '
             'sys.argv = [%r, "--testfiles", %r, "--tmdir", %r, "--modelsdir", %r, "--datastep", %r]; '
             'runpy.run_path(%r, run_name="__main__")'
-            % (SHIMS, script, data_file, tm_dir, models_dir, str(DATASTEP), os.path.join(REF, 'test', script)))
+            % (paths, script, data_file, tm_dir, models_dir, str(DATASTEP), os.path.join(REF, 'test', script)))
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
-    res = subprocess.run([sys.executable, '-c', code], cwd=os.path.join(REF, 'test'), env=env, capture_output=True, text=True)
+    res = subprocess.run([sys.executable, '-c', code], cwd=os.path.join(layout, 'test'), env=env, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError('%s failed:\n%s' % (script, res.stderr[-3000:]))
     return res.stdout
@@ -154,7 +187,9 @@ def main():
     with open(os.path.join(OUT, 'tm_syn_pinning.pickle'), 'wb') as fh:
         pickle.dump(tm, fh)
     V, J = len(params.camera_names), len(params.joint_list)
-    with tempfile.TemporaryDirectory() as mdir:
+    with tempfile.TemporaryDirectory() as layout:
+        mdir = os.path.join(layout, 'models_panoptic')
+        os.makedirs(mdir)
         save_models(mdir, syn, V, J)
         report = {}
         for key, script in (('model', 'metrics_from_model.py'), ('triangulation', 'metrics_from_triangulation.py')):
@@ -162,6 +197,14 @@ def main():
             print(text)
             report[key] = parse_report(text)
             assert 'mpjpe_mm' in report[key] and len(report[key]['ap']) == 6, text
+        text = run_reference('sm_metrics.py', data_file, OUT, mdir)
+        print(text)
+        report['sm_metrics'] = parse_sm(text)
+        assert len(report['sm_metrics']) == 4, text
+        text = run_reference('reprojection_error.py', data_file, OUT, mdir)
+        print(text)
+        report['reprojection_error'] = parse_reprojection(text)
+        assert len(report['reprojection_error']) == V, text
     report['inputs'] = {'testfile': TEST_NAME, 'tm': 'tm_syn_pinning.pickle', 'datastep': DATASTEP,
                         'gat': {'kind': 'matcher', 'noise_seed': GAT_NOISE_SEED, 'noise_bound': GAT_NOISE},
                         'mlp': {'kind': 'decoder', 'noise_seed': MLP_NOISE_SEED, 'noise_bound': MLP_NOISE}}

@@ -511,17 +511,21 @@ def decode_pose(out_row, n_joints):
 # metrics_from_triangulation.py:234-272)
 # --------------------------------------------------------------------------------------
 
-def triangulate_person(skels, calib):
+def triangulate_person(skels, calib, positive_ids_only=False, all_joints=False):
     """All joint keys of the person's skeletons (no "ID"/joint-0 filter, cameras in
     parameters.cameras order), pairwise DLT, keep pairs within 5 cm of the upper median
     along axes_3D['Y'][0], mean.  Returns {joint_idx: (3,) f64}; joints outside
-    used_joints come back as zeros (caller copy, :259-272)."""
+    used_joints come back as zeros (caller copy, :259-272).
+    positive_ids_only / all_joints: the variant of test/reprojection_error.py:289-302, whose
+    gather keeps joints with values[0] > 0 only and which uses `triangulate`'s result as it is."""
     params = calib.params
     axis = params.axes_3D['Y'][0]
     pts = {}
     for cam in params.camera_names:
         if cam in skels:
             for j, pos in skels[cam].items():
+                if positive_ids_only and not (j != 'ID' and pos[0] > 0.):
+                    continue
                 pts.setdefault(j, {})[cam] = np.array([pos[1], pos[2]])
     res = {}
     for ji in params.joint_list:
@@ -539,6 +543,8 @@ def triangulate_person(skels, calib):
             med = np.sort(d)[d.shape[0] // 2]
             keep = np.abs(d - med) < 0.05
             res[ji] = np.mean(lst[keep], axis=0)
+    if all_joints:
+        return res
     out = {}
     for ji in params.joint_list:
         if ji in res:
@@ -575,6 +581,6 @@ def run_frame(frame, calib, gat_sd, gat_prm, mlp_sd=None, mode='mlp'):
             res['poses'] = np.stack([decode_pose(out[i], len(params.joint_list)) for i in range(out.shape[0])])
         else:
             res['poses'] = np.zeros((0, len(params.joint_list), 3), np.float32)
-    else:
+    elif mode == 'tri':
         res['tri'] = [triangulate_person(person_skeletons(p, g['jsons_for_head'], sm), calib) for p in persons]
     return res

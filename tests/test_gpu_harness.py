@@ -66,3 +66,38 @@ def test_reprojection_error_harness():
     tri = [v for (kind, cam), v in out.items() if kind == 'triang']
     assert len(tri) == 5 and max(t[1] for t in tri) < 2.0
     assert any(kind == 'est' for kind, _ in out)
+
+
+def _expected():
+    hd = os.path.join(GOLDEN, 'harness')
+    with open(os.path.join(hd, 'harness_expected.json')) as fh:
+        return hd, json.load(fh)
+
+
+def test_sm_metrics_harness_reproduces_the_reference_script(tmp_path):
+    """f2: harness/sm_metrics.py on the engine against the four numbers
+    /root/reference/test/sm_metrics.py printed for the same files."""
+    hd, exp = _expected()
+    mdir = harness_model_files(str(tmp_path), exp['inputs'])
+    m = importlib.import_module('3d_multi_pose_estimator_amd.harness.sm_metrics')
+    out = m.main(['--testfiles', os.path.join(hd, exp['inputs']['testfile']), '--tmdir', hd, '--modelsdir', mdir,
+                  '--datastep', str(exp['inputs']['datastep']), '--batch', '7'])
+    for k, v in exp['sm_metrics'].items():
+        assert out[k] == pytest.approx(v, rel=1e-12, abs=1e-12), k
+
+
+def test_reprojection_harness_reproduces_the_reference_script(tmp_path):
+    """f3: harness/reprojection_error.py on the engine: per-camera medians of the reprojection
+    error of the MLP estimate and of the triangulation as /root/reference/test/reprojection_error.py
+    printed them (the means are dominated by a few points projected through z ~ 0: log scale)."""
+    import numpy as np
+    hd, exp = _expected()
+    mdir = harness_model_files(str(tmp_path), exp['inputs'])
+    m = importlib.import_module('3d_multi_pose_estimator_amd.harness.reprojection_error')
+    out = m.main(['--testfiles', os.path.join(hd, exp['inputs']['testfile']), '--tmdir', hd, '--modelsdir', mdir,
+                  '--datastep', str(exp['inputs']['datastep']), '--batch', '7'])
+    for cam, kinds in exp['reprojection_error'].items():
+        for kind, (mean, median) in kinds.items():
+            g = out[(kind, cam)]
+            assert g[1] == pytest.approx(median, rel=2e-4), (cam, kind, g, median)
+            assert abs(np.log10(g[0]) - np.log10(mean)) < 0.5, (cam, kind, g, mean)

@@ -271,3 +271,22 @@ def test_bench_under_external_launcher_uses_its_world():
     out = json.loads(line[0])
     assert out['n_gpus'] == 2 and out['launcher'] == 'external' and out['gather_ok']
     assert not [l for l in outs[1][0].splitlines() if l.startswith('{')]      # only rank 0 prints
+
+
+def test_projection_helpers_match_reference_formulas():
+    """pose_estimator_utils.apply_distortion / from_homogeneous(2) / get_distortion_coefficients:
+    host-side tensor helpers of the reprojection check (reference pose_estimator_utils.py:32-50).
+    Checked against the closed form, and apply_distortion against the harness' own projection."""
+    peu = pkg('pose_estimator_utils')
+    par = pkg('parameters').parameters
+    v = torch.tensor([[0.10, -0.20, 0.30], [0.05, 0.40, -0.25], [1.0, 1.0, 1.0]])
+    kd = peu.get_distortion_coefficients(2).cpu()
+    assert kd.tolist() == pytest.approx([par.kd0[2], par.kd1[2], par.kd2[2]])
+    out = peu.apply_distortion(kd, v)
+    r2 = v[0] ** 2 + v[1] ** 2
+    f = 1 + kd[0] * r2 + kd[1] * r2 ** 2 + kd[2] * r2 ** 3
+    assert torch.allclose(out[0], v[0] * f, rtol=1e-6, atol=0) and torch.allclose(out[1], v[1] * f, rtol=1e-6, atol=0)
+    assert torch.equal(out[2], v[2]) and torch.equal(v[2], torch.ones(3))          # input untouched, w kept
+    h = torch.tensor([[2.0, 4.0], [6.0, 8.0], [2.0, 4.0]])
+    assert torch.equal(peu.from_homogeneous(h), torch.tensor([[1.0, 1.0], [3.0, 2.0]]))
+    assert torch.equal(peu.from_homogeneous2(h), torch.tensor([[1.0, 1.0], [3.0, 2.0], [1.0, 1.0]]))

@@ -172,3 +172,80 @@ def test_harness_bookkeeping_reproduces_reference_report(mode, key, tmp_path):
     assert abs(got['mpjpe_mm'] - want['mpjpe_mm']) < 1e-6
     for th, triple in want['ap'].items():
         assert got['ap'][th] == pytest.approx(triple, rel=1e-12, abs=1e-12), th
+
+
+def _harness_inputs(tmp_path):
+    import json
+    import pickle
+    import torch
+    from conftest import GOLDEN, harness_model_files
+    hd = os.path.join(GOLDEN, 'harness')
+    exp = json.load(open(os.path.join(hd, 'harness_expected.json')))
+    mdir = harness_model_files(str(tmp_path), exp['inputs'])
+    prm = pickle.load(open(os.path.join(mdir, 'skeleton_matching.prms'), 'rb'))
+    prm = dict(prm, nonlinearity=prm['nonlinearity'].negative_slope)
+    gat_sd = {k: v.numpy() for k, v in torch.load(os.path.join(mdir, 'skeleton_matching.tch')).items()}
+    mlp_sd = {k: v.numpy() for k, v in torch.load(os.path.join(mdir, 'pose_estimator.pytorch'))['model_state_dict'].items()}
+    return hd, exp, prm, gat_sd, mlp_sd
+
+
+def test_sm_metrics_bookkeeping_reproduces_reference_report(tmp_path):
+    """f2: harness/sm_metrics.py (GT grouping from the 3D bodies, label lists, sklearn metrics)
+    with the oracle as the inference side prints what /root/reference/test/sm_metrics.py printed."""
+    import argparse
+    onp = oracle()
+    sm = pkg('harness.sm_metrics')
+    calib = env().calib
+    hd, exp, prm, gat_sd, _ = _harness_inputs(tmp_path)
+    args = argparse.Namespace(synthetic=0, testfiles=[os.path.join(hd, exp['inputs']['testfile'])], datastep=exp['inputs']['datastep'])
+    work = sm.collect_work(args, calib)
+
+    def infer(frames, owners):
+        out = []
+        for frame in frames:
+            res = onp.run_frame(frame, calib, gat_sd, prm, None, mode='none')
+            out.append(None if res is None else (res['graph']['H'], [[h for h in p if h >= 0] for p in res['persons']]))
+        return out
+    got = sm.evaluate(work, infer, batch=6)
+    for k, v in exp['sm_metrics'].items():
+        assert got[k] == pytest.approx(v, rel=1e-12, abs=1e-12), k
+
+
+def test_reprojection_bookkeeping_reproduces_reference_report(tmp_path):
+    """f3: harness/reprojection_error.py with the oracle as the inference side against the numbers
+    /root/reference/test/reprojection_error.py printed: the per-camera MEDIANS (the means are
+    dominated by a few points that project through z ~ 0 and come out as 1e6..1e10 px; they are
+    compared on the log scale only)."""
+    import argparse
+    onp = oracle()
+    rp = pkg('harness.reprojection_error')
+    calib = env().calib
+    hd, exp, prm, gat_sd, mlp_sd = _harness_inputs(tmp_path)
+    args = argparse.Namespace(synthetic=0, testfiles=[os.path.join(hd, exp['inputs']['testfile'])], datastep=exp['inputs']['datastep'])
+    work = rp.collect_work(args, calib)
+    sm = list(calib.params.used_cameras_skeleton_matching)
+
+    def infer(frames, owners):
+        out = []
+        for frame in frames:
+            res = onp.run_frame(frame, calib, gat_sd, prm, mlp_sd, mode='mlp')
+            people = []
+            if res is not None:
+                k = 0
+                for p in res['persons']:
+                    skels = onp.person_skeletons(p, res['graph']['jsons_for_head'], sm)
+                    row, kept = onp.mlp_input_row(skels, calib)
+                    est = None
+                    if kept:
+                        est = res['poses'][k]
+                        k += 1
+                    tri = onp.triangulate_person(skels, calib, positive_ids_only=True, all_joints=True)
+                    people.append((skels, est, {j: v.astype(np.float32) for j, v in tri.items()}))
+            out.append(people)
+        return out
+    got = rp.evaluate(work, infer, calib, batch=6)
+    for cam, kinds in exp['reprojection_error'].items():
+        for kind, (mean, median) in kinds.items():
+            g = got[(kind, cam)]
+            assert g[1] == pytest.approx(median, rel=2e-4), (cam, kind, g, median)
+            assert abs(np.log10(g[0]) - np.log10(mean)) < 0.5, (cam, kind, g, mean)
