@@ -454,21 +454,24 @@ extern "C" {
 
 const char *mpe_pack_last_error(void) { return g_pack_error.c_str(); }
 
-int mpe_pack_json(const char *json, size_t len, const char *const *camera_names, int32_t n_cameras, int32_t n_joints,
-                  int32_t frame_start, int32_t frame_step, int32_t max_frames, int32_t n_threads, mpe_packed **out) {
-    if (!json || !camera_names || !out || n_cameras < 1 || n_cameras > MPE_MAX_CAMERAS || n_joints < 1 ||
-        n_joints > MPE_MAX_JOINTS || frame_step < 1 || frame_start < 0) {
+// parse the selected frames (thread pool); on failure g_pack_error is set
+static int parse_selected(const char *json, size_t len, const char *const *camera_names, int32_t n_cameras, int32_t n_joints,
+                          int32_t frame_start, int32_t frame_step, int32_t max_frames, int32_t n_threads,
+                          std::vector<FrameOut> *fo_out) {
+    if (!json || !camera_names || n_cameras < 1 || n_cameras > MPE_MAX_CAMERAS || n_joints < 1 || n_joints > MPE_MAX_JOINTS ||
+        frame_step < 1 || frame_start < 0) {
         g_pack_error = "mpe_pack_json: bad argument";
         return MPE_ERR_INVALID;
     }
-    *out = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::string> cams(camera_names, camera_names + n_cameras);
     std::vector<std::pair<const char *, const char *>> ext;
-    std::string err;
-    if (!split_frames(json, json + len, &ext, &err)) {
-        g_pack_error = err;
-        return MPE_ERR_INVALID;
+    {
+        std::string err;
+        if (!split_frames(json, json + len, &ext, &err)) {
+            g_pack_error = err;
+            return MPE_ERR_INVALID;
+        }
     }
     std::vector<std::pair<const char *, const char *>> sel;
     for (size_t i = (size_t)frame_start; i < ext.size(); i += (size_t)frame_step) {
@@ -477,7 +480,8 @@ int mpe_pack_json(const char *json, size_t len, const char *const *camera_names,
     }
     const auto t1 = std::chrono::steady_clock::now();
     const int B = (int)sel.size();
-    std::vector<FrameOut> fo((size_t)B);
+    std::vector<FrameOut> &fo = *fo_out;
+    fo.assign((size_t)B, FrameOut());
     std::atomic<int> next{0};
     std::atomic<bool> failed{false};
     auto work = [&]() {
@@ -494,7 +498,6 @@ int mpe_pack_json(const char *json, size_t len, const char *const *camera_names,
     for (int t = 1; t < nt; ++t) pool.emplace_back(work);
     work();
     for (auto &t : pool) t.join();
-    const auto t2 = std::chrono::steady_clock::now();
     if (failed) {
         for (int i = 0; i < B; ++i)
             if (!fo[i].error.empty()) {
@@ -503,55 +506,112 @@ int mpe_pack_json(const char *json, size_t len, const char *const *camera_names,
             }
         return MPE_ERR_INVALID;
     }
+    if (getenv("MPE_PACK_TIMING")) {
+        const auto t2 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "mpe_pack_json: split %.1f ms, parse %.1f ms (%d threads)\n", ms(t0, t1), ms(t1, t2), nt);
+    }
+    return MPE_OK;
+}
+
+// per-frame results -> the structure-of-arrays batch in caller-visible arrays
+static void assemble(const std::vector<FrameOut> &fo, int n_cameras, int n_joints, int32_t *frame_head_off, int32_t *frame_en_off,
+                     int32_t *slot_cam, int32_t *slot_n, int32_t *head_cam, int32_t *skeleton_index, uint32_t *joint_mask,
+                     uint32_t *tri_mask, double *xy, float *vp) {
+    const int B = (int)fo.size();
+    frame_head_off[0] = frame_en_off[0] = 0;
+    for (int f = 0; f < B; ++f) {
+        long tot = 0, sq = 0;
+        for (int s = 0; s < n_cameras; ++s) {
+            slot_cam[(size_t)f * n_cameras + s] = -1;
+            slot_n[(size_t)f * n_cameras + s] = 0;
+        }
+        for (size_t s = 0; s < fo[f].slot_cam.size(); ++s) {
+            slot_cam[(size_t)f * n_cameras + s] = fo[f].slot_cam[s];
+            slot_n[(size_t)f * n_cameras + s] = fo[f].slot_n[s];
+            tot += fo[f].slot_n[s];
+            sq += (long)fo[f].slot_n[s] * fo[f].slot_n[s];
+        }
+        frame_head_off[f + 1] = frame_head_off[f] + (int32_t)tot;
+        frame_en_off[f + 1] = frame_en_off[f] + (int32_t)((tot * tot - sq) / 2);
+    }
+    const size_t per = (size_t)n_joints * 2;
+    for (int f = 0; f < B; ++f) {
+        size_t h = (size_t)frame_head_off[f];
+        if (!fo[f].heads.empty()) {
+            memcpy(&xy[h * per], fo[f].xy.data(), fo[f].xy.size() * sizeof(double));
+            memcpy(&vp[h * per], fo[f].vp.data(), fo[f].vp.size() * sizeof(float));
+        }
+        for (const HeadInfo &hd : fo[f].heads) {
+            head_cam[h] = hd.cam;
+            skeleton_index[h] = hd.skeleton_index;
+            joint_mask[h] = hd.joint_mask;
+            tri_mask[h] = hd.tri_mask;
+            ++h;
+        }
+    }
+}
+
+int mpe_pack_json(const char *json, size_t len, const char *const *camera_names, int32_t n_cameras, int32_t n_joints,
+                  int32_t frame_start, int32_t frame_step, int32_t max_frames, int32_t n_threads, mpe_packed **out) {
+    if (!out) {
+        g_pack_error = "mpe_pack_json: bad argument";
+        return MPE_ERR_INVALID;
+    }
+    *out = nullptr;
+    std::vector<FrameOut> fo;
+    const int rc = parse_selected(json, len, camera_names, n_cameras, n_joints, frame_start, frame_step, max_frames, n_threads, &fo);
+    if (rc) return rc;
     mpe_packed *pk = new (std::nothrow) mpe_packed();
     if (!pk) return MPE_ERR_NOMEM;
+    const int B = (int)fo.size();
     pk->V = n_cameras;
     pk->J = n_joints;
     pk->n_frames = B;
+    size_t H = 0;
+    for (const FrameOut &f : fo) H += f.heads.size();
     pk->frame_head_off.assign((size_t)B + 1, 0);
     pk->frame_en_off.assign((size_t)B + 1, 0);
     pk->slot_cam.assign((size_t)B * n_cameras, -1);
     pk->slot_n.assign((size_t)B * n_cameras, 0);
-    for (int f = 0; f < B; ++f) {
-        long tot = 0, sq = 0;
-        for (size_t s = 0; s < fo[f].slot_cam.size(); ++s) {
-            pk->slot_cam[(size_t)f * n_cameras + s] = fo[f].slot_cam[s];
-            pk->slot_n[(size_t)f * n_cameras + s] = fo[f].slot_n[s];
-            tot += fo[f].slot_n[s];
-            sq += (long)fo[f].slot_n[s] * fo[f].slot_n[s];
-        }
-        pk->frame_head_off[f + 1] = pk->frame_head_off[f] + (int32_t)tot;
-        pk->frame_en_off[f + 1] = pk->frame_en_off[f] + (int32_t)((tot * tot - sq) / 2);
-    }
-    const size_t H = (size_t)pk->frame_head_off[B];
     pk->head_cam.resize(H);
     pk->skeleton_index.resize(H);
     pk->joint_mask.resize(H);
     pk->tri_mask.resize(H);
     pk->xy.assign(H * n_joints * 2, 0.0);
     pk->vp.assign(H * n_joints * 2, 0.f);
-    for (int f = 0; f < B; ++f) {
-        size_t h = (size_t)pk->frame_head_off[f];
-        const size_t per = (size_t)n_joints * 2;
-        if (!fo[f].heads.empty()) {
-            memcpy(&pk->xy[h * per], fo[f].xy.data(), fo[f].xy.size() * sizeof(double));
-            memcpy(&pk->vp[h * per], fo[f].vp.data(), fo[f].vp.size() * sizeof(float));
-        }
-        for (const HeadInfo &hd : fo[f].heads) {
-            pk->head_cam[h] = hd.cam;
-            pk->skeleton_index[h] = hd.skeleton_index;
-            pk->joint_mask[h] = hd.joint_mask;
-            pk->tri_mask[h] = hd.tri_mask;
-            ++h;
-        }
-    }
-    if (getenv("MPE_PACK_TIMING")) {
-        const auto t3 = std::chrono::steady_clock::now();
-        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "mpe_pack_json: split %.1f ms, parse %.1f ms (%d threads), assemble %.1f ms\n", ms(t0, t1), ms(t1, t2), nt,
-                ms(t2, t3));
-    }
+    assemble(fo, n_cameras, n_joints, pk->frame_head_off.data(), pk->frame_en_off.data(), pk->slot_cam.data(), pk->slot_n.data(),
+             pk->head_cam.data(), pk->skeleton_index.data(), pk->joint_mask.data(), pk->tri_mask.data(), pk->xy.data(),
+             pk->vp.data());
     *out = pk;
+    return MPE_OK;
+}
+
+int mpe_pack_json_into(const char *json, size_t len, const char *const *camera_names, int32_t n_cameras, int32_t n_joints,
+                       int32_t frame_start, int32_t frame_step, int32_t max_frames, int32_t n_threads,
+                       const mpe_pack_dst *dst, int32_t *n_frames, int32_t *n_heads, int32_t *n_edge_nodes) {
+    if (!dst || !n_frames || !n_heads || !n_edge_nodes || !dst->frame_head_off || !dst->frame_en_off || !dst->slot_cam ||
+        !dst->slot_n || !dst->head_cam || !dst->skeleton_index || !dst->joint_mask || !dst->tri_mask || !dst->xy || !dst->vp ||
+        dst->max_frames < 1 || dst->max_heads < 1) {
+        g_pack_error = "mpe_pack_json_into: bad argument";
+        return MPE_ERR_INVALID;
+    }
+    if (max_frames <= 0 || max_frames > dst->max_frames) max_frames = dst->max_frames;
+    std::vector<FrameOut> fo;
+    const int rc = parse_selected(json, len, camera_names, n_cameras, n_joints, frame_start, frame_step, max_frames, n_threads, &fo);
+    if (rc) return rc;
+    size_t H = 0;
+    for (const FrameOut &f : fo) H += f.heads.size();
+    if (H > (size_t)dst->max_heads) {
+        g_pack_error = "mpe_pack_json_into: " + std::to_string(H) + " skeletons exceed the destination's max_heads = " +
+                       std::to_string(dst->max_heads);
+        return MPE_ERR_CAPACITY;
+    }
+    assemble(fo, n_cameras, n_joints, dst->frame_head_off, dst->frame_en_off, dst->slot_cam, dst->slot_n, dst->head_cam,
+             dst->skeleton_index, dst->joint_mask, dst->tri_mask, dst->xy, dst->vp);
+    *n_frames = (int32_t)fo.size();
+    *n_heads = (int32_t)H;
+    *n_edge_nodes = dst->frame_en_off[fo.size()];
     return MPE_OK;
 }
 

@@ -55,6 +55,13 @@ class mpe_packed_arrays(C.Structure):
                 ('xy', c_f64p), ('vp', c_f32p)]
 
 
+class mpe_pack_dst(C.Structure):
+    _fields_ = [('max_frames', C.c_int32), ('max_heads', C.c_int32),
+                ('frame_head_off', C.c_void_p), ('frame_en_off', C.c_void_p), ('slot_cam', C.c_void_p), ('slot_n', C.c_void_p),
+                ('head_cam', C.c_void_p), ('skeleton_index', C.c_void_p), ('joint_mask', C.c_void_p), ('tri_mask', C.c_void_p),
+                ('xy', C.c_void_p), ('vp', C.c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/mpe.h declares
 SYMBOLS = {
     'mpe_create': (C.c_int, [C.POINTER(mpe_config), C.POINTER(C.c_void_p)]),
@@ -97,6 +104,9 @@ SYMBOLS = {
     'mpe_pack_json': (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     'mpe_packed_view': (C.c_int, [C.c_void_p, C.POINTER(mpe_packed_arrays)]),
+    'mpe_pack_json_into': (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int32, C.POINTER(mpe_pack_dst), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'mpe_packed_free': (None, [C.c_void_p]),
     'mpe_pack_last_error': (C.c_char_p, []),
     'mpe_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),

@@ -92,6 +92,82 @@ class BatchArena:
         return self.buf.data_ptr() + self.offsets[name][0]
 
 
+class CapacityArena:
+    """One contiguous buffer laid out for CAPACITIES (max_frames, max_heads) instead of one batch's
+    exact sizes: the native packer (`mpe_pack_json_into`) parses straight into a page-locked one,
+    its device twin receives every batch in a single copy, and the `mpe_batch` pointers never
+    change.  `where` = 'pinned', 'host' or a device."""
+
+    FIELDS = (('frame_head_off', np.int32, 'F1'), ('frame_en_off', np.int32, 'F1'), ('slot_cam', np.int32, 'FV'),
+              ('slot_n', np.int32, 'FV'), ('head_cam', np.int32, 'H'), ('skeleton_index', np.int32, 'H'),
+              ('joint_mask', np.uint32, 'H'), ('tri_mask', np.uint32, 'H'), ('xy', np.float64, 'HJ2'), ('vp', np.float32, 'HJ2'))
+
+    def __init__(self, V, J, max_frames, max_heads, where):
+        import torch
+        self.V, self.J, self.max_frames, self.max_heads = V, J, int(max_frames), int(max_heads)
+        count = {'F1': max_frames + 1, 'FV': max_frames * V, 'H': max_heads, 'HJ2': max_heads * J * 2}
+        self.offsets = {}
+        off = 0
+        for name, dt, kind in self.FIELDS:
+            n = int(count[kind])
+            self.offsets[name] = (off, n, dt)
+            off += (n * np.dtype(dt).itemsize + 255) // 256 * 256
+        self.nbytes = off
+        if where == 'pinned':
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8).pin_memory()
+        elif where == 'host':
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8)
+        else:
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=where)
+
+    def ptr(self, name):
+        return self.buf.data_ptr() + self.offsets[name][0]
+
+    def view(self, name, n):
+        """Host arenas: numpy view of the first n elements of an array (no copy)."""
+        off, _, dt = self.offsets[name]
+        return self.buf.numpy()[off: off + n * np.dtype(dt).itemsize].view(dt)
+
+
+def pack_json_into(text, params, arena, frame_start=0, frame_step=1, max_frames=0, n_threads=0):
+    """Native packer straight into a host CapacityArena (page-locked for the production path):
+    returns a PackedBatch whose arrays are VIEWS of the arena (valid until the arena is packed into
+    again)."""
+    import ctypes as C
+
+    from . import lib as L
+    lib = L.load()
+    if isinstance(text, str):
+        text = text.encode()
+    sm = list(params.used_cameras_skeleton_matching)
+    V, J = len(sm), len(params.joint_list)
+    assert arena.V == V and arena.J == J
+    names = (C.c_char_p * V)(*[c.encode() for c in sm])
+    dst = L.mpe_pack_dst()
+    dst.max_frames, dst.max_heads = arena.max_frames, arena.max_heads
+    for name, _, _ in CapacityArena.FIELDS:
+        setattr(dst, name, C.c_void_p(arena.ptr(name)))
+    nf, nh, ne = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib.mpe_pack_json_into(text, len(text), names, V, J, frame_start, frame_step, max_frames, n_threads, C.byref(dst),
+                                C.byref(nf), C.byref(nh), C.byref(ne))
+    if rc != 0:
+        raise ValueError('mpe_pack_json_into: %s' % lib.mpe_pack_last_error().decode())
+    B, H = nf.value, nh.value
+    pb = PackedBatch(V, J)
+    pb.n_frames = B
+    pb.frame_head_off = arena.view('frame_head_off', B + 1)
+    pb.frame_en_off = arena.view('frame_en_off', B + 1)
+    pb.slot_cam = arena.view('slot_cam', B * V).reshape(B, V)
+    pb.slot_n = arena.view('slot_n', B * V).reshape(B, V)
+    pb.head_cam = arena.view('head_cam', H)
+    pb.skeleton_index = arena.view('skeleton_index', H)
+    pb.joint_mask = arena.view('joint_mask', H)
+    pb.tri_mask = arena.view('tri_mask', H)
+    pb.xy = arena.view('xy', H * J * 2).reshape(H, J, 2)
+    pb.vp = arena.view('vp', H * J * 2).reshape(H, J, 2)
+    return pb
+
+
 class DeviceBatch:
     def __init__(self, pb, device, arena=None):
         """arena = None: nine independent device tensors uploaded from pageable numpy arrays
@@ -122,6 +198,12 @@ class DeviceBatch:
             for name, _ in ARRAYS:
                 setattr(s, 'd_' + name, C.c_void_p(arena.ptr(name)))
         self.struct = s
+
+    def rebind(self, pb):
+        """Capacity arenas: the same device buffer now holds another batch (sizes only change)."""
+        self.host = pb
+        self.struct.n_frames, self.struct.n_heads, self.struct.n_edge_nodes = pb.n_frames, pb.n_heads, pb.n_edge_nodes
+        return self
 
     def upload(self, pinned):
         """One H2D copy of the whole batch from a pinned BatchArena of the same layout, on the

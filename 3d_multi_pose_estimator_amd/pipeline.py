@@ -11,7 +11,7 @@ import torch
 
 from . import lib as L
 from .calibration import Calibration
-from .packing import DeviceBatch, PackedBatch, pack_frames, pack_json
+from .packing import CapacityArena, DeviceBatch, PackedBatch, pack_frames, pack_json, pack_json_into
 
 
 def _f32p(a):
@@ -129,6 +129,73 @@ class Engine:
     def pack_json(self, text, frame_start=0, frame_step=1, max_frames=0, n_threads=0):
         """Native (C++) packer: JSON text of a list of frames -> PackedBatch."""
         return pack_json(text, self.params, frame_start, frame_step, max_frames, n_threads)
+
+    def stream_json(self, text, chunk_frames=None, mode='mlp', frame_step=1, n_threads=0):
+        """Frame JSON (bytes, the reference's wire format) -> 3D poses, chunk by chunk, with the
+        host side off the critical path: the native packer parses chunk i+1 straight into a
+        page-locked arena (worker thread; the C call releases the GIL) while chunk i is copied to
+        the device in ONE transfer and runs mpe_match_batch + the 3D stage; results come back into
+        page-locked memory.  Yields (PackedBatch view, poses [B,Pcap,J,3], n_persons [B]) per chunk;
+        the views and the result arrays are reused two chunks later."""
+        from concurrent.futures import ThreadPoolExecutor
+        if isinstance(text, str):
+            text = text.encode()
+        B = int(chunk_frames or self.max_frames)
+        if B > self.max_frames:
+            raise ValueError('chunk of %d frames exceeds max_frames=%d' % (B, self.max_frames))
+        H = B * self.hpf
+        host = [CapacityArena(self.V, self.J, B, H, 'pinned') for _ in range(2)]
+        dev = [CapacityArena(self.V, self.J, B, H, self.device) for _ in range(2)]
+        dbs = [None, None]
+        out_dt = torch.float32 if mode == 'mlp' else torch.float64
+        out = [(torch.empty((B, self.pcap, self.J, 3), dtype=out_dt).pin_memory(),
+                torch.empty((B,), dtype=torch.int32).pin_memory()) for _ in range(2)]
+        uploaded = [torch.cuda.Event() for _ in range(2)]
+        done = [torch.cuda.Event() for _ in range(2)]
+        pool = ThreadPoolExecutor(1)
+
+        def parse(i):
+            return pack_json_into(text, self.params, host[i & 1], frame_start=i * B * frame_step, frame_step=frame_step,
+                                  max_frames=B, n_threads=n_threads)
+        try:
+            fut = pool.submit(parse, 0)
+            i = 0
+            pending = None                                  # (slot, pb) whose results are still in flight
+            while True:
+                pb = fut.result()
+                if pb.n_frames == 0:
+                    break
+                k = i & 1
+                self.check_capacity(pb)
+                # arrays of the views are exact-size; keep a private copy of the offsets the caller may read
+                if dbs[k] is None:
+                    dbs[k] = DeviceBatch(pb, self.device, arena=dev[k])
+                db = dbs[k].rebind(pb)
+                dev[k].buf.copy_(host[k].buf, non_blocking=True)
+                uploaded[k].record()
+                _, persons, n_persons = self.match(db, want_scores=False)
+                poses = (self.mlp3d(db, persons, n_persons) if mode == 'mlp' else self.triangulate(db, persons, n_persons))[0]
+                out[k][0][:pb.n_frames].copy_(poses, non_blocking=True)
+                out[k][1][:pb.n_frames].copy_(n_persons, non_blocking=True)
+                done[k].record()
+                last = pb.n_frames < B
+                if pending is not None:
+                    pk, ppb = pending
+                    done[pk].synchronize()
+                    yield ppb, out[pk][0][:ppb.n_frames].numpy(), out[pk][1][:ppb.n_frames].numpy()
+                pending = (k, pb)
+                if last:
+                    break
+                # the other host arena may be parsed into again once ITS upload has completed
+                # (that was chunk i-1, whose results were just handed out)
+                fut = pool.submit(parse, i + 1)
+                i += 1
+            if pending is not None:
+                pk, ppb = pending
+                done[pk].synchronize()
+                yield ppb, out[pk][0][:ppb.n_frames].numpy(), out[pk][1][:ppb.n_frames].numpy()
+        finally:
+            pool.shutdown(wait=True)
 
     def to_device(self, pb):
         if isinstance(pb, DeviceBatch):

@@ -245,6 +245,23 @@ int mpe_pack_json(const char *json, size_t len, const char *const *camera_names,
                   int32_t n_joints, int32_t frame_start, int32_t frame_step, int32_t max_frames,
                   int32_t n_threads, mpe_packed **out);
 int mpe_packed_view(const mpe_packed *pk, mpe_packed_arrays *view);
+/* The same parse straight into caller-provided arrays -- e.g. views of ONE page-locked buffer
+ * that then travels to the device in a single copy (no intermediate host copies).  Capacities
+ * max_frames / max_heads are the caller's array sizes: frame_head_off / frame_en_off hold
+ * max_frames + 1 entries, slot_cam / slot_n max_frames * n_cameras, the per-head arrays max_heads
+ * (xy / vp max_heads * n_joints * 2).  At most min(max_frames argument, dst->max_frames) frames are
+ * parsed; MPE_ERR_CAPACITY if their skeletons exceed dst->max_heads. */
+typedef struct {
+    int32_t max_frames, max_heads;
+    int32_t *frame_head_off, *frame_en_off, *slot_cam, *slot_n, *head_cam, *skeleton_index;
+    uint32_t *joint_mask, *tri_mask;
+    double *xy;
+    float *vp;
+} mpe_pack_dst;
+int mpe_pack_json_into(const char *json, size_t len, const char *const *camera_names, int32_t n_cameras,
+                       int32_t n_joints, int32_t frame_start, int32_t frame_step, int32_t max_frames,
+                       int32_t n_threads, const mpe_pack_dst *dst, int32_t *n_frames, int32_t *n_heads,
+                       int32_t *n_edge_nodes);
 void mpe_packed_free(mpe_packed *pk);
 const char *mpe_pack_last_error(void);
 

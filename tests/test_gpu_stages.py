@@ -379,3 +379,48 @@ def test_attention_paths_give_identical_bits(monkeypatch):
             assert np.array_equal(sc, ref[0]) and np.array_equal(sh, ref[1]), key
     finally:
         eng.close()
+
+
+def test_native_packer_into_pinned_arena_feeds_the_device_path():
+    """f1: frame JSON -> mpe_pack_json_into (page-locked capacity arena) -> ONE H2D copy -> match:
+    persons equal the reference's (golden fixtures), and Engine.stream_json (parse of chunk i+1
+    overlapped with the device work of chunk i) gives bit-identical poses to the Python-packed path."""
+    onp = oracle()
+    packing = pkg('packing')
+    e = env('panoptic')
+    eng = engine_for('panoptic')
+    names = ['c2_5x4_clean', 'c2_5x4_messy', 'c2_5x4_reordered', 'c2_3x2', 'c4_5x10', 'c1_2view_1person']
+    frames, want = [], []
+    for name in names:
+        arr, fr = load_case(name)
+        for n, f in enumerate(fr):
+            frames.append(onp.processed_input(f))
+            want.append(arr['f%d_persons' % n])
+    text = json.dumps(frames).encode()
+    pinned = packing.CapacityArena(eng.V, eng.J, 4, 4 * eng.hpf, 'pinned')
+    dev = packing.CapacityArena(eng.V, eng.J, 4, 4 * eng.hpf, eng.device)
+    got = []
+    for start in range(0, len(frames), 4):
+        pb = packing.pack_json_into(text, e.params, pinned, frame_start=start, max_frames=4)
+        eng.check_capacity(pb)
+        db = packing.DeviceBatch(pb, eng.device, arena=dev)
+        dev.buf.copy_(pinned.buf, non_blocking=True)
+        _, persons, n_persons = eng.match(db)
+        persons, n_persons = persons.cpu().numpy(), n_persons.cpu().numpy()
+        got += [persons[f, :n_persons[f]] for f in range(pb.n_frames)]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    # streaming form against the batch form
+    ref_poses, ref_n = [], []
+    for start in range(0, len(frames), 4):
+        db = eng.to_device(eng.pack(frames[start:start + 4]))
+        _, persons, n_persons = eng.match(db)
+        ref_poses.append(eng.mlp3d(db, persons, n_persons)[0].cpu().numpy())
+        ref_n.append(n_persons.cpu().numpy())
+    chunks = list((poses.copy(), n.copy()) for _, poses, n in eng.stream_json(text, chunk_frames=4, mode='mlp'))
+    assert len(chunks) == len(ref_poses)
+    for (poses, n), rp, rn in zip(chunks, ref_poses, ref_n):
+        assert np.array_equal(n, rn)
+        for f in range(len(n)):
+            assert np.array_equal(poses[f, :n[f]], rp[f, :n[f]])
