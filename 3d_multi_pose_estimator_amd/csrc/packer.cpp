@@ -402,39 +402,83 @@ bool parse_frame(const char *b, const char *e, const std::vector<std::string> &c
     return false;
 }
 
-// extents of the elements of the top-level array (bracket depth with string awareness)
-bool split_frames(const char *b, const char *e, std::vector<std::pair<const char *, const char *>> *out, std::string *err) {
-    const char *p = b;
-    while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
-    if (p >= e) { *err = "empty document"; return false; }
-    if (*p == '{') {            // a single frame
-        out->push_back({p, e});
+// Extents of the elements of the top-level array: a RESUMABLE scan (bracket depth with string
+// awareness).  Most of a frame's bytes sit inside the per-camera JSON strings (the skeleton lists
+// are JSON inside JSON), so inside a string the scanner jumps from one quote / backslash to the next
+// with memchr instead of walking bytes.
+struct FrameScanner {
+    const char *b = nullptr, *e = nullptr, *p = nullptr;
+    int depth = 0;
+    bool started = false, finished = false, single = false;
+    const char *start = nullptr;
+    std::vector<std::pair<const char *, const char *>> ext;
+    std::string err;
+
+    bool begin(const char *b_, const char *e_) {
+        b = p = b_;
+        e = e_;
+        while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+        if (p >= e) { err = "empty document"; return false; }
+        if (*p == '{') {            // a single frame
+            ext.push_back({p, e});
+            finished = single = true;
+            return true;
+        }
+        if (*p != '[') { err = "top level must be a list of frames"; return false; }
+        ++p;
+        started = true;
         return true;
     }
-    if (*p != '[') { *err = "top level must be a list of frames"; return false; }
-    ++p;
-    int depth = 0;
-    bool in_str = false;
-    const char *start = nullptr;
-    for (; p < e; ++p) {
-        const char ch = *p;
-        if (in_str) {
-            if (ch == '\\') { ++p; continue; }
-            if (ch == '"') in_str = false;
-            continue;
+
+    // scan on until at least `want` frames are known or the list ends; false on malformed input
+    bool extend(size_t want) {
+        static const struct Special {
+            bool is[256] = {};
+            Special() { is[(unsigned char)'"'] = is[(unsigned char)'{'] = is[(unsigned char)'}'] = is[(unsigned char)'['] = is[(unsigned char)']'] = true; }
+        } special;
+        while (!finished && ext.size() < want) {
+            while (p < e && !special.is[(unsigned char)*p]) ++p;      // numbers, commas, blanks: nothing to track
+            if (p >= e) { err = "unterminated top-level list"; return false; }
+            const char ch = *p;
+            if (ch == '"') {
+                // skip the string: next quote that is not escaped
+                const char *q = p + 1;
+                for (;;) {
+                    const char *hit = static_cast<const char *>(memchr(q, '"', (size_t)(e - q)));
+                    if (!hit) { err = "unterminated string"; return false; }
+                    const char *bs = hit;               // count the backslashes in front of it
+                    while (bs > q && bs[-1] == '\\') --bs;
+                    q = hit + 1;
+                    if (((hit - bs) & 1) == 0) break;   // even number: the quote closes the string
+                }
+                p = q;
+                continue;
+            }
+            if (ch == '{' || ch == '[') {
+                if (depth == 0) start = p;
+                ++depth;
+            } else if (ch == '}' || ch == ']') {
+                if (depth == 0) {                       // end of the top-level list
+                    finished = true;
+                    break;
+                }
+                --depth;
+                if (depth == 0) ext.push_back({start, p + 1});
+            }
+            ++p;
         }
-        if (ch == '"') { in_str = true; continue; }
-        if (ch == '{' || ch == '[') {
-            if (depth == 0) start = p;
-            ++depth;
-        } else if (ch == '}' || ch == ']') {
-            if (depth == 0) return true;          // end of the top-level list
-            --depth;
-            if (depth == 0) out->push_back({start, p + 1});
-        }
+        return true;
     }
-    *err = "unterminated top-level list";
-    return false;
+};
+
+bool split_frames(const char *b, const char *e, std::vector<std::pair<const char *, const char *>> *out, std::string *err) {
+    FrameScanner sc;
+    if (!sc.begin(b, e) || !sc.extend((size_t)-1)) {
+        *err = sc.err;
+        return false;
+    }
+    *out = std::move(sc.ext);
+    return true;
 }
 
 }  // namespace
@@ -457,22 +501,30 @@ const char *mpe_pack_last_error(void) { return g_pack_error.c_str(); }
 // parse the selected frames (thread pool); on failure g_pack_error is set
 static int parse_selected(const char *json, size_t len, const char *const *camera_names, int32_t n_cameras, int32_t n_joints,
                           int32_t frame_start, int32_t frame_step, int32_t max_frames, int32_t n_threads,
-                          std::vector<FrameOut> *fo_out) {
-    if (!json || !camera_names || n_cameras < 1 || n_cameras > MPE_MAX_CAMERAS || n_joints < 1 || n_joints > MPE_MAX_JOINTS ||
+                          std::vector<FrameOut> *fo_out, FrameScanner *index = nullptr) {
+    if ((!json && !index) || !camera_names || n_cameras < 1 || n_cameras > MPE_MAX_CAMERAS || n_joints < 1 || n_joints > MPE_MAX_JOINTS ||
         frame_step < 1 || frame_start < 0) {
         g_pack_error = "mpe_pack_json: bad argument";
         return MPE_ERR_INVALID;
     }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::string> cams(camera_names, camera_names + n_cameras);
-    std::vector<std::pair<const char *, const char *>> ext;
-    {
+    std::vector<std::pair<const char *, const char *>> own;
+    if (index) {
+        // scan only as far as this window needs (the scanner resumes where it stopped)
+        const size_t want = max_frames > 0 ? (size_t)frame_start + (size_t)(max_frames - 1) * frame_step + 1 : (size_t)-1;
+        if (!index->extend(want)) {
+            g_pack_error = index->err;
+            return MPE_ERR_INVALID;
+        }
+    } else {
         std::string err;
-        if (!split_frames(json, json + len, &ext, &err)) {
+        if (!split_frames(json, json + len, &own, &err)) {
             g_pack_error = err;
             return MPE_ERR_INVALID;
         }
     }
+    const std::vector<std::pair<const char *, const char *>> &ext = index ? index->ext : own;
     std::vector<std::pair<const char *, const char *>> sel;
     for (size_t i = (size_t)frame_start; i < ext.size(); i += (size_t)frame_step) {
         if (max_frames > 0 && (int32_t)sel.size() >= max_frames) break;
@@ -604,6 +656,58 @@ int mpe_pack_json_into(const char *json, size_t len, const char *const *camera_n
     for (const FrameOut &f : fo) H += f.heads.size();
     if (H > (size_t)dst->max_heads) {
         g_pack_error = "mpe_pack_json_into: " + std::to_string(H) + " skeletons exceed the destination's max_heads = " +
+                       std::to_string(dst->max_heads);
+        return MPE_ERR_CAPACITY;
+    }
+    assemble(fo, n_cameras, n_joints, dst->frame_head_off, dst->frame_en_off, dst->slot_cam, dst->slot_n, dst->head_cam,
+             dst->skeleton_index, dst->joint_mask, dst->tri_mask, dst->xy, dst->vp);
+    *n_frames = (int32_t)fo.size();
+    *n_heads = (int32_t)H;
+    *n_edge_nodes = dst->frame_en_off[fo.size()];
+    return MPE_OK;
+}
+
+struct mpe_json_index {
+    FrameScanner sc;
+};
+
+int mpe_json_index_create(const char *json, size_t len, mpe_json_index **out) {
+    if (!json || !out) {
+        g_pack_error = "mpe_json_index_create: bad argument";
+        return MPE_ERR_INVALID;
+    }
+    *out = nullptr;
+    mpe_json_index *ix = new (std::nothrow) mpe_json_index();
+    if (!ix) return MPE_ERR_NOMEM;
+    if (!ix->sc.begin(json, json + len)) {
+        g_pack_error = ix->sc.err;
+        delete ix;
+        return MPE_ERR_INVALID;
+    }
+    *out = ix;
+    return MPE_OK;
+}
+
+void mpe_json_index_free(mpe_json_index *ix) { delete ix; }
+
+int mpe_pack_indexed_into(mpe_json_index *ix, const char *const *camera_names, int32_t n_cameras, int32_t n_joints,
+                          int32_t frame_start, int32_t frame_step, int32_t max_frames, int32_t n_threads,
+                          const mpe_pack_dst *dst, int32_t *n_frames, int32_t *n_heads, int32_t *n_edge_nodes) {
+    if (!ix || !dst || !n_frames || !n_heads || !n_edge_nodes || !dst->frame_head_off || !dst->frame_en_off || !dst->slot_cam ||
+        !dst->slot_n || !dst->head_cam || !dst->skeleton_index || !dst->joint_mask || !dst->tri_mask || !dst->xy || !dst->vp ||
+        dst->max_frames < 1 || dst->max_heads < 1) {
+        g_pack_error = "mpe_pack_indexed_into: bad argument";
+        return MPE_ERR_INVALID;
+    }
+    if (max_frames <= 0 || max_frames > dst->max_frames) max_frames = dst->max_frames;
+    std::vector<FrameOut> fo;
+    const int rc = parse_selected(nullptr, 0, camera_names, n_cameras, n_joints, frame_start, frame_step, max_frames, n_threads, &fo,
+                                  &ix->sc);
+    if (rc) return rc;
+    size_t H = 0;
+    for (const FrameOut &f : fo) H += f.heads.size();
+    if (H > (size_t)dst->max_heads) {
+        g_pack_error = "mpe_pack_indexed_into: " + std::to_string(H) + " skeletons exceed the destination's max_heads = " +
                        std::to_string(dst->max_heads);
         return MPE_ERR_CAPACITY;
     }

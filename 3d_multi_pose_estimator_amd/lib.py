@@ -107,6 +107,11 @@ SYMBOLS = {
     'mpe_pack_json_into': (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.POINTER(mpe_pack_dst), C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'mpe_json_index_create': (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    'mpe_json_index_free': (None, [C.c_void_p]),
+    'mpe_pack_indexed_into': (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.POINTER(mpe_pack_dst), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'mpe_packed_free': (None, [C.c_void_p]),
     'mpe_pack_last_error': (C.c_char_p, []),
     'mpe_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),

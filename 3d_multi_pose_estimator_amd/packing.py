@@ -129,14 +129,38 @@ class CapacityArena:
         return self.buf.numpy()[off: off + n * np.dtype(dt).itemsize].view(dt)
 
 
+class JsonIndex:
+    """Resumable frame index of one JSON document (mpe_json_index): windows of the document are
+    packed without scanning it again.  Keeps the bytes alive."""
+
+    def __init__(self, text):
+        import ctypes as C
+
+        from . import lib as L
+        self.lib = L.load()
+        self.text = text.encode() if isinstance(text, str) else text
+        self.handle = C.c_void_p()
+        if self.lib.mpe_json_index_create(self.text, len(self.text), C.byref(self.handle)) != 0:
+            raise ValueError('mpe_json_index_create: %s' % self.lib.mpe_pack_last_error().decode())
+
+    def close(self):
+        if self.handle:
+            self.lib.mpe_json_index_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
 def pack_json_into(text, params, arena, frame_start=0, frame_step=1, max_frames=0, n_threads=0):
     """Native packer straight into a host CapacityArena (page-locked for the production path):
     returns a PackedBatch whose arrays are VIEWS of the arena (valid until the arena is packed into
-    again)."""
+    again).  `text` = bytes / str, or a JsonIndex of a document that is consumed in windows."""
     import ctypes as C
 
     from . import lib as L
     lib = L.load()
+    index = text if isinstance(text, JsonIndex) else None
     if isinstance(text, str):
         text = text.encode()
     sm = list(params.used_cameras_skeleton_matching)
@@ -148,8 +172,12 @@ def pack_json_into(text, params, arena, frame_start=0, frame_step=1, max_frames=
     for name, _, _ in CapacityArena.FIELDS:
         setattr(dst, name, C.c_void_p(arena.ptr(name)))
     nf, nh, ne = C.c_int32(), C.c_int32(), C.c_int32()
-    rc = lib.mpe_pack_json_into(text, len(text), names, V, J, frame_start, frame_step, max_frames, n_threads, C.byref(dst),
-                                C.byref(nf), C.byref(nh), C.byref(ne))
+    if index is not None:
+        rc = lib.mpe_pack_indexed_into(index.handle, names, V, J, frame_start, frame_step, max_frames, n_threads, C.byref(dst),
+                                       C.byref(nf), C.byref(nh), C.byref(ne))
+    else:
+        rc = lib.mpe_pack_json_into(text, len(text), names, V, J, frame_start, frame_step, max_frames, n_threads, C.byref(dst),
+                                    C.byref(nf), C.byref(nh), C.byref(ne))
     if rc != 0:
         raise ValueError('mpe_pack_json_into: %s' % lib.mpe_pack_last_error().decode())
     B, H = nf.value, nh.value

@@ -11,7 +11,7 @@ import torch
 
 from . import lib as L
 from .calibration import Calibration
-from .packing import CapacityArena, DeviceBatch, PackedBatch, pack_frames, pack_json, pack_json_into
+from .packing import CapacityArena, DeviceBatch, JsonIndex, PackedBatch, pack_frames, pack_json, pack_json_into
 
 
 def _f32p(a):
@@ -153,9 +153,10 @@ class Engine:
         uploaded = [torch.cuda.Event() for _ in range(2)]
         done = [torch.cuda.Event() for _ in range(2)]
         pool = ThreadPoolExecutor(1)
+        index = JsonIndex(text)                 # the document is scanned once, window by window
 
         def parse(i):
-            return pack_json_into(text, self.params, host[i & 1], frame_start=i * B * frame_step, frame_step=frame_step,
+            return pack_json_into(index, self.params, host[i & 1], frame_start=i * B * frame_step, frame_step=frame_step,
                                   max_frames=B, n_threads=n_threads)
         try:
             fut = pool.submit(parse, 0)
@@ -196,6 +197,7 @@ class Engine:
                 yield ppb, out[pk][0][:ppb.n_frames].numpy(), out[pk][1][:ppb.n_frames].numpy()
         finally:
             pool.shutdown(wait=True)
+            index.close()
 
     def to_device(self, pb):
         if isinstance(pb, DeviceBatch):

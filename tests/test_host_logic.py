@@ -290,3 +290,31 @@ def test_projection_helpers_match_reference_formulas():
     h = torch.tensor([[2.0, 4.0], [6.0, 8.0], [2.0, 4.0]])
     assert torch.equal(peu.from_homogeneous(h), torch.tensor([[1.0, 1.0], [3.0, 2.0]]))
     assert torch.equal(peu.from_homogeneous2(h), torch.tensor([[1.0, 1.0], [3.0, 2.0], [1.0, 1.0]]))
+
+
+def test_json_index_windows_equal_one_shot(calib):
+    """mpe_json_index: a document consumed in windows (scanned once, resumably) packs to the same
+    arrays as the one-shot packer, including the last short window and a window past the end."""
+    import json
+    packing = pkg('packing')
+    if not os.path.exists(pkg('lib').LIB_PATH):
+        pytest.skip('library not built')
+    frames = []
+    for name in CASES:
+        frames += load_case(name)[1]
+    text = json.dumps(frames)
+    whole = packing.pack_json(text, calib.params)
+    V, J = whole.V, whole.J
+    arena = packing.CapacityArena(V, J, 4, 400, 'host')
+    ix = packing.JsonIndex(text)
+    h = 0
+    for start in range(0, len(frames) + 4, 4):
+        pb = packing.pack_json_into(ix, calib.params, arena, frame_start=start, max_frames=4)
+        assert pb.n_frames == max(0, min(4, len(frames) - start))
+        n = pb.n_heads
+        assert np.array_equal(pb.xy, whole.xy[h:h + n]) and np.array_equal(pb.vp, whole.vp[h:h + n])
+        assert np.array_equal(pb.head_cam, whole.head_cam[h:h + n]) and np.array_equal(pb.joint_mask, whole.joint_mask[h:h + n])
+        assert np.array_equal(pb.slot_n, whole.slot_n[start:start + 4])
+        h += n
+    assert h == whole.n_heads
+    ix.close()
