@@ -354,7 +354,8 @@ struct FrameTopo {
     int *base;    // [V * V] frame-local node id of the first edge-node of pair (p, q), p < q
 };
 
-__device__ __forceinline__ void build_topo(FrameTopo tp, const int32_t *__restrict__ sn, int V, int H, int t, int nthreads) {
+template <typename SN>
+__device__ __forceinline__ void build_topo(FrameTopo tp, SN sn, int V, int H, int t, int nthreads) {
     if (t == 0) {
         int acc = 0;
         for (int s = 0; s < V; ++s) {
@@ -377,8 +378,8 @@ __device__ __forceinline__ void build_topo(FrameTopo tp, const int32_t *__restri
 }
 
 // source node (frame-local id) of in-edge e of head v
-__device__ __forceinline__ int head_in_edge(const FrameTopo &tp, const int32_t *__restrict__ sn, int V, int v, int s,
-                                            int e) {
+template <typename SN>
+__device__ __forceinline__ int head_in_edge(const FrameTopo &tp, SN sn, int V, int v, int s, int e) {
     if (e == 0) return v;
     const int st = tp.start[s], ns = sn[s], i = v - st;
     int u = e - 1;
@@ -397,7 +398,7 @@ __device__ __forceinline__ int slot_of_head(const FrameTopo &tp, int V, int v) {
 
 // Weighted sum over the in-edges of a head destination, canonical order: eight accumulators, the
 // j-th over the in-edges e = j, j+8, ... in ascending order, combined as
-// ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)).  Eight independent chains keep four to eight row loads in flight
+// ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)).  Eight independent chains keep eight row loads in flight
 // (a head of the 23 x 10 rig has 221 in-edges); for the three in-edges of an edge-node the same
 // rule reads (v1*w1 + v2*w2) + v3*w3.  `row(e, out)` fetches VEC columns of the e-th source row,
 // `wt(e)` its softmax weight.
@@ -630,22 +631,33 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
 }
 
 // ---------------------------------------------------------------------------------------
-// Fused attention stage: one workgroup per (frame, attention head), for frames whose per-head
-// tables fit in LDS.  What lives in LDS is small: the a1/a2 coefficients of the frame's nodes for
-// this head (from the fc2 epilogue, or computed here in the canonical order when the GEMM did not
-// provide them), the pair table, the softmax weights, and the feature rows of the HEAD nodes only
-// (H x D' floats: they are gathered three times by every edge-node).  The edge-node rows -- 89 %
-// of the slice at 5x4 -- are used exactly once, so they stream global -> registers -> global: a
-// thread issues the 16-byte loads of its first PF items BEFORE the softmax phase and finds them in
-// registers after it.  ft2 is read once, the output written once.
+// Fused attention stage for frames whose head slice fits in LDS: one workgroup per
+// (frame, attention head).  It loads ft2[:, head, :] of the frame once (N x D' floats, dense
+// 16-byte chunks: every LDS access of the hot loops is a ds_read/write_b128), takes a1/a2 from the
+// fc2 epilogue (or computes them in the canonical order when the GEMM did not), and writes the
+// activated output slice -- ft2 is read once and nothing else touches HBM.
 // ---------------------------------------------------------------------------------------
-constexpr int FUSED_PF = 8;      // row chunks a thread has in flight across the softmax phase
-
+// floats of the small LDS tables of k_gat_fused, rounded up to 1 KiB (the feature image follows)
 __host__ __device__ inline size_t fused_tables_floats(int hmax, int V, int n_cap, int m_cap) {
     const size_t deg = (size_t)hmax + 1;
-    const size_t n = 2 * (size_t)n_cap + 2 * hmax * deg + (size_t)m_cap * 4 + (V + 1) + (size_t)V * V;
-    return (n + 3) & ~(size_t)3;
+    const size_t n = 2 * (size_t)n_cap + 2 * hmax * deg + (size_t)m_cap * 4 + (V + 1) + (size_t)V * V + MPE_MAX_CAMERAS;
+    return (n + 255) & ~(size_t)255;
 }
+
+// Workgroup barrier that orders LDS traffic only: global loads and LDS-DMA pieces issued before it
+// stay in flight (a plain __syncthreads() carries a full workgroup fence, i.e. s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// The same without any fence: this wave's LDS operations are complete (lgkmcnt), outstanding
+// global loads / LDS-DMA pieces are NOT waited for.  Only for code whose LDS reads after the barrier
+// never touch bytes an in-flight DMA piece writes.
+__device__ __forceinline__ void lds_barrier_raw() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int FUSED_PIECES = 8;     // LDS-DMA pieces per wave of the overlapped staging (8 x 4 x 1 KiB = 32 KiB image)
 
 template <int VEC, int G>
 __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap, int m_cap,
@@ -655,10 +667,10 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
                                                    const int32_t *__restrict__ node_off,
                                                    const int32_t *__restrict__ en_pair,
                                                    const float *__restrict__ attn_l,
-                                                   const float *__restrict__ attn_r, AggArgs a) {
+                                                   const float *__restrict__ attn_r, AggArgs a, int overlap) {
 #pragma clang fp contract(off)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    extern __shared__ __attribute__((aligned(1024))) float s_dyn[];
     // XCD-aware order: workgroups with equal (id % 8) share an L2; the attention heads of one
     // frame read neighbouring 160-byte pieces of the same rows, so they go to the same XCD
     const int bid = blockIdx.x, nwg = gridDim.x;
@@ -676,6 +688,9 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
             for (int m = threadIdx.x; m < M; m += blockDim.x) a.out[(size_t)eb + m] = 0.f;
         return;
     }
+    const int Dp = D;                               // dense rows: 16-byte chunks when VEC = 4 (then D % 4 == 0)
+    // LDS: the small tables first, the feature image last (1 KiB aligned, 1 KiB of slack behind it:
+    // the last DMA piece of the image may run past its end)
     float *s_a1 = s_dyn;                            // [n_cap]
     float *s_a2 = s_a1 + n_cap;                     // [n_cap]
     float *s_wh = s_a2 + n_cap;                     // [hmax][max_deg] softmax weights of heads
@@ -685,59 +700,115 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     FrameTopo tp;
     tp.start = reinterpret_cast<int *>(s_wen + (size_t)m_cap * 3);                  // [V + 1]
     tp.base = tp.start + V + 1;                     // [V * V]
-    float *s_fh = s_dyn + fused_tables_floats(max_deg - 1, V, n_cap, m_cap);        // [hmax][D] rows of the head nodes
-    // without the fc2 epilogue's coefficients the whole slice is needed once for a1/a2: it then
-    // goes through LDS as well (image behind the head rows; the launcher sizes LDS for it)
-    float *s_ft = s_fh;                             // [n_cap][D] in that case, head rows first
-    const int t = threadIdx.x;
+    int *s_sn = tp.base + V * V;                    // [V] heads per camera slot of this frame
+    float *s_ft = s_dyn + fused_tables_floats(max_deg - 1, V, n_cap, m_cap);         // [n_cap][Dp]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool l0 = a.en_const_ft2 != nullptr;
     const int c0 = hh * D;
     const int DV = D / VEC;
     const int32_t *sn = slot_n + (size_t)f * V;
-    const size_t row0 = (size_t)(l0 ? hb : nb);     // first row of the frame in a.ft2 / a.a12
 
-    auto row_chunk = [&](int node, int d, float *v) {
-        if (l0 && node >= H) ld_ftv<VEC>(a.en_const_ft2, (size_t)(c0 + d), 0, v);
-        else ld_ftv<VEC>(a.ft2, (row0 + node) * a.ld + c0 + d, a.ft_half, v);
-    };
-
-    // phase 1: head rows (or, without coefficients, the whole slice) -> LDS; coefficients, pair table,
-    // topology scalars
-    const int n_lds = a.a12_ready ? H : N;
-    for (int i = t; i < n_lds * DV; i += blockDim.x) {
-        const int node = i / DV, d = (i - node * DV) * VEC;
-        float v[VEC];
-        row_chunk(node, d, v);
-        vecf o;
+    // phase 1: feature slice -> LDS (layer 0: ft2 holds head rows only, edge-nodes share one row),
+    // coefficients of this attention head, pair table, topology scalars.  fp32 rows of whole 16-byte
+    // chunks go straight into LDS (global_load_lds_dwordx4: a wave-instruction fills 1 KiB = 64
+    // consecutive chunks of the dense image, every lane with its own source address), so all of a
+    // thread's requests are in flight at once; other shapes are staged through registers, four
+    // requests at a time.
+    if (VEC == 4 && overlap) {
+        // Small frames with coefficients from the GEMM (the production case).  Every global load the
+        // softmax phase depends on is issued FIRST (inline asm: the compiler then adds no waits of its
+        // own), then exactly FUSED_PIECES image pieces per wave with no branch around them; vmcnt counts
+        // in issue order, so `s_waitcnt vmcnt(FUSED_PIECES)` means "my table values are here" while the
+        // image is still landing, and the softmax phase runs underneath it (raw barriers).
+        const int total = N * DV;
+        const size_t row0 = (size_t)(l0 ? hb : nb);
+        const int tn = t < N ? t : N - 1, tm = t < M ? t : M - 1, tv = t < V ? t : V - 1;
+        const float *pr_ = (l0 && tn >= H) ? a.en_const_a : a.a12 + (row0 + tn) * 32;
+        const float *p1 = pr_ + hh, *p2 = pr_ + 16 + hh;
+        const int32_t *pe = en_pair + 2 * (size_t)(eb + tm), *ps = sn + tv;
+        float r1, r2;
+        int e1, e2, sv;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r1) : "v"(p1) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r2) : "v"(p2) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(e1) : "v"(pe) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(e2) : "v"(pe) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(sv) : "v"(ps) : "memory");
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) o[k] = v[k];
-        *reinterpret_cast<vecf *>(s_ft + node * D + d) = o;
+        for (int u = 0; u < FUSED_PIECES; ++u) {
+            const int c0_ = wave * 64 + u * 256;
+            int c = c0_ + lane;
+            c = c < total ? c : total - 1;                   // pieces past the image repeat its last chunk (slack space)
+            const int node = c / DV, d = (c - node * DV) * 4;
+            const float *src = (l0 && node >= H) ? a.en_const_ft2 + (c0 + d) : a.ft2 + (row0 + node) * a.ld + c0 + d;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(s_ft + (size_t)c0_ * 4), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(r1), "+v"(r2), "+v"(e1), "+v"(e2), "+v"(sv)::"memory");
+        static_assert(FUSED_PIECES == 8, "the wait above counts the pieces");
+        if (t < N) {
+            s_a1[t] = r1;
+            s_a2[t] = r2;
+        }
+        if (t < M) s_pair[t] = (e1 << 16) | e2;
+        if (t < V) s_sn[t] = sv;
+        lds_barrier_raw();
+        build_topo(tp, s_sn, V, H, t, blockDim.x);
+        lds_barrier_raw();
+    } else {
+    if (VEC == 4 && !a.ft_half) {
+        const int total = N * DV;
+        for (int c0_ = wave * 64; c0_ < total; c0_ += 256) {
+            int c = c0_ + lane;
+            c = c < total ? c : total - 1;                   // tail lanes repeat the last chunk (same bytes, same slot)
+            const int node = c / DV, d = (c - node * DV) * 4;
+            const float *src = (l0 && node >= H) ? a.en_const_ft2 + (c0 + d)
+                                                  : a.ft2 + (size_t)((l0 ? hb : nb) + node) * a.ld + c0 + d;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(s_ft + (size_t)c0_ * 4), 16, 0, 0);
+        }
+    } else {
+        const int total = N * DV;
+        for (int i0 = t; i0 < total; i0 += 4 * blockDim.x) {
+            float v[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int i = i0 + u * blockDim.x;
+                i = i < total ? i : total - 1;
+                const int node = i / DV, d = (i - node * DV) * VEC;
+                if (l0 && node >= H) ld_ftv<VEC>(a.en_const_ft2, (size_t)(c0 + d), 0, v[u]);
+                else ld_ftv<VEC>(a.ft2, (size_t)((l0 ? hb : nb) + node) * a.ld + c0 + d, a.ft_half, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * blockDim.x;
+                if (i < total) {
+                    const int node = i / DV, d = (i - node * DV) * VEC;
+                    vecf o;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) o[k] = v[u][k];
+                    *reinterpret_cast<vecf *>(s_ft + node * Dp + d) = o;
+                }
+            }
+        }
     }
     if (a.a12_ready) {
         for (int node = t; node < N; node += blockDim.x) {
-            const float *r = (l0 && node >= H) ? a.en_const_a : a.a12 + (row0 + node) * 32;
+            const float *r = (l0 && node >= H) ? a.en_const_a : a.a12 + (size_t)((l0 ? hb : nb) + node) * 32;
             s_a1[node] = r[hh];
             s_a2[node] = r[16 + hh];
         }
     }
     for (int m = t; m < M; m += blockDim.x)
         s_pair[m] = (en_pair[2 * (size_t)(eb + m)] << 16) | en_pair[2 * (size_t)(eb + m) + 1];
-    build_topo(tp, sn, V, H, t, blockDim.x);
-    // the edge-node rows of this thread's first items: requested now, consumed in phase 3
-    const int total = N * DV;
-    float pf[FUSED_PF][VEC];
-#pragma unroll
-    for (int u = 0; u < FUSED_PF; ++u) {
-        int i = H * DV + t + u * 256;
-        i = i < total ? i : total - 1;               // tail threads repeat the last chunk (unused)
-        const int node = i / DV, d = (i - node * DV) * VEC;
-        row_chunk(node, d, pf[u]);
-    }
+    if (t < V) s_sn[t] = sn[t];
     __syncthreads();
+    build_topo(tp, s_sn, V, H, t, blockDim.x);
+    __syncthreads();
+    }
     if (!a.a12_ready) {
         // a1 = <ft, attn_l[head]>, a2 = <ft, attn_r[head]> (the GEMM epilogue did not provide them)
         for (int node = t; node < N; node += blockDim.x) {
-            const float *fv = s_ft + node * D;
+            const float *fv = s_ft + node * Dp;
             float x1 = 0.f, x2 = 0.f;
             if (D == 40) {
                 coef40([&](int d) { return fv[d]; }, attn_l + c0, attn_r + c0, hh & 1, x1, x2);
@@ -773,13 +844,13 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
         const int gl = t & (G - 1);
         for (int h = t / G; h < H; h += 256 / G) {
             const int s = slot_of_head(tp, V, h);
-            const int deg = 1 + H - sn[s];
+            const int deg = 1 + H - s_sn[s];
             float *w = s_wh + h * max_deg;
             int *src = s_src + h * max_deg;
             const float a2v = s_a2[h];
             float mx = -INFINITY;
             for (int e = gl; e < deg; e += G) {
-                const int u = head_in_edge(tp, sn, V, h, s, e);
+                const int u = head_in_edge(tp, s_sn, V, h, s, e);
                 src[e] = u;
                 float x = s_a1[u] + a2v;
                 x = x > 0.f ? x : x * a.alpha;
@@ -798,80 +869,63 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
         }
     }
     __syncthreads();
-    // phase 3a: edge-node destinations (three in-edges: h1, h2 from LDS, self from the prefetch)
-    auto en_item = [&](int i, const float *self) {
+    // phase 3: weighted sums in edge order, activation, store
+    const int first = (a.score_mode && !a.out_heads) ? H : 0;
+    for (int i = first * DV + t; i < N * DV; i += blockDim.x) {
         const int node = i / DV, d = (i - node * DV) * VEC;
-        const int m = node - H;
-        const int pr = s_pair[m];
-        const int h1 = pr >> 16, h2 = pr & 0xFFFF;
-        const float w1 = s_wen[m * 3 + 0], w2 = s_wen[m * 3 + 1], w3 = s_wen[m * 3 + 2];
-        const vecf f1 = *reinterpret_cast<const vecf *>(s_fh + h1 * D + d);
-        const vecf f2 = *reinterpret_cast<const vecf *>(s_fh + h2 * D + d);
         vecf o;
+        if (node >= H) {
+            const int m = node - H;
+            const int pr = s_pair[m];
+            const int h1 = pr >> 16, h2 = pr & 0xFFFF;
+            const float w1 = s_wen[m * 3 + 0], w2 = s_wen[m * 3 + 1], w3 = s_wen[m * 3 + 2];
+            const vecf f1 = *reinterpret_cast<const vecf *>(s_ft + h1 * Dp + d);
+            const vecf f2 = *reinterpret_cast<const vecf *>(s_ft + h2 * Dp + d);
+            const vecf f3 = *reinterpret_cast<const vecf *>(s_ft + node * Dp + d);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            float acc = f1[k] * w1;
-            acc = acc + f2[k] * w2;
-            acc = acc + self[k] * w3;
-            o[k] = agg_activate(acc, a.out_mode, a.out_slope);
-        }
-        if (a.score_mode) a.out[(size_t)eb + m] = o[0];
-        else *reinterpret_cast<vecf *>(a.out + (size_t)(nb + node) * a.ld_out + c0 + d) = o;
-    };
-#pragma unroll
-    for (int u = 0; u < FUSED_PF; ++u) {
-        const int i = H * DV + t + u * 256;
-        if (i < total) en_item(i, pf[u]);
-    }
-    for (int i = H * DV + t + FUSED_PF * 256; i < total; i += 256) {     // frames larger than PF x 256 chunks
-        const int node = i / DV, d = (i - node * DV) * VEC;
-        float self[VEC];
-        row_chunk(node, d, self);
-        en_item(i, self);
-    }
-    // phase 3b: head destinations (in-degree 1 + heads of the other cameras)
-    if (!a.score_mode || a.out_heads) {
-        for (int i = t; i < H * DV; i += 256) {
-            const int node = i / DV, d = (i - node * DV) * VEC;
+            for (int k = 0; k < VEC; ++k) {
+                float acc = f1[k] * w1;
+                acc = acc + f2[k] * w2;
+                acc = acc + f3[k] * w3;
+                o[k] = agg_activate(acc, a.out_mode, a.out_slope);
+            }
+        } else {
             const int s = slot_of_head(tp, V, node);
-            const int deg = 1 + H - sn[s];
+            const int deg = 1 + H - s_sn[s];
             const int *src = s_src + node * max_deg;
             const float *w = s_wh + node * max_deg;
             float acc[VEC];
             weighted_sum8<VEC>(
                 deg,
                 [&](int e, float *fv) {
-                    const int u = src[e];
-                    if (u < H) {
-                        const vecf x = *reinterpret_cast<const vecf *>(s_fh + u * D + d);
+                    const vecf x = *reinterpret_cast<const vecf *>(s_ft + src[e] * Dp + d);
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) fv[k] = x[k];
-                    } else {
-                        row_chunk(u, d, fv);
-                    }
+                    for (int k = 0; k < VEC; ++k) fv[k] = x[k];
                 },
                 [&](int e) { return w[e]; }, acc);
-            if (a.score_mode) {
-                a.out_heads[(size_t)hb + node] = agg_activate(acc[0], a.out_mode, a.out_slope);
-            } else {
-                vecf o;
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) o[k] = agg_activate(acc[k], a.out_mode, a.out_slope);
-                *reinterpret_cast<vecf *>(a.out + (size_t)(nb + node) * a.ld_out + c0 + d) = o;
-            }
+            for (int k = 0; k < VEC; ++k) o[k] = agg_activate(acc[k], a.out_mode, a.out_slope);
+        }
+        if (a.score_mode) {
+            if (node >= H) a.out[(size_t)eb + (node - H)] = o[0];
+            else a.out_heads[(size_t)hb + node] = o[0];
+        } else {
+            *reinterpret_cast<vecf *>(a.out + (size_t)(nb + node) * a.ld_out + c0 + d) = o;
         }
     }
 }
 
-// LDS bytes of k_gat_fused for frames of up to `hmax` heads: tables + head rows, or + the whole
-// slice when the coefficients are not provided by the GEMM
-static size_t fused_lds_bytes(int hmax, int V, int out_dim, bool whole_slice, int *n_cap, int *m_cap) {
+// LDS bytes of k_gat_fused for frames of up to `hmax` heads
+static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_cap) {
     const int mc = hmax * hmax * (V - 1) / (2 * V) + 1;
     const int nc = hmax + mc;
-    const size_t bytes = (fused_tables_floats(hmax, V, nc, mc) + (size_t)(whole_slice ? nc : hmax) * out_dim) * sizeof(float);
+    const int Dp = out_dim;
+    size_t image = (size_t)nc * Dp + 256;
+    if (image < (size_t)FUSED_PIECES * 1024) image = (size_t)FUSED_PIECES * 1024;      // overlapped staging issues whole pieces
+    const size_t bytes = (fused_tables_floats(hmax, V, nc, mc) + image) * sizeof(float);
     *n_cap = nc;
     *m_cap = mc;
-    return (bytes + 15) & ~(size_t)15;
+    return bytes;
 }
 
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
@@ -893,12 +947,16 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
                                 const int32_t *en_pair, const float *attn_l, const float *attn_r, float *a12,
                                 const AggArgs &a, int n_rows_ft2) {
     int n_cap, m_cap;
-    const size_t shm = fused_lds_bytes(max_heads_per_frame, V, a.out_dim, !a.a12_ready, &n_cap, &m_cap);
+    const size_t shm = fused_lds_bytes(max_heads_per_frame, V, a.out_dim, &n_cap, &m_cap);
     const bool no_fuse = getenv("MPE_NO_FUSED_ATTENTION") != nullptr;       // read per call: tests toggle it
     if (shm <= FUSED_LDS_LIMIT && !no_fuse && b.n_frames > 0) {
         const int vec = agg_vec(a);
         // lane-group width of the head softmax: the in-degree of a head is at most max_heads_per_frame
         const int grp = max_heads_per_frame + 1 <= 16 ? 16 : max_heads_per_frame + 1 <= 32 ? 32 : 64;
+        // overlapped staging: coefficients from the GEMM, fp32 rows of 16-byte chunks, tables of at most one
+        // entry per thread, image of at most FUSED_PIECES x 256 chunks
+        const int overlap = (vec == 4 && a.a12_ready && !a.ft_half && n_cap <= 256 && m_cap <= 256 &&
+                             n_cap * (a.out_dim / 4) <= FUSED_PIECES * 256 && !getenv("MPE_FUSED_NO_OVERLAP")) ? 1 : 0;
         const void *fn = nullptr;
 #define MPE_FUSED(V_, G_)                                                                                     \
     do {                                                                                                      \
@@ -909,7 +967,7 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
         }                                                                                                     \
         hipLaunchKernelGGL((k_gat_fused<V_, G_>), dim3(b.n_frames * a.heads), dim3(256), shm, s, V,            \
                            max_heads_per_frame + 1, n_cap, m_cap, b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, \
-                           node_off, en_pair, attn_l, attn_r, a);                                             \
+                           node_off, en_pair, attn_l, attn_r, a, overlap);                                    \
     } while (0)
 #define MPE_FUSED_G(V_)                     \
     do {                                    \
