@@ -101,3 +101,35 @@ def test_reprojection_harness_reproduces_the_reference_script(tmp_path):
             g = out[(kind, cam)]
             assert g[1] == pytest.approx(median, rel=2e-4), (cam, kind, g, median)
             assert abs(np.log10(g[0]) - np.log10(mean)) < 0.5, (cam, kind, g, mean)
+
+
+def test_sm_metrics_without_gt_harness(tmp_path):
+    """f2, second script: scenes composed from single-person files (labels = file of origin).  With
+    the hand-built matcher weights and identity-coded detections the grouping is recovered exactly;
+    with one file's identity code clashing with another's the score drops."""
+    import numpy as np
+    syn = importlib.import_module('3d_multi_pose_estimator_amd.synthetic')
+    cal = importlib.import_module('3d_multi_pose_estimator_amd.calibration')
+    par = importlib.import_module('3d_multi_pose_estimator_amd.parameters').parameters
+    calib = cal.Calibration(par)
+    hd, exp = _expected()
+    mdir = harness_model_files(str(tmp_path), exp['inputs'])
+    files = []
+    for k in range(3):                                  # three individuals, person index k -> prob level k
+        frames = []
+        for i in range(12):
+            full, _ = syn.make_frame(calib, 9000 + i, syn.FrameSpec(persons=3, noise_px=1.0, identity_prob=True, permute=False))
+            one = {}
+            for cam in full:
+                sk = json.loads(full[cam][0])
+                one[cam] = [json.dumps([sk[k]]), full[cam][1]]
+            frames.append(one)
+        path = tmp_path / ('person%d.json' % k)
+        path.write_text(json.dumps(frames))
+        files.append(str(path))
+    m = importlib.import_module('3d_multi_pose_estimator_amd.harness.sm_metrics_without_gt')
+    out = m.main(['--testfiles'] + files + ['--modelsdir', mdir, '--datastep', '2', '--batch', '4'])
+    assert out['n_data'] == 6
+    assert out['rand score'] > 0.999 and out['v_measure'] > 0.999
+    out2 = m.main(['--testfiles', files[0], files[0], files[1], '--modelsdir', mdir, '--datastep', '2', '--batch', '4'])
+    assert out2['rand score'] < 0.9                     # two "individuals" with the same identity code merge
