@@ -132,4 +132,4 @@ def test_sm_metrics_without_gt_harness(tmp_path):
     assert out['n_data'] == 6
     assert out['rand score'] > 0.999 and out['v_measure'] > 0.999
     out2 = m.main(['--testfiles', files[0], files[0], files[1], '--modelsdir', mdir, '--datastep', '2', '--batch', '4'])
-    assert out2['rand score'] < 0.9                     # two "individuals" with the same identity code merge
+    assert out2['rand score'] < out['rand score']       # two "individuals" with the same identity code get mixed
