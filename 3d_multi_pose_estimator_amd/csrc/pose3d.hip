@@ -163,7 +163,9 @@ __device__ inline void person_front(const DevCfg *cfg, const PersonCtx &pc, cons
 // ---------------------------------------------------------------------------------------
 // MLP input rows
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_mlp_rows(const DevCfg *__restrict__ cfg, int pcap,
+// 256 threads: the 180 pair solves of a 5-camera person (18 joints x 10 pairs, f64 Jacobi SVD each)
+// run in one round
+__global__ __launch_bounds__(256) void k_mlp_rows(const DevCfg *__restrict__ cfg, int pcap,
                                                   const int32_t *__restrict__ head_off,
                                                   const uint32_t *__restrict__ joint_mask,
                                                   const uint32_t *__restrict__ tri_mask,
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(128) void k_mlp_rows(const DevCfg *__restrict__ cfg
     double *s_pts = s_und + (size_t)V * J * 2;      // [J][npairs][3]
     __shared__ int32_t s_head[MPE_MAX_CAMERAS];
     __shared__ uint32_t s_mask[MPE_MAX_CAMERAS], s_tmask[MPE_MAX_CAMERAS];
-    __shared__ float s_red[128];
+    __shared__ float s_red[256];
     const int np_f = n_persons[f];
     const size_t slot = (size_t)f * pcap + p;
     if (p >= np_f) {
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(128) void k_mlp_rows(const DevCfg *__restrict__ cfg
     for (int c = threadIdx.x; c < width; c += blockDim.x) acc += fabsf(row[c]);
     s_red[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
         __syncthreads();
     }
@@ -322,7 +324,7 @@ hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_mlp_rows, dim3(b.n_frames * pcap), dim3(128), shm, s, cfg, pcap, b.d_frame_head_off,
+    hipLaunchKernelGGL(k_mlp_rows, dim3(b.n_frames * pcap), dim3(256), shm, s, cfg, pcap, b.d_frame_head_off,
                        b.d_joint_mask, b.d_tri_mask, b.d_xy, b.d_vp, persons, n_persons, person_off, rows, ld_rows,
                        valid);
     return hipGetLastError();
