@@ -332,14 +332,16 @@ def run_rank(args):
 def io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, timed, distributed, total):
     """SURVEY.md §8(d) metric as written: from compact 2D keypoints in host pinned memory to 3D
     poses back in host pinned memory.  Two buffer sets; the H2D of step i+1 and the D2H of step
-    i-1 run on a copy stream while step i computes."""
+    i-1 run on two copy streams while step i computes."""
     pinned = packing.BatchArena(pb, 'pinned').fill(pb)
     sets = []
     for _ in range(2):
         arena = packing.BatchArena(pb, device)
         sets.append({'db': packing.DeviceBatch(pb, device, arena=arena), 'h2d': torch.cuda.Event(),
                      'done': torch.cuda.Event(), 'd2h': torch.cuda.Event(), 'out': None, 'host': None})
-    copy_s = torch.cuda.Stream(device)
+    copy_s = torch.cuda.Stream(device)              # H2D of the next batch
+    back_s = torch.cuda.Stream(device)              # D2H of the previous results (its own stream: behind the
+                                                    # compute of step i it must not hold up the H2D of step i+1)
     comp_s = torch.cuda.current_stream(device)
     first = [True, True]
 
@@ -361,11 +363,11 @@ def io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, t
             b['host'] = (torch.empty(poses.shape, dtype=poses.dtype).pin_memory(),
                          torch.empty(n_persons.shape, dtype=n_persons.dtype).pin_memory())
         b['out'] = (poses, n_persons, persons)          # keep the tensors alive until their D2H is done
-        with torch.cuda.stream(copy_s):
-            copy_s.wait_event(b['done'])
+        with torch.cuda.stream(back_s):
+            back_s.wait_event(b['done'])
             b['host'][0].copy_(poses, non_blocking=True)
             b['host'][1].copy_(n_persons, non_blocking=True)
-            b['d2h'].record(copy_s)
+            b['d2h'].record(back_s)
         first[i & 1] = False
         return poses, n_persons
 
@@ -376,7 +378,7 @@ def io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, t
             'h2d_bytes_per_step': int(pinned.nbytes),
             'd2h_bytes_per_step': int(sum(t.numel() * t.element_size() for t in sets[0]['host'])),
             'what': 'packed batch in pinned host memory -> one H2D copy -> match + 3D stage -> D2H of poses and '
-                    'n_persons into pinned host memory; double-buffered on a copy stream'}
+                    'n_persons into pinned host memory; double-buffered, H2D and D2H on their own streams'}
 
 
 def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
