@@ -57,8 +57,8 @@ TRAFFIC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--frames', type=int, default=1000, help='frames per rank and step (weak scaling)')
     ap.add_argument('--total-frames', type=int, default=0,
                     help='strong scaling: this many frames per step in total, sharded over the ranks (configs[3]: 100000 with --persons 10)')

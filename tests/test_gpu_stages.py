@@ -424,3 +424,34 @@ def test_native_packer_into_pinned_arena_feeds_the_device_path():
         assert np.array_equal(n, rn)
         for f in range(len(n)):
             assert np.array_equal(poses[f, :n[f]], rp[f, :n[f]])
+
+
+def test_weights_can_be_set_twice_before_the_first_batch():
+    """mpe_set_gat_layer / mpe_set_mlp_layer called again for the same layer replace the first
+    upload (the old device copies are freed), and the workspace flags make a context whose
+    weights are complete only later usable: MPE_ERR_STATE first, normal results afterwards."""
+    onp = oracle()
+    L = pkg('lib')
+    e = env('panoptic')
+    sd, prm = e.gat
+    arr, frames = load_case('c2_5x4_clean')
+    eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=2, max_persons_per_camera=4)
+    try:
+        db = eng.to_device(eng.pack([onp.processed_input(frames[0])]))
+        with pytest.raises(L.MpeError) as ei:
+            eng.gat_scores(db)                           # no weights yet
+        assert ei.value.code == -3
+        wrong = {k: (v * 0.5).astype(np.float32) for k, v in sd.items()}
+        eng.load_gat(wrong, prm)
+        eng.load_gat(sd, prm)                            # second upload wins
+        eng.load_mlp({k: v * 2 for k, v in e.mlp.items()})
+        eng.load_mlp(e.mlp)
+        sc = eng.gat_scores(db).cpu().numpy()
+        H = db.n_heads
+        np.testing.assert_allclose(sc, arr['f0_scores'][H:], rtol=0, atol=2e-5)
+        y = eng.mlp_forward(torch.from_numpy(arr['f0_mlp_in']).cuda()).cpu().numpy()
+        np.testing.assert_allclose(y, arr['f0_mlp_out'], rtol=0, atol=2e-6)
+        with pytest.raises(L.MpeError):
+            eng.load_gat(sd, prm)                        # frozen after the first batch
+    finally:
+        eng.close()
