@@ -252,7 +252,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // MTT = MFMA row tiles per wave: 2 (128-row workgroup tile, 3 workgroups per CU) or 3 (192 rows, 2 per
 // CU: 12 % fewer staging requests per MFMA and 120 instead of 80 MFMAs per barrier).  A row's bits do
 // not depend on MTT (same k order, same chains).
-template <bool LEAKY, bool ACC64, int NTT, bool A12 = false, int MTT = 2, bool SCHED = false>
+template <bool LEAKY, bool ACC64, int NTT, bool A12 = false, int MTT = 2>
 __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 5 || MTT > 2) ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
                                                        const float *__restrict__ W, int ldw,
                                                        const float *__restrict__ bias, float *__restrict__ C,
@@ -381,7 +381,12 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
                                                  (lds_void *)(base + W_OFF + (wave + 4 * g) * 8 * ROWF), 16, 0, 0);
     };
 
-    auto compute = [&](int cur) {
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                       // own DMA landed (vmcnt 0) + everybody's, and everybody
+                                               // is done reading the other buffer
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const int cur = (kt & 1) * STAGE;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int co = hh ? c1 : c0;
@@ -407,78 +412,6 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
                     for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] += (double)acc[nt][mt][i];
                     acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-        }
-    };
-
-    issue(0, 0);
-    if constexpr (SCHED) {
-        // Experiment: the next stage's DMA pieces are spread between this stage's MFMAs instead of
-        // being issued as one burst behind the barrier (one basic block per stage: the last stage is
-        // peeled, every piece is unconditional -- waves 2,3 repeat the last weight group).
-        constexpr int NDMA = MTT * 2 + WPW;
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            __syncthreads();
-            const int cur = (kt & 1) * STAGE;
-            const int koff = (kt + 1) * GEMM_BK;
-            float *base = lds + ((kt + 1) & 1) * STAGE;
-            auto piece = [&](int i) {                      // i-th DMA piece of this wave for the next stage
-                if (i < MTT * 2) {
-                    __builtin_amdgcn_global_load_lds((glb_void *)(a_src[i] + koff),
-                                                     (lds_void *)(base + (wave * WROWS + i * 8) * ROWF), 16, 0, 0);
-                } else {
-                    const int g = i - MTT * 2;
-                    int grp = wave + 4 * g;
-                    grp = grp < WG ? grp : WG - 1;
-                    __builtin_amdgcn_global_load_lds((glb_void *)(w_src[g] + koff),
-                                                     (lds_void *)(base + W_OFF + grp * 8 * ROWF), 16, 0, 0);
-                }
-            };
-            int next_piece = 0;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int co = hh ? c1 : c0;
-                f32x4 af[MTT], wf[NTT];
-#pragma unroll
-                for (int mt = 0; mt < MTT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + co]);
-#pragma unroll
-                for (int nt = 0; nt < NTT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + co]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                    for (int nt = 0; nt < NTT; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < MTT; ++mt)
-                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (hh == 0) {                         // two pieces behind each group of MFMAs of the first half
-#pragma unroll
-                        for (int r = 0; r < 2; ++r)
-                            if (next_piece < NDMA) piece(next_piece++);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            static_assert(!SCHED || NDMA <= 8, "two pieces per MFMA group of the first half");
-            if (ACC64) {
-#pragma unroll
-                for (int nt = 0; nt < NTT; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MTT; ++mt) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] += (double)acc[nt][mt][i];
-                        acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-            }
-        }
-        __syncthreads();
-        compute(((nk - 1) & 1) * STAGE);
-    } else {
-        for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();                   // own DMA landed (vmcnt 0) + everybody's, and everybody
-                                               // is done reading the other buffer
-            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-            compute((kt & 1) * STAGE);
         }
     }
 
@@ -1034,11 +967,7 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
             hipLaunchKernelGGL((k_linear_dma<L_, A_, (N_) <= 5 ? (N_) : 5, false, 3>), dim3(ntm3 * ntn_), block,   \
                                dma_lds_bytes((N_) <= 5 ? (N_) : 5, 3), s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, \
                                k_pad, slope, ntn_, n_major, a_rows, c_rows);                                      \
-        } else if (sched && (N_) <= 5)                                                                            \
-            hipLaunchKernelGGL((k_linear_dma<L_, A_, (N_) <= 5 ? (N_) : 5, false, 2, true>), dim3(ntm * ntn_), block, \
-                               dma_lds_bytes(N_), s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, \
-                               n_major, a_rows, c_rows);                                                          \
-        else                                                                                                      \
+        } else                                                                                                    \
             hipLaunchKernelGGL((k_linear_dma<L_, A_, N_>), dim3(ntm * ntn_), block, dma_lds_bytes(N_), s, A, lda, W, ldw, \
                                bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows);         \
     } while (0)
@@ -1053,7 +982,6 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
         // 192-row workgroup tiles (3 MFMA row tiles per wave, 2 workgroups per CU): experiment switch
         static const int force_mt = getenv("MPE_GEMM_MT") ? atoi(getenv("MPE_GEMM_MT")) : 0;
         const bool tall = force_mt == 3 && !a_rows && !c_rows;
-        static const bool sched = getenv("MPE_GEMM_SCHED") != nullptr;      // experiment: DMA pieces spread between MFMAs
         const int ntm3 = (m_cap + 191) / 192;
         static PerDeviceFlag dma_attr;
         if (!dma_attr.test()) {
@@ -1081,11 +1009,7 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
                 hipLaunchKernelGGL((k_linear_dma<false, false, 5, true, 3>), dim3(ntm3 * ntn_), block, dma_lds_bytes(5, 3), s, A, lda,
                                    W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows,
                                    coef->attn_l, coef->attn_r, coef->a12);
-            } else if (sched && !acc64)
-                hipLaunchKernelGGL((k_linear_dma<false, false, 5, true, 2, true>), dim3(ntm * ntn_), block, dma_lds_bytes(5), s, A,
-                                   lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows,
-                                   coef->attn_l, coef->attn_r, coef->a12);
-            else if (acc64)
+            } else if (acc64)
                 hipLaunchKernelGGL((k_linear_dma<false, true, 5, true>), dim3(ntm * ntn_), block, dma_lds_bytes(5), s, A, lda, W,
                                    ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows, coef->attn_l,
                                    coef->attn_r, coef->a12);
