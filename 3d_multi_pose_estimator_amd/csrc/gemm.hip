@@ -249,11 +249,8 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // mirrored by coef40() in gat.hip for the paths that compute the coefficients elsewhere): lane
 // group q = 0..3 of the MFMA layout runs one fma chain over the features it owns in ascending
 // order, then (s_q + s_q^1) + (s_q^2 + s_q^3).
-// MTT = MFMA row tiles per wave: 2 (128-row workgroup tile, 3 workgroups per CU) or 3 (192 rows, 2 per
-// CU: 12 % fewer staging requests per MFMA and 120 instead of 80 MFMAs per barrier).  A row's bits do
-// not depend on MTT (same k order, same chains).
-template <bool LEAKY, bool ACC64, int NTT, bool A12 = false, int MTT = 2>
-__global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 5 || MTT > 2) ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
+template <bool LEAKY, bool ACC64, int NTT, bool A12 = false>
+__global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
                                                        const float *__restrict__ W, int ldw,
                                                        const float *__restrict__ bias, float *__restrict__ C,
                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
@@ -267,22 +264,20 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
                                                        int grp_stride = 0, long w_grp_stride = 0) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];   // 2 stages of (128 + 16 NTT) rows x 128 B
     constexpr int ROWF = 32;                   // floats per tile row (dense)
-    constexpr int BM_ = MTT * 64;              // activation rows per workgroup
-    constexpr int WROWS = MTT * 16;            // ... per wave
-    constexpr int W_OFF = BM_ * ROWF;          // weight rows follow the activation rows
-    constexpr int STAGE = (BM_ + NTT * 16) * ROWF;
+    constexpr int W_OFF = GEMM_BM * ROWF;      // weight rows follow the activation rows
+    constexpr int STAGE = (GEMM_BM + NTT * 16) * ROWF;
 
     int M = m_cap;
     if (d_m) {
         int dm = *d_m;
         M = dm < m_cap ? dm : m_cap;
     }
-    int ntm = (M + BM_ - 1) / BM_;
+    int ntm = (M + GEMM_BM - 1) / GEMM_BM;
     if (grp_count) {
         // grouped GEMM: group g multiplies its own rows (row list g) with its own weight matrix;
         // every 128-row tile belongs to one group, the device-side counts give the tile ranges
         ntm = 0;
-        for (int g = 0; g < n_grp; ++g) ntm += (grp_count[g] + BM_ - 1) / BM_;
+        for (int g = 0; g < n_grp; ++g) ntm += (grp_count[g] + GEMM_BM - 1) / GEMM_BM;
     }
     const int bid = blockIdx.x, nwg = ntm * ntn;
     if (bid >= nwg) return;
@@ -306,7 +301,7 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
     if (grp_count) {
         int g = 0, t0 = 0;
         for (;;) {
-            const int nt_g = (grp_count[g] + BM_ - 1) / BM_;
+            const int nt_g = (grp_count[g] + GEMM_BM - 1) / GEMM_BM;
             if (tm < t0 + nt_g || g == n_grp - 1) break;
             t0 += nt_g;
             ++g;
@@ -317,16 +312,16 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
         c_rows += (size_t)g * grp_stride;
         W += (size_t)g * w_grp_stride;
     }
-    const int m0 = tm * BM_, n0 = tn * BN;
+    const int m0 = tm * GEMM_BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int dr = lane >> 3, dp = lane & 7;          // DMA role: row within the 8-row group, chunk position
 
     // per-lane source pointers: 4 activation groups (rows 32w + 8g + dr), up to 3 weight groups
-    const float *a_src[MTT * 2];
+    const float *a_src[4];
 #pragma unroll
-    for (int g = 0; g < MTT * 2; ++g) {
-        const int row = wave * WROWS + g * 8 + dr;
+    for (int g = 0; g < 4; ++g) {
+        const int row = wave * 32 + g * 8 + dr;
         int grow = m0 + row;
         grow = grow < M ? grow : M - 1;
         if (a_rows) grow = a_rows[grow];           // gathered rows (grouped layer-0 GEMM)
@@ -345,19 +340,19 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
 
     const int fq = lane >> 4, fr = lane & 15;
     const int fsw = dma_swz(fr);
-    int a_rd[MTT], w_rd[NTT];
+    int a_rd[MT], w_rd[NTT];
 #pragma unroll
-    for (int mt = 0; mt < MTT; ++mt) a_rd[mt] = (wave * WROWS + mt * 16 + fr) * ROWF;
+    for (int mt = 0; mt < MT; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * ROWF;
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) w_rd[nt] = W_OFF + (nt * 16 + fr) * ROWF;
     const int c0 = ((fq * 2 + 0) ^ fsw) << 2, c1 = ((fq * 2 + 1) ^ fsw) << 2;
 
-    f32x4 acc[NTT][MTT];
-    double run[ACC64 ? NTT : 1][ACC64 ? MTT : 1][4];
+    f32x4 acc[NTT][MT];
+    double run[ACC64 ? NTT : 1][ACC64 ? MT : 1][4];
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MTT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (ACC64) {
 #pragma unroll
@@ -371,9 +366,9 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
         const int koff = kt * GEMM_BK;
         float *base = lds + buf * STAGE;
 #pragma unroll
-        for (int g = 0; g < MTT * 2; ++g)
+        for (int g = 0; g < 4; ++g)
             __builtin_amdgcn_global_load_lds((glb_void *)(a_src[g] + koff),
-                                             (lds_void *)(base + (wave * WROWS + g * 8) * ROWF), 16, 0, 0);
+                                             (lds_void *)(base + (wave * 32 + g * 8) * ROWF), 16, 0, 0);
 #pragma unroll
         for (int g = 0; g < WPW; ++g)
             if ((g + 1) * 4 <= WG || wave + 4 * g < WG)
@@ -390,9 +385,9 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int co = hh ? c1 : c0;
-            f32x4 af[MTT], wf[NTT];
+            f32x4 af[MT], wf[NTT];
 #pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + co]);
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + co]);
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + co]);
 #pragma unroll
@@ -400,14 +395,14 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
 #pragma unroll
                 for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < MTT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
         }
         if (ACC64) {
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MTT; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] += (double)acc[nt][mt][i];
                     acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -415,12 +410,12 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
         }
     }
 
-    float pl[2][MTT], pr[2][MTT];          // A12: per (head of the tile, row tile) partial dot products
+    float pl[2][MT], pr[2][MT];          // A12: per (head of the tile, row tile) partial dot products
     if (A12) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) pl[h][mt] = pr[h][mt] = 0.f;
+            for (int mt = 0; mt < MT; ++mt) pl[h][mt] = pr[h][mt] = 0.f;
     }
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) {
@@ -432,8 +427,8 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
             ar = *reinterpret_cast<const f32x4 *>(attn_r + nb);
         }
 #pragma unroll
-        for (int mt = 0; mt < MTT; ++mt) {
-            const int m = m0 + wave * WROWS + mt * 16 + fr;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wave * 32 + mt * 16 + fr;
             f32x4 v;
             if (ACC64) {
 #pragma unroll
@@ -471,13 +466,13 @@ __global__ __launch_bounds__(256, (NTT > 10 || (MTT > 2 && ACC64)) ? 1 : (NTT > 
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 float x = pl[h][mt], y = pr[h][mt];
                 x = x + __shfl_xor(x, 16);
                 y = y + __shfl_xor(y, 16);
                 x = x + __shfl_xor(x, 32);
                 y = y + __shfl_xor(y, 32);
-                const int m = m0 + wave * WROWS + mt * 16 + fr;
+                const int m = m0 + wave * 32 + mt * 16 + fr;
                 const int head = (n0 / 40) + h;
                 if (fq == 0 && m < M && head * 40 < n) {
                     const int mo = c_rows ? c_rows[m] : m;
@@ -872,7 +867,7 @@ hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsi
     return hipGetLastError();
 }
 
-static size_t dma_lds_bytes(int ntt, int mtt = 2) { return (size_t)2 * (mtt * 64 + ntt * 16) * 32 * sizeof(float); }
+static size_t dma_lds_bytes(int ntt) { return (size_t)2 * (GEMM_BM + ntt * 16) * 32 * sizeof(float); }
 
 // the wide-tile instantiations use more than 64 KB of dynamic LDS
 static bool dma_set_lds_attributes() {
@@ -960,17 +955,8 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
     hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
                        slope, ntn, n_major, tune)
 #define MPE_LAUNCH_DMA(L_, A_, N_)                                                                                \
-    do {                                                                                                          \
-        if (tall && (N_) <= 5) {                                                                                  \
-            const void *fn_ = reinterpret_cast<const void *>(k_linear_dma<L_, A_, (N_) <= 5 ? (N_) : 5, false, 3>); \
-            (void)hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(5, 3)); \
-            hipLaunchKernelGGL((k_linear_dma<L_, A_, (N_) <= 5 ? (N_) : 5, false, 3>), dim3(ntm3 * ntn_), block,   \
-                               dma_lds_bytes((N_) <= 5 ? (N_) : 5, 3), s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, \
-                               k_pad, slope, ntn_, n_major, a_rows, c_rows);                                      \
-        } else                                                                                                    \
-            hipLaunchKernelGGL((k_linear_dma<L_, A_, N_>), dim3(ntm * ntn_), block, dma_lds_bytes(N_), s, A, lda, W, ldw, \
-                               bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows);         \
-    } while (0)
+    hipLaunchKernelGGL((k_linear_dma<L_, A_, N_>), dim3(ntm * ntn_), block, dma_lds_bytes(N_), s, A, lda, W, ldw, bias, \
+                       C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows)
     if (!(tune & 8) || a_rows || c_rows) {      // LDS-DMA staging is the default; MPE_GEMM_TUNE=8 selects the register-staged kernel
         // Feature-tile width: 64 or 80, whichever leaves fewer (tiles on the busiest CU) x width;
         // the MLP layers at a few thousand person rows balance exactly with 64.  160 and 208
@@ -979,10 +965,6 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
         // full kernel and need plain fp32 accumulation.  The padded weight rows cover any tile
         // that starts below n.
         static const int force_bn = getenv("MPE_GEMM_BN") ? atoi(getenv("MPE_GEMM_BN")) : 0;
-        // 192-row workgroup tiles (3 MFMA row tiles per wave, 2 workgroups per CU): experiment switch
-        static const int force_mt = getenv("MPE_GEMM_MT") ? atoi(getenv("MPE_GEMM_MT")) : 0;
-        const bool tall = force_mt == 3 && !a_rows && !c_rows;
-        const int ntm3 = (m_cap + 191) / 192;
         static PerDeviceFlag dma_attr;
         if (!dma_attr.test()) {
             dma_set_lds_attributes();
@@ -1003,13 +985,7 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
         // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile)
         if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !force_bn) {
             const int ntn_ = (n + 79) / 80;
-            if (tall && !acc64) {
-                const void *fn_ = reinterpret_cast<const void *>(k_linear_dma<false, false, 5, true, 3>);
-                (void)hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(5, 3));
-                hipLaunchKernelGGL((k_linear_dma<false, false, 5, true, 3>), dim3(ntm3 * ntn_), block, dma_lds_bytes(5, 3), s, A, lda,
-                                   W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows,
-                                   coef->attn_l, coef->attn_r, coef->a12);
-            } else if (acc64)
+            if (acc64)
                 hipLaunchKernelGGL((k_linear_dma<false, true, 5, true>), dim3(ntm * ntn_), block, dma_lds_bytes(5), s, A, lda, W,
                                    ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows, coef->attn_l,
                                    coef->attn_r, coef->a12);
