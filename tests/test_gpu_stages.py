@@ -455,3 +455,25 @@ def test_weights_can_be_set_twice_before_the_first_batch():
             eng.load_gat(sd, prm)                        # frozen after the first batch
     finally:
         eng.close()
+
+
+def test_empty_batch_and_graphless_batch():
+    """Degenerate batches through every batch entry point: zero frames, and frames without any
+    cross-camera pair (no graph: the reference skips them, metrics_from_model.py:195-196)."""
+    onp = oracle()
+    e = env('panoptic')
+    eng = engine_for('panoptic')
+    _, frames = load_case('c2_5x4_clean')
+    one_cam = {'trackerb': onp.processed_input(frames[0])['trackerb']}
+    for batch in ([], [{}], [one_cam, {}, one_cam]):
+        db = eng.to_device(eng.pack(batch))
+        scores, persons, n_persons = eng.match(db)
+        poses, valid = eng.mlp3d(db, persons, n_persons)
+        tri, jv = eng.triangulate(db, persons, n_persons)
+        eng.sync_status()
+        assert scores.numel() == 0 and n_persons.shape[0] == len(batch)
+        assert int(n_persons.sum()) == 0 and not bool(valid.any()) and not bool(jv.any())
+    text = json.dumps([one_cam, {}])
+    chunks = list(eng.stream_json(text, chunk_frames=4))
+    assert len(chunks) == 1 and chunks[0][2].tolist() == [0, 0]
+    assert list(eng.stream_json('[]', chunk_frames=4)) == []
