@@ -698,6 +698,7 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
 int mpe_head_features(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_feat) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;        // an empty batch has nothing to write (outputs may be NULL)
     DeviceGuard dg(ctx);
     if (!d_feat) return fail(ctx, MPE_ERR_INVALID, "d_feat is NULL");
     HIPCHK(ctx, launch_head_features(static_cast<hipStream_t>(stream), ctx->d_cfg, *b, ctx->cfg.n_joints, d_feat,
@@ -709,6 +710,7 @@ int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float 
                     float *d_scores_en, float *d_scores_heads) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;        // an empty batch has nothing to write (outputs may be NULL)
     DeviceGuard dg(ctx);
     if (!d_scores_en) return fail(ctx, MPE_ERR_INVALID, "d_scores_en is NULL");
     return run_gat(ctx, static_cast<hipStream_t>(stream), b, d_scores_en, d_scores_heads, d_feats, ld_feats);
@@ -748,6 +750,7 @@ int mpe_gat_layer(mpe_ctx *ctx, void *stream, const mpe_batch *b, int32_t layer,
                   float *d_out, int32_t ld_out, int32_t activation) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;        // an empty batch has nothing to write (outputs may be NULL)
     DeviceGuard dg(ctx);
     if ((rc = ensure_gat_workspace(ctx))) return rc;
     if (activation < 0 || activation > 2) return fail(ctx, MPE_ERR_INVALID, "activation: 0 LeakyReLU, 1 sigmoid, 2 none");
@@ -783,6 +786,7 @@ int mpe_edge_softmax_aggregate(mpe_ctx *ctx, void *stream, const mpe_batch *b, i
                                int32_t ld_ft2, float *d_out, int32_t ld_out) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;        // an empty batch has nothing to write (outputs may be NULL)
     DeviceGuard dg(ctx);
     if ((rc = ensure_gat_workspace(ctx))) return rc;
     if (layer < 0 || layer >= ctx->gat_layers) return fail(ctx, MPE_ERR_INVALID, "GAT layer index %d out of range", layer);
@@ -820,6 +824,7 @@ int mpe_cluster_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const floa
                       int32_t *d_n_persons) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;        // an empty batch has nothing to write (outputs may be NULL)
     DeviceGuard dg(ctx);
     if (!d_scores || !d_persons || !d_n_persons) return fail(ctx, MPE_ERR_INVALID, "mpe_cluster_batch: NULL output");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -834,6 +839,7 @@ int mpe_match_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_sco
                     int32_t *d_n_persons) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;        // an empty batch has nothing to write (outputs may be NULL)
     DeviceGuard dg(ctx);
     if (!d_persons || !d_n_persons) return fail(ctx, MPE_ERR_INVALID, "mpe_match_batch: NULL output");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -852,6 +858,7 @@ int mpe_mlp_input_rows(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int
                        const int32_t *d_n_persons, float *d_rows, int32_t ld_rows, uint8_t *d_valid) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;        // an empty batch has nothing to write (outputs may be NULL)
     DeviceGuard dg(ctx);
     const int width = ctx->cfg.n_cameras * ctx->cfg.n_joints * ctx->cfg.numbers_per_joint;
     if (!d_persons || !d_n_persons || !d_rows || ld_rows < width)
@@ -911,6 +918,7 @@ int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_
                     const int32_t *d_n_persons, float *d_poses, uint8_t *d_valid) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;        // an empty batch has nothing to write (outputs may be NULL)
     DeviceGuard dg(ctx);
     if ((rc = ensure_mlp_workspace(ctx))) return rc;
     if (!d_persons || !d_n_persons || !d_poses) return fail(ctx, MPE_ERR_INVALID, "mpe_mlp3d_batch: NULL argument");
@@ -933,6 +941,7 @@ int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const 
                           const int32_t *d_n_persons, double *d_poses, uint8_t *d_joint_valid, uint32_t flags) {
     int rc = check_batch(ctx, b);
     if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;        // an empty batch has nothing to write (outputs may be NULL)
     DeviceGuard dg(ctx);
     if (!d_persons || !d_n_persons || !d_poses || !d_joint_valid)
         return fail(ctx, MPE_ERR_INVALID, "mpe_triangulate_batch: NULL argument");

@@ -130,7 +130,8 @@ int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64);
  * get_person_proposal_from_network_output (skeleton_matching_utils.py:12-132).
  *   d_scores   [n_edge_nodes]  sigmoid output of every edge-node (may be NULL)
  *   d_persons  [n_frames][Pcap][V] frame-local head id per camera, -1 = None
- *   d_n_persons[n_frames] */
+ *   d_n_persons[n_frames]
+ * A batch of zero frames is accepted by every batch entry point and does nothing. */
 int mpe_match_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
                     float *d_scores, int32_t *d_persons, int32_t *d_n_persons);
 
