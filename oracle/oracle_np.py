@@ -157,33 +157,39 @@ def _t(x):
 def gat_layer(sd, l, h, src, dst, alpha, num_heads):
     """GraphAttention2.forward (gat2.py:50-76): fc1, LeakyReLU(alpha), fc2, a1/a2 by bmm,
     e = LeakyReLU(alpha)(a1[src]+a2[dst]), softmax over incoming edges of dst
-    (DGL edge_softmax: max, exp, sum, div), out[v] = sum_e score_e * ft2[src_e]."""
+    (DGL edge_softmax: max, exp, sum, div), out[v] = sum_e score_e * ft2[src_e].
+    Runs in the dtype of `h` (float32 = the reference; float64 = the same network without fp32
+    rounding, used by tests to size the reference's own rounding noise)."""
     p = 'layers.%d.' % l
     N = h.shape[0]
-    ft1 = torch.nn.functional.linear(h, _t(sd[p + 'fc1.weight']), _t(sd[p + 'fc1.bias']))
+    dt = h.dtype
+
+    def w(name):
+        return _t(sd[p + name]).to(dt)
+    ft1 = torch.nn.functional.linear(h, w('fc1.weight'), w('fc1.bias'))
     h2 = torch.nn.functional.leaky_relu(ft1, alpha)
-    ft2 = torch.nn.functional.linear(h2, _t(sd[p + 'fc2.weight']), _t(sd[p + 'fc2.bias'])).reshape((N, num_heads, -1))
+    ft2 = torch.nn.functional.linear(h2, w('fc2.weight'), w('fc2.bias')).reshape((N, num_heads, -1))
     head_ft = ft2.transpose(0, 1)
-    a1 = torch.bmm(head_ft, _t(sd[p + 'attn_l'])).transpose(0, 1)
-    a2 = torch.bmm(head_ft, _t(sd[p + 'attn_r'])).transpose(0, 1)
+    a1 = torch.bmm(head_ft, w('attn_l')).transpose(0, 1)
+    a2 = torch.bmm(head_ft, w('attn_r')).transpose(0, 1)
     s = torch.from_numpy(np.asarray(src)).long()
     d = torch.from_numpy(np.asarray(dst)).long()
     e = torch.nn.functional.leaky_relu(a1[s] + a2[d], alpha)                 # E x H x 1
     idx = d.view(-1, 1, 1).expand_as(e)
-    mx = torch.full((N, num_heads, 1), float('-inf')).scatter_reduce(0, idx, e, reduce='amax', include_self=True)
+    mx = torch.full((N, num_heads, 1), float('-inf'), dtype=dt).scatter_reduce(0, idx, e, reduce='amax', include_self=True)
     score = torch.exp(e - mx[d])
-    ssum = torch.zeros((N, num_heads, 1)).index_add_(0, d, score)
+    ssum = torch.zeros((N, num_heads, 1), dtype=dt).index_add_(0, d, score)
     a = score / ssum[d]
     out = torch.zeros_like(ft2).index_add_(0, d, ft2[s] * a)
     return out, {'ft2': ft2, 'a1': a1, 'a2': a2}
 
 
-def gat_forward(sd, prm, feats, src, dst, keep=False):
+def gat_forward(sd, prm, feats, src, dst, keep=False, dtype=torch.float32):
     """GAT2.forward (gat2.py:137-149) with activation LeakyReLU(0.01) and Sigmoid
     (train_skeleton_matching.py:54, :34).  Returns N scores (caller squeezes N x 1 x 1)."""
     heads = list(prm['heads']) + [1]
     L = prm['gnn_layers']
-    h = _t(feats).float()
+    h = _t(feats).to(dtype)
     inter = []
     for l in range(L - 1):
         h, _ = gat_layer(sd, l, h, src, dst, prm['alpha'], heads[l])
