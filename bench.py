@@ -149,7 +149,9 @@ def run_rank(args):
         if rank == 0:
             print('bench.py: --gpus %d but WORLD_SIZE=%d; the launcher decides: running %d ranks'
                   % (args.gpus, world, world), file=sys.stderr)
-    distributed = world > 1
+    # MPE_BENCH_FORCE_DIST=1: initialise the process group even at world size 1 (rehearses the RCCL
+    # init / barrier / all-gather path on a one-GPU box)
+    distributed = world > 1 or bool(os.environ.get('MPE_BENCH_FORCE_DIST'))
     use_gpu = not args.dry_run
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
