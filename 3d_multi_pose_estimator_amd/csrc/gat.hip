@@ -766,6 +766,19 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(s_ft + (size_t)c0_ * 4), 16, 0, 0);
         }
+    } else if (!a.ft_half) {
+        // fp32 rows that are not whole 16-byte chunks (30-wide attention heads): the same dense image,
+        // written by 4-byte LDS-DMA pieces (a wave-instruction fills 64 consecutive floats)
+        const int total = N * D;
+        for (int c0_ = wave * 64; c0_ < total; c0_ += 256) {
+            int c = c0_ + lane;
+            c = c < total ? c : total - 1;
+            const int node = c / D, d = c - node * D;
+            const float *src = (l0 && node >= H) ? a.en_const_ft2 + (c0 + d)
+                                                  : a.ft2 + (size_t)((l0 ? hb : nb) + node) * a.ld + c0 + d;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(s_ft + (size_t)c0_), 4, 0, 0);
+        }
     } else {
         const int total = N * DV;
         for (int i0 = t; i0 < total; i0 += 4 * blockDim.x) {
@@ -921,7 +934,8 @@ static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_c
     const int nc = hmax + mc;
     const int Dp = out_dim;
     size_t image = (size_t)nc * Dp + 256;
-    if (image < (size_t)FUSED_PIECES * 1024) image = (size_t)FUSED_PIECES * 1024;      // overlapped staging issues whole pieces
+    if (out_dim % 4 == 0 && image < (size_t)FUSED_PIECES * 1024)
+        image = (size_t)FUSED_PIECES * 1024;                                           // overlapped staging issues whole pieces
     const size_t bytes = (fused_tables_floats(hmax, V, nc, mc) + image) * sizeof(float);
     *n_cap = nc;
     *m_cap = mc;
