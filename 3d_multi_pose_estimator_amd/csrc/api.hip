@@ -435,13 +435,13 @@ int gat_attention(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, const 
     const GatLayer &g = ctx->gat[l];
     HIPCHK(ctx, launch_gat_attention(s, *b, ctx->cfg.n_cameras, ctx->cfg.max_heads_per_frame, ctx->node_off,
                                      ctx->head_frame, ctx->en_frame, ctx->en_pair, g.attn_l, g.attn_r, ctx->a12, a,
-                                     n_rows_ft2));
+                                     n_rows_ft2, ctx->head_src));
     return MPE_OK;
 }
 
 int gat_topology(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b) {
     HIPCHK(ctx, launch_topology(s, *b, ctx->cfg.n_cameras, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair,
-                                ctx->cfg.max_heads_per_frame, ctx->d_status));
+                                ctx->cfg.max_heads_per_frame, ctx->d_status, ctx->head_src));
     return MPE_OK;
 }
 
@@ -560,6 +560,9 @@ int mpe_create(const mpe_config *cfg, mpe_ctx **out) {
         if ((rc = dev_alloc(ctx, &ctx->en_frame, (size_t)cfg->max_edge_nodes))) break;
         if ((rc = dev_alloc(ctx, &ctx->en_pair, (size_t)cfg->max_edge_nodes * 2))) break;
         if ((rc = dev_alloc(ctx, &ctx->node_off, (size_t)cfg->max_frames + 1))) break;
+        if (head_src_entries(cfg->max_heads_per_frame) &&
+            (rc = dev_alloc(ctx, &ctx->head_src, head_src_entries(cfg->max_heads_per_frame) * cfg->max_frames)))
+            break;
         ctx->cl_keys_per_frame = cluster_keys_per_frame(cfg->max_heads_per_frame);
         ctx->cl_scratch_per_frame = cluster_scratch_per_frame(cfg->max_heads_per_frame);
         if ((rc = dev_alloc(ctx, &ctx->cl_keys, ctx->cl_keys_per_frame * cfg->max_frames, false))) break;

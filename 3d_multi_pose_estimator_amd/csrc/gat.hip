@@ -59,12 +59,28 @@ __global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head
         }
 }
 
+__global__ void k_head_sources(int V, int hmax, const int32_t *__restrict__ head_off,
+                               const int32_t *__restrict__ slot_n, uint16_t *__restrict__ head_src);
+
+// Frames of up to HEAD_SRC_MAX_HEADS heads get a per-frame table of the in-edge sources of their heads
+// (k_head_sources); the fused attention kernel then reads it instead of deriving the sources again in
+// each of its (frame, attention head) workgroups.
+constexpr int HEAD_SRC_MAX_HEADS = 63;
+
+size_t head_src_entries(int max_heads_per_frame) {
+    return max_heads_per_frame <= HEAD_SRC_MAX_HEADS ? (size_t)max_heads_per_frame * (max_heads_per_frame + 1) : 0;
+}
+
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
-                           int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status) {
+                           int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status,
+                           uint16_t *head_src) {
     if (b.n_frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_topology, dim3(b.n_frames), dim3(128), 0, s, b.n_frames, V, b.d_frame_head_off,
                        b.d_frame_en_off, b.d_slot_n, node_off, head_frame, en_frame, en_pair, max_heads_per_frame,
                        status);
+    if (head_src && head_src_entries(max_heads_per_frame))
+        hipLaunchKernelGGL(k_head_sources, dim3(b.n_frames), dim3(256), 0, s, V, max_heads_per_frame,
+                           b.d_frame_head_off, b.d_slot_n, head_src);
     return hipGetLastError();
 }
 
@@ -396,6 +412,36 @@ __device__ __forceinline__ int slot_of_head(const FrameTopo &tp, int V, int v) {
     return s;
 }
 
+// In-edge sources of every head of a frame, [hmax][hmax + 1] per frame: entry (h, e) = frame-local id
+// of the source node of in-edge e of head h, 0xFFFF for e >= in-degree and for rows h >= H.  Frames
+// beyond hmax heads (flagged by k_topology) get an all-0xFFFF table.
+__global__ __launch_bounds__(256) void k_head_sources(int V, int hmax, const int32_t *__restrict__ head_off,
+                                                      const int32_t *__restrict__ slot_n,
+                                                      uint16_t *__restrict__ head_src) {
+    __shared__ int s_topo[MPE_MAX_CAMERAS + 1 + MPE_MAX_CAMERAS * MPE_MAX_CAMERAS];
+    __shared__ int s_n[MPE_MAX_CAMERAS];
+    const int f = blockIdx.x, t = threadIdx.x;
+    const int H = head_off[f + 1] - head_off[f];
+    const int max_deg = hmax + 1;
+    FrameTopo tp;
+    tp.start = s_topo;
+    tp.base = s_topo + V + 1;
+    if (t < V) s_n[t] = slot_n[(size_t)f * V + t];
+    __syncthreads();
+    build_topo(tp, s_n, V, H, t, blockDim.x);
+    __syncthreads();
+    uint16_t *dst = head_src + (size_t)f * hmax * max_deg;
+    for (int i = t; i < hmax * max_deg; i += blockDim.x) {
+        const int h = i / max_deg, e = i - h * max_deg;
+        int u = 0xFFFF;
+        if (H <= hmax && h < H) {
+            const int sl = slot_of_head(tp, V, h);
+            if (e < 1 + H - s_n[sl]) u = head_in_edge(tp, s_n, V, h, sl, e);
+        }
+        dst[i] = (uint16_t)u;
+    }
+}
+
 // Weighted sum over the in-edges of a head destination, canonical order: eight accumulators, the
 // j-th over the in-edges e = j, j+8, ... in ascending order, combined as
 // ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)).  Eight independent chains keep eight row loads in flight
@@ -640,7 +686,7 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
 // floats of the small LDS tables of k_gat_fused, rounded up to 1 KiB (the feature image follows)
 __host__ __device__ inline size_t fused_tables_floats(int hmax, int V, int n_cap, int m_cap) {
     const size_t deg = (size_t)hmax + 1;
-    const size_t n = 2 * (size_t)n_cap + 2 * hmax * deg + (size_t)m_cap * 4 + (V + 1) + (size_t)V * V + MPE_MAX_CAMERAS;
+    const size_t n = 2 * (size_t)n_cap + 2 * hmax * deg + (size_t)m_cap * 4 + (V + 1) + (size_t)V * V + MPE_MAX_CAMERAS + hmax;
     return (n + 255) & ~(size_t)255;
 }
 
@@ -667,7 +713,8 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
                                                    const int32_t *__restrict__ node_off,
                                                    const int32_t *__restrict__ en_pair,
                                                    const float *__restrict__ attn_l,
-                                                   const float *__restrict__ attn_r, AggArgs a, int overlap) {
+                                                   const float *__restrict__ attn_r, AggArgs a, int overlap,
+                                                   const uint16_t *__restrict__ head_src) {
 #pragma clang fp contract(off)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     extern __shared__ __attribute__((aligned(1024))) float s_dyn[];
@@ -701,6 +748,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     tp.start = reinterpret_cast<int *>(s_wen + (size_t)m_cap * 3);                  // [V + 1]
     tp.base = tp.start + V + 1;                     // [V * V]
     int *s_sn = tp.base + V * V;                    // [V] heads per camera slot of this frame
+    int *s_deg = s_sn + MPE_MAX_CAMERAS;            // [hmax] in-degree of the heads
     float *s_ft = s_dyn + fused_tables_floats(max_deg - 1, V, n_cap, m_cap);         // [n_cap][Dp]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool l0 = a.en_const_ft2 != nullptr;
@@ -722,12 +770,16 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
         // image is still landing, and the softmax phase runs underneath it (raw barriers).
         const int total = N * DV;
         const size_t row0 = (size_t)(l0 ? hb : nb);
-        const int tn = t < N ? t : N - 1, tm = t < M ? t : M - 1, tv = t < V ? t : V - 1;
+        const int tn = t < N ? t : N - 1, tm = t < M ? t : M - 1;
+        const int n_src2 = (max_deg - 1) * max_deg / 2;          // dwords (entry pairs) of the frame's source table
+        const int ts = t < n_src2 ? t : n_src2 - 1;
         const float *pr_ = (l0 && tn >= H) ? a.en_const_a : a.a12 + (row0 + tn) * 32;
         const float *p1 = pr_ + hh, *p2 = pr_ + 16 + hh;
-        const int32_t *pe = en_pair + 2 * (size_t)(eb + tm), *ps = sn + tv;
+        const int32_t *pe = en_pair + 2 * (size_t)(eb + tm);
+        const uint32_t *ps = reinterpret_cast<const uint32_t *>(head_src + (size_t)f * (max_deg - 1) * max_deg) + ts;
         float r1, r2;
-        int e1, e2, sv;
+        int e1, e2;
+        uint32_t sv;
         asm volatile("global_load_dword %0, %1, off" : "=v"(r1) : "v"(p1) : "memory");
         asm volatile("global_load_dword %0, %1, off" : "=v"(r2) : "v"(p2) : "memory");
         asm volatile("global_load_dword %0, %1, off" : "=v"(e1) : "v"(pe) : "memory");
@@ -750,9 +802,11 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
             s_a2[t] = r2;
         }
         if (t < M) s_pair[t] = (e1 << 16) | e2;
-        if (t < V) s_sn[t] = sv;
-        lds_barrier_raw();
-        build_topo(tp, s_sn, V, H, t, blockDim.x);
+        if (t < n_src2) {
+            const int lo = sv & 0xFFFF, hi = sv >> 16;
+            s_src[2 * t] = lo == 0xFFFF ? -1 : lo;
+            s_src[2 * t + 1] = hi == 0xFFFF ? -1 : hi;
+        }
         lds_barrier_raw();
     } else {
     if (VEC == 4 && !a.ft_half) {
@@ -813,10 +867,25 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     }
     for (int m = t; m < M; m += blockDim.x)
         s_pair[m] = (en_pair[2 * (size_t)(eb + m)] << 16) | en_pair[2 * (size_t)(eb + m) + 1];
-    if (t < V) s_sn[t] = sn[t];
-    __syncthreads();
-    build_topo(tp, s_sn, V, H, t, blockDim.x);
-    __syncthreads();
+    if (head_src) {
+        const uint16_t *tab = head_src + (size_t)f * (max_deg - 1) * max_deg;
+        for (int i = t; i < H * max_deg; i += blockDim.x) {
+            const int u = tab[i];
+            s_src[i] = u == 0xFFFF ? -1 : u;
+        }
+        __syncthreads();
+    } else {
+        if (t < V) s_sn[t] = sn[t];
+        __syncthreads();
+        build_topo(tp, s_sn, V, H, t, blockDim.x);
+        __syncthreads();
+        for (int i = t; i < H * max_deg; i += blockDim.x) {
+            const int h = i / max_deg, e = i - h * max_deg;
+            const int sl = slot_of_head(tp, V, h);
+            s_src[i] = e < 1 + H - s_sn[sl] ? head_in_edge(tp, s_sn, V, h, sl, e) : -1;
+        }
+        __syncthreads();
+    }
     }
     if (!a.a12_ready) {
         // a1 = <ft, attn_l[head]>, a2 = <ft, attn_r[head]> (the GEMM epilogue did not provide them)
@@ -856,21 +925,23 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     if (!a.score_mode || a.out_heads) {
         const int gl = t & (G - 1);
         for (int h = t / G; h < H; h += 256 / G) {
-            const int s = slot_of_head(tp, V, h);
-            const int deg = 1 + H - s_sn[s];
             float *w = s_wh + h * max_deg;
-            int *src = s_src + h * max_deg;
+            const int *src = s_src + h * max_deg;           // in-edge sources, -1 behind the in-degree
             const float a2v = s_a2[h];
             float mx = -INFINITY;
-            for (int e = gl; e < deg; e += G) {
-                const int u = head_in_edge(tp, s_sn, V, h, s, e);
-                src[e] = u;
-                float x = s_a1[u] + a2v;
-                x = x > 0.f ? x : x * a.alpha;
-                w[e] = x;
-                mx = fmaxf(mx, x);
+            int deg = 0;
+            for (int e = gl; e < max_deg; e += G) {
+                const int u = src[e];
+                if (u >= 0) {
+                    float x = s_a1[u] + a2v;
+                    x = x > 0.f ? x : x * a.alpha;
+                    w[e] = x;
+                    mx = fmaxf(mx, x);
+                    deg = e + 1;
+                }
             }
             mx = group_max<G>(mx);
+            deg = (int)group_max<G>((float)deg);
             float sum = 0.f;
             for (int e = gl; e < deg; e += G) {
                 const float ex = expf(w[e] - mx);
@@ -879,6 +950,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
             }
             sum = group_sum<G>(sum);
             for (int e = gl; e < deg; e += G) w[e] = w[e] / sum;
+            if (gl == 0) s_deg[h] = deg;
         }
     }
     __syncthreads();
@@ -903,8 +975,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
                 o[k] = agg_activate(acc, a.out_mode, a.out_slope);
             }
         } else {
-            const int s = slot_of_head(tp, V, node);
-            const int deg = 1 + H - s_sn[s];
+            const int deg = s_deg[node];
             const int *src = s_src + node * max_deg;
             const float *w = s_wh + node * max_deg;
             float acc[VEC];
@@ -959,7 +1030,7 @@ constexpr size_t FUSED_LDS_LIMIT = 160 * 1024;      // all of a CU's LDS (one wo
 hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                                 const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
                                 const int32_t *en_pair, const float *attn_l, const float *attn_r, float *a12,
-                                const AggArgs &a, int n_rows_ft2) {
+                                const AggArgs &a, int n_rows_ft2, const uint16_t *head_src) {
     int n_cap, m_cap;
     const size_t shm = fused_lds_bytes(max_heads_per_frame, V, a.out_dim, &n_cap, &m_cap);
     const bool no_fuse = getenv("MPE_NO_FUSED_ATTENTION") != nullptr;       // read per call: tests toggle it
@@ -969,7 +1040,10 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
         const int grp = max_heads_per_frame + 1 <= 16 ? 16 : max_heads_per_frame + 1 <= 32 ? 32 : 64;
         // overlapped staging: coefficients from the GEMM, fp32 rows of 16-byte chunks, tables of at most one
         // entry per thread, image of at most FUSED_PIECES x 256 chunks
-        const int overlap = (vec == 4 && a.a12_ready && !a.ft_half && n_cap <= 256 && m_cap <= 256 &&
+        if (!head_src_entries(max_heads_per_frame)) head_src = nullptr;
+        // (the source table then travels as at most one dword = two entries per thread)
+        const int overlap = (vec == 4 && a.a12_ready && !a.ft_half && n_cap <= 256 && m_cap <= 256 && head_src &&
+                             max_heads_per_frame * (max_heads_per_frame + 1) <= 512 &&
                              n_cap * (a.out_dim / 4) <= FUSED_PIECES * 256 && !getenv("MPE_FUSED_NO_OVERLAP")) ? 1 : 0;
         const void *fn = nullptr;
 #define MPE_FUSED(V_, G_)                                                                                     \
@@ -981,7 +1055,7 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
         }                                                                                                     \
         hipLaunchKernelGGL((k_gat_fused<V_, G_>), dim3(b.n_frames * a.heads), dim3(256), shm, s, V,            \
                            max_heads_per_frame + 1, n_cap, m_cap, b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, \
-                           node_off, en_pair, attn_l, attn_r, a, overlap);                                    \
+                           node_off, en_pair, attn_l, attn_r, a, overlap, head_src);                          \
     } while (0)
 #define MPE_FUSED_G(V_)                     \
     do {                                    \

@@ -114,6 +114,7 @@ struct mpe_ctx {
     int32_t *head_frame = nullptr; // [max_heads]
     int32_t *en_frame = nullptr;   // [max_edge_nodes]
     int32_t *en_pair = nullptr;    // [max_edge_nodes][2] frame-local head ids
+    uint16_t *head_src = nullptr;  // [max_frames][hmax][hmax + 1] in-edge sources of the heads (small frames only)
     int32_t *node_off = nullptr;   // [max_frames+1]
     uint64_t *cl_keys = nullptr;   // clustering scratch
     int32_t *cl_scratch = nullptr;
@@ -162,7 +163,10 @@ hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsi
 
 // gat.hip
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
-                           int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status);
+                           int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status,
+                           uint16_t *head_src);
+// entries of the per-frame in-edge source table of the heads, or 0 when frames of that capacity do not get one
+size_t head_src_entries(int max_heads_per_frame);
 hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
                                 int ld_feat, int col0, int stride_cam, bool dense);
 hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,
@@ -190,7 +194,7 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
 hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                                 const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
                                 const int32_t *en_pair, const float *attn_l, const float *attn_r, float *a12,
-                                const AggArgs &a, int n_rows_ft2);
+                                const AggArgs &a, int n_rows_ft2, const uint16_t *head_src);
 
 // cluster.hip
 size_t cluster_keys_per_frame(int max_heads_per_frame);
