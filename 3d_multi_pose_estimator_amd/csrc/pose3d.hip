@@ -11,7 +11,8 @@
 //                          value (here: one-sided Jacobi SVD in registers).
 // One workgroup per (frame, person); pair solves are spread over the lanes, sums run in the
 // reference's pair order.  f64 arithmetic is kept un-contracted (no fma fusion) to stay as
-// close as possible to the CPU evaluation order.
+// close as possible to the CPU evaluation order, except inside the Jacobi SVD (an iteration to
+// convergence whose result does not depend on the rounding of single steps beyond a few ulp).
 #include "mpe_internal.h"
 
 namespace mpe {
@@ -47,7 +48,7 @@ __device__ inline void undistort_point(const DevCfg *cfg, int cam, double u, dou
 // Right singular vector of the smallest singular value of the 4x4 DLT matrix, dehomogenised.
 __device__ inline void dlt_solve(const double *P1, const double *P2, double x1, double y1, double x2, double y2,
                                  double *out) {
-#pragma clang fp contract(off)
+#pragma clang fp contract(fast)
     double A[4][4], Vm[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -74,9 +75,12 @@ __device__ inline void dlt_solve(const double *P1, const double *P2, double x1, 
                 }
                 if (ga * ga <= 1.6e-31 * (al * be) || ga == 0.0) continue;
                 rotated = true;
-                const double zeta = (be - al) / (2.0 * ga);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (be - al) / (2 ga), written with one
+                // division and one square root; c = 1 / sqrt(1 + t^2)
+                const double d = be - al, g2 = 2.0 * fabs(ga);
+                const double sg = (d == 0.0 || (d > 0.0) == (ga > 0.0)) ? 1.0 : -1.0;
+                const double t = sg * g2 / (fabs(d) + sqrt(d * d + g2 * g2));
+                const double c = rsqrt(1.0 + t * t), s = c * t;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const double ap = A[i][p], aq = A[i][q];
