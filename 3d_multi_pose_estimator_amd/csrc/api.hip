@@ -560,8 +560,9 @@ int mpe_create(const mpe_config *cfg, mpe_ctx **out) {
         if ((rc = dev_alloc(ctx, &ctx->en_frame, (size_t)cfg->max_edge_nodes))) break;
         if ((rc = dev_alloc(ctx, &ctx->en_pair, (size_t)cfg->max_edge_nodes * 2))) break;
         if ((rc = dev_alloc(ctx, &ctx->node_off, (size_t)cfg->max_frames + 1))) break;
-        if (head_src_entries(cfg->max_heads_per_frame) &&
-            (rc = dev_alloc(ctx, &ctx->head_src, head_src_entries(cfg->max_heads_per_frame) * cfg->max_frames)))
+        if (head_src_entries(cfg->max_heads_per_frame, cfg->n_cameras) &&
+            (rc = dev_alloc(ctx, &ctx->head_src, head_src_entries(cfg->max_heads_per_frame, cfg->n_cameras) * cfg->max_frames,
+                            false)))
             break;
         ctx->cl_keys_per_frame = cluster_keys_per_frame(cfg->max_heads_per_frame);
         ctx->cl_scratch_per_frame = cluster_scratch_per_frame(cfg->max_heads_per_frame);

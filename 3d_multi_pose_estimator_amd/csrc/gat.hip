@@ -62,13 +62,14 @@ __global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head
 __global__ void k_head_sources(int V, int hmax, const int32_t *__restrict__ head_off,
                                const int32_t *__restrict__ slot_n, uint16_t *__restrict__ head_src);
 
-// Frames of up to HEAD_SRC_MAX_HEADS heads get a per-frame table of the in-edge sources of their heads
-// (k_head_sources); the fused attention kernel then reads it instead of deriving the sources again in
-// each of its (frame, attention head) workgroups.
-constexpr int HEAD_SRC_MAX_HEADS = 63;
-
-size_t head_src_entries(int max_heads_per_frame) {
-    return max_heads_per_frame <= HEAD_SRC_MAX_HEADS ? (size_t)max_heads_per_frame * (max_heads_per_frame + 1) : 0;
+// Per-frame table of the in-edge sources of the heads (k_head_sources, [hmax][hmax + 1] uint16 per
+// frame): the attention kernels read it instead of deriving the sources again in every workgroup of
+// every layer.  Frames whose node ids do not fit 16 bits get none (the kernels then fall back to the
+// arithmetic).
+size_t head_src_entries(int max_heads_per_frame, int V) {
+    const size_t h = (size_t)max_heads_per_frame;
+    const size_t nodes = h + h * h * (size_t)(V - 1) / (2 * (size_t)V) + 1;
+    return nodes <= 65535 ? h * (h + 1) : 0;
 }
 
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
@@ -78,9 +79,9 @@ hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *no
     hipLaunchKernelGGL(k_topology, dim3(b.n_frames), dim3(128), 0, s, b.n_frames, V, b.d_frame_head_off,
                        b.d_frame_en_off, b.d_slot_n, node_off, head_frame, en_frame, en_pair, max_heads_per_frame,
                        status);
-    if (head_src && head_src_entries(max_heads_per_frame))
-        hipLaunchKernelGGL(k_head_sources, dim3(b.n_frames), dim3(256), 0, s, V, max_heads_per_frame,
-                           b.d_frame_head_off, b.d_slot_n, head_src);
+    if (head_src && head_src_entries(max_heads_per_frame, V))
+        hipLaunchKernelGGL(k_head_sources, dim3(b.n_frames), dim3(256), (size_t)max_heads_per_frame * sizeof(int), s, V,
+                           max_heads_per_frame, b.d_frame_head_off, b.d_slot_n, head_src);
     return hipGetLastError();
 }
 
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(256) void k_head_sources(int V, int hmax, const int
                                                       uint16_t *__restrict__ head_src) {
     __shared__ int s_topo[MPE_MAX_CAMERAS + 1 + MPE_MAX_CAMERAS * MPE_MAX_CAMERAS];
     __shared__ int s_n[MPE_MAX_CAMERAS];
+    extern __shared__ int s_slot[];                 // [hmax] camera slot of every head
     const int f = blockIdx.x, t = threadIdx.x;
     const int H = head_off[f + 1] - head_off[f];
     const int max_deg = hmax + 1;
@@ -430,13 +432,24 @@ __global__ __launch_bounds__(256) void k_head_sources(int V, int hmax, const int
     __syncthreads();
     build_topo(tp, s_n, V, H, t, blockDim.x);
     __syncthreads();
+    const bool ok = H <= hmax;
+    if (ok)
+        for (int h = t; h < H; h += blockDim.x) s_slot[h] = slot_of_head(tp, V, h);
+    __syncthreads();
     uint16_t *dst = head_src + (size_t)f * hmax * max_deg;
     for (int i = t; i < hmax * max_deg; i += blockDim.x) {
         const int h = i / max_deg, e = i - h * max_deg;
         int u = 0xFFFF;
-        if (H <= hmax && h < H) {
-            const int sl = slot_of_head(tp, V, h);
-            if (e < 1 + H - s_n[sl]) u = head_in_edge(tp, s_n, V, h, sl, e);
+        if (ok && h < H) {
+            const int sl = s_slot[h], st = tp.start[sl], ns = s_n[sl];
+            if (e == 0) {
+                u = h;
+            } else if (e < 1 + H - ns) {
+                int o = e - 1;
+                if (o >= st) o += ns;               // the (e-1)-th head that is not in slot sl
+                const int p = s_slot[o], k = o - tp.start[p], ii = h - st;
+                u = p < sl ? tp.base[p * V + sl] + k * ns + ii : tp.base[sl * V + p] + ii * s_n[p] + k;
+            }
         }
         dst[i] = (uint16_t)u;
     }
@@ -566,7 +579,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_aggregate_heads(
     int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
     const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off,
-    const int32_t *__restrict__ head_frame, AggArgs a) {
+    const int32_t *__restrict__ head_frame, AggArgs a, const uint16_t *__restrict__ head_src, int src_stride) {
 #pragma clang fp contract(off)
     extern __shared__ float s_dyn[];
     const int heads = a.heads, hd = a.heads * a.out_dim;
@@ -594,21 +607,36 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
         v = gh - hb;
         nb = node_off[f];
         sn = slot_n + (size_t)f * V;
-        if (live && half == 0) build_topo(tp, sn, V, H, lane, 64);
+        if (live && half == 0 && !head_src) build_topo(tp, sn, V, H, lane, 64);
     }
     __syncthreads();
-    int s = 0;
     if (live) {
-        s = slot_of_head(tp, V, v);
-        deg = 1 + H - sn[s];
-        if (half == 0) {
+        if (head_src) {
+            // in-edge sources from the per-frame table (0xFFFF behind the in-degree); both waves of a
+            // row derive the in-degree, the first one fills the LDS list
+            const uint16_t *tab = head_src + ((size_t)f * (src_stride - 1) + v) * src_stride;
             int *src = s_src + r_own * max_deg;
-            for (int e = lane; e < deg; e += 64) src[e] = head_in_edge(tp, sn, V, v, s, e);
-            if (lane == 0) {
-                s_f[r_own] = f;
-                s_v[r_own] = v;
-                s_H[r_own] = H;
+            int dg = 0;
+            for (int e = lane; e < src_stride; e += 64) {
+                const int u = tab[e];
+                if (u != 0xFFFF) {
+                    if (half == 0) src[e] = u;
+                    dg = e + 1;
+                }
             }
+            deg = (int)wave_max((float)dg);
+        } else {
+            const int sl = slot_of_head(tp, V, v);
+            deg = 1 + H - sn[sl];
+            if (half == 0) {
+                int *src = s_src + r_own * max_deg;
+                for (int e = lane; e < deg; e += 64) src[e] = head_in_edge(tp, sn, V, v, sl, e);
+            }
+        }
+        if (half == 0 && lane == 0) {
+            s_f[r_own] = f;
+            s_v[r_own] = v;
+            s_H[r_own] = H;
         }
     }
     if (half == 0 && lane == 0) s_deg[r_own] = deg;
@@ -1015,7 +1043,7 @@ static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_c
 
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                             const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
-                            const int32_t *en_pair, const AggArgs &a);
+                            const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src);
 
 static int agg_vec(const AggArgs &a) {
     if (!a.score_mode && a.ld % 4 == 0 && a.ld_out % 4 == 0) {
@@ -1040,7 +1068,7 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
         const int grp = max_heads_per_frame + 1 <= 16 ? 16 : max_heads_per_frame + 1 <= 32 ? 32 : 64;
         // overlapped staging: coefficients from the GEMM, fp32 rows of 16-byte chunks, tables of at most one
         // entry per thread, image of at most FUSED_PIECES x 256 chunks
-        if (!head_src_entries(max_heads_per_frame)) head_src = nullptr;
+        if (!head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
         // (the source table then travels as at most one dword = two entries per thread)
         const int overlap = (vec == 4 && a.a12_ready && !a.ft_half && n_cap <= 256 && m_cap <= 256 && head_src &&
                              max_heads_per_frame * (max_heads_per_frame + 1) <= 512 &&
@@ -1076,13 +1104,14 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
         hipError_t e = launch_attn_coef(s, a.ft2, a.ld, n_rows_ft2, a.heads, a.out_dim, attn_l, attn_r, a12, a.ft_half);
         if (e != hipSuccess) return e;
     }
-    return launch_aggregate(s, b, V, max_heads_per_frame, node_off, head_frame, en_frame, en_pair, a2);
+    return launch_aggregate(s, b, V, max_heads_per_frame, node_off, head_frame, en_frame, en_pair, a2, head_src);
 }
 
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                             const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
-                            const int32_t *en_pair, const AggArgs &a) {
+                            const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src) {
     const int vec = agg_vec(a);
+    if (!head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
     if (b.n_edge_nodes > 0) {
         const unsigned blocks = (unsigned)((b.n_edge_nodes + EN_ROWS - 1) / EN_ROWS);
 #define MPE_EN(V_)                                                                                      \
@@ -1115,7 +1144,8 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
         const int grid = (b.n_heads + AGG_ROWS - 1) / AGG_ROWS;
 #define MPE_HEADS(V_)                                                                                   \
     hipLaunchKernelGGL(k_aggregate_heads<V_>, dim3(grid), dim3(256), shm, s, b.n_heads, V, max_deg,         \
-                       b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a)
+                       b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a, head_src,       \
+                       max_heads_per_frame + 1)
         if (vec == 4 && a.ft_half && a.out_dim % 8 == 0) MPE_HEADS(8);
         else if (vec == 4) MPE_HEADS(4);
         else if (vec == 2) MPE_HEADS(2);

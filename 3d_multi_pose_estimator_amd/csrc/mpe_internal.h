@@ -166,7 +166,7 @@ hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *no
                            int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status,
                            uint16_t *head_src);
 // entries of the per-frame in-edge source table of the heads, or 0 when frames of that capacity do not get one
-size_t head_src_entries(int max_heads_per_frame);
+size_t head_src_entries(int max_heads_per_frame, int V);
 hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
                                 int ld_feat, int col0, int stride_cam, bool dense);
 hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,
@@ -189,7 +189,7 @@ struct AggArgs {
 };
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                             const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
-                            const int32_t *en_pair, const AggArgs &a);
+                            const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src);
 
 hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                                 const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
