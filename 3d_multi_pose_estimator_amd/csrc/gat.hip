@@ -507,6 +507,8 @@ __device__ __forceinline__ void weighted_sum8(int deg, RowFn row, WFn wt, float 
 
 constexpr int EN_ROWS = 16;     // edge-node rows per workgroup
 
+// Phase A: one thread per (row, attention head) computes the 3-way softmax weights and one per row
+// the three source rows; phase B: one thread per (row, VEC columns) does the weighted sum from them.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *__restrict__ head_off,
                                                       const int32_t *__restrict__ en_off,
@@ -515,37 +517,31 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
                                                       const int32_t *__restrict__ en_pair, AggArgs a) {
 #pragma clang fp contract(off)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
-    const int hd = a.heads * a.out_dim;
+    __shared__ float s_w[EN_ROWS][16][3];           // softmax weights of (h1, h2, self) per attention head
+    __shared__ long s_src[EN_ROWS][3];              // ft2 row of h1, h2, self (self: -1 at layer 0 = the shared row)
+    __shared__ long s_dst[EN_ROWS];                 // output row
+    const int hd = a.heads * a.out_dim, heads = a.heads;
     const int per_row = hd / VEC;
     const int m0 = blockIdx.x * EN_ROWS;
     const int rows = min(EN_ROWS, n_en - m0);
     const bool l0 = a.en_const_ft2 != nullptr;
-    for (int i = threadIdx.x; i < rows * per_row; i += blockDim.x) {
-        const int r = i / per_row;
-        const int c = (i - r * per_row) * VEC;
+    for (int i = threadIdx.x; i < rows * heads; i += blockDim.x) {
+        const int r = i / heads, hh = i - r * heads;
         const int m = m0 + r;
         const int f = en_frame[m];
         const int hb = head_off[f], H = head_off[f + 1] - hb;
         const int nb = node_off[f];
         const int v = H + (m - en_off[f]);
         const int h1 = en_pair[2 * (size_t)m], h2 = en_pair[2 * (size_t)m + 1];
-        const int hh = c / a.out_dim;
         const float *ra1, *ra2, *ra3;     // a1|a2 rows of h1, h2, self
-        float v1[VEC], v2[VEC], v3[VEC];  // feature rows
         if (l0) {
             ra1 = a.a12 + (size_t)(hb + h1) * 32;
             ra2 = a.a12 + (size_t)(hb + h2) * 32;
             ra3 = a.en_const_a;
-            ld_ftv<VEC>(a.ft2, (size_t)(hb + h1) * a.ld + c, a.ft_half, v1);
-            ld_ftv<VEC>(a.ft2, (size_t)(hb + h2) * a.ld + c, a.ft_half, v2);
-            ld_ftv<VEC>(a.en_const_ft2, (size_t)c, 0, v3);
         } else {
             ra1 = a.a12 + (size_t)(nb + h1) * 32;
             ra2 = a.a12 + (size_t)(nb + h2) * 32;
             ra3 = a.a12 + (size_t)(nb + v) * 32;
-            ld_ftv<VEC>(a.ft2, (size_t)(nb + h1) * a.ld + c, a.ft_half, v1);
-            ld_ftv<VEC>(a.ft2, (size_t)(nb + h2) * a.ld + c, a.ft_half, v2);
-            ld_ftv<VEC>(a.ft2, (size_t)(nb + v) * a.ld + c, a.ft_half, v3);
         }
         const float a2v = ra3[16 + hh];
         float e1 = ra1[hh] + a2v, e2 = ra2[hh] + a2v, e3 = ra3[hh] + a2v;
@@ -555,7 +551,27 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
         const float mx = fmaxf(fmaxf(e1, e2), e3);
         const float x1 = expf(e1 - mx), x2 = expf(e2 - mx), x3 = expf(e3 - mx);
         const float sum = (x1 + x2) + x3;
-        const float w1 = x1 / sum, w2 = x2 / sum, w3 = x3 / sum;
+        s_w[r][hh][0] = x1 / sum;
+        s_w[r][hh][1] = x2 / sum;
+        s_w[r][hh][2] = x3 / sum;
+        if (hh == 0) {
+            s_src[r][0] = (long)(l0 ? hb : nb) + h1;
+            s_src[r][1] = (long)(l0 ? hb : nb) + h2;
+            s_src[r][2] = l0 ? -1 : (long)nb + v;
+            s_dst[r] = (long)nb + v;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * per_row; i += blockDim.x) {
+        const int r = i / per_row;
+        const int c = (i - r * per_row) * VEC;
+        const int hh = c / a.out_dim;
+        float v1[VEC], v2[VEC], v3[VEC];  // feature rows
+        ld_ftv<VEC>(a.ft2, (size_t)s_src[r][0] * a.ld + c, a.ft_half, v1);
+        ld_ftv<VEC>(a.ft2, (size_t)s_src[r][1] * a.ld + c, a.ft_half, v2);
+        if (l0) ld_ftv<VEC>(a.en_const_ft2, (size_t)c, 0, v3);
+        else ld_ftv<VEC>(a.ft2, (size_t)s_src[r][2] * a.ld + c, a.ft_half, v3);
+        const float w1 = s_w[r][hh][0], w2 = s_w[r][hh][1], w3 = s_w[r][hh][2];
         vecf o;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
@@ -564,8 +580,8 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
             acc = acc + v3[k] * w3;
             o[k] = agg_activate(acc, a.out_mode, a.out_slope);
         }
-        if (a.score_mode) a.out[m] = o[0];
-        else *reinterpret_cast<vecf *>(a.out + (size_t)(nb + v) * a.ld_out + c) = o;
+        if (a.score_mode) a.out[m0 + r] = o[0];
+        else *reinterpret_cast<vecf *>(a.out + (size_t)s_dst[r] * a.ld_out + c) = o;
     }
 }
 
