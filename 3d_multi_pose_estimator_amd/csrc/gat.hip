@@ -268,24 +268,34 @@ __device__ __forceinline__ void coef40(F ft, const float *__restrict__ al, const
     o2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
 }
 
-constexpr int COEF_ROWS = 8;
+constexpr int COEF_ROWS = 32;      // rows per workgroup (fewer when the rows are wide: 48 KiB of LDS at most)
 
 __global__ __launch_bounds__(256) void k_attn_coef(const float *__restrict__ ft2, int ld, int n_rows, int heads,
                                                    int out_dim, const float *__restrict__ attn_l,
                                                    const float *__restrict__ attn_r, float *__restrict__ a12,
-                                                   int ft_half) {
-    extern __shared__ float s_ft[];                 // [COEF_ROWS][hd]
+                                                   int ft_half, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float s_ft[];   // [rows_per_wg][hdp], hdp = hd rounded up to 4 (+4: bank spread)
     const int hd = heads * out_dim;
-    const int r0 = blockIdx.x * COEF_ROWS;
-    const int nr = min(COEF_ROWS, n_rows - r0);
-    for (int i = threadIdx.x; i < nr * hd; i += blockDim.x) {
-        const int r = i / hd, c = i - r * hd;
-        s_ft[r * hd + c] = ld_ft(ft2, (size_t)(r0 + r) * ld + c, ft_half);
+    const int hd4 = (hd + 3) / 4, hdp = hd4 * 4 + 4;
+    const int r0 = blockIdx.x * rows_per_wg;
+    const int nr = min(rows_per_wg, n_rows - r0);
+    if (!ft_half && ld % 4 == 0 && hd4 * 4 <= ld) {
+        // fp32 rows: 16-byte loads (the row stride covers the rounded-up width)
+        for (int i = threadIdx.x; i < nr * hd4; i += blockDim.x) {
+            const int r = i / hd4, c4 = i - r * hd4;
+            *reinterpret_cast<float4 *>(s_ft + r * hdp + c4 * 4) =
+                *reinterpret_cast<const float4 *>(ft2 + (size_t)(r0 + r) * ld + c4 * 4);
+        }
+    } else {
+        for (int i = threadIdx.x; i < nr * hd; i += blockDim.x) {
+            const int r = i / hd, c = i - r * hd;
+            s_ft[r * hdp + c] = ld_ft(ft2, (size_t)(r0 + r) * ld + c, ft_half);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nr * heads; i += blockDim.x) {
         const int r = i / heads, h = i - r * heads;
-        const float *fv = s_ft + r * hd + h * out_dim;
+        const float *fv = s_ft + r * hdp + h * out_dim;
         float x1 = 0.f, x2 = 0.f;
         if (out_dim == 40) {
             coef40([&](int d) { return fv[d]; }, attn_l + h * 40, attn_r + h * 40, h & 1, x1, x2);
@@ -304,10 +314,12 @@ __global__ __launch_bounds__(256) void k_attn_coef(const float *__restrict__ ft2
 hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,
                             const float *attn_l, const float *attn_r, float *a12, int ft_half) {
     if (n_rows <= 0) return hipSuccess;
-    const int grid = (n_rows + COEF_ROWS - 1) / COEF_ROWS;
-    const size_t shm = (size_t)COEF_ROWS * heads * out_dim * sizeof(float);
-    hipLaunchKernelGGL(k_attn_coef, dim3(grid), dim3(256), shm, s, ft2, ld, n_rows, heads, out_dim, attn_l, attn_r,
-                       a12, ft_half);
+    const size_t row_bytes = (size_t)((heads * out_dim + 3) / 4 * 4 + 4) * sizeof(float);
+    int rows = (int)((size_t)48 * 1024 / row_bytes);
+    rows = rows < 1 ? 1 : rows > COEF_ROWS ? COEF_ROWS : rows;
+    const int grid = (n_rows + rows - 1) / rows;
+    hipLaunchKernelGGL(k_attn_coef, dim3(grid), dim3(256), rows * row_bytes, s, ft2, ld, n_rows, heads, out_dim, attn_l,
+                       attn_r, a12, ft_half, rows);
     return hipGetLastError();
 }
 
