@@ -758,21 +758,45 @@ __global__ __launch_bounds__(CB_THREADS) void k_cluster_block(const DevCfg *__re
     }
     __threadfence_block();
     __syncthreads();
-    for (int k = 2; k <= n; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int x = t; x < n / 2; x += CB_THREADS) {
-                const int i = ((x & ~(j - 1)) << 1) | (x & (j - 1));
-                const int p = i | j;
-                const bool up = (i & k) == 0;
-                const uint64_t a = keys[i], b = keys[p];
-                if ((a > b) == up) {
-                    keys[i] = b;
-                    keys[p] = a;
-                }
+    // bitonic network over n keys.  Keys that do not fit the LDS array live in global memory; the
+    // compare-exchange passes whose partner distance stays inside a CB_KCAP-key chunk (all but a few)
+    // then run on one chunk at a time staged in LDS.  The keys are unique (low bits = matching index),
+    // so the sorted order does not depend on how the network is scheduled.
+    auto pass = [&](uint64_t *buf, int cnt, int j, int k, int base) {
+        for (int x = t; x < cnt / 2; x += CB_THREADS) {
+            const int i = ((x & ~(j - 1)) << 1) | (x & (j - 1));
+            const int p = i | j;
+            const bool up = ((base + i) & k) == 0;
+            const uint64_t a = buf[i], b = buf[p];
+            if ((a > b) == up) {
+                buf[i] = b;
+                buf[p] = a;
             }
-            __threadfence_block();
-            __syncthreads();
         }
+        __threadfence_block();
+        __syncthreads();
+    };
+    if (n <= CB_KCAP) {
+        for (int k = 2; k <= n; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) pass(keys, n, j, k, 0);
+    } else {
+        for (int k = CB_KCAP; k <= n; k <<= 1) {
+            for (int j = k >> 1; j >= CB_KCAP; j >>= 1) pass(keys, n, j, k, 0);       // partners in different chunks
+            for (int c0 = 0; c0 < n; c0 += CB_KCAP) {
+                for (int i = t; i < CB_KCAP; i += CB_THREADS) s_keys[i] = keys[c0 + i];
+                __syncthreads();
+                if (k == CB_KCAP) {                                                   // all stages up to the chunk size
+                    for (int kk = 2; kk <= CB_KCAP; kk <<= 1)
+                        for (int j = kk >> 1; j > 0; j >>= 1) pass(s_keys, CB_KCAP, j, kk, c0);
+                } else {
+                    for (int j = CB_KCAP >> 1; j > 0; j >>= 1) pass(s_keys, CB_KCAP, j, k, c0);
+                }
+                for (int i = t; i < CB_KCAP; i += CB_THREADS) keys[c0 + i] = s_keys[i];
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+    }
     const int n_nodes = s_sc[NNODES];
 
     // greedy rules, 1024 pending matchings per chunk, one round per accepted matching

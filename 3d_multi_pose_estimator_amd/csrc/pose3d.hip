@@ -167,9 +167,11 @@ __device__ inline void person_front(const DevCfg *cfg, const PersonCtx &pc, cons
 // ---------------------------------------------------------------------------------------
 // MLP input rows
 // ---------------------------------------------------------------------------------------
-// 256 threads: the 180 pair solves of a 5-camera person (18 joints x 10 pairs, f64 Jacobi SVD each)
-// run in one round
-__global__ __launch_bounds__(256) void k_mlp_rows(const DevCfg *__restrict__ cfg, int pcap,
+// NT = 256 threads: the 180 pair solves of a 5-camera person (18 joints x 10 pairs, f64 Jacobi SVD
+// each) run in one round; NT = 1024 for rigs whose pair tables leave room for one workgroup per CU
+// only (23 cameras: 4554 pair solves per person, 116 KB of LDS)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_mlp_rows(const DevCfg *__restrict__ cfg, int pcap,
                                                   const int32_t *__restrict__ head_off,
                                                   const uint32_t *__restrict__ joint_mask,
                                                   const uint32_t *__restrict__ tri_mask,
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void k_mlp_rows(const DevCfg *__restrict__ cfg
     double *s_pts = s_und + (size_t)V * J * 2;      // [J][npairs][3]
     __shared__ int32_t s_head[MPE_MAX_CAMERAS];
     __shared__ uint32_t s_mask[MPE_MAX_CAMERAS], s_tmask[MPE_MAX_CAMERAS];
-    __shared__ float s_red[256];
+    __shared__ float s_red[NT];
     const int np_f = n_persons[f];
     const size_t slot = (size_t)f * pcap + p;
     if (p >= np_f) {
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void k_mlp_rows(const DevCfg *__restrict__ cfg
     for (int c = threadIdx.x; c < width; c += blockDim.x) acc += fabsf(row[c]);
     s_red[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = NT / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
         __syncthreads();
     }
@@ -323,12 +325,19 @@ hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const
                            float *rows, int ld_rows, uint8_t *valid) {
     if (b.n_frames <= 0) return hipSuccess;
     const size_t shm = ((size_t)V * J * 2 + (size_t)J * (V * (V - 1) / 2) * 3) * sizeof(double);
-    if (shm > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_rows),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return e;
+    if (shm > 40 * 1024) {
+        // fewer than four workgroups per CU by LDS: widen the workgroup instead
+        if (shm > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_rows<1024>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_mlp_rows<1024>, dim3(b.n_frames * pcap), dim3(1024), shm, s, cfg, pcap, b.d_frame_head_off,
+                           b.d_joint_mask, b.d_tri_mask, b.d_xy, b.d_vp, persons, n_persons, person_off, rows, ld_rows,
+                           valid);
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_mlp_rows, dim3(b.n_frames * pcap), dim3(256), shm, s, cfg, pcap, b.d_frame_head_off,
+    hipLaunchKernelGGL(k_mlp_rows<256>, dim3(b.n_frames * pcap), dim3(256), shm, s, cfg, pcap, b.d_frame_head_off,
                        b.d_joint_mask, b.d_tri_mask, b.d_xy, b.d_vp, persons, n_persons, person_off, rows, ld_rows,
                        valid);
     return hipGetLastError();
