@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
     __shared__ long s_src[EN_ROWS][3];              // ft2 row of h1, h2, self (self: -1 at layer 0 = the shared row)
     __shared__ long s_dst[EN_ROWS];                 // output row
     const int hd = a.heads * a.out_dim, heads = a.heads;
-    const int per_row = hd / VEC;
+    const int per_row = (hd + VEC - 1) / VEC;       // a VEC-column group may straddle two attention heads
     const int m0 = blockIdx.x * EN_ROWS;
     const int rows = min(EN_ROWS, n_en - m0);
     const bool l0 = a.en_const_ft2 != nullptr;
@@ -583,13 +583,26 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
         ld_ftv<VEC>(a.ft2, (size_t)s_src[r][1] * a.ld + c, a.ft_half, v2);
         if (l0) ld_ftv<VEC>(a.en_const_ft2, (size_t)c, 0, v3);
         else ld_ftv<VEC>(a.ft2, (size_t)s_src[r][2] * a.ld + c, a.ft_half, v3);
-        const float w1 = s_w[r][hh][0], w2 = s_w[r][hh][1], w3 = s_w[r][hh][2];
+        float w1[VEC], w2[VEC], w3[VEC];
+        const bool one_head = VEC == 1 || (c + VEC <= hd && (c + VEC - 1) / a.out_dim == hh);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            // columns behind the row's width (padding of the last group) reuse the last head: finite, never read
+            int hk = hh;
+            if (!one_head) {
+                hk = (c + k) / a.out_dim;
+                hk = hk < heads ? hk : heads - 1;
+            }
+            w1[k] = s_w[r][hk][0];
+            w2[k] = s_w[r][hk][1];
+            w3[k] = s_w[r][hk][2];
+        }
         vecf o;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            float acc = v1[k] * w1;
-            acc = acc + v2[k] * w2;
-            acc = acc + v3[k] * w3;
+            float acc = v1[k] * w1[k];
+            acc = acc + v2[k] * w2[k];
+            acc = acc + v3[k] * w3[k];
             o[k] = agg_activate(acc, a.out_mode, a.out_slope);
         }
         if (a.score_mode) a.out[m0 + r] = o[0];
@@ -1145,8 +1158,13 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
 #define MPE_EN(V_)                                                                                      \
     hipLaunchKernelGGL(k_aggregate_en<V_>, dim3(blocks), dim3(256), 0, s, b.n_edge_nodes, b.d_frame_head_off, \
                        b.d_frame_en_off, node_off, en_frame, en_pair, a)
+        // the edge-node kernel takes 16-byte groups whatever the head width (a group may straddle two
+        // heads), as long as the rounded-up row fits the row strides
+        const int hd4 = (a.heads * a.out_dim + 3) / 4 * 4;
+        const bool wide = !a.score_mode && !a.ft_half && a.ld % 4 == 0 && a.ld_out % 4 == 0 && hd4 <= a.ld && hd4 <= a.ld_out &&
+                          !a.en_const_ft2;
         if (vec == 4 && a.ft_half && a.out_dim % 8 == 0) MPE_EN(8);    // fp16 rows: 8 columns = one 16-byte load
-        else if (vec == 4) MPE_EN(4);
+        else if (vec == 4 || wide) MPE_EN(4);
         else if (vec == 2) MPE_EN(2);
         else MPE_EN(1);
 #undef MPE_EN
