@@ -1101,6 +1101,7 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
                                 const int32_t *en_pair, const float *attn_l, const float *attn_r, float *a12,
                                 const AggArgs &a, int n_rows_ft2, const uint16_t *head_src) {
     int n_cap, m_cap;
+    if (getenv("MPE_NO_HEAD_SRC_TABLE")) head_src = nullptr;                // read per call: tests toggle it
     const size_t shm = fused_lds_bytes(max_heads_per_frame, V, a.out_dim, &n_cap, &m_cap);
     const bool no_fuse = getenv("MPE_NO_FUSED_ATTENTION") != nullptr;       // read per call: tests toggle it
     if (shm <= FUSED_LDS_LIMIT && !no_fuse && b.n_frames > 0) {

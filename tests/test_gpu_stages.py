@@ -362,19 +362,27 @@ def test_attention_paths_give_identical_bits(monkeypatch):
         frames = [onp.processed_input(syn.make_frame(e.calib, 6000 + i, specs[i % 4])[0]) for i in range(96)]
         db = eng.to_device(eng.pack(frames))
         res = {}
+
+        def switch(name, on):
+            if on:
+                monkeypatch.setenv(name, '1')
+            else:
+                monkeypatch.delenv(name, raising=False)
+
+        # ... and two sources of the heads' in-edge lists (the per-batch table of k_head_sources, or the
+        # arithmetic inside the kernels that frames too large for the table fall back to), and the fused
+        # kernel stages its image with or without the overlapped softmax phase
         for fused in (True, False):
             for epi in (True, False):
-                if fused:
-                    monkeypatch.delenv('MPE_NO_FUSED_ATTENTION', raising=False)
-                else:
-                    monkeypatch.setenv('MPE_NO_FUSED_ATTENTION', '1')
-                if epi:
-                    monkeypatch.delenv('MPE_NO_COEF_EPILOGUE', raising=False)
-                else:
-                    monkeypatch.setenv('MPE_NO_COEF_EPILOGUE', '1')
-                sc, sh = eng.gat_scores(db, heads=True)
-                res[(fused, epi)] = (sc.cpu().numpy(), sh.cpu().numpy())
-        ref = res[(True, True)]
+                for table in (True, False):
+                    for overlap in ((True, False) if fused else (True,)):
+                        switch('MPE_NO_FUSED_ATTENTION', not fused)
+                        switch('MPE_NO_COEF_EPILOGUE', not epi)
+                        switch('MPE_NO_HEAD_SRC_TABLE', not table)
+                        switch('MPE_FUSED_NO_OVERLAP', not overlap)
+                        sc, sh = eng.gat_scores(db, heads=True)
+                        res[(fused, epi, table, overlap)] = (sc.cpu().numpy(), sh.cpu().numpy())
+        ref = res[(True, True, True, True)]
         for key, (sc, sh) in res.items():
             assert np.array_equal(sc, ref[0]) and np.array_equal(sh, ref[1]), key
     finally:
