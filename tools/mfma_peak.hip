@@ -3,6 +3,7 @@
 // against.   hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // same loop with eight different random operand pairs per lane (data toggling as in a real GEMM)
@@ -446,6 +447,112 @@ void run_wide(int blocks_per_cu, int cus, int nk, int share, int rows_a, bool wr
     hipFree(W);
 }
 
+// deeper prefetch at the same LDS footprint: 16-deep half-stages in a ring of four buffers (4 x 13.3 KB
+// = the 53 KB of the two 32-deep buffers), three half-stages in flight behind counted vmcnt waits and
+// raw barriers.  Rows are 64 B; chunk position = chunk ^ ((row >> 2) & 3) keeps the fragment reads
+// conflict-free (rows four apart share banks).
+template <int SPLIT>
+__global__ __launch_bounds__(256, 3) void k_stage_deep(float *out, int nk, const float *A, const float *W, int ld, int rows_a, int share) {
+    constexpr int HS = (128 + 80) * 16;             // floats per half-stage buffer
+    __shared__ __attribute__((aligned(1024))) float lds[4 * HS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fq = lane >> 4, fr = lane & 15, dr = lane >> 2, dp = lane & 3;   // DMA role: row within a 16-row group, chunk position
+    auto swz = [](int row) { return (row >> 2) & 3; };
+    int a_rd[2], w_rd[5];
+    for (int mt = 0; mt < 2; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * 16 + ((fq ^ swz(fr)) << 2);
+    for (int nt = 0; nt < 5; ++nt) w_rd[nt] = 128 * 16 + (nt * 16 + fr) * 16 + ((fq ^ swz(fr)) << 2);
+    const float *a_src[2], *w_src[2];
+    const int m0 = ((blockIdx.x / share) * 128) % rows_a;
+    for (int g = 0; g < 2; ++g) {
+        const int row = wave * 32 + g * 16 + dr;
+        a_src[g] = A + (size_t)(m0 + row) * ld + ((dp ^ swz(row)) << (SPLIT ? 3 : 2));
+    }
+    // weight rows: 5 groups of 16; wave 0 takes groups 0 and 4, waves 1..3 one group each
+    for (int g = 0; g < 2; ++g) {
+        const int grp = g == 0 ? wave : 4;
+        const int row = grp * 16 + dr;
+        w_src[g] = W + (size_t)((blockIdx.x % share) * 80 + row) * ld + ((dp ^ swz(row)) << (SPLIT ? 3 : 2));
+    }
+    const bool extra = wave == 0;
+    auto issue = [&](int h, int buf) {
+        // SPLIT: the half-stage takes the even / odd 16-byte chunks of its 32-deep stage (the chunk
+        // partition of the production kernels: bit-identical sums), i.e. 16-byte pieces at a 32-byte stride
+        const int koff = SPLIT ? (h >> 1) * 32 + (h & 1) * 4 : h * 16;
+        float *base = lds + buf * HS;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[g] + koff), (lds_void_t *)(base + (wave * 32 + g * 16) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(w_src[0] + koff), (lds_void_t *)(base + 128 * 16 + wave * 16 * 16), 16, 0, 0);
+        if (extra)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(w_src[1] + koff), (lds_void_t *)(base + 128 * 16 + 4 * 16 * 16), 16, 0, 0);
+    };
+    f32x4 acc[5][2];
+    for (int nt = 0; nt < 5; ++nt)
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nh = nk * 2;
+    issue(0, 0);
+    if (nh > 1) issue(1, 1);
+    if (nh > 2) issue(2, 2);
+    for (int h = 0; h < nh; ++h) {
+        const int left = nh - 1 - h;                 // half-stages issued after h that may stay in flight (at most 2)
+        if (left >= 2) {
+            if (extra) __builtin_amdgcn_s_waitcnt(0xF78);
+            else __builtin_amdgcn_s_waitcnt(0xF76);
+        } else if (left == 1) {
+            if (extra) __builtin_amdgcn_s_waitcnt(0xF74);
+            else __builtin_amdgcn_s_waitcnt(0xF73);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0xF70);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (h + 3 < nh) issue(h + 3, (h + 3) & 3);
+        const int cur = (h & 3) * HS;
+        f32x4 af[2], wf[5];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt]]);
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt]]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
+    }
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 5; ++nt)
+        for (int mt = 0; mt < 2; ++mt) sum += acc[nt][mt];
+    out[blockIdx.x * 256 + threadIdx.x] = sum[0] + sum[1] + sum[2] + sum[3];
+}
+
+template <int SPLIT>
+void run_deep(int blocks_per_cu, int cus, int nk, int share, int rows_a) {
+    const int grid = cus * blocks_per_cu, ld = nk * 32;
+    float *out, *A, *W;
+    hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+    hipMalloc(&A, (size_t)(rows_a + 128) * ld * sizeof(float));
+    hipMalloc(&W, (size_t)(share * 80) * ld * sizeof(float));
+    hipMemset(A, 0x3c, (size_t)(rows_a + 128) * ld * sizeof(float));
+    hipMemset(W, 0x3c, (size_t)(share * 80) * ld * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_stage_deep<SPLIT>, dim3(grid), dim3(256), 0, 0, out, nk, A, W, ld, rows_a, share);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_stage_deep<SPLIT>, dim3(grid), dim3(256), 0, 0, out, nk, A, W, ld, rows_a, share);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 4.0 * grid * 4 * (double)nk * 80 * 2048.0;
+    printf("16-deep half-stages%s, ring of 4 buffers, 3 in flight, K = %d, %d share, %d rows, workgroups/CU %d: %.1f TFLOP/s (%.2f ms) [%s]\n", SPLIT ? " (even / odd chunks)" : "", nk * 32, share, rows_a, blocks_per_cu, flop / ms / 1e9, ms / 4, hipGetErrorString(hipGetLastError()));
+    hipFree(out);
+    hipFree(A);
+    hipFree(W);
+}
+
 template <int MODE>
 void run_stage(int blocks_per_cu, int cus, int nk, int share = 5, int rows_a = 65536) {
     const int grid = cus * blocks_per_cu, ld = nk * 32;
@@ -534,10 +641,26 @@ void run_rand(int blocks_per_cu, int cus) {
     hipFree(rnd);
 }
 
-int main() {
+int main(int argc, char **argv) {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     printf("%s, %d CUs, clock %d MHz\n", p.name, p.multiProcessorCount, p.clockRate / 1000);
+    if (argc > 1 && !strcmp(argv[1], "deep")) {
+        // prefetch-depth comparison only
+        run_stage<1>(3, p.multiProcessorCount, 96, 5, 8192);
+        run_deep<0>(3, p.multiProcessorCount, 96, 5, 8192);
+        run_deep<1>(3, p.multiProcessorCount, 96, 5, 8192);
+        run_stage<1>(6, p.multiProcessorCount, 96, 38, 4096);
+        run_deep<0>(6, p.multiProcessorCount, 96, 38, 4096);
+        run_deep<1>(6, p.multiProcessorCount, 96, 38, 4096);
+        run_stage<1>(27, p.multiProcessorCount, 13, 5, 180224);
+        run_deep<0>(27, p.multiProcessorCount, 13, 5, 180224);
+        run_deep<1>(27, p.multiProcessorCount, 13, 5, 180224);
+        run_stage<1>(27, p.multiProcessorCount, 13, 5, 8192);
+        run_deep<0>(27, p.multiProcessorCount, 13, 5, 8192);
+        run_deep<1>(27, p.multiProcessorCount, 13, 5, 8192);
+        return 0;
+    }
     run<10>(1, p.multiProcessorCount);
     run<10>(2, p.multiProcessorCount);
     run<10>(3, p.multiProcessorCount);
