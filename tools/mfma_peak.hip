@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // same loop with eight different random operand pairs per lane (data toggling as in a real GEMM)
@@ -447,6 +448,23 @@ void run_wide(int blocks_per_cu, int cus, int nk, int share, int rows_a, bool wr
     hipFree(W);
 }
 
+// operand fill: MFMA_PEAK_RANDOM=1 -> pseudo-random floats in [-0.5, 0.5) instead of the constant byte
+// pattern (the switching activity of the multipliers, hence power and clock, depends on the operand bits)
+__global__ void k_fill_rand(float *p, size_t n, unsigned seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+        p[i] = (float)(x >> 8) / 16777216.f - 0.5f;
+    }
+}
+static void fill_operand(float *p, size_t n, unsigned seed) {
+    if (getenv("MFMA_PEAK_RANDOM")) hipLaunchKernelGGL(k_fill_rand, dim3(4096), dim3(256), 0, 0, p, n, seed);
+    else hipMemset(p, 0x3c, n * sizeof(float));
+    hipDeviceSynchronize();
+}
+
 // deeper prefetch at the same LDS footprint: 16-deep half-stages in a ring of four buffers (4 x 13.3 KB
 // = the 53 KB of the two 32-deep buffers), three half-stages in flight behind counted vmcnt waits and
 // raw barriers.  Rows are 64 B; chunk position = chunk ^ ((row >> 2) & 3) keeps the fragment reads
@@ -533,8 +551,8 @@ void run_deep(int blocks_per_cu, int cus, int nk, int share, int rows_a) {
     hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
     hipMalloc(&A, (size_t)(rows_a + 128) * ld * sizeof(float));
     hipMalloc(&W, (size_t)(share * 80) * ld * sizeof(float));
-    hipMemset(A, 0x3c, (size_t)(rows_a + 128) * ld * sizeof(float));
-    hipMemset(W, 0x3c, (size_t)(share * 80) * ld * sizeof(float));
+    fill_operand(A, (size_t)(rows_a + 128) * ld, 1u);
+    fill_operand(W, (size_t)(share * 80) * ld, 2u);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -560,8 +578,8 @@ void run_stage(int blocks_per_cu, int cus, int nk, int share = 5, int rows_a = 6
     hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
     hipMalloc(&A, (size_t)(rows_a + 128) * ld * sizeof(float));
     hipMalloc(&W, (size_t)(share * 80) * ld * sizeof(float));
-    hipMemset(A, 0x3c, (size_t)(rows_a + 128) * ld * sizeof(float));     // 0x3c3c3c3c = 0.0115 as float
-    hipMemset(W, 0x3c, (size_t)(share * 80) * ld * sizeof(float));
+    fill_operand(A, (size_t)(rows_a + 128) * ld, 1u);     // default 0x3c3c3c3c = 0.0115 as float
+    fill_operand(W, (size_t)(share * 80) * ld, 2u);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
