@@ -14,6 +14,8 @@
 // graph_generator.py:573-605), identical to packing.py: cameras in key order, cameras outside
 // used_cameras_skeleton_matching skipped, skeletons without a joint key skipped, numbers
 // converted with strtod (correctly rounded, like Python's float()).
+#include <sched.h>
+
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -22,6 +24,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -492,7 +496,102 @@ struct mpe_packed {
     std::string err;
 };
 
+// Frame index of one document, filled by a background thread: the serial scan for the frame extents
+// (4-5 GB/s) runs ahead of the windows that are being parsed, so packing a window costs its parse time
+// only.  Extents are published in batches; readers wait for the frame they need.
+struct mpe_json_index {
+    FrameScanner sc;                      // owned by the scan thread once it runs
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::pair<const char *, const char *>> pub;   // published extents (guarded by mu)
+    bool done = false, failed = false, stop = false;
+    std::string err;
+
+    void run() {
+        size_t sent = 0;
+        for (;;) {
+            const bool ok = sc.extend(sent + 64);
+            bool quit;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (; sent < sc.ext.size(); ++sent) pub.push_back(sc.ext[sent]);
+                if (!ok) {
+                    failed = true;
+                    err = sc.err;
+                }
+                if (!ok || sc.finished) done = true;
+                quit = done || stop;
+            }
+            cv.notify_all();
+            if (quit) return;
+        }
+    }
+
+    // extent of frame idx: 1 = found, 0 = the document has fewer frames, -1 = malformed before it
+    int get(size_t idx, std::pair<const char *, const char *> *out) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return pub.size() > idx || done; });
+        if (idx < pub.size()) {
+            *out = pub[idx];
+            return 1;
+        }
+        return failed ? -1 : 0;
+    }
+
+    ~mpe_json_index() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 static thread_local std::string g_pack_error;
+
+// Worker threads when the caller does not say: the CPUs this process may actually use -- the smaller of
+// the hardware threads, the affinity mask and the cgroup CPU quota (a container on a 256-thread host is
+// often limited to a few cores; 256 runnable parsers then only starve the scan thread).
+static int default_threads() {
+    static const int n = [] {
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+#ifdef __linux__
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) {
+            const int a = CPU_COUNT(&set);
+            if (a > 0 && a < hw) hw = a;
+        }
+        double quota = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                  // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            long period = 0;
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atof(q) / (double)period;
+            fclose(f);
+        } else {
+            long q = -1, per = 0;                                                // cgroup v1
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (fscanf(g, "%ld", &q) != 1) q = -1;
+                fclose(g);
+            }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(g, "%ld", &per) != 1) per = 0;
+                fclose(g);
+            }
+            if (q > 0 && per > 0) quota = (double)q / (double)per;
+        }
+        if (quota >= 1.0 && quota < hw) hw = (int)quota;
+#endif
+        if (const char *e = getenv("MPE_PACK_THREADS")) {
+            const int v = atoi(e);
+            if (v > 0) hw = v;
+        }
+        return hw;
+    }();
+    return n;
+}
+
 
 extern "C" {
 
@@ -501,7 +600,7 @@ const char *mpe_pack_last_error(void) { return g_pack_error.c_str(); }
 // parse the selected frames (thread pool); on failure g_pack_error is set
 static int parse_selected(const char *json, size_t len, const char *const *camera_names, int32_t n_cameras, int32_t n_joints,
                           int32_t frame_start, int32_t frame_step, int32_t max_frames, int32_t n_threads,
-                          std::vector<FrameOut> *fo_out, FrameScanner *index = nullptr) {
+                          std::vector<FrameOut> *fo_out, mpe_json_index *index = nullptr) {
     if ((!json && !index) || !camera_names || n_cameras < 1 || n_cameras > MPE_MAX_CAMERAS || n_joints < 1 || n_joints > MPE_MAX_JOINTS ||
         frame_step < 1 || frame_start < 0) {
         g_pack_error = "mpe_pack_json: bad argument";
@@ -509,47 +608,84 @@ static int parse_selected(const char *json, size_t len, const char *const *camer
     }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::string> cams(camera_names, camera_names + n_cameras);
-    std::vector<std::pair<const char *, const char *>> own;
-    if (index) {
-        // scan only as far as this window needs (the scanner resumes where it stopped)
-        const size_t want = max_frames > 0 ? (size_t)frame_start + (size_t)(max_frames - 1) * frame_step + 1 : (size_t)-1;
-        if (!index->extend(want)) {
+    std::vector<std::pair<const char *, const char *>> sel;
+    std::vector<FrameOut> &fo = *fo_out;
+    std::atomic<int> next{0};
+    std::atomic<bool> failed{false}, malformed{false};
+    int B = 0, nt = n_threads > 0 ? n_threads : default_threads();
+    auto t1 = t0;
+    if (index && max_frames > 0) {
+        // frames are parsed as the background scan publishes them; the window ends where the document does
+        std::atomic<int> limit{max_frames};
+        fo.assign((size_t)max_frames, FrameOut());
+        auto work = [&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= limit.load()) return;
+                std::pair<const char *, const char *> ext;
+                const int r = index->get((size_t)frame_start + (size_t)i * frame_step, &ext);
+                if (r <= 0) {
+                    if (r < 0) malformed = true;
+                    int cur = limit.load();
+                    while (i < cur && !limit.compare_exchange_weak(cur, i)) {}
+                    return;
+                }
+                if (!parse_frame(ext.first, ext.second, cams, n_joints, &fo[i])) failed = true;
+            }
+        };
+        if (nt < 1) nt = 1;
+        if (nt > max_frames) nt = max_frames;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (malformed) {
+            std::lock_guard<std::mutex> lk(index->mu);
             g_pack_error = index->err;
             return MPE_ERR_INVALID;
         }
+        B = limit.load();
+        fo.resize((size_t)B);
     } else {
-        std::string err;
-        if (!split_frames(json, json + len, &own, &err)) {
-            g_pack_error = err;
-            return MPE_ERR_INVALID;
+        std::vector<std::pair<const char *, const char *>> own;
+        if (index) {
+            // every frame of the document: wait for the scan to finish
+            std::pair<const char *, const char *> ext;
+            if (index->get((size_t)-2, &ext) < 0) {
+                std::lock_guard<std::mutex> lk(index->mu);
+                g_pack_error = index->err;
+                return MPE_ERR_INVALID;
+            }
+            std::lock_guard<std::mutex> lk(index->mu);
+            own = index->pub;
+        } else {
+            std::string err;
+            if (!split_frames(json, json + len, &own, &err)) {
+                g_pack_error = err;
+                return MPE_ERR_INVALID;
+            }
         }
-    }
-    const std::vector<std::pair<const char *, const char *>> &ext = index ? index->ext : own;
-    std::vector<std::pair<const char *, const char *>> sel;
-    for (size_t i = (size_t)frame_start; i < ext.size(); i += (size_t)frame_step) {
-        if (max_frames > 0 && (int32_t)sel.size() >= max_frames) break;
-        sel.push_back(ext[i]);
-    }
-    const auto t1 = std::chrono::steady_clock::now();
-    const int B = (int)sel.size();
-    std::vector<FrameOut> &fo = *fo_out;
-    fo.assign((size_t)B, FrameOut());
-    std::atomic<int> next{0};
-    std::atomic<bool> failed{false};
-    auto work = [&]() {
-        for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= B) return;
-            if (!parse_frame(sel[i].first, sel[i].second, cams, n_joints, &fo[i])) failed = true;
+        for (size_t i = (size_t)frame_start; i < own.size(); i += (size_t)frame_step) {
+            if (max_frames > 0 && (int32_t)sel.size() >= max_frames) break;
+            sel.push_back(own[i]);
         }
-    };
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
-    if (nt < 1) nt = 1;
-    if (nt > B) nt = B > 0 ? B : 1;
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
+        t1 = std::chrono::steady_clock::now();
+        B = (int)sel.size();
+        fo.assign((size_t)B, FrameOut());
+        auto work = [&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= B) return;
+                if (!parse_frame(sel[i].first, sel[i].second, cams, n_joints, &fo[i])) failed = true;
+            }
+        };
+        if (nt < 1) nt = 1;
+        if (nt > B) nt = B > 0 ? B : 1;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    }
     if (failed) {
         for (int i = 0; i < B; ++i)
             if (!fo[i].error.empty()) {
@@ -667,10 +803,6 @@ int mpe_pack_json_into(const char *json, size_t len, const char *const *camera_n
     return MPE_OK;
 }
 
-struct mpe_json_index {
-    FrameScanner sc;
-};
-
 int mpe_json_index_create(const char *json, size_t len, mpe_json_index **out) {
     if (!json || !out) {
         g_pack_error = "mpe_json_index_create: bad argument";
@@ -684,6 +816,7 @@ int mpe_json_index_create(const char *json, size_t len, mpe_json_index **out) {
         delete ix;
         return MPE_ERR_INVALID;
     }
+    ix->th = std::thread([ix] { ix->run(); });
     *out = ix;
     return MPE_OK;
 }
@@ -702,7 +835,7 @@ int mpe_pack_indexed_into(mpe_json_index *ix, const char *const *camera_names, i
     if (max_frames <= 0 || max_frames > dst->max_frames) max_frames = dst->max_frames;
     std::vector<FrameOut> fo;
     const int rc = parse_selected(nullptr, 0, camera_names, n_cameras, n_joints, frame_start, frame_step, max_frames, n_threads, &fo,
-                                  &ix->sc);
+                                  ix);
     if (rc) return rc;
     size_t H = 0;
     for (const FrameOut &f : fo) H += f.heads.size();

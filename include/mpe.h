@@ -263,10 +263,13 @@ int mpe_pack_json_into(const char *json, size_t len, const char *const *camera_n
                        int32_t n_joints, int32_t frame_start, int32_t frame_step, int32_t max_frames,
                        int32_t n_threads, const mpe_pack_dst *dst, int32_t *n_frames, int32_t *n_heads,
                        int32_t *n_edge_nodes);
-/* A document that is consumed in windows (frame_start, max_frames): the index remembers the frame
- * extents found so far and resumes its scan where it stopped, so the document is scanned once, and
- * only as far as the windows asked for.  `json` must stay valid and unchanged while the index lives.
- * One index may be used from one thread at a time. */
+/* A document that is consumed in windows (frame_start, max_frames): the index scans the document for
+ * its frame extents ONCE, in a background thread it starts at creation, ahead of the windows; a window
+ * is parsed as its frames are published (n_threads = 0: as many workers as the process may use: the
+ * smaller of the hardware threads, the affinity mask and the cgroup CPU quota; MPE_PACK_THREADS
+ * overrides).  A malformed document fails the first window that reaches the damage.  `json` must stay
+ * valid and unchanged while the index lives; mpe_json_index_free joins the scan thread.  One index may
+ * be used from one caller thread at a time. */
 typedef struct mpe_json_index mpe_json_index;
 int mpe_json_index_create(const char *json, size_t len, mpe_json_index **out);
 void mpe_json_index_free(mpe_json_index *ix);
