@@ -318,3 +318,15 @@ def test_json_index_windows_equal_one_shot(calib):
         h += n
     assert h == whole.n_heads
     ix.close()
+    # a cut-off document: the background scan fails at the damage; windows in front of it still pack, the
+    # first window that needs a frame behind it raises, and closing the index (joins the scan thread) works
+    cut = text.encode()[:int(len(text) * 0.7)]
+    ix = packing.JsonIndex(cut)
+    pb = packing.pack_json_into(ix, calib.params, arena, frame_start=0, max_frames=2)
+    assert pb.n_frames == 2 and np.array_equal(pb.slot_n, whole.slot_n[:2])
+    with pytest.raises(ValueError, match='unterminated'):
+        for start in range(2, len(frames) + 4, 2):
+            packing.pack_json_into(ix, calib.params, arena, frame_start=start, max_frames=2)
+    ix.close()
+    # an index that is dropped before anything was packed (scan thread still running or already done)
+    packing.JsonIndex(text).close()
