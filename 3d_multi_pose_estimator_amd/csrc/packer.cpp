@@ -15,6 +15,9 @@
 // used_cameras_skeleton_matching skipped, skeletons without a joint key skipped, numbers
 // converted with strtod (correctly rounded, like Python's float()).
 #include <sched.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <atomic>
 #include <chrono>
@@ -406,6 +409,95 @@ bool parse_frame(const char *b, const char *e, const std::vector<std::string> &c
     return false;
 }
 
+// ---- byte searches of the frame scanner -------------------------------------------------------
+// scalar forms (any CPU) and AVX2 forms (32 bytes per step), chosen once at start-up
+static const char *find_special_scalar(const char *p, const char *e) {
+    static const struct Special {
+        bool is[256] = {};
+        Special() { is[(unsigned char)'"'] = is[(unsigned char)'{'] = is[(unsigned char)'}'] = is[(unsigned char)'['] = is[(unsigned char)']'] = true; }
+    } special;
+    while (p < e && !special.is[(unsigned char)*p]) ++p;      // numbers, commas, blanks: nothing to track
+    return p;
+}
+
+// first quote at or after q that closes the string (even number of backslashes in front of it, counted
+// back to `lo`, the first byte of the string body); nullptr if there is none
+static const char *find_closing_quote_scalar(const char *q, const char *e, const char *lo) {
+    for (;;) {
+        const char *hit = static_cast<const char *>(memchr(q, '"', (size_t)(e - q)));
+        if (!hit) return nullptr;
+        const char *bs = hit;               // count the backslashes in front of it
+        while (bs > lo && bs[-1] == '\\') --bs;
+        if (((hit - bs) & 1) == 0) return hit;
+        q = hit + 1;
+    }
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static const char *find_special_avx2(const char *p, const char *e) {
+    const __m256i q = _mm256_set1_epi8('"'), a = _mm256_set1_epi8('{'), b = _mm256_set1_epi8('}'), c = _mm256_set1_epi8('['),
+                  d = _mm256_set1_epi8(']');
+    while (p + 32 <= e) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p));
+        const __m256i m = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, q), _mm256_cmpeq_epi8(v, a)),
+                                          _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, b), _mm256_cmpeq_epi8(v, c)),
+                                                          _mm256_cmpeq_epi8(v, d)));
+        const unsigned bits = (unsigned)_mm256_movemask_epi8(m);
+        if (bits) return p + __builtin_ctz(bits);
+        p += 32;
+    }
+    return find_special_scalar(p, e);
+}
+
+// Inside the camera strings nearly every quote is an escaped one (\"): a quote with exactly one
+// backslash in front is skipped in the mask, one with none closes the string, and only quotes behind two
+// or more backslashes (rare) are settled by counting the run.
+__attribute__((target("avx2"))) static const char *find_closing_quote_avx2(const char *q, const char *e, const char *lo) {
+    const __m256i vq = _mm256_set1_epi8('"'), vb = _mm256_set1_epi8('\\');
+    // backslashes in the two bytes in front of the block
+    uint64_t prev2 = 0;
+    if (q - lo >= 1 && q[-1] == '\\') prev2 |= 2;
+    if (q - lo >= 2 && q[-2] == '\\') prev2 |= 1;
+    while (q + 32 <= e) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q));
+        const uint64_t mq = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vq));
+        const uint64_t mb = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, vb));
+        const uint64_t MB = (mb << 2) | prev2;             // bit i + 2 = backslash at byte i of the block
+        if (mq) {
+            const uint64_t esc1 = mq & (MB >> 1);          // a backslash right in front
+            const uint64_t esc2 = esc1 & MB;               // and one in front of that: count the run
+            uint64_t m = (mq & ~esc1) | esc2;
+            while (m) {
+                const int i = __builtin_ctzll(m);
+                if (!((esc2 >> i) & 1)) return q + i;
+                const char *hit = q + i, *bs = hit;
+                while (bs > lo && bs[-1] == '\\') --bs;
+                if (((hit - bs) & 1) == 0) return hit;
+                m &= m - 1;
+            }
+        }
+        prev2 = (mb >> 30) & 3;
+        q += 32;
+    }
+    return find_closing_quote_scalar(q, e, lo);
+}
+#endif
+
+typedef const char *(*find_special_fn)(const char *, const char *);
+typedef const char *(*find_quote_fn)(const char *, const char *, const char *);
+static find_special_fn g_find_special = find_special_scalar;
+static find_quote_fn g_find_quote = find_closing_quote_scalar;
+static const bool g_scan_simd = [] {
+#if defined(__x86_64__)
+    if (!getenv("MPE_PACK_NO_SIMD") && __builtin_cpu_supports("avx2")) {
+        g_find_special = find_special_avx2;
+        g_find_quote = find_closing_quote_avx2;
+        return true;
+    }
+#endif
+    return false;
+}();
+
 // Extents of the elements of the top-level array: a RESUMABLE scan (bracket depth with string
 // awareness).  Most of a frame's bytes sit inside the per-camera JSON strings (the skeleton lists
 // are JSON inside JSON), so inside a string the scanner jumps from one quote / backslash to the next
@@ -436,26 +528,15 @@ struct FrameScanner {
 
     // scan on until at least `want` frames are known or the list ends; false on malformed input
     bool extend(size_t want) {
-        static const struct Special {
-            bool is[256] = {};
-            Special() { is[(unsigned char)'"'] = is[(unsigned char)'{'] = is[(unsigned char)'}'] = is[(unsigned char)'['] = is[(unsigned char)']'] = true; }
-        } special;
         while (!finished && ext.size() < want) {
-            while (p < e && !special.is[(unsigned char)*p]) ++p;      // numbers, commas, blanks: nothing to track
+            p = g_find_special(p, e);
             if (p >= e) { err = "unterminated top-level list"; return false; }
             const char ch = *p;
             if (ch == '"') {
                 // skip the string: next quote that is not escaped
-                const char *q = p + 1;
-                for (;;) {
-                    const char *hit = static_cast<const char *>(memchr(q, '"', (size_t)(e - q)));
-                    if (!hit) { err = "unterminated string"; return false; }
-                    const char *bs = hit;               // count the backslashes in front of it
-                    while (bs > q && bs[-1] == '\\') --bs;
-                    q = hit + 1;
-                    if (((hit - bs) & 1) == 0) break;   // even number: the quote closes the string
-                }
-                p = q;
+                const char *hit = g_find_quote(p + 1, e, p + 1);
+                if (!hit) { err = "unterminated string"; return false; }
+                p = hit + 1;
                 continue;
             }
             if (ch == '{' || ch == '[') {

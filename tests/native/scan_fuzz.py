@@ -1,0 +1,29 @@
+"""Fuzz of the frame scanner (csrc/packer.cpp): random frames whose keys and values are full of
+backslash runs, quotes and brackets inside strings; every frame must be found and parse as an object
+(unused camera names -> the parser skips the values).  Run with MPE_PACK_NO_SIMD=1 for the scalar
+searches; tests/test_host_logic.py drives both."""
+import importlib, json, os, random, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+PKG='3d_multi_pose_estimator_amd'
+par=importlib.import_module(PKG+'.parameters'); packing=importlib.import_module(PKG+'.packing')
+random.seed(int(sys.argv[1]) if len(sys.argv)>1 else 1)
+def rnd_string():
+    n=random.randint(0,90)
+    alphabet=['\\','"','{','}','[',']','a',' ',',','\\\\','\\"','x'*33]
+    return ''.join(random.choice(alphabet) for _ in range(n))
+def rnd_val(d=0):
+    r=random.random()
+    if d>3 or r<0.3: return rnd_string()
+    if r<0.5: return random.random()*1e3
+    if r<0.75: return [rnd_val(d+1) for _ in range(random.randint(0,4))]
+    return {rnd_string(): rnd_val(d+1) for _ in range(random.randint(0,3))}
+frames=[{('zz%d'%k)+rnd_string(): rnd_val() for k in range(random.randint(0,4))} for _ in range(300)]
+text=json.dumps(frames).encode()
+arena=packing.CapacityArena(5,18,64,640,'cpu')
+ix=packing.JsonIndex(text)
+tot=0
+for st in range(0,400,64):
+    pb=packing.pack_json_into(ix, par.parameters, arena, frame_start=st, max_frames=64); tot+=pb.n_frames
+ix.close()
+print('frames', tot, 'simd', not os.environ.get('MPE_PACK_NO_SIMD'))
+assert tot==300

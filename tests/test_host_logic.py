@@ -330,3 +330,23 @@ def test_json_index_windows_equal_one_shot(calib):
     ix.close()
     # an index that is dropped before anything was packed (scan thread still running or already done)
     packing.JsonIndex(text).close()
+
+
+def test_frame_scanner_fuzz_simd_and_scalar():
+    """The frame scanner's byte searches (AVX2 where the CPU has it, scalar otherwise) on random
+    documents with escaped quotes, backslash runs and brackets inside strings: all frames found,
+    each parses.  The scalar searches are chosen at load time (MPE_PACK_NO_SIMD), hence subprocesses."""
+    import subprocess
+    import sys
+    if not os.path.exists(pkg('lib').LIB_PATH):
+        pytest.skip('library not built')
+    script = os.path.join(ROOT, 'tests', 'native', 'scan_fuzz.py')
+    for seed in (1, 2, 3):
+        for no_simd in (False, True):
+            env = dict(os.environ)
+            env.pop('MPE_PACK_NO_SIMD', None)
+            if no_simd:
+                env['MPE_PACK_NO_SIMD'] = '1'
+            r = subprocess.run([sys.executable, script, str(seed)], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert 'frames 300 simd %s' % (not no_simd) in r.stdout
