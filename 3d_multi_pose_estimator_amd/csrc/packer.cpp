@@ -200,6 +200,41 @@ bool read_number(Cursor &c, double *v) {
 
 bool skip_value(Cursor &c);
 
+typedef const char *(*find_special_fn)(const char *, const char *);
+typedef const char *(*find_quote_fn)(const char *, const char *, const char *);
+extern find_special_fn g_find_special;      // next of " { } [ ]          (scalar or AVX2, chosen at start-up)
+extern find_quote_fn g_find_quote;          // next quote that closes a string
+
+// Skip one balanced container at the OUTER level (plain JSON text, not the body of a string) without
+// descending into it: jump from one structural byte to the next, strings skipped whole, bracket kinds
+// checked with a small stack.  This is where the unused ground-truth lists of a frame (about 40 % of
+// its bytes) go by.  Containers nested deeper than the stack fall back to the recursive skip.
+bool skip_balanced(Cursor &c, bool *too_deep) {
+    char stack[64];
+    int depth = 0;
+    const char *p = c.p;
+    *too_deep = false;
+    for (;;) {
+        p = g_find_special(p, c.end);
+        if (p >= c.end) return false;
+        const char ch = *p;
+        if (ch == '"') {
+            const char *hit = g_find_quote(p + 1, c.end, p + 1);
+            if (!hit) return false;
+            p = hit + 1;
+            continue;
+        }
+        if (ch == '{' || ch == '[') {
+            if (depth == 64) { *too_deep = true; return false; }
+            stack[depth++] = ch;
+        } else {
+            if (depth == 0 || stack[depth - 1] != (ch == '}' ? '{' : '[')) return false;
+            if (--depth == 0) { c.p = p + 1; return true; }
+        }
+        ++p;
+    }
+}
+
 bool skip_container(Cursor &c, char open, char close) {
     if (c.p >= c.end || *c.p != open) return false;
     ++c.p;
@@ -227,6 +262,11 @@ bool skip_value(Cursor &c) {
     skip_ws(c);
     if (c.p >= c.end) return false;
     if (at_quote(c)) return read_string(c, nullptr);
+    if (!c.inner && (*c.p == '{' || *c.p == '[')) {
+        bool too_deep = false;
+        if (skip_balanced(c, &too_deep)) return true;
+        if (!too_deep) return false;
+    }
     if (*c.p == '{') return skip_container(c, '{', '}');
     if (*c.p == '[') return skip_container(c, '[', ']');
     if (c.end - c.p >= 4 && !strncmp(c.p, "null", 4)) { c.p += 4; return true; }
@@ -483,10 +523,8 @@ __attribute__((target("avx2"))) static const char *find_closing_quote_avx2(const
 }
 #endif
 
-typedef const char *(*find_special_fn)(const char *, const char *);
-typedef const char *(*find_quote_fn)(const char *, const char *, const char *);
-static find_special_fn g_find_special = find_special_scalar;
-static find_quote_fn g_find_quote = find_closing_quote_scalar;
+find_special_fn g_find_special = find_special_scalar;
+find_quote_fn g_find_quote = find_closing_quote_scalar;
 static const bool g_scan_simd = [] {
 #if defined(__x86_64__)
     if (!getenv("MPE_PACK_NO_SIMD") && __builtin_cpu_supports("avx2")) {
