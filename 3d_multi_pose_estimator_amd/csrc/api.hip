@@ -979,7 +979,7 @@ int mpe_profile_enable(mpe_ctx *ctx, int32_t on) {
     if (!ctx) return MPE_ERR_INVALID;
     DeviceGuard dg(ctx);
     ctx->profiling = on != 0;
-    ctx->prof_used = 0;
+    if (on == 1) ctx->prof_used = 0;        // 1 = start afresh, 2 = resume (keep the records), 0 = pause / off
     return MPE_OK;
 }
 

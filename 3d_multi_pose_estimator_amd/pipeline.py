@@ -366,8 +366,10 @@ class Engine:
             self.lib.mpe_free_device(self.ctx, dbias)
 
     # ---- profiling --------------------------------------------------------------------
-    def profile(self, on):
-        self._chk(self.lib.mpe_profile_enable(self.ctx, 1 if on else 0))
+    def profile(self, on, resume=False):
+        """Per-GEMM HIP event pairs on/off.  resume=True keeps the records taken so far (sampling: events
+        on every n-th batch only, since the event packets cost ~2 % of a step)."""
+        self._chk(self.lib.mpe_profile_enable(self.ctx, (2 if resume else 1) if on else 0))
 
     def profile_read(self):
         ms, fl, n, tot = C.c_double(), C.c_double(), C.c_int64(), C.c_double()

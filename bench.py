@@ -80,6 +80,9 @@ def parse_args(argv=None):
                     help='2 = software pipeline across steps: matching of batch i+1 overlaps the 3D stage of batch i')
     ap.add_argument('--no-io', action='store_true', help='skip the second (pinned host -> poses in pinned host) timed region')
     ap.add_argument('--no-profile', action='store_true', help='no per-GEMM HIP events (roofline comes out null)')
+    ap.add_argument('--profile-every', type=int, default=8,
+                    help='HIP event pairs around the GEMM launches on every n-th timed step (the event packets cost ~2 %% of a '
+                         'step when taken on every step)')
     ap.add_argument('--dry-run', action='store_true',
                     help='no GPU work: exercises launch, rendezvous, sharding and the all-gather with stand-in results '
                          '(CPU tests of the N > 1 path); prints no throughput')
@@ -278,11 +281,23 @@ def run_rank(args):
     eng.sync_status()
     for _ in range(args.warmup):
         step()
+    every = max(1, args.profile_every)
+    sampled = len(range(0, args.steps, every))
     if not args.no_profile:
         eng.profile(True)
-    elapsed, (poses, n_persons) = timed(lambda i: step(), args.steps)
+        eng.profile(False)
+
+    def timed_step(i):
+        # live HIP events around the GEMM launches of every `every`-th step of the timed region
+        if not args.no_profile:
+            eng.profile(i % every == 0, resume=True)
+        return step()
+
+    elapsed, (poses, n_persons) = timed(timed_step, args.steps)
     prof = eng.profile_read() if not args.no_profile else None
     eng.profile(False)
+    if prof is not None:
+        prof['sampled_steps'] = sampled
 
     # ---- contract form: pinned host -> H2D -> compute -> D2H into pinned host, double-buffered ----
     io = None
@@ -407,8 +422,9 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
         'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': src,
         'launches': prof['gemm_launches'], 'avg_launch_ms': prof['gemm_ms'] / max(1, prof['gemm_launches']),
-        'flop_per_step': prof['gemm_flop'] / args.steps,
-        'gemm_share_of_step': gemm_s / elapsed,
+        'sampled_steps': prof.get('sampled_steps', args.steps),
+        'flop_per_step': prof['gemm_flop'] / max(1, prof.get('sampled_steps', args.steps)),
+        'gemm_share_of_step': gemm_s * args.steps / max(1, prof.get('sampled_steps', args.steps)) / elapsed,
         'flop_definition': 'algorithmic 2*M*N*K of the launches (layer-0 edge-node rows de-duplicated)'
                            + ('; NOTE: reduced-precision run, bf16 launches are priced against the fp32 peak here' if reduced else ''),
         'hbm': {'achieved': hbm_tbs, 'peak': PEAK_HBM_TBS, 'unit': 'TB/s', 'frac': hbm_tbs / PEAK_HBM_TBS,

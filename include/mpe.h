@@ -282,7 +282,7 @@ const char *mpe_pack_last_error(void);
 /* Timing probe for bench.py: average duration (ms) of the dominant GEMM launches measured
  * with HIP events on the launch stream during the last mpe_match_batch / mpe_mlp3d_batch
  * when profiling is enabled; see bench.py. */
-int mpe_profile_enable(mpe_ctx *ctx, int32_t on);
+int mpe_profile_enable(mpe_ctx *ctx, int32_t on);      /* 1 = on, records cleared; 2 = on, records kept (resume); 0 = off (records kept until read) */
 int mpe_profile_read(mpe_ctx *ctx, double *gemm_ms, double *gemm_flop, int64_t *gemm_launches,
                      double *total_ms);
 
