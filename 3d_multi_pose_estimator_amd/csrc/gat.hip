@@ -526,10 +526,11 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
                                                       const int32_t *__restrict__ en_off,
                                                       const int32_t *__restrict__ node_off,
                                                       const int32_t *__restrict__ en_frame,
-                                                      const int32_t *__restrict__ en_pair, AggArgs a) {
+                                                      const int32_t *__restrict__ en_pair, AggArgs a, int hmax) {
 #pragma clang fp contract(off)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     __shared__ float s_w[EN_ROWS][16][3];           // softmax weights of (h1, h2, self) per attention head
+    __shared__ int s_over[EN_ROWS];                 // row of a frame beyond max_heads_per_frame (flagged by k_topology): score 0
     __shared__ long s_src[EN_ROWS][3];              // ft2 row of h1, h2, self (self: -1 at layer 0 = the shared row)
     __shared__ long s_dst[EN_ROWS];                 // output row
     const int hd = a.heads * a.out_dim, heads = a.heads;
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
             s_src[r][1] = (long)(l0 ? hb : nb) + h2;
             s_src[r][2] = l0 ? -1 : (long)nb + v;
             s_dst[r] = (long)nb + v;
+            s_over[r] = H > hmax ? 1 : 0;
         }
     }
     __syncthreads();
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
             acc = acc + v3[k] * w3[k];
             o[k] = agg_activate(acc, a.out_mode, a.out_slope);
         }
-        if (a.score_mode) a.out[m0 + r] = o[0];
+        if (a.score_mode) a.out[m0 + r] = s_over[r] ? 0.f : o[0];
         else *reinterpret_cast<vecf *>(a.out + (size_t)s_dst[r] * a.ld_out + c) = o;
     }
 }
@@ -1158,7 +1160,7 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
         const unsigned blocks = (unsigned)((b.n_edge_nodes + EN_ROWS - 1) / EN_ROWS);
 #define MPE_EN(V_)                                                                                      \
     hipLaunchKernelGGL(k_aggregate_en<V_>, dim3(blocks), dim3(256), 0, s, b.n_edge_nodes, b.d_frame_head_off, \
-                       b.d_frame_en_off, node_off, en_frame, en_pair, a)
+                       b.d_frame_en_off, node_off, en_frame, en_pair, a, max_heads_per_frame)
         // the edge-node kernel takes 16-byte groups whatever the head width (a group may straddle two
         // heads), as long as the rounded-up row fits the row strides
         const int hd4 = (a.heads * a.out_dim + 3) / 4 * 4;

@@ -251,11 +251,17 @@ def test_reduced_mode_cluster_agreement_with_oracle(tmp_path):
         eng.close()
 
 
-def test_frame_beyond_capacity_is_flagged_on_device():
+@pytest.mark.parametrize('general_path', [False, True])
+def test_frame_beyond_capacity_is_flagged_on_device(general_path, monkeypatch):
     """mpe.h per-frame capacity contract: a frame with more skeletons than max_heads_per_frame
     that slips past the host (here: the packed batch is uploaded without Engine.check_capacity)
     is detected by k_topology, yields zero scores and no persons, leaves its neighbours intact,
-    and mpe_sync_status returns MPE_ERR_CAPACITY exactly once."""
+    and mpe_sync_status returns MPE_ERR_CAPACITY exactly once -- on the fused attention kernel and on
+    the general kernels (what larger frames run on)."""
+    if general_path:
+        monkeypatch.setenv('MPE_NO_FUSED_ATTENTION', '1')
+    else:
+        monkeypatch.delenv('MPE_NO_FUSED_ATTENTION', raising=False)
     onp = oracle()
     syn = pkg('synthetic')
     L = pkg('lib')
