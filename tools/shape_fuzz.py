@@ -1,0 +1,92 @@
+"""Diagnostic: the whole path (match + MLP rows + MLP 3D) against the oracle on frames of RANDOM
+shape: 0-6 persons, random camera subsets and orders, empty cameras, spurious skeletons, dropped
+joints, ID keys, detector noise.  Clusters must equal the oracle's (or differ only where the deciding
+score gap is below the measured score deviation), scores within 2e-5, MLP rows within 3e-7.
+
+    python tools/shape_fuzz.py [n_frames] [seed]      -> gpurun_out/shape_fuzz.json
+"""
+import importlib, json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import oracle_np as onp
+PKG = '3d_multi_pose_estimator_amd'
+
+
+def first_divergence(s_gpu, s_ref, thr=0.5):
+    """score gap at the first diverging decision of the greedy pass, and the gap the measured score
+    deviation can explain (as tools/parity_rate.py)"""
+    dev = float(np.abs(s_gpu - s_ref).max())
+    og = [m for m in np.argsort(-s_gpu, kind='stable') if s_gpu[m] > thr]
+    orf = [m for m in np.argsort(-s_ref, kind='stable') if s_ref[m] > thr]
+    for k in range(max(len(og), len(orf))):
+        a = og[k] if k < len(og) else None
+        b = orf[k] if k < len(orf) else None
+        if a == b:
+            continue
+        if a is None or b is None:
+            m = b if a is None else a
+            return abs(float(s_ref[m]) - thr), dev
+        return abs(float(s_ref[a]) - float(s_ref[b])), 2.0 * dev
+    return None, dev
+
+
+syn = importlib.import_module(PKG + '.synthetic'); cal = importlib.import_module(PKG + '.calibration')
+par = importlib.import_module(PKG + '.parameters'); pipeline = importlib.import_module(PKG + '.pipeline')
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+calib = cal.Calibration(par.parameters)
+names = list(calib.params.camera_names)
+sd = syn.gat_state_dict(7, 902, logit_gain=25.0, logit_shift=0.698); prm = syn.gat_params(902)
+mlp_sd = syn.mlp_state_dict(11, 1260)
+frames = []
+for i in range(n):
+    k = rng.randint(1, len(names) + 1)
+    cams = list(rng.permutation(names)[:k])
+    empty = tuple(c for c in cams if rng.rand() < 0.15)
+    spec = syn.FrameSpec(persons=int(rng.randint(0, 7)), cameras=cams, noise_px=float(rng.choice([0.0, 1.0, 3.0])),
+                         joint_drop=float(rng.choice([0.0, 0.2, 0.6])), add_id_key=bool(rng.rand() < 0.3),
+                         spurious=int(rng.randint(0, 3)), empty_cameras=empty, float_conf=bool(rng.rand() < 0.7))
+    frames.append(onp.processed_input(syn.make_frame(calib, 9000 + i, spec)[0]))
+sm = list(calib.params.used_cameras_skeleton_matching)
+eng = pipeline.Engine(par.parameters, calib, max_frames=n, max_persons_per_camera=9)
+eng.load_gat(sd, prm); eng.load_mlp(mlp_sd)
+db = eng.to_device(eng.pack(frames))
+scores, persons, n_persons = eng.match(db)
+eng.sync_status()
+poses, valid = eng.mlp3d(db, persons, n_persons)
+scores, persons, n_persons = scores.cpu().numpy(), persons.cpu().numpy(), n_persons.cpu().numpy()
+poses, valid = poses.cpu().numpy(), valid.cpu().numpy()
+rep = {'frames': n, 'graphless': 0, 'clusters_equal': 0, 'explained': 0, 'unexplained': [], 'max_score_diff': 0.0,
+       'max_pose_diff_mm': 0.0, 'poses_compared': 0, 'heads_max': 0}
+for f in range(n):
+    h0, H, e0, M = db.host.frame_counts(f)
+    rep['heads_max'] = max(rep['heads_max'], int(H))
+    res = onp.run_frame(frames[f], calib, sd, prm, mlp_sd, 'mlp')
+    if res is None or M == 0:
+        rep['graphless'] += 1
+        assert n_persons[f] == 0, f
+        continue
+    sc = res['scores']
+    want = np.array(res['persons'], np.int32).reshape(-1, len(sm))
+    rep['max_score_diff'] = max(rep['max_score_diff'], float(np.abs(scores[e0:e0 + M] - sc).max()))
+    if n_persons[f] == len(want) and np.array_equal(persons[f, :len(want)], want):
+        rep['clusters_equal'] += 1
+        kept = [p for p in range(len(want)) if valid[f, p]]
+        if len(kept) == len(res['poses']):
+            for i, p in enumerate(kept):
+                rep['max_pose_diff_mm'] = max(rep['max_pose_diff_mm'], 1e3 * float(np.abs(poses[f, p] - res['poses'][i]).max()))
+                rep['poses_compared'] += 1
+        else:
+            rep['unexplained'].append({'frame': f, 'kept_gpu': len(kept), 'kept_ref': len(res['poses'])})
+    else:
+        gap, allowed = first_divergence(scores[e0:e0 + M], sc)
+        if gap is not None and gap <= allowed:
+            rep['explained'] += 1
+        else:
+            rep['unexplained'].append({'frame': f, 'gap': gap, 'allowed': allowed})
+print(json.dumps(rep))
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+json.dump(rep, open(os.path.join(ROOT, 'gpurun_out', 'shape_fuzz.json'), 'w'), indent=1)
+assert not rep['unexplained'] and rep['max_score_diff'] <= 2e-5 and rep['max_pose_diff_mm'] <= 0.05
