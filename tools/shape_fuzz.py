@@ -1,7 +1,8 @@
 """Diagnostic: the whole path (match + MLP rows + MLP 3D) against the oracle on frames of RANDOM
 shape: 0-6 persons, random camera subsets and orders, empty cameras, spurious skeletons, dropped
 joints, ID keys, detector noise.  Clusters must equal the oracle's (or differ only where the deciding
-score gap is below the measured score deviation), scores within 2e-5, MLP rows within 3e-7.
+score gap is below the measured score deviation), scores within 2e-5, poses within 5e-6 of the output
+magnitude (fp32 noise of both sides; the per-row error budget is asserted in the tests).
 
     python tools/shape_fuzz.py [n_frames] [seed]      -> gpurun_out/shape_fuzz.json
 """
@@ -59,7 +60,7 @@ poses, valid = eng.mlp3d(db, persons, n_persons)
 scores, persons, n_persons = scores.cpu().numpy(), persons.cpu().numpy(), n_persons.cpu().numpy()
 poses, valid = poses.cpu().numpy(), valid.cpu().numpy()
 rep = {'frames': n, 'graphless': 0, 'clusters_equal': 0, 'explained': 0, 'unexplained': [], 'max_score_diff': 0.0,
-       'max_pose_diff_mm': 0.0, 'poses_compared': 0, 'heads_max': 0}
+       'max_pose_diff_mm': 0.0, 'max_pose_rel_diff': 0.0, 'max_abs_pose_m': 0.0, 'poses_compared': 0, 'heads_max': 0}
 for f in range(n):
     h0, H, e0, M = db.host.frame_counts(f)
     rep['heads_max'] = max(rep['heads_max'], int(H))
@@ -76,7 +77,11 @@ for f in range(n):
         kept = [p for p in range(len(want)) if valid[f, p]]
         if len(kept) == len(res['poses']):
             for i, p in enumerate(kept):
-                rep['max_pose_diff_mm'] = max(rep['max_pose_diff_mm'], 1e3 * float(np.abs(poses[f, p] - res['poses'][i]).max()))
+                d = float(np.abs(poses[f, p] - res['poses'][i]).max())
+                big = float(np.abs(res['poses'][i]).max())
+                rep['max_pose_diff_mm'] = max(rep['max_pose_diff_mm'], 1e3 * d)
+                rep['max_abs_pose_m'] = max(rep['max_abs_pose_m'], big)
+                rep['max_pose_rel_diff'] = max(rep['max_pose_rel_diff'], d / max(big, 1.0))
                 rep['poses_compared'] += 1
         else:
             rep['unexplained'].append({'frame': f, 'kept_gpu': len(kept), 'kept_ref': len(res['poses'])})
@@ -89,4 +94,6 @@ for f in range(n):
 print(json.dumps(rep))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 json.dump(rep, open(os.path.join(ROOT, 'gpurun_out', 'shape_fuzz.json'), 'w'), indent=1)
-assert not rep['unexplained'] and rep['max_score_diff'] <= 2e-5 and rep['max_pose_diff_mm'] <= 0.05
+# poses: both sides are fp32 evaluations of a hash-weight MLP whose outputs reach tens of metres on partial
+# persons; the bound is relative to the output magnitude (the per-row error budget lives in the tests)
+assert not rep['unexplained'] and rep['max_score_diff'] <= 2e-5 and rep['max_pose_rel_diff'] <= 5e-6, rep
