@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ALL_CASES, CASES, GOLDEN, env, load_case, oracle, pkg
+from conftest import ALL_CASES, CASES, GOLDEN, ROOT, env, load_case, oracle, pkg
 
 pytestmark = pytest.mark.gpu
 
@@ -673,3 +673,18 @@ def test_cluster_kernels_agree_on_random_frames(calib, monkeypatch):
                 assert np.array_equal(res[kernel][0][f, :k], res['lds'][0][f, :k]), (kernel, f)
     finally:
         eng.close()
+
+
+def test_random_frame_shapes_vs_oracle():
+    """tools/shape_fuzz.py on 150 frames of random shape (0-6 persons, camera subsets and orders, empty
+    cameras, spurious skeletons, dropped joints, ID keys, noise; single-camera and empty frames
+    included): clusters equal to the oracle's (or the deciding score gap explained by the measured
+    score deviation), scores within 2e-5, poses within 5e-6 of the output magnitude.  Runs as a child
+    process (the tool is a script); it asserts by itself and writes gpurun_out/shape_fuzz.json."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'shape_fuzz.py'), '150', '5'], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep['clusters_equal'] + rep['explained'] + rep['graphless'] == 150 and rep['clusters_equal'] >= 60
