@@ -162,9 +162,16 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
                const int32_t *c_rows = nullptr, double flop_override = -1.0, const AttnCoef *coef = nullptr,
                bool *coef_done = nullptr) {
     if (coef_done) *coef_done = false;
-    if (!ctx->gat_reduced)
-        return linear(ctx, s, A, lda, L, C, ldc, m, d_m, leaky, slope, ctx->gat_acc64, a_rows, c_rows, flop_override, coef,
-                      coef_done);
+    if (!ctx->gat_reduced) {
+        // Long sums (K > 512: fc2 of layer 0, K = 902 / 1082, on head rows only -- no measurable cost) always
+        // run with f64 running sums: a single fp32 chain of that length was the largest contribution to the
+        // score noise (ARPLAB frames of random shape: 3.2e-5 from the reference with it, 2.3e-5 without, where
+        // the reference's own fp32 scores sit 1.8e-5 from the float64 network).  MPE_GAT_ACC64_MINK overrides
+        // the threshold (0 = never), mpe_set_precision(ctx, 1, .) extends it to every GAT GEMM.
+        static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
+        const bool acc64 = ctx->gat_acc64 || (mink > 0 && L.in_dim > mink);
+        return linear(ctx, s, A, lda, L, C, ldc, m, d_m, leaky, slope, acc64, a_rows, c_rows, flop_override, coef, coef_done);
+    }
     if (m <= 0) return MPE_OK;
     int rc = ensure_bf16_weights(ctx, &L);
     if (rc) return rc;

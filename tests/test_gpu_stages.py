@@ -498,8 +498,8 @@ def test_score_noise_against_the_f64_network():
     evaluated in float64 (oracle, no fp32 rounding anywhere).  The reference's own fp32 scores sit
     e_ref from it (torch-CPU summation order, amplified by the fixture weights' logit gain of 25);
     the HIP path sits e_gpu from it.  Required: the HIP path is not a noisier fp32 evaluation than
-    the reference by more than a factor (its GEMMs are single fp32 chains over K up to 1082 where
-    MKL blocks), and with f64 running sums (`mpe_set_precision(ctx, 1, .)`) it is at least as close
+    the reference by more than a factor (its GEMMs are single fp32 chains over K <= 512 where MKL
+    blocks; longer sums, i.e. layer 0, carry f64 running sums by default), and with f64 running sums (`mpe_set_precision(ctx, 1, .)`) it is at least as close
     to the f64 network as the reference.  The figures go to gpurun_out/score_noise.json."""
     onp = oracle()
     report = {}
@@ -537,5 +537,5 @@ def test_score_noise_against_the_f64_network():
     with open(os.path.join(out, 'score_noise.json'), 'w') as fh:
         json.dump(report, fh, indent=1)
     print(json.dumps({k: v for k, v in report.items() if k.startswith('worst')}))
-    assert worst_ratio <= 3.0, worst_ratio
+    assert worst_ratio <= 2.5, worst_ratio
     assert worst_ratio64 <= 1.0, worst_ratio64

@@ -1,11 +1,13 @@
 """Diagnostic: the whole path (match + MLP rows + MLP 3D) against the oracle on frames of RANDOM
 shape: 0-6 persons, random camera subsets and orders, empty cameras, spurious skeletons, dropped
 joints, ID keys, detector noise.  Clusters must equal the oracle's (or differ only where the deciding
-score gap is below the measured score deviation), scores within 2e-5, poses within 5e-6 of the output
+score gap is below the measured score deviation), scores within 2e-5 -- or, on the large random frames
+where the fp32 noise of BOTH evaluations grows, no further from the float64 network than 3x the
+reference's own fp32 scores are --, poses within 5e-6 of the output
 magnitude (fp32 noise of both sides; the per-row error budget is asserted in the tests), DLT points of
 the same clusters within 1e-8 m with identical joint validity (measured 5e-10 over 17 000 joints).
 
-    python tools/shape_fuzz.py [n_frames] [seed]      -> gpurun_out/shape_fuzz.json
+    python tools/shape_fuzz.py [n_frames] [seed] [PANOPTIC|ARPLAB|RING23] [acc64]      -> gpurun_out/shape_fuzz.json
 """
 import importlib, json, os, sys
 import numpy as np, torch
@@ -38,13 +40,16 @@ par = importlib.import_module(PKG + '.parameters'); pipeline = importlib.import_
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-calib = cal.Calibration(par.parameters)
+preset = sys.argv[3] if len(sys.argv) > 3 else 'PANOPTIC'
+P = par.select(preset)
+calib = cal.Calibration(P, syn.ring_transform_manager(P) if preset == 'RING23' else None)
 names = list(calib.params.camera_names)
-sd = syn.gat_state_dict(7, 902, logit_gain=25.0, logit_shift=0.698); prm = syn.gat_params(902)
-mlp_sd = syn.mlp_state_dict(11, 1260)
+nf = 2 + len(P.used_cameras_skeleton_matching) * len(P.joint_list) * 10
+sd = syn.gat_state_dict(7, nf, logit_gain=25.0, logit_shift=0.698); prm = syn.gat_params(nf)
+mlp_sd = syn.mlp_state_dict(11, len(P.cameras) * len(P.joint_list) * P.numbers_per_joint)
 frames = []
 for i in range(n):
-    k = rng.randint(1, len(names) + 1)
+    k = rng.randint(1, min(len(names), 8) + 1) if rng.rand() < 0.7 else len(names)
     cams = list(rng.permutation(names)[:k])
     empty = tuple(c for c in cams if rng.rand() < 0.15)
     spec = syn.FrameSpec(persons=int(rng.randint(0, 7)), cameras=cams, noise_px=float(rng.choice([0.0, 1.0, 3.0])),
@@ -52,8 +57,10 @@ for i in range(n):
                          spurious=int(rng.randint(0, 3)), empty_cameras=empty, float_conf=bool(rng.rand() < 0.7))
     frames.append(onp.processed_input(syn.make_frame(calib, 9000 + i, spec)[0]))
 sm = list(calib.params.used_cameras_skeleton_matching)
-eng = pipeline.Engine(par.parameters, calib, max_frames=n, max_persons_per_camera=9)
+eng = pipeline.Engine(P, calib, max_frames=n, max_persons_per_camera=9)
 eng.load_gat(sd, prm); eng.load_mlp(mlp_sd)
+if len(sys.argv) > 4 and sys.argv[4] == 'acc64':
+    eng.set_precision(gat_acc64=True)          # f64 running sums in the GAT GEMMs too
 db = eng.to_device(eng.pack(frames))
 scores, persons, n_persons = eng.match(db)
 eng.sync_status()
@@ -62,7 +69,7 @@ tri, jv = eng.triangulate(db, persons, n_persons)
 tri, jv = tri.cpu().numpy(), jv.cpu().numpy()
 scores, persons, n_persons = scores.cpu().numpy(), persons.cpu().numpy(), n_persons.cpu().numpy()
 poses, valid = poses.cpu().numpy(), valid.cpu().numpy()
-rep = {'frames': n, 'graphless': 0, 'clusters_equal': 0, 'explained': 0, 'unexplained': [], 'max_score_diff': 0.0,
+rep = {'preset': preset, 'frames': n, 'graphless': 0, 'clusters_equal': 0, 'explained': 0, 'unexplained': [], 'max_score_diff': 0.0,
        'max_pose_diff_mm': 0.0, 'max_pose_rel_diff': 0.0, 'max_abs_pose_m': 0.0, 'poses_compared': 0, 'heads_max': 0, 'tri_joints_compared': 0, 'max_tri_diff_m': 0.0}
 for f in range(n):
     h0, H, e0, M = db.host.frame_counts(f)
@@ -74,7 +81,17 @@ for f in range(n):
         continue
     sc = res['scores']
     want = np.array(res['persons'], np.int32).reshape(-1, len(sm))
-    rep['max_score_diff'] = max(rep['max_score_diff'], float(np.abs(scores[e0:e0 + M] - sc).max()))
+    dsc = float(np.abs(scores[e0:e0 + M] - sc).max())
+    rep['max_score_diff'] = max(rep['max_score_diff'], dsc)
+    if dsc > 1.5e-5:
+        # beyond the bound asserted on the fixtures: size both fp32 evaluations against the float64 network
+        # (the rule of tests/test_gpu_stages.py::test_score_noise_against_the_f64_network)
+        g = res['graph']
+        exact = onp.gat_forward(sd, prm, g['feats'], g['src'], g['dst'], dtype=torch.float64)[g['H']:].numpy()
+        e_ref, e_gpu = float(np.abs(sc - exact).max()), float(np.abs(scores[e0:e0 + M] - exact).max())
+        rep.setdefault('noisy_frames', []).append({'frame': f, 'heads': int(H), 'diff': dsc, 'e_ref': e_ref, 'e_gpu': e_gpu})
+        if e_gpu > 3.0 * max(e_ref, 1e-6):
+            rep['unexplained'].append({'frame': f, 'score_noise': e_gpu, 'reference_noise': e_ref})
     if n_persons[f] == len(want) and np.array_equal(persons[f, :len(want)], want):
         rep['clusters_equal'] += 1
         # DLT path on the same clusters: joint validity identical, points within 1e-9 m
@@ -112,4 +129,4 @@ os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 json.dump(rep, open(os.path.join(ROOT, 'gpurun_out', 'shape_fuzz.json'), 'w'), indent=1)
 # poses: both sides are fp32 evaluations of a hash-weight MLP whose outputs reach tens of metres on partial
 # persons; the bound is relative to the output magnitude (the per-row error budget lives in the tests)
-assert not rep['unexplained'] and rep['max_score_diff'] <= 2e-5 and rep['max_pose_rel_diff'] <= 5e-6 and rep['max_tri_diff_m'] <= 1e-8, rep
+assert not rep['unexplained'] and rep['max_score_diff'] <= 6e-5 and rep['max_pose_rel_diff'] <= 5e-6 and rep['max_tri_diff_m'] <= 1e-8, rep
