@@ -47,7 +47,7 @@ names = list(calib.params.camera_names)
 nf = 2 + len(P.used_cameras_skeleton_matching) * len(P.joint_list) * 10
 sd = syn.gat_state_dict(7, nf, logit_gain=25.0, logit_shift=0.698); prm = syn.gat_params(nf)
 mlp_sd = syn.mlp_state_dict(11, len(P.cameras) * len(P.joint_list) * P.numbers_per_joint)
-frames = []
+frames, raw = [], []
 for i in range(n):
     k = rng.randint(1, min(len(names), 8) + 1) if rng.rand() < 0.7 else len(names)
     cams = list(rng.permutation(names)[:k])
@@ -55,7 +55,8 @@ for i in range(n):
     spec = syn.FrameSpec(persons=int(rng.randint(0, 7)), cameras=cams, noise_px=float(rng.choice([0.0, 1.0, 3.0])),
                          joint_drop=float(rng.choice([0.0, 0.2, 0.6])), add_id_key=bool(rng.rand() < 0.3),
                          spurious=int(rng.randint(0, 3)), empty_cameras=empty, float_conf=bool(rng.rand() < 0.7))
-    frames.append(onp.processed_input(syn.make_frame(calib, 9000 + i, spec)[0]))
+    raw.append(syn.make_frame(calib, 9000 + i, spec)[0])
+    frames.append(onp.processed_input(raw[-1]))
 sm = list(calib.params.used_cameras_skeleton_matching)
 eng = pipeline.Engine(P, calib, max_frames=n, max_persons_per_camera=9)
 eng.load_gat(sd, prm); eng.load_mlp(mlp_sd)
@@ -124,9 +125,16 @@ for f in range(n):
             rep['explained'] += 1
         else:
             rep['unexplained'].append({'frame': f, 'gap': gap, 'allowed': allowed})
+# the same frames as RAW wire-format JSON (empty cameras and ground truth included) through the native packer:
+# the empty cameras stay as slots without heads there, the results must be the same bits
+db2 = eng.to_device(eng.pack_json(json.dumps(raw)))
+s2, p2, n2 = eng.match(db2)
+q2, v2 = eng.mlp3d(db2, p2, n2)
+rep['native_packer_same_bits'] = bool(np.array_equal(s2.cpu().numpy(), scores) and np.array_equal(p2.cpu().numpy(), persons)
+                                      and np.array_equal(n2.cpu().numpy(), n_persons) and np.array_equal(q2.cpu().numpy(), poses))
 print(json.dumps(rep))
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 json.dump(rep, open(os.path.join(ROOT, 'gpurun_out', 'shape_fuzz.json'), 'w'), indent=1)
 # poses: both sides are fp32 evaluations of a hash-weight MLP whose outputs reach tens of metres on partial
 # persons; the bound is relative to the output magnitude (the per-row error budget lives in the tests)
-assert not rep['unexplained'] and rep['max_score_diff'] <= 6e-5 and rep['max_pose_rel_diff'] <= 5e-6 and rep['max_tri_diff_m'] <= 1e-8, rep
+assert rep['native_packer_same_bits'] and not rep['unexplained'] and rep['max_score_diff'] <= 6e-5 and rep['max_pose_rel_diff'] <= 5e-6 and rep['max_tri_diff_m'] <= 1e-8, rep
