@@ -3,8 +3,9 @@
 // The reference materialises, per frame, a DGL graph with a dense N x 902 feature matrix
 // (graph_generator.py:813-876) and runs apply_edges / edge_softmax / update_all on it
 // (gat2.py:57-66).  For graph alternative '3' the topology is a pure function of the
-// per-camera skeleton counts, so no graph object exists here: kernels derive the in-edges
-// of a node from slot_n[frame][V]:
+// per-camera skeleton counts, so no graph object exists here: the in-edges of a node follow
+// from slot_n[frame][V] (k_topology writes the pair list of the edge-nodes, k_head_sources the
+// in-edge sources of the heads, once per batch; every layer's attention kernels read those):
 //
 //   head h (slot s, index i):   (h,h), then every edge-node X that pairs h with a head of
 //                               another slot, in ascending X  (edge ids are created per
