@@ -539,3 +539,36 @@ def test_score_noise_against_the_f64_network():
     print(json.dumps({k: v for k, v in report.items() if k.startswith('worst')}))
     assert worst_ratio <= 2.5, worst_ratio
     assert worst_ratio64 <= 1.0, worst_ratio64
+
+
+def test_run_pipelined_gives_the_same_bits_as_sequential_calls():
+    """Engine.run_pipelined: matching of batch i+1 overlaps the 3D stage of batch i on two streams
+    (disjoint workspaces); every batch must come out with the bits of the plain call sequence."""
+    onp = oracle()
+    syn = pkg('synthetic')
+    e = env('panoptic')
+    eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=12, max_persons_per_camera=5)
+    eng.load_gat(*e.gat)
+    eng.load_mlp(e.mlp)
+    specs = [syn.FrameSpec(persons=4), syn.FrameSpec(persons=2, joint_drop=0.2), syn.FrameSpec(persons=3, empty_cameras=('trackerc',))]
+    batches = []
+    for b in range(5):
+        frames = [onp.processed_input(syn.make_frame(e.calib, 7000 + 40 * b + i, specs[(b + i) % 3])[0]) for i in range(3 + 2 * b)]
+        batches.append(eng.to_device(eng.pack(frames)))
+    want = []
+    for db in batches:
+        _, persons, n_persons = eng.match(db, want_scores=False)
+        want.append((eng.mlp3d(db, persons, n_persons)[0].cpu().numpy(), n_persons.cpu().numpy(), persons.cpu().numpy()))
+    got = [(p.cpu().numpy(), n.cpu().numpy(), q.cpu().numpy()) for p, n, q, _ in eng.run_pipelined(batches)]
+    assert len(got) == len(want)
+    for (p1, n1, q1), (p2, n2, q2) in zip(want, got):
+        assert np.array_equal(n1, n2) and np.array_equal(q1, q2)
+        for f in range(len(n1)):
+            assert np.array_equal(p1[f, :n1[f]], p2[f, :n1[f]])
+    tri_want = [eng.triangulate(db, torch.from_numpy(w[2]).to(eng.device), torch.from_numpy(w[1]).to(eng.device))[0].cpu().numpy()
+                for db, w in zip(batches, want)]
+    tri_got = [p.cpu().numpy() for p, n, q, _ in eng.run_pipelined(batches, mode='tri')]
+    for a, b, w in zip(tri_want, tri_got, want):
+        for f in range(len(w[1])):
+            assert np.array_equal(a[f, :w[1][f]], b[f, :w[1][f]], equal_nan=True)
+    eng.close()
