@@ -7,7 +7,7 @@ reference's own fp32 scores are --, poses within 5e-6 of the output
 magnitude (fp32 noise of both sides; the per-row error budget is asserted in the tests), DLT points of
 the same clusters within 1e-8 m with identical joint validity (measured 5e-10 over 17 000 joints).
 
-    python tools/shape_fuzz.py [n_frames] [seed] [PANOPTIC|ARPLAB|RING23] [acc64]      -> gpurun_out/shape_fuzz.json
+    python tools/shape_fuzz.py [n_frames] [seed] [PANOPTIC|ARPLAB|RING23] [acc64|-] [max persons per camera]      -> gpurun_out/shape_fuzz.json
 """
 import importlib, json, os, sys
 import numpy as np, torch
@@ -41,6 +41,7 @@ par = importlib.import_module(PKG + '.parameters'); pipeline = importlib.import_
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 preset = sys.argv[3] if len(sys.argv) > 3 else 'PANOPTIC'
+ppc = int(sys.argv[5]) if len(sys.argv) > 5 else 9        # engine capacity: skeletons per camera (9: room for the spurious ones)
 P = par.select(preset)
 calib = cal.Calibration(P, syn.ring_transform_manager(P) if preset == 'RING23' else None)
 names = list(calib.params.camera_names)
@@ -52,13 +53,13 @@ for i in range(n):
     k = rng.randint(1, min(len(names), 8) + 1) if rng.rand() < 0.7 else len(names)
     cams = list(rng.permutation(names)[:k])
     empty = tuple(c for c in cams if rng.rand() < 0.15)
-    spec = syn.FrameSpec(persons=int(rng.randint(0, 7)), cameras=cams, noise_px=float(rng.choice([0.0, 1.0, 3.0])),
+    spec = syn.FrameSpec(persons=int(rng.randint(0, 7)) if ppc >= 9 else int(rng.randint(0, ppc + 1)), cameras=cams, noise_px=float(rng.choice([0.0, 1.0, 3.0])),
                          joint_drop=float(rng.choice([0.0, 0.2, 0.6])), add_id_key=bool(rng.rand() < 0.3),
-                         spurious=int(rng.randint(0, 3)), empty_cameras=empty, float_conf=bool(rng.rand() < 0.7))
+                         spurious=int(rng.randint(0, 3)) if ppc >= 9 else 0, empty_cameras=empty, float_conf=bool(rng.rand() < 0.7))
     raw.append(syn.make_frame(calib, 9000 + i, spec)[0])
     frames.append(onp.processed_input(raw[-1]))
 sm = list(calib.params.used_cameras_skeleton_matching)
-eng = pipeline.Engine(P, calib, max_frames=n, max_persons_per_camera=9)
+eng = pipeline.Engine(P, calib, max_frames=n, max_persons_per_camera=ppc)
 eng.load_gat(sd, prm); eng.load_mlp(mlp_sd)
 if len(sys.argv) > 4 and sys.argv[4] == 'acc64':
     eng.set_precision(gat_acc64=True)          # f64 running sums in the GAT GEMMs too
@@ -70,7 +71,7 @@ tri, jv = eng.triangulate(db, persons, n_persons)
 tri, jv = tri.cpu().numpy(), jv.cpu().numpy()
 scores, persons, n_persons = scores.cpu().numpy(), persons.cpu().numpy(), n_persons.cpu().numpy()
 poses, valid = poses.cpu().numpy(), valid.cpu().numpy()
-rep = {'preset': preset, 'frames': n, 'graphless': 0, 'clusters_equal': 0, 'explained': 0, 'unexplained': [], 'max_score_diff': 0.0,
+rep = {'preset': preset, 'max_persons_per_camera': ppc, 'frames': n, 'graphless': 0, 'clusters_equal': 0, 'explained': 0, 'unexplained': [], 'max_score_diff': 0.0,
        'max_pose_diff_mm': 0.0, 'max_pose_rel_diff': 0.0, 'max_abs_pose_m': 0.0, 'poses_compared': 0, 'heads_max': 0, 'tri_joints_compared': 0, 'max_tri_diff_m': 0.0}
 for f in range(n):
     h0, H, e0, M = db.host.frame_counts(f)
