@@ -187,6 +187,7 @@ __global__ __launch_bounds__(NT) void k_mlp_rows(const DevCfg *__restrict__ cfg,
     const int npairs = V * (V - 1) / 2;
     double *s_und = s_dyn64;                       // [V][J][2]
     double *s_pts = s_und + (size_t)V * J * 2;      // [J][npairs][3]
+    float *s_row = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(s_pts + (size_t)J * npairs * 3) + 15) & ~(uintptr_t)15);   // [ld_rows], 16-byte aligned: the row is assembled here
     __shared__ int32_t s_head[MPE_MAX_CAMERAS];
     __shared__ uint32_t s_mask[MPE_MAX_CAMERAS], s_tmask[MPE_MAX_CAMERAS];
     __shared__ float s_red[NT];
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(NT) void k_mlp_rows(const DevCfg *__restrict__ cfg,
         // get_3D_from_triangulation only uses joints whose values[0] > 0 (reference :75)
         s_tmask[threadIdx.x] = lh >= 0 ? tri_mask[h0 + lh] : 0u;
     }
-    float *row = rows + r * ld_rows;
+    float *row = s_row;                              // written once, coalesced, at the end
     for (int c = threadIdx.x; c < ld_rows; c += blockDim.x) row[c] = 0.f;
     __syncthreads();
     PersonCtx pc{f, p, V, J, npairs, h0};
@@ -283,6 +284,13 @@ __global__ __launch_bounds__(NT) void k_mlp_rows(const DevCfg *__restrict__ cfg,
         __syncthreads();
     }
     if (threadIdx.x == 0 && valid) valid[slot] = s_red[0] > 1.f ? 1 : 0;
+    float *dst = rows + r * ld_rows;
+    if ((ld_rows & 3) == 0) {
+        for (int c = threadIdx.x * 4; c < ld_rows; c += blockDim.x * 4)
+            *reinterpret_cast<float4 *>(dst + c) = *reinterpret_cast<const float4 *>(row + c);
+    } else {
+        for (int c = threadIdx.x; c < ld_rows; c += blockDim.x) dst[c] = row[c];
+    }
 }
 
 // exclusive prefix of n_persons (single workgroup) + total
@@ -324,7 +332,7 @@ hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const
                            const int32_t *persons, const int32_t *n_persons, const int32_t *person_off, int pcap,
                            float *rows, int ld_rows, uint8_t *valid) {
     if (b.n_frames <= 0) return hipSuccess;
-    const size_t shm = ((size_t)V * J * 2 + (size_t)J * (V * (V - 1) / 2) * 3) * sizeof(double);
+    const size_t shm = ((size_t)V * J * 2 + (size_t)J * (V * (V - 1) / 2) * 3) * sizeof(double) + (size_t)ld_rows * sizeof(float) + 16;
     if (shm > 40 * 1024) {
         // fewer than four workgroups per CU by LDS: widen the workgroup instead
         if (shm > 64 * 1024) {
