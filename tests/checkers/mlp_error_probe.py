@@ -2,7 +2,7 @@
 torch-CPU fp32 (the oracle), the GPU fp32-chain GEMM and the GPU f64-running-sum GEMM."""
 import importlib, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import oracle_np as onp
 PKG = '3d_multi_pose_estimator_amd'

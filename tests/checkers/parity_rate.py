@@ -3,11 +3,11 @@
 differing frame the score gap at the FIRST diverging decision of the greedy clustering against the
 largest gap the measured deviation can explain.  Writes gpurun_out/parity_rate.json.
 
-    python tools/parity_rate.py [n_frames]
+    python tests/checkers/parity_rate.py [n_frames]
 """
 import importlib, json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import oracle_np as onp
 PKG = '3d_multi_pose_estimator_amd'

@@ -7,19 +7,19 @@ reference's own fp32 scores are --, poses within 5e-6 of the output
 magnitude (fp32 noise of both sides; the per-row error budget is asserted in the tests), DLT points of
 the same clusters within 1e-8 m with identical joint validity (measured 5e-10 over 17 000 joints).
 
-    python tools/shape_fuzz.py [n_frames] [seed] [PANOPTIC|ARPLAB|RING23] [acc64|-] [max persons per camera]      -> gpurun_out/shape_fuzz.json
+    python tests/checkers/shape_fuzz.py [n_frames] [seed] [PANOPTIC|ARPLAB|RING23] [acc64|-] [max persons per camera]      -> gpurun_out/shape_fuzz.json
 """
 import importlib, json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle')); 
 import oracle_np as onp
 PKG = '3d_multi_pose_estimator_amd'
 
 
 def first_divergence(s_gpu, s_ref, thr=0.5):
     """score gap at the first diverging decision of the greedy pass, and the gap the measured score
-    deviation can explain (as tools/parity_rate.py)"""
+    deviation can explain (as tests/checkers/parity_rate.py)"""
     dev = float(np.abs(s_gpu - s_ref).max())
     og = [m for m in np.argsort(-s_gpu, kind='stable') if s_gpu[m] > thr]
     orf = [m for m in np.argsort(-s_ref, kind='stable') if s_ref[m] > thr]

@@ -677,7 +677,7 @@ def test_cluster_kernels_agree_on_random_frames(calib, monkeypatch):
 
 @pytest.mark.parametrize('preset,n', [('PANOPTIC', 150), ('ARPLAB', 80), ('RING23', 12)])
 def test_random_frame_shapes_vs_oracle(preset, n):
-    """tools/shape_fuzz.py on frames of random shape (0-6 persons, camera subsets and orders, empty
+    """tests/checkers/shape_fuzz.py on frames of random shape (0-6 persons, camera subsets and orders, empty
     cameras, spurious skeletons, dropped joints, ID keys, noise; single-camera and empty frames
     included) on the three rigs: clusters equal to the oracle's (or the deciding score gap explained by
     the measured score deviation), scores within 2e-5 or no noisier than 2.5-3x the reference's own fp32
@@ -686,7 +686,7 @@ def test_random_frame_shapes_vs_oracle(preset, n):
     process (the tool is a script); it asserts by itself and writes gpurun_out/shape_fuzz.json."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'shape_fuzz.py'), str(n), '5', preset], capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'checkers', 'shape_fuzz.py'), str(n), '5', preset], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])

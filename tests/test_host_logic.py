@@ -350,3 +350,12 @@ def test_frame_scanner_fuzz_simd_and_scalar():
             r = subprocess.run([sys.executable, script, str(seed)], env=env, capture_output=True, text=True, timeout=300)
             assert r.returncode == 0, r.stdout + r.stderr
             assert 'frames 300 simd %s' % (not no_simd) in r.stdout
+
+
+def test_tools_do_not_use_the_oracle():
+    """The oracle is test infrastructure: only tests/ (incl. tests/checkers/), smoke() and the bench's
+    cpu_baseline leg may touch it -- the diagnostics under tools/ must not."""
+    for name in sorted(os.listdir(os.path.join(ROOT, 'tools'))):
+        if name.endswith(('.py', '.sh')):
+            text = open(os.path.join(ROOT, 'tools', name)).read()
+            assert 'oracle' not in text.replace('vs the oracle', '').replace("the oracle's", ''), name

@@ -22,8 +22,8 @@ timeout -k 10 300 python bench.py --preset RING23 --persons 10 --frames 96 --cpu
 timeout -k 10 300 python bench.py --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 --reduced > $O/bench_ring96_reduced.json 2>> $O/bench_default.err
 timeout -k 10 300 python bench.py --frames 1 --cpu-sample 0 --steps 200 --warmup 20 > $O/bench_1frame.json 2>> $O/bench_default.err
 timeout -k 10 600 python tools/json_to_poses.py 16000 1000 > $O/json_to_poses.log 2>&1; tail -3 $O/json_to_poses.log
-timeout -k 10 900 python tools/parity_rate.py 1000 > $O/parity_rate.log 2>&1; tail -2 $O/parity_rate.log | cut -c1-300
-for pr in PANOPTIC ARPLAB RING23; do timeout -k 10 600 python tools/shape_fuzz.py $([ $pr = RING23 ] && echo 60 || echo 300) 21 $pr > $O/shape_fuzz_$pr.log 2>&1; cp gpurun_out/shape_fuzz.json $O/shape_fuzz_$pr.json; tail -1 $O/shape_fuzz_$pr.log | cut -c1-200; done
+timeout -k 10 900 python tests/checkers/parity_rate.py 1000 > $O/parity_rate.log 2>&1; tail -2 $O/parity_rate.log | cut -c1-300
+for pr in PANOPTIC ARPLAB RING23; do timeout -k 10 600 python tests/checkers/shape_fuzz.py $([ $pr = RING23 ] && echo 60 || echo 300) 21 $pr > $O/shape_fuzz_$pr.log 2>&1; cp gpurun_out/shape_fuzz.json $O/shape_fuzz_$pr.json; tail -1 $O/shape_fuzz_$pr.log | cut -c1-200; done
 for f in default tri streams2 5x10 c4_shard ring24 ring96 ring96_reduced 1frame; do python3 -c "
 import json,sys
 d=json.load(open('$O/bench_$f.json'))
