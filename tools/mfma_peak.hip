@@ -571,6 +571,129 @@ void run_deep(int blocks_per_cu, int cus, int nk, int share, int rows_a) {
     hipFree(W);
 }
 
+// fc1 -> LeakyReLU -> fc2 of one GAT layer in ONE launch (the round-1 review's item 7), as a timing model:
+// a workgroup owns 64 rows; phase 1 computes h2 = leaky(A W1^T) in five 80-column passes (A and W1 tiles
+// staged per 32-deep stage as in the production kernel) and keeps the 64 x 400 h2 tile in LDS (row stride
+// 420 floats: conflict-free fragment reads); phase 2 computes h2 W2^T in five passes with only the W2 tile
+// staged, its A fragments read from the h2 tile.  107.5 KB + 36 KB of LDS: one workgroup per CU.
+__global__ __launch_bounds__(256, 1) void k_fused_fc12(float *out, int nk, const float *A, const float *W1, const float *W2, int ld, float *C) {
+    constexpr int HSTR = 420, ROWS = 64, STG = (ROWS + 80) * 32;
+    extern __shared__ __attribute__((aligned(1024))) float lds[];
+    float *h2 = lds;                                   // [64][420]
+    float *stg = lds + ROWS * HSTR + 64;               // 2 stages of (64 + 80) rows x 32 floats (1 KiB aligned below)
+    stg = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(stg) + 1023) & ~(uintptr_t)1023);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fq = lane >> 4, fr = lane & 15, dr = lane >> 3, dp = lane & 7;
+    auto swz = [](int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); };
+    const int m0 = blockIdx.x * ROWS;
+    const int a_rd = (wave * 16 + fr) * 32;
+    int w_rd[5];
+    for (int nt = 0; nt < 5; ++nt) w_rd[nt] = ROWS * 32 + (nt * 16 + fr) * 32;
+    const int c0 = ((fq * 2 + 0) ^ swz(fr)) << 2, c1 = ((fq * 2 + 1) ^ swz(fr)) << 2;
+    const float *a_src[2];
+    for (int g = 0; g < 2; ++g) {
+        const int row = wave * 16 + g * 8 + dr;
+        a_src[g] = A + (size_t)(m0 + row) * ld + ((dp ^ swz(row)) << 2);
+    }
+    for (int i = threadIdx.x; i < ROWS * HSTR; i += 256) h2[i] = 0.f;      // incl. the K padding columns
+    __syncthreads();
+    f32x4 total = {0.f, 0.f, 0.f, 0.f};
+    for (int phase = 0; phase < 2; ++phase) {
+        const float *W = phase ? W2 : W1;
+        for (int pass = 0; pass < 5; ++pass) {
+            // weight rows of this pass: 10 groups of 8, dealt round-robin to the four waves
+            const float *w_src[3];
+            for (int g = 0; g < 3; ++g) {
+                int grp = wave + 4 * g;
+                if (grp > 9) grp = 9;
+                const int row = grp * 8 + dr;
+                w_src[g] = W + (size_t)(pass * 80 + row) * ld + ((dp ^ swz(row)) << 2);
+            }
+            auto issue = [&](int kt, int buf) {
+                const int koff = kt * 32;
+                float *base = stg + buf * STG;
+                if (phase == 0) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+                        __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[g] + koff), (lds_void_t *)(base + (wave * 16 + g * 8) * 32), 16, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    if (wave + 4 * g < 10)
+                        __builtin_amdgcn_global_load_lds((glb_void_t *)(w_src[g] + koff), (lds_void_t *)(base + ROWS * 32 + (wave + 4 * g) * 8 * 32), 16, 0, 0);
+            };
+            f32x4 acc[5];
+            for (int nt = 0; nt < 5; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            issue(0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                __syncthreads();
+                if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+                const float *cur = stg + (kt & 1) * STG;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    f32x4 af, wf[5];
+                    if (phase == 0) af = *reinterpret_cast<const f32x4 *>(cur + a_rd + (hh ? c1 : c0));
+                    else af = *reinterpret_cast<const f32x4 *>(h2 + (wave * 16 + fr) * HSTR + kt * 32 + (fq * 2 + hh) * 4);
+#pragma unroll
+                    for (int nt = 0; nt < 5; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(cur + w_rd[nt] + (hh ? c1 : c0));
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int nt = 0; nt < 5; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[s], acc[nt], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (phase == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    f32x4 v = acc[nt];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * 0.15f;
+                    *reinterpret_cast<f32x4 *>(h2 + (wave * 16 + fr) * HSTR + pass * 80 + nt * 16 + fq * 4) = v;
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    *reinterpret_cast<f32x4 *>(C + (size_t)(m0 + wave * 16 + fr) * 400 + pass * 80 + nt * 16 + fq * 4) = acc[nt];
+                    total += acc[nt];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = total[0] + total[1] + total[2] + total[3];
+}
+
+void run_fused_fc12(int cus, int rows) {
+    const int nk = 13, ld = nk * 32, grid = rows / 64;
+    const size_t shm = (size_t)(64 * 420 + 64 + 256 + 2 * (64 + 80) * 32) * sizeof(float) + 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_fc12), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    float *out, *A, *W1, *W2, *C;
+    hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+    hipMalloc(&A, (size_t)(rows + 128) * ld * sizeof(float));
+    hipMalloc(&W1, (size_t)(400 + 208) * ld * sizeof(float));
+    hipMalloc(&W2, (size_t)(400 + 208) * ld * sizeof(float));
+    hipMalloc(&C, (size_t)(rows + 128) * 400 * sizeof(float));
+    fill_operand(A, (size_t)(rows + 128) * ld, 1u);
+    fill_operand(W1, (size_t)(400 + 208) * ld, 2u);
+    fill_operand(W2, (size_t)(400 + 208) * ld, 3u);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_fused_fc12, dim3(grid), dim3(256), shm, 0, out, nk, A, W1, W2, ld, C);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_fused_fc12, dim3(grid), dim3(256), shm, 0, out, nk, A, W1, W2, ld, C);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 4.0 * grid * 2.0 * 5 * nk * (64.0 * 80 * 32 * 2);
+    printf("fc1 -> fc2 fused, 64-row h2 tile in LDS (%zu KB, 1 workgroup/CU), K = N = 400 (padded 416), %d rows: %.1f TFLOP/s (%.2f ms for both GEMMs) [%s]\n",
+           shm / 1024, rows, flop / ms / 1e9, ms / 4, hipGetErrorString(hipGetLastError()));
+    hipFree(out); hipFree(A); hipFree(W1); hipFree(W2); hipFree(C);
+}
+
 template <int MODE>
 void run_stage(int blocks_per_cu, int cus, int nk, int share = 5, int rows_a = 65536) {
     const int grid = cus * blocks_per_cu, ld = nk * 32;
@@ -663,6 +786,13 @@ int main(int argc, char **argv) {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     printf("%s, %d CUs, clock %d MHz\n", p.name, p.multiProcessorCount, p.clockRate / 1000);
+    if (argc > 1 && !strcmp(argv[1], "fused")) {
+        // the two GEMMs of a GAT layer: two launches of the production loop vs one fused launch
+        run_stage<1>(27, p.multiProcessorCount, 13, 5, 180224);
+        run_wide<5>(27, p.multiProcessorCount, 13, 5, 180224, true);
+        run_fused_fc12(p.multiProcessorCount, 180224);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "deep")) {
         // prefetch-depth comparison only
         run_stage<1>(3, p.multiProcessorCount, 96, 5, 8192);
