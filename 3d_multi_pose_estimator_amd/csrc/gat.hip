@@ -840,6 +840,10 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
         // own), then exactly FUSED_PIECES image pieces per wave with no branch around them; vmcnt counts
         // in issue order, so `s_waitcnt vmcnt(FUSED_PIECES)` means "my table values are here" while the
         // image is still landing, and the softmax phase runs underneath it (raw barriers).
+        // NOTHING may branch at run time between the hand-issued loads and that wait: the compiler does
+        // not know the loads are asynchronous and is free to copy their destination registers at a
+        // control-flow join (measured: a run-time `if` around the piece loop gave NaNs in 8 % of the
+        // frames); variants of this block have to be template parameters.
         const int total = N * DV;
         const size_t row0 = (size_t)(l0 ? hb : nb);
         const int tn = t < N ? t : N - 1, tm = t < M ? t : M - 1;
