@@ -236,6 +236,10 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
 // stage: [wait own DMA + barrier] -> issue DMA of the next stage into the other buffer ->
 // 80 MFMAs on this one.
 // ---------------------------------------------------------------------------------------
+#ifndef MPE_EXP
+#define MPE_EXP 0
+#endif
+constexpr int tune_prio = MPE_EXP;      // experiment bits of a diagnostic build (csrc/Makefile `exp`); 0 in the product
 __device__ __forceinline__ int dma_swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -249,8 +253,16 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // mirrored by coef40() in gat.hip for the paths that compute the coefficients elsewhere): lane
 // group q = 0..3 of the MFMA layout runs one fma chain over the features it owns in ascending
 // order, then (s_q + s_q^1) + (s_q^2 + s_q^3).
-template <bool LEAKY, bool ACC64, int NTT, bool A12 = false>
-__global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_dma(const float *__restrict__ A, int lda,
+// LDR (the default since round 3): the K stages are requested by a FIFTH wave of the workgroup
+// (the loader wave; 320-thread workgroups) instead of by the four MFMA waves.  Measured with
+// tools/dma_interf.hip: a staging instruction (LDS-DMA or plain global load alike) issued from a
+// wave that also streams MFMAs costs ~40 cycles of that wave's MFMA issue when it is alone on its
+// SIMD and ~120 cycles of MFMA-pipe time with two such waves on the SIMD (6.5 of them per wave and
+// stage: MFMA pipe busy 0.65-0.75), whereas the same requests issued by a wave that issues no MFMA
+// leave the MFMA waves of its SIMD at exactly the cycle count of the staging-free loop (busy 1.000).
+// The loader waits for its stage (vmcnt(0)) in front of the stage barrier all five waves share.
+template <bool LEAKY, bool ACC64, int NTT, bool A12 = false, int NL = 0>
+__global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) : NL == 2 ? 5 : (NTT > 10 ? 1 : NTT > 5 ? 2 : 3)) void k_linear_dma(const float *__restrict__ A, int lda,
                                                        const float *__restrict__ W, int ldw,
                                                        const float *__restrict__ bias, float *__restrict__ C,
                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
@@ -314,8 +326,55 @@ __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_
     }
     const int m0 = tm * GEMM_BM, n0 = tn * BN;
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr bool LDR = NL > 0;
+    const int tid = threadIdx.x, wave = LDR ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, lane = tid & 63;
     const int dr = lane >> 3, dp = lane & 7;          // DMA role: row within the 8-row group, chunk position
+    const int nk = k_pad / GEMM_BK;
+
+    if (LDR && wave >= 4) {
+        // ---- loader wave(s): the 16 activation groups and 2*NTT weight groups of every stage, dealt
+        // round-robin to the NL loader waves ----
+        constexpr int NW = NTT * 2;
+        constexpr int NLD = NL > 0 ? NL : 1;          // (NL == 0 never runs this block)
+        constexpr int NA_L = 16 / NLD, NW_L = (NW + NLD - 1) / NLD;
+        const int li = wave - 4;
+        if (tune_prio & 1) __builtin_amdgcn_s_setprio(3);
+        const float *la[NA_L], *lw[NW_L];
+#pragma unroll
+        for (int g = 0; g < NA_L; ++g) {
+            const int row = (li * NA_L + g) * 8 + dr;
+            int grow = m0 + row;
+            grow = grow < M ? grow : M - 1;
+            if (a_rows) grow = a_rows[grow];
+            la[g] = A + (size_t)grow * lda + ((dp ^ dma_swz(row)) << 2);
+        }
+#pragma unroll
+        for (int g = 0; g < NW_L; ++g) {
+            int grp = li + NLD * g;
+            if (grp > NW - 1) grp = NW - 1;
+            const int row = grp * 8 + dr;
+            lw[g] = W + (size_t)(n0 + row) * ldw + ((dp ^ dma_swz(row)) << 2);
+        }
+        auto fill = [&](int kt, int buf) {
+            if (tune_prio & 8) return;         // ABLATION (timing only, wrong data): no staging at all
+            const int koff = kt * GEMM_BK;
+            float *base = lds + buf * STAGE;
+#pragma unroll
+            for (int g = 0; g < NA_L; ++g)
+                __builtin_amdgcn_global_load_lds((glb_void *)(la[g] + koff), (lds_void *)(base + (li * NA_L + g) * 8 * ROWF), 16, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NW_L; ++g)
+                if ((g + 1) * NLD <= NW || li + NLD * g < NW)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(lw[g] + koff), (lds_void *)(base + W_OFF + (li + NLD * g) * 8 * ROWF), 16, 0, 0);
+        };
+        fill(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (tune_prio & 4) __builtin_amdgcn_s_barrier();      // ABLATION (timing only, wrong data): do not wait for the landing
+            else __syncthreads();              // vmcnt(0): stage kt has landed; the MFMA waves are done with the other buffer
+            if (kt + 1 < nk) fill(kt + 1, (kt + 1) & 1);
+        }
+        return;
+    }
 
     // per-lane source pointers: 4 activation groups (rows 32w + 8g + dr), up to 3 weight groups
     const float *a_src[4];
@@ -360,11 +419,11 @@ __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_
             }
         }
 
-    const int nk = k_pad / GEMM_BK;
-
     auto issue = [&](int kt, int buf) {
+        if (LDR) return;                       // the loader wave stages
         const int koff = kt * GEMM_BK;
         float *base = lds + buf * STAGE;
+        if (tune_prio & 2) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             __builtin_amdgcn_global_load_lds((glb_void *)(a_src[g] + koff),
@@ -374,6 +433,7 @@ __global__ __launch_bounds__(256, NTT > 10 ? 1 : NTT > 5 ? 2 : 3) void k_linear_
             if ((g + 1) * 4 <= WG || wave + 4 * g < WG)
                 __builtin_amdgcn_global_load_lds((glb_void *)(w_src[g] + koff),
                                                  (lds_void *)(base + W_OFF + (wave + 4 * g) * 8 * ROWF), 16, 0, 0);
+        if (tune_prio & 2) __builtin_amdgcn_s_setprio(0);
     };
 
     issue(0, 0);
@@ -883,22 +943,81 @@ bool linear_uses_tile_kernel(int m_cap, int n) {
     return (long)((m_cap + 15) / 16) * ((n + 15) / 16) > skinny_waves;
 }
 
+// ---------------------------------------------------------------------------------------
+// Launch side of k_linear_dma.
+//
+// NL = loader waves per workgroup (0, 2 or 4; the template header says why they exist).  What
+// each instantiation gets, measured on the default bench (profiles/r03_gemm_loader_waves.txt):
+//   plain fp32 chain, NTT 4|5      NL 4   65 VGPRs, 3 workgroups x 8 waves per CU       -4 %
+//   fc2 + attention coefficients   NL 4   95 VGPRs (the epilogue's partial sums), 2 workgroups x 8 waves per CU: -5 %;
+//                                         3 x 8 waves needs 80 VGPRs and spills (+3.5 %), two loader waves +6 %
+//   f64 running sums, NTT 4 (MLP)  NL 4   128 VGPRs, 2 workgroups x 8 waves per CU      -6 %
+//   f64 running sums, NTT 5        NL 0   160 VGPRs: the round-2 form (layer-0 fc2, head rows only)
+//   wide tiles (MPE_GEMM_BN)       NL 0
+// MPE_GEMM_LOADER=0 forces the round-2 form everywhere (A/B, and one leg of the switch matrix).
+// ---------------------------------------------------------------------------------------
+struct DmaLaunch {
+    const float *A;
+    int lda;
+    const float *W;
+    int ldw;
+    const float *bias;
+    float *C;
+    int ldc, m_cap;
+    const int32_t *d_m;
+    int n, k_pad;
+    float slope;
+    int ntn, n_major;
+    const int32_t *a_rows, *c_rows;
+    const float *attn_l = nullptr, *attn_r = nullptr;
+    float *a12 = nullptr;
+    const int32_t *grp_count = nullptr;
+    int n_grp = 0, grp_stride = 0;
+    long w_grp_stride = 0;
+};
+
+template <bool L, bool A64, int N, bool A12, int NL>
+static void launch_dma(hipStream_t s, int grid, const DmaLaunch &a) {
+    hipLaunchKernelGGL((k_linear_dma<L, A64, N, A12, NL>), dim3(grid), dim3(256 + 64 * NL), dma_lds_bytes(N), s, a.A, a.lda, a.W,
+                       a.ldw, a.bias, a.C, a.ldc, a.m_cap, a.d_m, a.n, a.k_pad, a.slope, a.ntn, a.n_major, a.a_rows, a.c_rows,
+                       a.attn_l, a.attn_r, a.a12, a.grp_count, a.n_grp, a.grp_stride, a.w_grp_stride);
+}
+
+static bool gemm_loader_waves_on() {
+    static const int v = getenv("MPE_GEMM_LOADER") ? atoi(getenv("MPE_GEMM_LOADER")) : 1;
+    return v != 0;
+}
+
+// plain fp32 chain (no f64 sums, no coefficient epilogue), NTT 4 or 5
+template <int N>
+static void launch_dma_plain(hipStream_t s, int grid, const DmaLaunch &a, bool leaky) {
+    if (gemm_loader_waves_on()) {
+        if (leaky) launch_dma<true, false, N, false, 4>(s, grid, a);
+        else launch_dma<false, false, N, false, 4>(s, grid, a);
+    } else if (leaky) launch_dma<true, false, N, false, 0>(s, grid, a);
+    else launch_dma<false, false, N, false, 0>(s, grid, a);
+}
+
+template <int N>
+static void launch_dma_acc64(hipStream_t s, int grid, const DmaLaunch &a, bool leaky) {
+    if (N == 4 && gemm_loader_waves_on()) {
+        if (leaky) launch_dma<true, true, 4, false, 4>(s, grid, a);
+        else launch_dma<false, true, 4, false, 4>(s, grid, a);
+    } else if (leaky) launch_dma<true, true, N, false, 0>(s, grid, a);
+    else launch_dma<false, true, N, false, 0>(s, grid, a);
+}
+
 hipError_t launch_linear_grouped(hipStream_t s, const float *A, int lda, const float *W, int ldw, long w_grp_stride,
                                  const float *bias, float *C, int ldc, int m_cap, const int32_t *grp_count, int n_grp,
                                  const int32_t *row_lists, int grp_stride, int n, int k_pad, bool leaky, float slope) {
     if (m_cap <= 0 || n <= 0 || n_grp <= 0) return hipSuccess;
     const int ntm_cap = (m_cap + GEMM_BM - 1) / GEMM_BM + n_grp;       // sum of per-group ceilings
-    const int ntn_ = (n + 79) / 80;
-    const int n_major = 0;
-    dim3 grid(ntm_cap * ntn_), block(256);
-    if (leaky)
-        hipLaunchKernelGGL((k_linear_dma<true, false, 5>), grid, block, (size_t)2 * (GEMM_BM + 80) * 32 * sizeof(float), s, A, lda,
-                           W, ldw, bias, C, ldc, m_cap, nullptr, n, k_pad, slope, ntn_, n_major, row_lists, row_lists, nullptr,
-                           nullptr, nullptr, grp_count, n_grp, grp_stride, w_grp_stride);
-    else
-        hipLaunchKernelGGL((k_linear_dma<false, false, 5>), grid, block, (size_t)2 * (GEMM_BM + 80) * 32 * sizeof(float), s, A,
-                           lda, W, ldw, bias, C, ldc, m_cap, nullptr, n, k_pad, slope, ntn_, n_major, row_lists, row_lists,
-                           nullptr, nullptr, nullptr, grp_count, n_grp, grp_stride, w_grp_stride);
+    DmaLaunch a{A, lda, W, ldw, bias, C, ldc, m_cap, nullptr, n, k_pad, slope, (n + 79) / 80, 0, row_lists, row_lists};
+    a.grp_count = grp_count;
+    a.n_grp = n_grp;
+    a.grp_stride = grp_stride;
+    a.w_grp_stride = w_grp_stride;
+    launch_dma_plain<5>(s, ntm_cap * a.ntn, a, leaky);
     return hipGetLastError();
 }
 
@@ -950,76 +1069,70 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
 #undef MPE_LAUNCH_SK
         return hipGetLastError();
     }
-    dim3 grid(ntm * ntn), block(256);
+    if ((tune & 8) && !a_rows && !c_rows) {     // MPE_GEMM_TUNE=8: the register-staged kernel of round 1 (A/B)
+        dim3 grid(ntm * ntn), block(256);
 #define MPE_LAUNCH(L_, A_)                                                                                   \
     hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
                        slope, ntn, n_major, tune)
-#define MPE_LAUNCH_DMA(L_, A_, N_)                                                                                \
-    hipLaunchKernelGGL((k_linear_dma<L_, A_, N_>), dim3(ntm * ntn_), block, dma_lds_bytes(N_), s, A, lda, W, ldw, bias, \
-                       C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows)
-    if (!(tune & 8) || a_rows || c_rows) {      // LDS-DMA staging is the default; MPE_GEMM_TUNE=8 selects the register-staged kernel
-        // Feature-tile width: 64 or 80, whichever leaves fewer (tiles on the busiest CU) x width;
-        // the MLP layers at a few thousand person rows balance exactly with 64.  160 and 208
-        // (fewer staged bytes and DMA requests per MFMA, +10 % in the isolated loop of
-        // tools/mfma_peak.hip) are compiled for experiments (MPE_GEMM_BN) but did not pay in the
-        // full kernel and need plain fp32 accumulation.  The padded weight rows cover any tile
-        // that starts below n.
-        static const int force_bn = getenv("MPE_GEMM_BN") ? atoi(getenv("MPE_GEMM_BN")) : 0;
-        static PerDeviceFlag dma_attr;
-        if (!dma_attr.test()) {
-            dma_set_lds_attributes();
-            dma_attr.set();
-        }
-        const int widths[4] = {64, 80, 160, 208};
-        int best = 1;
-        double best_cost = 1e300;
-        for (int i = 0; i < 4; ++i) {
-            if (i >= 2 && (acc64 || force_bn != widths[i])) continue;
-            const int tiles = ntm * ((n + widths[i] - 1) / widths[i]);
-            const double cost = force_bn == widths[i] ? -1.0 : (double)((tiles + 255) / 256) * widths[i];
-            if (cost < best_cost) {
-                best_cost = cost;
-                best = i;
-            }
-        }
-        // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile)
-        if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !force_bn) {
-            const int ntn_ = (n + 79) / 80;
-            if (acc64)
-                hipLaunchKernelGGL((k_linear_dma<false, true, 5, true>), dim3(ntm * ntn_), block, dma_lds_bytes(5), s, A, lda, W,
-                                   ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows, coef->attn_l,
-                                   coef->attn_r, coef->a12);
-            else
-                hipLaunchKernelGGL((k_linear_dma<false, false, 5, true>), dim3(ntm * ntn_), block, dma_lds_bytes(5), s, A, lda, W,
-                                   ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn_, n_major, a_rows, c_rows, coef->attn_l,
-                                   coef->attn_r, coef->a12);
-            if (coef_done) *coef_done = true;
-            return hipGetLastError();
-        }
-        const int ntn_ = (n + widths[best] - 1) / widths[best];
-#define MPE_DMA_WIDTH(N_)                                    \
-    do {                                                     \
-        if (leaky && acc64) MPE_LAUNCH_DMA(true, true, N_);  \
-        else if (leaky) MPE_LAUNCH_DMA(true, false, N_);     \
-        else if (acc64) MPE_LAUNCH_DMA(false, true, N_);     \
-        else MPE_LAUNCH_DMA(false, false, N_);               \
-    } while (0)
-        if (best == 0) MPE_DMA_WIDTH(4);
-        else if (best == 1) MPE_DMA_WIDTH(5);
-        else if (best == 2) {
-            if (leaky) MPE_LAUNCH_DMA(true, false, 10);
-            else MPE_LAUNCH_DMA(false, false, 10);
-        } else {
-            if (leaky) MPE_LAUNCH_DMA(true, false, 13);
-            else MPE_LAUNCH_DMA(false, false, 13);
-        }
-#undef MPE_DMA_WIDTH
-    } else if (leaky && acc64) MPE_LAUNCH(true, true);
-    else if (leaky) MPE_LAUNCH(true, false);
-    else if (acc64) MPE_LAUNCH(false, true);
-    else MPE_LAUNCH(false, false);
+        if (leaky && acc64) MPE_LAUNCH(true, true);
+        else if (leaky) MPE_LAUNCH(true, false);
+        else if (acc64) MPE_LAUNCH(false, true);
+        else MPE_LAUNCH(false, false);
 #undef MPE_LAUNCH
-#undef MPE_LAUNCH_DMA
+        return hipGetLastError();
+    }
+    // Feature-tile width: 64 or 80, whichever leaves fewer (tiles on the busiest CU) x width; the
+    // MLP layers at a few thousand person rows balance exactly with 64.  160 and 208 (fewer staged
+    // bytes and DMA requests per MFMA, +10 % in the isolated loop of tools/mfma_peak.hip) are
+    // compiled for experiments (MPE_GEMM_BN) but did not pay in the full kernel and need plain fp32
+    // accumulation.  The padded weight rows cover any tile that starts below n.
+    static const int force_bn = getenv("MPE_GEMM_BN") ? atoi(getenv("MPE_GEMM_BN")) : 0;
+    static PerDeviceFlag dma_attr;
+    if (!dma_attr.test()) {
+        dma_set_lds_attributes();
+        dma_attr.set();
+    }
+    DmaLaunch a{A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, 0, n_major, a_rows, c_rows};
+    // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile)
+    if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !force_bn) {
+        a.ntn = (n + 79) / 80;
+        a.attn_l = coef->attn_l;
+        a.attn_r = coef->attn_r;
+        a.a12 = coef->a12;
+        const int grid = ntm * a.ntn;
+        if (acc64) launch_dma<false, true, 5, true, 0>(s, grid, a);
+        else if (gemm_loader_waves_on()) launch_dma<false, false, 5, true, 4>(s, grid, a);
+        else launch_dma<false, false, 5, true, 0>(s, grid, a);
+        if (coef_done) *coef_done = true;
+        return hipGetLastError();
+    }
+    const int widths[4] = {64, 80, 160, 208};
+    int best = 1;
+    double best_cost = 1e300;
+    for (int i = 0; i < 4; ++i) {
+        if (i >= 2 && (acc64 || force_bn != widths[i])) continue;
+        const int tiles = ntm * ((n + widths[i] - 1) / widths[i]);
+        const double cost = force_bn == widths[i] ? -1.0 : (double)((tiles + 255) / 256) * widths[i];
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = i;
+        }
+    }
+    a.ntn = (n + widths[best] - 1) / widths[best];
+    const int grid = ntm * a.ntn;
+    if (best == 0) {
+        if (acc64) launch_dma_acc64<4>(s, grid, a, leaky);
+        else launch_dma_plain<4>(s, grid, a, leaky);
+    } else if (best == 1) {
+        if (acc64) launch_dma_acc64<5>(s, grid, a, leaky);
+        else launch_dma_plain<5>(s, grid, a, leaky);
+    } else if (best == 2) {
+        if (leaky) launch_dma<true, false, 10, false, 0>(s, grid, a);
+        else launch_dma<false, false, 10, false, 0>(s, grid, a);
+    } else {
+        if (leaky) launch_dma<true, false, 13, false, 0>(s, grid, a);
+        else launch_dma<false, false, 13, false, 0>(s, grid, a);
+    }
     return hipGetLastError();
 }
 

@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmpe_hip.so')
+if os.environ.get('MPE_LIB_VARIANT'):      # diagnostics: an experiment build beside the product library (csrc/Makefile `exp`)
+    LIB_PATH = os.path.join(_HERE, 'libmpe_hip_%s.so' % os.environ['MPE_LIB_VARIANT'])
 
 MPE_MAX_CAMERAS = 32
 MPE_MAX_JOINTS = 32

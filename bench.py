@@ -6,7 +6,7 @@ configs[1] ("Panoptic 5-view, 4-person; GATv2 match + MLP 3D, 1k-frame batch on 
 With --mode tri the 3D stage is the DLT triangulation path (configs[2]).
 
 Launch.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N
-rank processes ITSELF (fresh children, started before this process makes any GPU call; RANK /
+rank processes ITSELF (fresh children; the parent makes no HIP call and does not import torch; RANK /
 LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relays rank 0's JSON line; under
 torchrun (`python -m torch.distributed.run ... bench.py --gpus N`) the ranks already exist and
 are used as they are.  One process per GPU, RCCL (`--backend nccl`) for the only exchange of the
@@ -99,15 +99,45 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(args):
-    """Parent of `python bench.py --gpus N`: N fresh rank processes, never a re-exec of a process
-    that has touched the GPU (this one has not: no torch.cuda call was made).  Rank 0 inherits
-    stdout, so its JSON line is this command's output."""
+def visible_gpu_count():
+    """Number of GPUs the rank processes will see, WITHOUT initialising HIP in this (parent)
+    process: an explicit *_VISIBLE_DEVICES list if one is set, else the KFD topology in sysfs
+    (a GPU node has simd_count > 0; CPU nodes have 0).  None if neither source exists -- the
+    ranks then find out themselves (a rank without a device fails and takes the job down)."""
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(',') if x.strip() != ''])
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        nodes = os.listdir(root)
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            with open(os.path.join(root, d, 'properties')) as fh:
+                for line in fh:
+                    k, _, v = line.partition(' ')
+                    if k == 'simd_count' and int(v) > 0:
+                        n += 1
+                        break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
+def launch_ranks(args, count_fn=visible_gpu_count, popen=subprocess.Popen):
+    """Parent of `python bench.py --gpus N`: N fresh rank processes, never a re-exec or fork of a
+    process that has touched the GPU -- this one makes NO HIP call and never loads the torch module
+    (the device count comes from the environment / sysfs, visible_gpu_count).  Rank 0 inherits
+    stdout, so its JSON line is this command's output.  All children are polled together: the
+    first rank that exits non-zero ends the job (its siblings would otherwise sit in the
+    rendezvous or in the all-gather until their own timeout)."""
     n = args.gpus
     if not args.dry_run and args.backend == 'nccl':
-        import torch
-        have = torch.cuda.device_count()          # counting devices does not initialise the GPU
-        if have < n:
+        have = count_fn()
+        if have is not None and have < n:
             print('bench.py: --gpus %d requested but %d GPU(s) visible' % (n, have), file=sys.stderr)
             return 2
     env = dict(os.environ)
@@ -117,22 +147,37 @@ def launch_ranks(args):
     for r in range(n):
         e = dict(env)
         e['RANK'] = e['LOCAL_RANK'] = str(r)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                           stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    deadline = time.time() + 3000
+    deadline = time.time() + float(os.environ.get('MPE_BENCH_RANK_TIMEOUT', '3000'))
+    live = list(procs)
     try:
-        for p in procs:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-            rc = rc or p.returncode
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while live and not rc:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code:
+                    rc = code
+                    break
+            if live and not rc:
+                if time.time() > deadline:
+                    rc = 124
+                    break
+                time.sleep(0.05)
     finally:
         for p in procs:                            # exact PIDs of our own children only
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
     if rc:
-        print('bench.py: a rank exited with code %d' % rc, file=sys.stderr)
+        print('bench.py: a rank exited with code %d; the remaining ranks were stopped' % rc, file=sys.stderr)
     return rc
 
 

@@ -253,6 +253,86 @@ def test_bench_gpus_flag_spawns_ranks(extra, total, scaling):
     assert out['gather_ok'] and out['scaling'] == scaling and out['frames_per_step_total'] == total
 
 
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_launch_ranks_parent_makes_no_gpu_call(monkeypatch):
+    """The NON --dry-run parent of `bench.py --gpus N`: the device count comes from the environment
+    or sysfs (never torch.cuda / HIP), too few devices -> exit code 2 before anything is started,
+    enough devices -> N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set.  torch must not
+    even be imported by the parent."""
+    import subprocess
+    import sys
+    bench = _bench_module()
+    started = []
+
+    class FakeProc:
+        def __init__(self, argv, env=None, stdout=None):
+            started.append((argv, env, stdout))
+            self.returncode = None
+
+        def poll(self):
+            self.returncode = 0
+            return 0
+
+        def wait(self, timeout=None):
+            return 0
+
+        def kill(self):
+            pass
+
+    args = bench.parse_args(['--gpus', '4'])
+    torch_before = 'torch' in sys.modules
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4'])
+    assert bench.launch_ranks(args, count_fn=lambda: 2, popen=FakeProc) == 2 and not started
+    assert bench.launch_ranks(args, count_fn=lambda: 8, popen=FakeProc) == 0
+    assert len(started) == 4
+    for r, (argv, env, stdout) in enumerate(started):
+        assert env['RANK'] == env['LOCAL_RANK'] == str(r) and env['WORLD_SIZE'] == '4'
+        assert env['MASTER_ADDR'] == '127.0.0.1' and env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+        assert (stdout is None) == (r == 0)                  # only rank 0 owns stdout
+        assert argv[-2:] == ['--gpus', '4']
+    assert ('torch' in sys.modules) == torch_before          # the parent did not import torch
+    # unknown count (no env list, no sysfs): start the ranks and let them find out
+    started.clear()
+    assert bench.launch_ranks(args, count_fn=lambda: None, popen=FakeProc) == 0 and len(started) == 4
+    # the count itself: an explicit list wins, no HIP involved
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,3,5')
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
+    assert bench.visible_gpu_count() == 0
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False)
+    monkeypatch.delenv('CUDA_VISIBLE_DEVICES', raising=False)
+    assert bench.visible_gpu_count() in (None, 0) or bench.visible_gpu_count() > 0   # sysfs or nothing; never raises
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    body = src[src.index('def launch_ranks'):src.index('# one rank')]
+    assert '\n        import torch' not in body and 'device_count(' not in body and 'torch.' not in body
+
+
+def test_launch_ranks_first_failing_rank_stops_the_others(monkeypatch):
+    """A rank that dies early must end the job: its siblings (blocked in rendezvous / all-gather)
+    are killed and the parent returns that rank's code instead of waiting for the deadline."""
+    import subprocess
+    import sys
+    import time as _t
+    bench = _bench_module()
+    script = 'import os,sys,time\nsys.exit(7) if os.environ["RANK"] == "1" else time.sleep(120)\n'
+
+    def popen(argv, env=None, stdout=None):
+        return subprocess.Popen([sys.executable, '-c', script], env=env, stdout=subprocess.DEVNULL)
+    args = bench.parse_args(['--gpus', '3'])
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '3'])
+    t0 = _t.time()
+    assert bench.launch_ranks(args, count_fn=lambda: 3, popen=popen) == 7
+    assert _t.time() - t0 < 30
+
+
 def test_bench_under_external_launcher_uses_its_world():
     """Under torchrun-style env (RANK/WORLD_SIZE set) bench.py must NOT spawn again."""
     import json

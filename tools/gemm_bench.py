@@ -8,9 +8,10 @@ cal = importlib.import_module(PKG + '.calibration'); par = importlib.import_modu
 pipeline = importlib.import_module(PKG + '.pipeline'); L = importlib.import_module(PKG + '.lib')
 eng = pipeline.Engine(par.parameters, cal.Calibration(par.parameters), max_frames=8, max_persons_per_camera=4)
 shapes = [(180000, 400, 400, 'gat fc1 400'), (180000, 400, 320, 'gat fc2 320'), (180000, 320, 320, 'gat 320'),
-          (180000, 150, 150, 'gat 150'), (20000, 902, 902, 'gat L0 fc1'), (20000, 902, 400, 'gat L0 fc2'),
-          (4000, 1260, 3072, 'mlp 1'), (4000, 3072, 3072, 'mlp 2'), (4000, 3072, 2048, 'mlp 3'),
-          (4000, 2048, 2048, 'mlp 4'), (4000, 1024, 1024, 'mlp 6'), (4000, 1024, 54, 'mlp 9')]
+          (180000, 320, 150, 'gat fc2 150'), (180000, 150, 150, 'gat 150'), (180000, 150, 1, 'gat fc2 1'),
+          (20000, 902, 902, 'gat L0 fc1'), (20000, 902, 400, 'gat L0 fc2'),
+          (4004, 1260, 3072, 'mlp 1'), (4004, 3072, 3072, 'mlp 2'), (4004, 3072, 2048, 'mlp 3'),
+          (4004, 2048, 2048, 'mlp 4'), (4004, 2048, 1024, 'mlp 5'), (4004, 1024, 1024, 'mlp 6'), (4004, 1024, 54, 'mlp 9')]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if any(a in s[3] for a in sys.argv[1:])]
 for m, k, n, name in shapes:
