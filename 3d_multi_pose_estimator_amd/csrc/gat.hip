@@ -836,14 +836,15 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     // requests at a time.
     if (VEC == 4 && overlap) {
         // Small frames with coefficients from the GEMM (the production case).  Every global load the
-        // softmax phase depends on is issued FIRST (inline asm: the compiler then adds no waits of its
-        // own), then exactly FUSED_PIECES image pieces per wave with no branch around them; vmcnt counts
-        // in issue order, so `s_waitcnt vmcnt(FUSED_PIECES)` means "my table values are here" while the
-        // image is still landing, and the softmax phase runs underneath it (raw barriers).
-        // NOTHING may branch at run time between the hand-issued loads and that wait: the compiler does
-        // not know the loads are asynchronous and is free to copy their destination registers at a
-        // control-flow join (measured: a run-time `if` around the piece loop gave NaNs in 8 % of the
-        // frames); variants of this block have to be template parameters.
+        // softmax phase depends on is issued FIRST, then exactly FUSED_PIECES image pieces per wave;
+        // vmcnt counts in issue order, so `s_waitcnt vmcnt(FUSED_PIECES)` means "my table values are
+        // here" while the image is still landing, and the softmax phase runs underneath it (raw
+        // barriers).  The five loads, the eight LDS-DMA pieces and the counted wait are ONE asm
+        // statement with early-clobber outputs: the compiler sees the five values defined only at its
+        // end, so it can neither read, copy nor spill a destination register that has not landed, and it
+        // cannot schedule anything into the window (the round-2 form used separate asm statements and
+        // was correct by convention only; a run-time branch inside that window once gave NaNs in 8 % of
+        // the frames).  tests/test_host_logic.py::test_fused_attention_window_isa pins the emitted ISA.
         const int total = N * DV;
         const size_t row0 = (size_t)(l0 ? hb : nb);
         const int tn = t < N ? t : N - 1, tm = t < M ? t : M - 1;
@@ -853,26 +854,59 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
         const float *p1 = pr_ + hh, *p2 = pr_ + 16 + hh;
         const int32_t *pe = en_pair + 2 * (size_t)(eb + tm);
         const uint32_t *ps = reinterpret_cast<const uint32_t *>(head_src + (size_t)f * (max_deg - 1) * max_deg) + ts;
+        const float *src[FUSED_PIECES];
+#pragma unroll
+        for (int u = 0; u < FUSED_PIECES; ++u) {
+            int c = wave * 64 + u * 256 + lane;
+            c = c < total ? c : total - 1;                   // pieces past the image repeat its last chunk (slack space)
+            const int node = c / DV, d = (c - node * DV) * 4;
+            src[u] = (l0 && node >= H) ? a.en_const_ft2 + (c0 + d) : a.ft2 + (row0 + node) * a.ld + c0 + d;
+        }
+        // LDS byte address of this wave's first piece; piece u lands 4 KiB (256 chunks) further
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(
+            (unsigned)(size_t)(__attribute__((address_space(3))) float *)s_ft + (unsigned)(wave * 64) * 16u);
         float r1, r2;
         int e1, e2;
         uint32_t sv;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(r1) : "v"(p1) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(r2) : "v"(p2) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(e1) : "v"(pe) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(e2) : "v"(pe) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(sv) : "v"(ps) : "memory");
-#pragma unroll
-        for (int u = 0; u < FUSED_PIECES; ++u) {
-            const int c0_ = wave * 64 + u * 256;
-            int c = c0_ + lane;
-            c = c < total ? c : total - 1;                   // pieces past the image repeat its last chunk (slack space)
-            const int node = c / DV, d = (c - node * DV) * 4;
-            const float *src = (l0 && node >= H) ? a.en_const_ft2 + (c0 + d) : a.ft2 + (row0 + node) * a.ld + c0 + d;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(s_ft + (size_t)c0_ * 4), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(r1), "+v"(r2), "+v"(e1), "+v"(e2), "+v"(sv)::"memory");
-        static_assert(FUSED_PIECES == 8, "the wait above counts the pieces");
+        unsigned m0_keep;
+        static_assert(FUSED_PIECES == 8, "the asm block below issues eight pieces and waits for vmcnt(8)");
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "global_load_dword %[r1], %[p1], off\n\t"
+            "global_load_dword %[r2], %[p2], off\n\t"
+            "global_load_dword %[e1], %[pe], off\n\t"
+            "global_load_dword %[e2], %[pe], off offset:4\n\t"
+            "global_load_dword %[sv], %[ps], off\n\t"
+            "s_mov_b32 m0, %[m0v]\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[s0], off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[s1], off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[s2], off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[s3], off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[s4], off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[s5], off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[s6], off\n\t"
+            "s_add_u32 m0, m0, 0x1000\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[s7], off\n\t"
+            "s_mov_b32 m0, %[keep]\n\t"
+            "s_waitcnt vmcnt(8)"
+            : [r1] "=&v"(r1), [r2] "=&v"(r2), [e1] "=&v"(e1), [e2] "=&v"(e2), [sv] "=&v"(sv), [keep] "=&s"(m0_keep)
+            : [p1] "v"(p1), [p2] "v"(p2), [pe] "v"(pe), [ps] "v"(ps), [m0v] "s"(m0v), [s0] "v"(src[0]), [s1] "v"(src[1]),
+              [s2] "v"(src[2]), [s3] "v"(src[3]), [s4] "v"(src[4]), [s5] "v"(src[5]), [s6] "v"(src[6]), [s7] "v"(src[7])
+            : "memory", "scc");
         if (t < N) {
             s_a1[t] = r1;
             s_a2[t] = r2;

@@ -31,7 +31,6 @@
 //     one barrier per stage; XCD-aware workgroup order so the tiles that share operands run
 //     on one XCD's L2.
 #include <cstdlib>
-#include <mutex>
 
 #include "mpe_internal.h"
 
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
         constexpr int NLD = NL > 0 ? NL : 1;          // (NL == 0 never runs this block)
         constexpr int NA_L = 16 / NLD, NW_L = (NW + NLD - 1) / NLD;
         const int li = wave - 4;
-        if (tune_prio & 1) __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(3);         // +0.7 %: the loaders' requests are not queued behind older MFMA waves
         const float *la[NA_L], *lw[NW_L];
 #pragma unroll
         for (int g = 0; g < NA_L; ++g) {
@@ -519,7 +518,8 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
             const int mo = c_rows ? c_rows[m] : m;
             float *dst = C + (size_t)mo * ldc + nb;
             if (nb + 3 < n) {
-                *reinterpret_cast<f32x4 *>(dst) = v;
+                if (tune_prio & 256) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));   // EXPERIMENT
+                else *reinterpret_cast<f32x4 *>(dst) = v;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -545,313 +545,6 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
                     a12[(size_t)mo * 32 + 16 + head] = y;
                 }
             }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Persistent form of k_linear_dma<.., NL = 4> (four MFMA waves + four loader waves): a workgroup walks
-// a sequence of tiles instead of ending after one, so that
-//   * the loader waves request stage 0 of the NEXT tile while the MFMA waves are still in the last
-//     stage and the epilogue of the current one (a tile's first stage in flight and the workgroup
-//     turn-over cost 6-9 % at the 13 stages of the graph-attention layers, tools/gemm_ksweep.py),
-//   * tiles are handed out dynamically (one atomic add per tile on a per-XCD-class counter), which
-//     keeps the balance of the hardware dispatcher that a static walk lost (round 1).
-// Tile order, LDS image, fragment layout, k order, f64 flush cadence and epilogue are those of
-// k_linear_dma: a row gives the same bits.  Needs nk >= 2 (the next tile id is fetched during stage 0
-// and handed to the other waves by the barrier of stage 1).
-//   tile_q [8]      zero at launch: tickets of the 8 XCD classes (workgroups with equal blockIdx % 8)
-//   tile_q_next [8] zeroed BY this launch for the next persistent launch on the same stream
-// ---------------------------------------------------------------------------------------
-template <bool LEAKY, bool ACC64, int NTT, bool A12>
-__global__ __launch_bounds__(512, (ACC64 || A12) ? 4 : 6) void k_linear_pers(const float *__restrict__ A, int lda,
-                                                       const float *__restrict__ W0, int ldw,
-                                                       const float *__restrict__ bias, float *__restrict__ C,
-                                                       int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
-                                                       int k_pad, float slope, int ntn, int n_major,
-                                                       const int32_t *__restrict__ a_rows0,
-                                                       const int32_t *__restrict__ c_rows0,
-                                                       const float *__restrict__ attn_l, const float *__restrict__ attn_r,
-                                                       float *__restrict__ a12, const int32_t *__restrict__ grp_count,
-                                                       int n_grp, int grp_stride, long w_grp_stride,
-                                                       int32_t *__restrict__ tile_q, int32_t *__restrict__ tile_q_next) {
-    extern __shared__ __attribute__((aligned(1024))) float lds[];   // 2 stages + 2 words (next tile id, by tile parity)
-    constexpr int ROWF = 32;
-    constexpr int W_OFF = GEMM_BM * ROWF;
-    constexpr int STAGE = (GEMM_BM + NTT * 16) * ROWF;
-    constexpr int BN = NTT * 16;
-    int *slot = reinterpret_cast<int *>(lds + 2 * STAGE);
-
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int bid = blockIdx.x;
-    if (bid == 0 && tid < 8) tile_q_next[tid] = 0;
-
-    int Mall = m_cap;
-    if (d_m) {
-        int dm = *d_m;
-        Mall = dm < m_cap ? dm : m_cap;
-    }
-    int ntm = (Mall + GEMM_BM - 1) / GEMM_BM;
-    if (grp_count) {
-        ntm = 0;
-        for (int g = 0; g < n_grp; ++g) ntm += (grp_count[g] + GEMM_BM - 1) / GEMM_BM;
-    }
-    const int nwg = ntm * ntn;
-    // XCD class x = bid % 8 owns a contiguous range of the tile order (as k_linear_dma); its workgroups
-    // take the first tiles of the range statically and the rest by ticket
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int cls_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int cls_count = q8 + (xcd < r8 ? 1 : 0);
-    const int cls_wgs = ((int)gridDim.x - xcd + 7) >> 3;
-    int j = bid >> 3;
-    if (j >= cls_count) return;                        // uniform for the workgroup
-
-    const int dr = lane >> 3, dp = lane & 7;
-    const int nk = k_pad / GEMM_BK;
-    if (tune_prio & 128) {                             // EXPERIMENT: de-phase the workgroups that share a CU
-        const int ph = ((bid >> 3) / 32) % 3;
-        for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(40);
-    }
-
-    // tile j of this class -> (rows, columns, group)
-    struct Tile {
-        int m0, n0, M;
-        const float *W;
-        const int32_t *a_rows, *c_rows;
-    };
-    auto decode = [&](int jj) {
-        const int swz = cls_base + jj;
-        int tm, tn;
-        if (n_major) {
-            constexpr int RB = 8;
-            const int band = swz / (RB * ntn), rem = swz - band * (RB * ntn);
-            const int rows = ntm - band * RB < RB ? ntm - band * RB : RB;
-            tn = rem / rows;
-            tm = band * RB + (rem - tn * rows);
-        } else {
-            tm = swz / ntn;
-            tn = swz - tm * ntn;
-        }
-        Tile t{0, tn * BN, Mall, W0, a_rows0, c_rows0};
-        if (grp_count) {
-            int g = 0, t0 = 0;
-            for (;;) {
-                const int nt_g = (grp_count[g] + GEMM_BM - 1) / GEMM_BM;
-                if (tm < t0 + nt_g || g == n_grp - 1) break;
-                t0 += nt_g;
-                ++g;
-            }
-            tm -= t0;
-            t.M = grp_count[g];
-            t.a_rows = a_rows0 + (size_t)g * grp_stride;
-            t.c_rows = c_rows0 + (size_t)g * grp_stride;
-            t.W = W0 + (size_t)g * w_grp_stride;
-        }
-        t.m0 = tm * GEMM_BM;
-        return t;
-    };
-
-    if (wave >= 4) {
-        // ---- loader waves ----
-        constexpr int NW = NTT * 2, NA_L = 4, NW_L = (NW + 3) / 4;
-        const int li = wave - 4;
-        __builtin_amdgcn_s_setprio(3);
-        const float *la[NA_L], *lw[NW_L];
-        auto setup = [&](const Tile &t) {
-#pragma unroll
-            for (int g = 0; g < NA_L; ++g) {
-                const int row = (li * NA_L + g) * 8 + dr;
-                int grow = t.m0 + row;
-                grow = grow < t.M ? grow : t.M - 1;
-                if (t.a_rows) grow = t.a_rows[grow];
-                la[g] = A + (size_t)grow * lda + ((dp ^ dma_swz(row)) << 2);
-            }
-#pragma unroll
-            for (int g = 0; g < NW_L; ++g) {
-                int grp = li + 4 * g;
-                if (grp > NW - 1) grp = NW - 1;
-                const int row = grp * 8 + dr;
-                lw[g] = t.W + (size_t)(t.n0 + row) * ldw + ((dp ^ dma_swz(row)) << 2);
-            }
-        };
-        auto fill = [&](int kt, int buf) {
-            const int koff = kt * GEMM_BK;
-            float *base = lds + buf * STAGE;
-#pragma unroll
-            for (int g = 0; g < NA_L; ++g)
-                __builtin_amdgcn_global_load_lds((glb_void *)(la[g] + koff), (lds_void *)(base + (li * NA_L + g) * 8 * ROWF), 16, 0, 0);
-#pragma unroll
-            for (int g = 0; g < NW_L; ++g)
-                if ((g + 1) * 4 <= NW || li + 4 * g < NW)
-                    __builtin_amdgcn_global_load_lds((glb_void *)(lw[g] + koff), (lds_void *)(base + W_OFF + (li + 4 * g) * 8 * ROWF), 16, 0, 0);
-        };
-        setup(decode(j));
-        int sc = 0;                                    // running stage count: buffer = sc & 1
-        int jcur = j;
-        fill(0, 0);
-        for (int t = 0;; ++t) {
-            int jn = 0;
-            for (int kt = 0; kt < nk; ++kt, ++sc) {
-                __syncthreads();                       // stage (t, kt) has landed; the MFMA waves are done with the other buffer
-                if (kt == 0 && li == 0) {              // ONE ticket per tile: lane 0 draws it, the wave shares it
-                    int tk = 0;
-                    if (tune_prio & 32) {              // EXPERIMENT: static walk (no ticket)
-                        jn = jcur + cls_wgs;
-                    } else {
-                        if (lane == 0) tk = __hip_atomic_fetch_add(&tile_q[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        jn = cls_wgs + __builtin_amdgcn_readfirstlane(tk);
-                    }
-                }
-                if (kt + 1 < nk) {
-                    fill(kt + 1, (sc + 1) & 1);
-                    if (kt == 0 && li == 0 && lane == 0) slot[(t + 1) & 1] = jn;      // (waits for the ticket; the stage wait follows anyway)
-                } else {
-                    // last stage of the tile: every loader learns the next tile (written in front of the
-                    // barrier of stage 1) and requests its first stage
-                    jn = slot[(t + 1) & 1];
-                    if (jn < cls_count) {
-                        setup(decode(jn));
-                        fill(0, (sc + 1) & 1);
-                    }
-                }
-            }
-            if (jn >= cls_count) return;
-            jcur = jn;
-        }
-    }
-
-    // ---- MFMA waves ----
-    const int fq = lane >> 4, fr = lane & 15;
-    const int fsw = dma_swz(fr);
-    int a_rd[MT], w_rd[NTT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * ROWF;
-#pragma unroll
-    for (int nt = 0; nt < NTT; ++nt) w_rd[nt] = W_OFF + (nt * 16 + fr) * ROWF;
-    const int c0 = ((fq * 2 + 0) ^ fsw) << 2, c1 = ((fq * 2 + 1) ^ fsw) << 2;
-    int sc = 0;
-    for (int t = 0;; ++t) {
-        const Tile tl = decode(j);
-        f32x4 acc[NTT][MT];
-        double run[ACC64 ? NTT : 1][ACC64 ? MT : 1][4];
-#pragma unroll
-        for (int nt = 0; nt < NTT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ACC64) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] = 0.0;
-                }
-            }
-        for (int kt = 0; kt < nk; ++kt, ++sc) {
-            // raw barrier: the MFMA waves wait for their LDS reads only.  __syncthreads() would add vmcnt(0), i.e.
-            // the completion of the previous tile's result stores (2-3 us), in front of the first stage of every tile
-            // -- the same wait that ends every workgroup of the one-tile kernel.  The stage's data is covered by the
-            // loader waves' own vmcnt(0) in front of this barrier.
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const int cur = (sc & 1) * STAGE;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int co = hh ? c1 : c0;
-                f32x4 af[MT], wf[NTT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + co]);
-#pragma unroll
-                for (int nt = 0; nt < NTT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + co]);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int nt = 0; nt < NTT; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
-            }
-            if (ACC64) {
-#pragma unroll
-                for (int nt = 0; nt < NTT; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] += (double)acc[nt][mt][i];
-                        acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-            }
-        }
-        const int jn = slot[(t + 1) & 1];              // written in front of the barrier of stage 1 of this tile
-
-        float pl[2][MT], pr[2][MT];
-        if (A12) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) pl[h][mt] = pr[h][mt] = 0.f;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTT; ++nt) {
-            const int nb = tl.n0 + nt * 16 + fq * 4;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
-            f32x4 al = {0.f, 0.f, 0.f, 0.f}, ar = {0.f, 0.f, 0.f, 0.f};
-            if (A12 && nb + 3 < n) {
-                al = *reinterpret_cast<const f32x4 *>(attn_l + nb);
-                ar = *reinterpret_cast<const f32x4 *>(attn_r + nb);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = tl.m0 + wave * 32 + mt * 16 + fr;
-                f32x4 v;
-                if (ACC64) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = (float)(run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] + (double)bv[i]);
-                } else {
-                    v = acc[nt][mt] + bv;
-                }
-                if (LEAKY) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
-                }
-                if (A12) {
-                    const int hp = (nt * 16 + fq * 4) >= 40 ? 1 : 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float l1 = __builtin_fmaf(v[i], al[i], hp ? pl[1][mt] : pl[0][mt]);
-                        const float r1 = __builtin_fmaf(v[i], ar[i], hp ? pr[1][mt] : pr[0][mt]);
-                        if (hp) { pl[1][mt] = l1; pr[1][mt] = r1; } else { pl[0][mt] = l1; pr[0][mt] = r1; }
-                    }
-                }
-                if (m >= tl.M) continue;
-                const int mo = tl.c_rows ? tl.c_rows[m] : m;
-                float *dst = C + (size_t)mo * ldc + nb;
-                if (nb + 3 < n) {
-                    *reinterpret_cast<f32x4 *>(dst) = v;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (nb + i < n) dst[i] = v[i];
-                }
-            }
-        }
-        if (A12) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    float x = pl[h][mt], y = pr[h][mt];
-                    x = x + __shfl_xor(x, 16);
-                    y = y + __shfl_xor(y, 16);
-                    x = x + __shfl_xor(x, 32);
-                    y = y + __shfl_xor(y, 32);
-                    const int m = tl.m0 + wave * 32 + mt * 16 + fr;
-                    const int head = (tl.n0 / 40) + h;
-                    if (fq == 0 && m < tl.M && head * 40 < n) {
-                        const int mo = tl.c_rows ? tl.c_rows[m] : m;
-                        a12[(size_t)mo * 32 + head] = x;
-                        a12[(size_t)mo * 32 + 16 + head] = y;
-                    }
-                }
-        }
-        if (jn >= cls_count) return;
-        j = jn;
     }
 }
 
@@ -1295,57 +988,6 @@ static void launch_dma(hipStream_t s, int grid, const DmaLaunch &a) {
                        a.attn_l, a.attn_r, a.a12, a.grp_count, a.n_grp, a.grp_stride, a.w_grp_stride);
 }
 
-// ---- persistent launches: ticket counters ----
-// Every persistent launch needs 8 zeroed counters.  A ring of slots per (device, stream): launch i uses
-// slot i and zeroes slot i + 1 (launches of one stream are ordered, so the next one finds it zero); the
-// ring itself is zeroed when it is created.
-struct TicketRing {
-    int device;
-    hipStream_t stream;
-    int32_t *base;
-    unsigned next;
-};
-constexpr int TICKET_SLOTS = 64;
-static bool next_tickets(hipStream_t s, int32_t **cur, int32_t **nxt) {
-    static std::vector<TicketRing> rings;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    TicketRing *r = nullptr;
-    for (auto &x : rings)
-        if (x.device == dev && x.stream == s) r = &x;
-    if (!r) {
-        int32_t *p = nullptr;
-        if (hipMalloc(&p, TICKET_SLOTS * 8 * sizeof(int32_t)) != hipSuccess) return false;
-        if (hipMemset(p, 0, TICKET_SLOTS * 8 * sizeof(int32_t)) != hipSuccess) return false;
-        rings.push_back(TicketRing{dev, s, p, 0u});
-        r = &rings.back();
-    }
-    *cur = r->base + (r->next % TICKET_SLOTS) * 8;
-    *nxt = r->base + ((r->next + 1) % TICKET_SLOTS) * 8;
-    ++r->next;
-    return true;
-}
-
-static bool gemm_persistent_on() {
-    static const int v = getenv("MPE_GEMM_PERSIST") ? atoi(getenv("MPE_GEMM_PERSIST")) : 1;
-    return v != 0;
-}
-
-template <bool L, bool A64, int N, bool A12>
-static bool launch_pers(hipStream_t s, int grid_tiles, const DmaLaunch &a) {
-    if (!gemm_persistent_on() || a.k_pad / GEMM_BK < 2) return false;
-    int32_t *cur, *nxt;
-    if (!next_tickets(s, &cur, &nxt)) return false;
-    const int slots = 256 * ((A64 || A12) ? 2 : 3);
-    const int grid = grid_tiles < slots ? grid_tiles : slots;
-    hipLaunchKernelGGL((k_linear_pers<L, A64, N, A12>), dim3(grid), dim3(512), dma_lds_bytes(N) + 16, s, a.A, a.lda, a.W, a.ldw,
-                       a.bias, a.C, a.ldc, a.m_cap, a.d_m, a.n, a.k_pad, a.slope, a.ntn, a.n_major, a.a_rows, a.c_rows, a.attn_l,
-                       a.attn_r, a.a12, a.grp_count, a.n_grp, a.grp_stride, a.w_grp_stride, cur, nxt);
-    return true;
-}
-
 static bool gemm_loader_waves_on() {
     static const int v = getenv("MPE_GEMM_LOADER") ? atoi(getenv("MPE_GEMM_LOADER")) : 1;
     return v != 0;
@@ -1355,7 +997,6 @@ static bool gemm_loader_waves_on() {
 template <int N>
 static void launch_dma_plain(hipStream_t s, int grid, const DmaLaunch &a, bool leaky) {
     if (gemm_loader_waves_on()) {
-        if (leaky ? launch_pers<true, false, N, false>(s, grid, a) : launch_pers<false, false, N, false>(s, grid, a)) return;
         if (leaky) launch_dma<true, false, N, false, 4>(s, grid, a);
         else launch_dma<false, false, N, false, 4>(s, grid, a);
     } else if (leaky) launch_dma<true, false, N, false, 0>(s, grid, a);
@@ -1365,7 +1006,6 @@ static void launch_dma_plain(hipStream_t s, int grid, const DmaLaunch &a, bool l
 template <int N>
 static void launch_dma_acc64(hipStream_t s, int grid, const DmaLaunch &a, bool leaky) {
     if (N == 4 && gemm_loader_waves_on()) {
-        if (leaky ? launch_pers<true, true, 4, false>(s, grid, a) : launch_pers<false, true, 4, false>(s, grid, a)) return;
         if (leaky) launch_dma<true, true, 4, false, 4>(s, grid, a);
         else launch_dma<false, true, 4, false, 4>(s, grid, a);
     } else if (leaky) launch_dma<true, true, N, false, 0>(s, grid, a);
@@ -1470,8 +1110,7 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
         a.a12 = coef->a12;
         const int grid = ntm * a.ntn;
         if (acc64) launch_dma<false, true, 5, true, 0>(s, grid, a);
-        else if (gemm_loader_waves_on() && launch_pers<false, false, 5, true>(s, grid, a)) {
-        } else if (gemm_loader_waves_on()) launch_dma<false, false, 5, true, 4>(s, grid, a);
+        else if (gemm_loader_waves_on()) launch_dma<false, false, 5, true, 4>(s, grid, a);
         else launch_dma<false, false, 5, true, 0>(s, grid, a);
         if (coef_done) *coef_done = true;
         return hipGetLastError();

@@ -96,7 +96,14 @@ def ring_variant(n_cameras=23):
         used_cameras=list(names), used_cameras_skeleton_matching=list(names))
 
 
-PRESETS = {'PANOPTIC': _panoptic, 'ARPLAB': _arplab, 'RING23': lambda: ring_variant(23)}
+def _arplab_robot():
+    """ARPLAB with the reference's "models using only the robot cameras" lines active
+    (reference parameters.py:110-112): six cameras configured, two used."""
+    robot = ['orinbot_l', 'orinbot_r']
+    return _arplab()._replace(used_cameras=list(robot), used_cameras_skeleton_matching=list(robot))
+
+
+PRESETS = {'PANOPTIC': _panoptic, 'ARPLAB': _arplab, 'ARPLAB_ROBOT': _arplab_robot, 'RING23': lambda: ring_variant(23)}
 
 CONFIGURATION = 'PANOPTIC'            # values = {PANOPTIC, ARPLAB} (reference parameters.py:47)
 

@@ -135,8 +135,10 @@ class Engine:
         host side off the critical path: the native packer parses chunk i+1 straight into a
         page-locked arena (worker thread; the C call releases the GIL) while chunk i is copied to
         the device in ONE transfer and runs mpe_match_batch + the 3D stage; results come back into
-        page-locked memory.  Yields (PackedBatch view, poses [B,Pcap,J,3], n_persons [B]) per chunk;
-        the views and the result arrays are reused two chunks later."""
+        page-locked memory.  Yields (PackedBatch view, poses [B,Pcap,J,3], n_persons [B]) per chunk.
+        LIFETIME: the yielded view and arrays are valid until the next `next()` on the generator only --
+        resuming it starts the parse of a later chunk into the arena behind the view (two host arenas)
+        and the result arrays of the slot are rewritten one chunk after that.  Copy what you keep."""
         from concurrent.futures import ThreadPoolExecutor
         if isinstance(text, str):
             text = text.encode()
@@ -207,27 +209,42 @@ class Engine:
         throughput at 1000-frame batches).  Results are the same bits as match() + mlp3d() / triangulate()
         called one after the other.  Each result is yielded once its 3D stage has finished."""
         s_match, s_3d = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
-        s_match.wait_stream(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
         pending = None
-        for b in batches:
-            db = self.to_device(b)
-            with torch.cuda.stream(s_match):
-                _, persons, n_persons = self.match(db, want_scores=False)
-                ev = torch.cuda.Event()
-                ev.record(s_match)
-            with torch.cuda.stream(s_3d):
-                s_3d.wait_event(ev)
-                poses = (self.mlp3d(db, persons, n_persons) if mode == 'mlp' else self.triangulate(db, persons, n_persons))[0]
-                done = torch.cuda.Event()
-                done.record(s_3d)
+        try:
+            for b in batches:
+                db = self.to_device(b)
+                # whatever produced this batch (an upload the iterator queued on the current stream) is ordered
+                # before its matching stage -- per batch, not once in front of the loop
+                s_match.wait_stream(cur)
+                with torch.cuda.stream(s_match):
+                    _, persons, n_persons = self.match(db, want_scores=False)
+                    ev = torch.cuda.Event()
+                    ev.record(s_match)
+                with torch.cuda.stream(s_3d):
+                    s_3d.wait_event(ev)
+                    poses = (self.mlp3d(db, persons, n_persons) if mode == 'mlp' else self.triangulate(db, persons, n_persons))[0]
+                    done = torch.cuda.Event()
+                    done.record(s_3d)
+                # tensors allocated on one stream and consumed on another: the allocator must not hand
+                # their memory out again before the consumer is done
+                for t_ in (persons, n_persons):
+                    t_.record_stream(s_3d)
+                prev, pending = pending, (done, poses, n_persons, persons, db)   # db: keeps the batch alive while it is in flight
+                if prev is not None:
+                    prev[0].synchronize()
+                    yield prev[1:]
+            if pending is not None:
+                last, pending = pending, None
+                last[0].synchronize()
+                yield last[1:]
+        finally:
+            # also on early exit (the consumer closed the generator): nothing of ours is still running on
+            # the side streams when the caller's stream goes on, and nothing in flight is freed under them
+            cur.wait_stream(s_match)
+            cur.wait_stream(s_3d)
             if pending is not None:
                 pending[0].synchronize()
-                yield pending[1:]
-            pending = (done, poses, n_persons, persons, db)      # db: keeps the batch alive while it is in flight
-        if pending is not None:
-            pending[0].synchronize()
-            yield pending[1:]
-        torch.cuda.current_stream(self.device).wait_stream(s_3d)
 
     def to_device(self, pb):
         if isinstance(pb, DeviceBatch):

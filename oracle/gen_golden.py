@@ -27,7 +27,10 @@ GAT_SEED = 7
 MLP_SEED = 11
 LOGIT_GAIN = 25.0
 LOGIT_SHIFT = 0.698
-VARIANT_SHIFT = {'arplab': 0.698 + 0.2952, 'ring23': 0.698 - 0.1833}   # centre each variant's logits
+VARIANT_SHIFT = {'arplab': 0.698 + 0.2952, 'ring23': 0.698 - 0.1833, 'arprobot': 0.698}   # centre each variant's logits
+# second MLP of every case: outputs inside the capture volume (a decoder of the triangulated points with dense
+# hash noise on every weight) -- the magnitude regime the 1e-3 mm item of the north star is about
+ROOM_NOISE_SEED, ROOM_NOISE = 3, 0.05
 
 
 def quiet():
@@ -56,13 +59,21 @@ def write_variant_parameters(params, tm, workdir):
     return fields['transformations_path']
 
 
-def check_arplab_against_reference(par):
-    """Our ARPLAB preset against the reference's file with its CONFIGURATION switch flipped
-    (evaluated in memory; the file itself is never modified or copied)."""
+def check_arplab_against_reference(par, robot_only=False):
+    """Our ARPLAB presets against the reference's file with its CONFIGURATION switch flipped and,
+    for the robot-camera variant, its two commented lines (parameters.py:110-112) swapped in for
+    the all-camera ones (evaluated in memory; the file itself is never modified or copied)."""
     src = open(os.path.join(refenv.REF, 'parameters.py')).read()
+    src = src.replace("CONFIGURATION = 'PANOPTIC'", "CONFIGURATION = 'ARPLAB'")
+    if robot_only:
+        a = "        # used_cameras=['orinbot_l', 'orinbot_r'],\n        # used_cameras_skeleton_matching = ['orinbot_l', 'orinbot_r'],"
+        b = ("        used_cameras=['trackera', 'trackerb', 'trackerc', 'trackerd', 'orinbot_l', 'orinbot_r'],\n"
+             "        used_cameras_skeleton_matching = ['trackera', 'trackerb', 'trackerc', 'trackerd', 'orinbot_l', 'orinbot_r'],")
+        assert a in src and b in src
+        src = src.replace(b, '').replace(a, a.replace('# ', ''))
     ns = {}
-    exec(compile(src.replace("CONFIGURATION = 'PANOPTIC'", "CONFIGURATION = 'ARPLAB'"), 'parameters_arplab', 'exec'), ns)
-    theirs, ours = ns['parameters'], par.select('ARPLAB')
+    exec(compile(src, 'parameters_arplab', 'exec'), ns)
+    theirs, ours = ns['parameters'], par.select('ARPLAB_ROBOT' if robot_only else 'ARPLAB')
     for f in theirs._fields:
         assert getattr(theirs, f) == getattr(ours, f), f
 
@@ -80,9 +91,9 @@ def main(variant='panoptic'):
         calib = cal.Calibration(our_params)
     else:
         OUT = os.path.join(OUT, variant)
-        if variant == 'arplab':
-            check_arplab_against_reference(par)
-            our_params = par.select('ARPLAB')
+        if variant in ('arplab', 'arprobot'):
+            check_arplab_against_reference(par, robot_only=variant == 'arprobot')
+            our_params = par.select('ARPLAB' if variant == 'arplab' else 'ARPLAB_ROBOT')
             tm = cal.load_transform_manager(os.path.join(refenv.REF, 'tm_arp.pickle'))
         else:
             our_params = par.select('RING23')
@@ -118,17 +129,29 @@ def main(variant='panoptic'):
     model = ref['gat2'].GAT2(None, syn.GAT_LAYERS, nf, 1, syn.GAT_HIDDEN, syn.GAT_HEADS, torch.nn.LeakyReLU(),
                              torch.nn.Sigmoid(), 0., 0., syn.GAT_ALPHA, False, bias=True)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in gat_sd.items()})
-    in_dim = len(rparams.cameras) * len(rparams.joint_list) * rparams.numbers_per_joint
+    # metrics_from_model.py:91 sizes the MLP from len(parameters.cameras), the dataset sizes its rows from
+    # len(parameters.used_cameras) (pose_estimator_dataset_from_json.py:237-285, reprojection_error.py:143): equal for the
+    # all-camera presets; with the robot-camera subset only the second is consistent with the rows, so that is used
+    n_used = len(rparams.used_cameras)
+    in_dim = n_used * len(rparams.joint_list) * rparams.numbers_per_joint
     mlp_sd = syn.mlp_state_dict(MLP_SEED, in_dim)
     with quiet():
         mlp = ref['mlp'].PoseEstimatorMLP(input_dimensions=in_dim, output_dimensions=54)
     mlp.load_state_dict({k: torch.from_numpy(v) for k, v in mlp_sd.items()})
+    room_sd = syn.decoder_mlp_state_dict(n_used, len(rparams.joint_list), rparams.numbers_per_joint,
+                                         noise_seed=ROOM_NOISE_SEED, noise_bound=ROOM_NOISE)
+    with quiet():
+        mlp_room = ref['mlp'].PoseEstimatorMLP(input_dimensions=in_dim, output_dimensions=54)
+    mlp_room.load_state_dict({k: torch.from_numpy(v) for k, v in room_sd.items()})
 
     F = syn.FrameSpec
     names = list(rparams.camera_names)
     if variant == 'arplab':
         cases = [('arp_6x3', F(persons=3, add_id_key=True, noise_px=1.0, float_conf=False), [0, 1]),
                  ('arp_robot_pair', F(persons=2, cameras=['orinbot_r', 'orinbot_l']), [2])]
+    elif variant == 'arprobot':
+        cases = [('arp_robot_only', F(persons=3, cameras=['orinbot_l', 'orinbot_r'], noise_px=1.0), [0, 1]),
+                 ('arp_robot_only_all_streams', F(persons=2, add_id_key=True), [3])]   # the other four cameras' skeletons arrive too
     elif variant == 'ring23':
         cases = [('ring23x3', F(persons=3, noise_px=0.5), [0]),
                  ('ring23_sparse', F(persons=2, cameras=names[3::4], joint_drop=0.1), [1])]
@@ -144,7 +167,8 @@ def main(variant='panoptic'):
         ('c4_5x10', F(persons=10, noise_px=1.0), [7]),
       ]
     meta = {'gat_seed': GAT_SEED, 'mlp_seed': MLP_SEED, 'logit_gain': LOGIT_GAIN, 'logit_shift': shift,
-            'num_feats': nf, 'mlp_in': in_dim, 'variant': variant, 'cases': {}}
+            'num_feats': nf, 'mlp_in': in_dim, 'variant': variant, 'cases': {},
+            'room_mlp': {'kind': 'decoder', 'noise_seed': ROOM_NOISE_SEED, 'noise_bound': ROOM_NOISE}}
     for name, spec, idxs in cases:
         frames_json = []
         arrays = {}
@@ -213,6 +237,9 @@ def main(variant='panoptic'):
                 arrays[p + 'mlp_in'] = np.stack(rows)
                 arrays[p + 'mlp_out'] = out.numpy()
                 arrays[p + 'poses'] = np.stack([(out[i] * 10.).numpy().reshape(-1, 3) for i in range(out.shape[0])])
+                out_room = mlp_room(x)
+                arrays[p + 'mlp_out_room'] = out_room.numpy()
+                arrays[p + 'poses_room'] = np.stack([(out_room[i] * 10.).numpy().reshape(-1, 3) for i in range(out_room.shape[0])])
             # ---- 3D stage B (metrics_from_triangulation.py:234-272)
             pe = ref['pose_estimator_dataset_from_json']
             tri = np.zeros((len(final_output), len(rparams.joint_list), 3))
@@ -223,7 +250,10 @@ def main(variant='panoptic'):
                 points_2D = {}
                 for cam_idx in rparams.cameras:
                     camera = rparams.camera_names[cam_idx]
-                    if person[camera] is not None:
+                    # person dicts carry used_cameras_skeleton_matching only (skeleton_matching_utils.py:125): with a camera
+                    # subset the caller's person[camera] (metrics_from_triangulation.py:240) raises KeyError for the unused
+                    # cameras; the fixture keeps the gather over the cameras the dict has
+                    if person.get(camera) is not None:
                         for j, pos in sc.jsons_for_head[person[camera]].items():
                             if j == 'ID':
                                 continue      # an "ID" entry would make the reference raise here; fixtures avoid it

@@ -29,6 +29,8 @@ def oracle():
 VARIANT_CASES = {
     'panoptic': ['c1_2view_1person', 'c2_5x4_clean', 'c2_5x4_messy', 'c2_5x4_reordered', 'c2_3x2', 'c4_5x10'],
     'arplab': ['arp_6x3', 'arp_robot_pair'],
+    # the reference's camera-subset preset (parameters.py:110-112): six cameras configured, the two robot cameras used
+    'arprobot': ['arp_robot_only', 'arp_robot_only_all_streams'],
     'ring23': ['ring23x3', 'ring23_sparse'],
 }
 CASES = VARIANT_CASES['panoptic']
@@ -50,13 +52,13 @@ class Env:
         if variant == 'panoptic':
             self.params = par.parameters
             self.calib = cal.Calibration(self.params)
-        elif variant == 'arplab':
-            self.params = par.select('ARPLAB')
+        elif variant in ('arplab', 'arprobot'):
+            self.params = par.select('ARPLAB' if variant == 'arplab' else 'ARPLAB_ROBOT')
             self.calib = cal.Calibration(self.params)          # package copy of tm_arp
         else:
             self.params = par.select('RING23')
             self.calib = cal.Calibration(self.params, syn.ring_transform_manager(self.params))
-        self._gat = self._mlp = None
+        self._gat = self._mlp = self._mlp_room = None
 
     @property
     def gat(self):
@@ -72,6 +74,17 @@ class Env:
         if self._mlp is None:
             self._mlp = pkg('synthetic').mlp_state_dict(self.meta['mlp_seed'], self.meta['mlp_in'])
         return self._mlp
+
+
+    @property
+    def mlp_room(self):
+        """The capture-volume MLP of the fixtures (`mlp_out_room` / `poses_room`): outputs within a few metres."""
+        if self._mlp_room is None:
+            m = self.meta['room_mlp']
+            p = self.params
+            self._mlp_room = pkg('synthetic').decoder_mlp_state_dict(
+                len(p.used_cameras), len(p.joint_list), p.numbers_per_joint, noise_seed=m['noise_seed'], noise_bound=m['noise_bound'])
+        return self._mlp_room
 
 
 _envs = {}

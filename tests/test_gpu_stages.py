@@ -320,7 +320,7 @@ def test_mlp_error_budget_every_golden_row():
     per variant, on the maxima over its rows; the measured figures are written to
     gpurun_out/mlp_error_budget.json (millimetres after the x10 decode)."""
     report = {}
-    for variant in ('panoptic', 'arplab', 'ring23'):
+    for variant in ('panoptic', 'arplab', 'arprobot', 'ring23'):
         e = env(variant)
         eng = engine_for(variant)
         xs, refs = [], []
@@ -347,6 +347,72 @@ def test_mlp_error_budget_every_golden_row():
     out = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, 'mlp_error_budget.json'), 'w') as fh:
+        json.dump(report, fh, indent=1)
+    print(json.dumps(report))
+
+
+def test_mlp_capture_volume_regime_every_golden_row():
+    """The 1e-3 mm item of the north star, made decidable in the regime it is about: MLP outputs inside
+    the capture volume (|pose| <= 5 m).  Fixtures `mlp_out_room` / `poses_room` = the REFERENCE's MLP
+    (utils/mlp.py:8-28, torch-CPU) with the capture-volume weights (`Env.mlp_room`: a decoder of the row's
+    triangulated points with dense hash noise, 5 %% of the He scale, on every weight) on the reference's own
+    input rows.  Rows whose persons are mixed-up skeletons triangulate far outside the room and are left
+    to test_mlp_error_budget_every_golden_row.  Per variant, on the rows in the room:
+
+        max_abs_mm        |gpu - ref| after the x10 decode (metrics_from_model.py:278-294)
+        max_abs_ulp       the same in fp32 ulps of the compared output element
+        ref_vs_exact_mm   the reference's own distance from the network evaluated in f64 (fp32 between layers)
+        gpu_vs_exact_mm   ours
+
+    Asserted: |gpu - exact| <= |ref - exact| and |gpu - ref| <= the sum (no additive slack); where the
+    reference's own noise floor allows it (ref_vs_exact <= 5e-4 mm) |gpu - ref| <= 1e-3 mm as the north star
+    words it, otherwise the item is recorded as UNMET with the floor next to it and the HIP side is held to
+    gpu_vs_exact <= 4e-3 mm and <= 14 ulp of the row's largest output (regression guards around the measured
+    1.9-3.6e-3 mm / 6.5-12 ulp; the reference sits at 3.6-5.4e-3 mm / 14-18 ulp).  Neither side can be within
+    1.5 ulp of the exact network: a layer is a sum of 32-deep fp32 fma chains (ours, f64 across the chains) or
+    of blocked fp32 sums (torch-CPU), and eight layers of that are worth a few ulp each.
+    Written to gpurun_out/mlp_capture_volume.json (profiles/r03_mlp_capture_volume.json)."""
+    report = {}
+    for variant in ('panoptic', 'arplab', 'arprobot', 'ring23'):
+        e = env(variant)
+        eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=16, max_persons_per_camera=10)      # row capacity 16 x pcap
+        try:
+            eng.load_mlp(e.mlp_room)
+            xs, refs = [], []
+            for v, name in ALL_CASES:
+                if v != variant:
+                    continue
+                arr, frames = load_case(name, variant)
+                for n in range(len(frames)):
+                    if 'f%d_mlp_in' % n in arr:
+                        xs.append(arr['f%d_mlp_in' % n])
+                        refs.append(arr['f%d_mlp_out_room' % n])
+            x = torch.from_numpy(np.concatenate(xs))
+            ref = np.concatenate(refs).astype(np.float64)
+            room = np.abs(ref).max(axis=1) <= 0.5                     # MLP units = metres / 10
+            assert room.sum() >= max(1, len(room) // 2), (variant, int(room.sum()), len(room))
+            exact = _exact_mlp(x, e.mlp_room).numpy()
+            gpu = eng.mlp_forward(x.cuda()).cpu().numpy().astype(np.float64)
+        finally:
+            eng.close()
+        ref, exact, gpu = ref[room], exact[room], gpu[room]
+        row_ulp = np.spacing(np.abs(ref).max(axis=1, keepdims=True).astype(np.float32)).astype(np.float64)
+        e_ref, e_gpu, d = np.abs(ref - exact), np.abs(gpu - exact), np.abs(gpu - ref)
+        rec = {'rows_in_room': int(room.sum()), 'rows': int(len(room)), 'largest_pose_m': float(np.abs(ref).max() * 10),
+               'max_abs_mm': float(d.max() * 1e4), 'max_abs_row_ulp': float((d / row_ulp).max()),
+               'ref_vs_exact_mm': float(e_ref.max() * 1e4), 'gpu_vs_exact_mm': float(e_gpu.max() * 1e4),
+               'ref_vs_exact_row_ulp': float((e_ref / row_ulp).max()), 'gpu_vs_exact_row_ulp': float((e_gpu / row_ulp).max())}
+        rec['north_star_1e-3_mm'] = 'met' if rec['max_abs_mm'] <= 1e-3 else 'unmet: reference noise floor %.2e mm' % rec['ref_vs_exact_mm']
+        report[variant] = rec
+        assert e_gpu.max() <= e_ref.max(), (variant, rec)
+        assert d.max() <= e_gpu.max() + e_ref.max(), (variant, rec)
+        if rec['ref_vs_exact_mm'] <= 5e-4:
+            assert rec['max_abs_mm'] <= 1e-3, (variant, rec)
+        else:
+            assert rec['gpu_vs_exact_mm'] <= 4e-3 and rec['gpu_vs_exact_row_ulp'] <= 14.0, (variant, rec)
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'mlp_capture_volume.json'), 'w') as fh:
         json.dump(report, fh, indent=1)
     print(json.dumps(report))
 
@@ -571,4 +637,29 @@ def test_run_pipelined_gives_the_same_bits_as_sequential_calls():
     for a, b, w in zip(tri_want, tri_got, want):
         for f in range(len(w[1])):
             assert np.array_equal(a[f, :w[1][f]], b[f, :w[1][f]], equal_nan=True)
+
+    # an iterator that uploads LAZILY (DeviceBatch.upload from pinned memory on the current stream, inside
+    # next()): each batch's copy must be ordered before its matching stage on the side stream
+    packing = pkg('packing')
+    pbs = [db.host for db in batches]
+
+    def lazy():
+        for pb in pbs:
+            pinned = packing.BatchArena(pb, 'pinned').fill(pb)
+            arena = packing.BatchArena(pb, eng.device)
+            db = packing.DeviceBatch(pb, eng.device, arena=arena)
+            arena.buf.zero_()                       # stale contents if the copy were not waited for
+            db.upload(pinned)
+            yield db
+    got2 = [(p.cpu().numpy(), n.cpu().numpy(), q.cpu().numpy()) for p, n, q, _ in eng.run_pipelined(lazy())]
+    for (p1, n1, q1), (p2, n2, q2) in zip(want, got2):
+        assert np.array_equal(n1, n2) and np.array_equal(q1, q2)
+        for f in range(len(n1)):
+            assert np.array_equal(p1[f, :n1[f]], p2[f, :n1[f]])
+    # closing the generator early must leave nothing running on the side streams
+    gen = eng.run_pipelined(batches)
+    first = next(gen)
+    gen.close()
+    torch.cuda.synchronize()
+    assert np.array_equal(first[1].cpu().numpy(), want[0][1])
     eng.close()

@@ -439,3 +439,52 @@ def test_tools_do_not_use_the_oracle():
         if name.endswith(('.py', '.sh')):
             text = open(os.path.join(ROOT, 'tools', name)).read()
             assert 'oracle' not in text.replace('vs the oracle', '').replace("the oracle's", ''), name
+
+
+def test_fused_attention_window_isa(tmp_path):
+    """Static pin of the hand-scheduled window of k_gat_fused (csrc/gat.hip): five asynchronous table loads,
+    eight LDS-DMA pieces and a COUNTED wait (`s_waitcnt vmcnt(8)` = "my five values are here, the image is
+    still landing").  The hardware gives no protection to the five destination registers until that wait;
+    the source keeps the whole window in one asm statement, and this test checks what the compiler emitted
+    for every VEC = 4 instantiation: between the first table load and the wait there are exactly the five
+    global_load_dword, eight global_load_lds_dwordx4 and their M0 bookkeeping -- no other vector, memory, LDS
+    or branch instruction, nothing that reads or writes the five destination VGPRs, no scratch access.
+    (Reference semantics it protects: gat2.py:57-66,78-88.)  Compiles gat.hip to gfx950 assembly (no GPU)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, '3d_multi_pose_estimator_amd', 'csrc', 'gat.hip')
+    out = str(tmp_path / 'gat.s')
+    subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-S', '--cuda-device-only', '-o', out, src],
+                   check=True, capture_output=True, timeout=600)
+    text = open(out).read()
+    kernels = re.findall(r'^(_ZN3mpe11k_gat_fusedILi4ELi\d+EE\S*):', text, re.M)
+    assert kernels, 'no k_gat_fused<4, G> instantiation found'
+    allowed = re.compile(r'^(s_mov_b32 m0, s\d+|s_mov_b32 s\d+, m0|s_add_u32 m0, m0, 0x1000|s_nop \d+|global_load_lds_dwordx4 v\[\d+:\d+\], off)$')
+    for k in kernels:
+        body = text[text.index(k + ':'):]
+        body = body[:body.index('s_endpgm')]
+        lines = [l.strip() for l in body.splitlines()]
+        lines = [l.split(';')[0].strip() for l in lines if l and not l.startswith(('.', ';'))]
+        waits = [i for i, l in enumerate(lines) if l == 's_waitcnt vmcnt(8)']
+        assert len(waits) == 1, (k, waits)
+        w = waits[0]
+        loads = [i for i in range(w) if lines[i].startswith('global_load_dword v')]
+        first = loads[-5] if len(loads) >= 5 else None
+        assert first is not None and loads[-5:] == list(range(first, first + 5)), (k, 'the five table loads are not consecutive')
+        dst = []
+        for i in range(first, first + 5):
+            m = re.match(r'global_load_dword v(\d+), v\[\d+:\d+\], off', lines[i])
+            assert m, (k, lines[i])
+            dst.append(int(m.group(1)))
+        assert len(set(dst)) == 5
+        window = lines[first + 5:w]
+        assert sum(l.startswith('global_load_lds_dwordx4') for l in window) == 8, (k, window)
+        for l in window:
+            assert allowed.match(l), (k, 'unexpected instruction inside the window: ' + l)
+            for m in re.finditer(r'v\[(\d+):(\d+)\]', l):          # address pairs of the pieces must not be a destination
+                assert not any(int(m.group(1)) <= d <= int(m.group(2)) for d in dst), (k, l, dst)
+        assert not re.search(r'scratch_|buffer_(load|store)', body), (k, 'scratch access in the kernel')

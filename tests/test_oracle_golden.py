@@ -9,19 +9,23 @@ import torch
 from conftest import ALL_CASES, CASES, env, golden_dir, load_case, oracle, pkg
 
 
-@pytest.mark.parametrize('variant', ['panoptic', 'arplab', 'ring23'])
+@pytest.mark.parametrize('variant', ['panoptic', 'arplab', 'arprobot', 'ring23'])
 def test_calibration_matches_reference_globals(variant):
     import os
-    calib = env(variant).calib
+    e = env(variant)
+    calib = e.calib
     g = np.load(os.path.join(golden_dir(variant), 'calibration_%s.npz' % variant))
-    assert np.array_equal(g['T_d'].astype(np.float64), calib.T_d.astype(np.float32).astype(np.float64))
-    assert np.array_equal(g['T_i32'], calib.T_i32)
-    assert np.array_equal(g['K32'], calib.K32)
-    assert np.array_equal(g['Kinv32'], calib.Kinv32)
-    assert np.array_equal(g['centre32'], calib.centre32)
+    # the graph generator's globals cover used_cameras_skeleton_matching in camera_names order
+    # (graph_generator.py:38-52), the 3D stage's cover every configured camera (dataset :28-47)
+    sm = [calib.index(c) for c in e.params.camera_names if c in e.params.used_cameras_skeleton_matching]
+    assert np.array_equal(g['T_d'].astype(np.float64), calib.T_d[sm].astype(np.float32).astype(np.float64))
+    assert np.array_equal(g['T_i32'], calib.T_i32[sm])
+    assert np.array_equal(g['K32'], calib.K32[sm])
+    assert np.array_equal(g['Kinv32'], calib.Kinv32[sm])
+    assert np.array_equal(g['centre32'], calib.centre32[sm])
     assert np.array_equal(g['dist'], calib.dist)
     assert np.array_equal(g['P'], calib.P)
-    assert len(g['features']) == 2 + calib.n_cameras * 18 * 10 == env(variant).meta['num_feats']
+    assert len(g['features']) == 2 + len(sm) * 18 * 10 == e.meta['num_feats']
 
 
 @pytest.mark.parametrize('variant,name', ALL_CASES)
@@ -125,6 +129,10 @@ def test_stage3d(variant, name):
         np.testing.assert_allclose(out.numpy(), arr[p + 'mlp_out'], rtol=1e-5, atol=1e-6)
         poses = np.stack([onp.decode_pose(out[i], 18) for i in range(out.shape[0])])
         np.testing.assert_allclose(poses, arr[p + 'poses'], rtol=1e-5, atol=1e-5)
+        # the capture-volume MLP of the fixtures (same reference module, second set of weights)
+        out_room = onp.mlp_forward(env(variant).mlp_room, torch.from_numpy(arr[p + 'mlp_in']))
+        np.testing.assert_allclose(out_room.numpy(), arr[p + 'mlp_out_room'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(arr[p + 'poses_room'].reshape(len(persons), -1), arr[p + 'mlp_out_room'] * np.float32(10.0))
 
 
 @pytest.mark.parametrize('mode,key', [('mlp', 'model'), ('tri', 'triangulation')])
