@@ -30,7 +30,7 @@ LOGIT_SHIFT = 0.698
 VARIANT_SHIFT = {'arplab': 0.698 + 0.2952, 'ring23': 0.698 - 0.1833, 'arprobot': 0.698}   # centre each variant's logits
 # second MLP of every case: outputs inside the capture volume (a decoder of the triangulated points with dense
 # hash noise on every weight) -- the magnitude regime the 1e-3 mm item of the north star is about
-ROOM_NOISE_SEED, ROOM_NOISE = 3, 0.05
+ROOM_NOISE_SEED, ROOM_NOISE = 3, 0.01
 
 
 def quiet():
