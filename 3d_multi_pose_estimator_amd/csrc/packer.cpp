@@ -449,6 +449,68 @@ bool parse_frame(const char *b, const char *e, const std::vector<std::string> &c
     return false;
 }
 
+// First level only (device-side parse, jsonparse.hip): the camera keys of a frame and, for every camera in
+// `cams`, the extent of the STRING that holds its skeleton list; everything else is skipped as parse_frame
+// does.  `unsupported` = a shape only the host parser handles (a skeleton list that is not a string, more
+// camera entries than configured): the caller then packs the window on the host.
+struct StrExtent {
+    int cam;
+    const char *b, *e;
+};
+bool index_frame(const char *b, const char *e, const std::vector<std::string> &cams, std::vector<StrExtent> *out, std::string *err,
+                 bool *unsupported) {
+    Cursor c{b, e, false};
+    skip_ws(c);
+    if (c.p >= c.end || *c.p != '{') { *err = "frame is not an object"; return false; }
+    ++c.p;
+    const int V = (int)cams.size();
+    skip_ws(c);
+    if (c.p < c.end && *c.p == '}') return true;
+    std::string key;
+    while (c.p < c.end) {
+        skip_ws(c);
+        if (!read_string(c, &key)) { *err = "bad camera key"; return false; }
+        skip_ws(c);
+        if (c.p >= c.end || *c.p != ':') { *err = "missing ':' after camera"; return false; }
+        ++c.p;
+        int cam = -1;
+        for (int i = 0; i < V; ++i)
+            if (cams[i] == key) { cam = i; break; }
+        skip_ws(c);
+        if (cam < 0) {
+            if (!skip_value(c)) { *err = "bad value of unused camera"; return false; }
+        } else {
+            if (c.p >= c.end || *c.p != '[') { *err = "camera entry is not a list"; return false; }
+            ++c.p;
+            if ((int)out->size() >= V) { *unsupported = true; return true; }
+            skip_ws(c);
+            if (c.p >= c.end || *c.p != '"') { *unsupported = true; return true; }
+            const char *hit = g_find_quote(c.p + 1, c.end, c.p + 1);
+            if (!hit) { *err = "skeleton string not closed"; return false; }
+            out->push_back({cam, c.p + 1, hit});
+            c.p = hit + 1;
+            bool closed = false;
+            while (c.p < c.end) {
+                skip_ws(c);
+                if (c.p >= c.end) break;
+                if (*c.p == ',') { ++c.p; if (!skip_value(c)) { *err = "bad camera entry"; return false; } continue; }
+                if (*c.p == ']') { ++c.p; closed = true; break; }
+                *err = "bad camera entry";
+                return false;
+            }
+            if (!closed) { *err = "unterminated camera entry"; return false; }
+        }
+        skip_ws(c);
+        if (c.p >= c.end) break;
+        if (*c.p == ',') { ++c.p; continue; }
+        if (*c.p == '}') return true;
+        *err = "bad frame object";
+        return false;
+    }
+    *err = "unterminated frame";
+    return false;
+}
+
 // ---- byte searches of the frame scanner -------------------------------------------------------
 // scalar forms (any CPU) and AVX2 forms (32 bytes per step), chosen once at start-up
 static const char *find_special_scalar(const char *p, const char *e) {
@@ -547,6 +609,21 @@ struct FrameScanner {
     const char *start = nullptr;
     std::vector<std::pair<const char *, const char *>> ext;
     std::string err;
+    // speculative parallel scan (mpe_json_index): `stops` = the '{' bytes later scanners started from, each on the
+    // guess that it opens a frame.  Reached with depth 0 the guess was right and this scanner stops there (`met`);
+    // passed at any other depth it was wrong and this scanner simply goes on (that scanner's frames are dropped).
+    std::vector<const char *> stops;        // guessed frame openings of the later parts, ascending
+    size_t si = 0;
+    const char *met_at = nullptr;
+    bool met = false;
+
+    // a scanner that starts in the middle of the document, at a '{' guessed to open a frame
+    void begin_at(const char *b_, const char *frame_open, const char *e_) {
+        b = b_;
+        p = frame_open;
+        e = e_;
+        started = true;
+    }
 
     bool begin(const char *b_, const char *e_) {
         b = p = b_;
@@ -578,7 +655,15 @@ struct FrameScanner {
                 continue;
             }
             if (ch == '{' || ch == '[') {
-                if (depth == 0) start = p;
+                if (depth == 0) {
+                    while (si < stops.size() && stops[si] < p) ++si;          // guesses passed at another depth were wrong
+                    if (si < stops.size() && stops[si] == p) {               // the frame a later part starts with: handed over
+                        met = finished = true;
+                        met_at = p;
+                        break;
+                    }
+                    start = p;
+                }
                 ++depth;
             } else if (ch == '}' || ch == ']') {
                 if (depth == 0) {                       // end of the top-level list
@@ -626,20 +711,98 @@ struct mpe_json_index {
     std::vector<std::pair<const char *, const char *>> pub;   // published extents (guarded by mu)
     bool done = false, failed = false, stop = false;
     std::string err;
+    // Speculative parallel scan.  The serial scan (6-8 GB/s) was the ceiling of the JSON path once the second
+    // level moved to the device.  The document is cut at P - 1 guessed frame boundaries (the byte pattern that
+    // closes a camera entry and a frame and opens the next: `]]}, {"`, else `}, {"`); part k > 0 is scanned by its
+    // own thread from its guess as if it were at the top level.  The scanner of part k - 1 VERIFIES the guess when
+    // it gets there: arriving at that '{' between frames (depth 0) it stops and part k's frames follow; arriving
+    // at any other depth the guess was wrong (e.g. inside the ground-truth lists), part k's frames are dropped and
+    // the scanner goes on through part k's range.  The published sequence is therefore exactly the serial
+    // one; a bad guess only costs speed.
+    struct Part {
+        FrameScanner sc;
+        const char *open = nullptr;
+        std::thread th;
+        bool ok = true;
+    };
+    std::vector<std::unique_ptr<Part>> parts;
+    std::atomic<bool> abort_parts{false};
+
+    void plan_parts(const char *b, const char *e, int P) {
+        const size_t len = (size_t)(e - b);
+        if (P < 2 || len < ((size_t)4 << 20) || sc.single) return;
+        std::vector<const char *> opens;
+        for (int k = 1; k < P; ++k) {
+            const char *from = b + len / (size_t)P * (size_t)k;
+            const size_t reach = len / (size_t)P / 2;
+            const char *open = nullptr;
+            const char *hit = static_cast<const char *>(memmem(from, (size_t)(e - from), "]]}, {\"", 7));
+            if (hit && (size_t)(hit - from) < reach) open = hit + 5;
+            else {
+                hit = static_cast<const char *>(memmem(from, (size_t)(e - from), "}, {\"", 5));
+                if (hit && (size_t)(hit - from) < reach) open = hit + 3;
+            }
+            if (open && (opens.empty() || open > opens.back())) opens.push_back(open);
+        }
+        sc.stops = opens;
+        for (size_t k = 0; k < opens.size(); ++k) {
+            parts.emplace_back(new Part());
+            Part *pt = parts.back().get();
+            pt->open = opens[k];
+            pt->sc.begin_at(b, opens[k], e);
+            pt->sc.stops.assign(opens.begin() + (long)k + 1, opens.end());
+        }
+        for (auto &up : parts) {
+            Part *pt = up.get();
+            pt->th = std::thread([this, pt] {
+                while (!pt->sc.finished && !abort_parts.load()) {
+                    if (!pt->sc.extend(pt->sc.ext.size() + 256)) {       // malformed FROM THIS GUESS: decided by the verifier
+                        pt->ok = false;
+                        return;
+                    }
+                }
+            });
+        }
+    }
+
+    void publish(FrameScanner &from, size_t *sent) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (; *sent < from.ext.size(); ++*sent) pub.push_back(from.ext[*sent]);
+    }
 
     void run() {
+        FrameScanner *cur = &sc;
         size_t sent = 0;
         for (;;) {
-            const bool ok = sc.extend(sent + 64);
+            const bool ok = cur->extend(sent + 64);
+            publish(*cur, &sent);
+            bool all = !ok;
+            std::string e2 = ok ? std::string() : cur->err;
+            if (ok && cur->finished) {
+                all = true;
+                if (cur->met) {
+                    // reached a later part's guess between two frames: the guess was right, that part's frames follow
+                    for (auto &up : parts)
+                        if (up->open == cur->met_at) {
+                            if (up->th.joinable()) up->th.join();
+                            if (!up->ok) e2 = up->sc.err;              // malformed from a verified boundary on
+                            else {
+                                cur = &up->sc;
+                                sent = 0;
+                                all = false;
+                            }
+                            break;
+                        }
+                }
+            }
             bool quit;
             {
                 std::lock_guard<std::mutex> lk(mu);
-                for (; sent < sc.ext.size(); ++sent) pub.push_back(sc.ext[sent]);
-                if (!ok) {
+                if (!e2.empty()) {
                     failed = true;
-                    err = sc.err;
+                    err = e2;
                 }
-                if (!ok || sc.finished) done = true;
+                if (all) done = true;
                 quit = done || stop;
             }
             cv.notify_all();
@@ -663,7 +826,10 @@ struct mpe_json_index {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
         }
+        abort_parts = true;
         if (th.joinable()) th.join();
+        for (auto &pt : parts)
+            if (pt && pt->th.joinable()) pt->th.join();
     }
 };
 
@@ -935,6 +1101,16 @@ int mpe_json_index_create(const char *json, size_t len, mpe_json_index **out) {
         delete ix;
         return MPE_ERR_INVALID;
     }
+    {
+        // scan threads: MPE_SCAN_THREADS, else a quarter of the CPUs this process may use (the rest parse / stage)
+        int P = 1;
+        if (const char *ev = getenv("MPE_SCAN_THREADS")) P = atoi(ev);
+        else {
+            const int hw = default_threads();
+            P = hw >= 16 ? 4 : hw >= 6 ? 2 : 1;
+        }
+        ix->plan_parts(json, json + len, P);
+    }
     ix->th = std::thread([ix] { ix->run(); });
     *out = ix;
     return MPE_OK;
@@ -968,6 +1144,103 @@ int mpe_pack_indexed_into(mpe_json_index *ix, const char *const *camera_names, i
     *n_frames = (int32_t)fo.size();
     *n_heads = (int32_t)H;
     *n_edge_nodes = dst->frame_en_off[fo.size()];
+    return MPE_OK;
+}
+
+int mpe_json_stage_window(mpe_json_index *ix, const char *const *camera_names, int32_t n_cameras, int32_t frame_start,
+                          int32_t frame_step, int32_t max_frames, int32_t n_threads, char *text_dst, size_t text_cap,
+                          mpe_json_entry *entries, int32_t entry_cap, int32_t *frame_entry_off, int32_t *n_frames,
+                          int32_t *n_entries, size_t *text_bytes) {
+    if (!ix || !camera_names || n_cameras < 1 || n_cameras > MPE_MAX_CAMERAS || frame_start < 0 || frame_step < 1 || max_frames < 1 ||
+        !text_dst || !entries || !frame_entry_off || !n_frames || !n_entries || !text_bytes) {
+        g_pack_error = "mpe_json_stage_window: bad argument";
+        return MPE_ERR_INVALID;
+    }
+    std::vector<std::string> cams(camera_names, camera_names + n_cameras);
+    // the window's frame extents (the background scan publishes them in order)
+    std::vector<std::pair<const char *, const char *>> sel;
+    for (int i = 0; i < max_frames; ++i) {
+        std::pair<const char *, const char *> ext;
+        const int r = ix->get((size_t)frame_start + (size_t)i * frame_step, &ext);
+        if (r < 0) {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            g_pack_error = ix->err;
+            return MPE_ERR_INVALID;
+        }
+        if (r == 0) break;
+        sel.push_back(ext);
+    }
+    const int B = (int)sel.size();
+    std::vector<std::vector<StrExtent>> per((size_t)B);
+    std::vector<std::string> errs((size_t)B);
+    std::atomic<int> next{0};
+    std::atomic<bool> failed{false}, unsupported{false};
+    int nt = n_threads > 0 ? n_threads : default_threads();
+    if (nt > B) nt = B > 0 ? B : 1;
+    auto run = [&](auto &&body) {
+        next = 0;
+        auto work = [&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= B) return;
+                body(i);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    };
+    run([&](int i) {
+        bool un = false;
+        per[(size_t)i].reserve((size_t)n_cameras);
+        if (!index_frame(sel[(size_t)i].first, sel[(size_t)i].second, cams, &per[(size_t)i], &errs[(size_t)i], &un)) failed = true;
+        if (un) unsupported = true;
+    });
+    if (failed) {
+        for (int i = 0; i < B; ++i)
+            if (!errs[(size_t)i].empty()) {
+                g_pack_error = "frame " + std::to_string(frame_start + i * frame_step) + ": " + errs[(size_t)i];
+                break;
+            }
+        return MPE_ERR_INVALID;
+    }
+    if (unsupported) {
+        g_pack_error = "mpe_json_stage_window: a frame needs the host parser (skeleton list not a string, or more camera entries than cameras)";
+        return MPE_ERR_UNSUPPORTED;
+    }
+    // text offsets (16-byte aligned strings), entry table
+    size_t off = 0;
+    int ne = 0;
+    std::vector<size_t> first_off((size_t)B);
+    for (int i = 0; i < B; ++i) {
+        frame_entry_off[i] = ne;
+        first_off[(size_t)i] = off;
+        for (const StrExtent &x : per[(size_t)i]) {
+            const size_t len = (size_t)(x.e - x.b);
+            if (ne >= entry_cap || off + len > text_cap || off + len > 0xFFFFFFF0u) {
+                g_pack_error = "mpe_json_stage_window: staging buffers too small";
+                return MPE_ERR_CAPACITY;
+            }
+            entries[ne].frame = i;
+            entries[ne].cam = x.cam;
+            entries[ne].begin = (uint32_t)off;
+            entries[ne].end = (uint32_t)(off + len);
+            ++ne;
+            off = (off + len + 15) & ~(size_t)15;
+        }
+    }
+    frame_entry_off[B] = ne;
+    run([&](int i) {
+        int k = frame_entry_off[i];
+        for (const StrExtent &x : per[(size_t)i]) {
+            memcpy(text_dst + entries[k].begin, x.b, (size_t)(x.e - x.b));
+            ++k;
+        }
+    });
+    *n_frames = B;
+    *n_entries = ne;
+    *text_bytes = off;
     return MPE_OK;
 }
 

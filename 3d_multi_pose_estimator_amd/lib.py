@@ -14,6 +14,7 @@ if os.environ.get('MPE_LIB_VARIANT'):      # diagnostics: an experiment build be
 
 MPE_MAX_CAMERAS = 32
 MPE_MAX_JOINTS = 32
+MPE_ERR_UNSUPPORTED = -6
 
 c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)
@@ -114,6 +115,12 @@ SYMBOLS = {
     'mpe_pack_indexed_into': (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.POINTER(mpe_pack_dst), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'mpe_json_stage_window': (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
+    'mpe_json_scratch_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'mpe_json_parse_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p]),
     'mpe_packed_free': (None, [C.c_void_p]),
     'mpe_pack_last_error': (C.c_char_p, []),
     'mpe_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),

@@ -152,6 +152,98 @@ class JsonIndex:
         self.close()
 
 
+class JsonStage:
+    """Staging buffer of the device-side parse (mpe_json_stage_window -> mpe_json_parse_device): the frame
+    -> entry table, the entry table and the skeleton strings of one window in ONE buffer, small fixed
+    parts first, so that a window travels host -> device as one copy of the used prefix.  `where` =
+    'pinned', 'host' or a device."""
+
+    ENTRY_BYTES = 16
+
+    def __init__(self, V, max_frames, text_cap, where):
+        import torch
+        self.V, self.max_frames, self.text_cap = V, int(max_frames), int(text_cap)
+        self.entry_cap = self.max_frames * V
+        self.off_feo = 0
+        self.off_entries = ((self.max_frames + 1) * 4 + 255) // 256 * 256
+        self.off_text = self.off_entries + (self.entry_cap * self.ENTRY_BYTES + 255) // 256 * 256
+        self.nbytes = self.off_text + self.text_cap
+        if where == 'pinned':
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8).pin_memory()
+        elif where == 'host':
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8)
+        else:
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=where)
+
+    def ptr(self, what):
+        return self.buf.data_ptr() + {'frame_entry_off': self.off_feo, 'entries': self.off_entries, 'text': self.off_text}[what]
+
+
+class NeedsHostParser(ValueError):
+    """The window holds a shape the device-side parser leaves to the host packer."""
+
+
+def stage_json_window(index, params, stage, frame_start=0, frame_step=1, max_frames=0, n_threads=0):
+    """First level of the wire format on the host (mpe_json_stage_window): -> (n_frames, n_entries,
+    bytes of the staging buffer in use).  Raises NeedsHostParser for shapes only the host packer handles."""
+    import ctypes as C
+
+    from . import lib as L
+    lib = L.load()
+    sm = list(params.used_cameras_skeleton_matching)
+    V = len(sm)
+    assert stage.V == V
+    names = (C.c_char_p * V)(*[c.encode() for c in sm])
+    nf, ne, tb = C.c_int32(), C.c_int32(), C.c_size_t()
+    mf = stage.max_frames if max_frames <= 0 or max_frames > stage.max_frames else max_frames
+    rc = lib.mpe_json_stage_window(index.handle, names, V, frame_start, frame_step, mf, n_threads,
+                                   C.c_void_p(stage.ptr('text')), stage.text_cap, C.c_void_p(stage.ptr('entries')), stage.entry_cap,
+                                   C.c_void_p(stage.ptr('frame_entry_off')), C.byref(nf), C.byref(ne), C.byref(tb))
+    if rc == L.MPE_ERR_UNSUPPORTED:
+        raise NeedsHostParser(lib.mpe_pack_last_error().decode())
+    if rc != 0:
+        raise ValueError('mpe_json_stage_window: %s' % lib.mpe_pack_last_error().decode())
+    return nf.value, ne.value, stage.off_text + tb.value
+
+
+class ParsedOnDevice:
+    """A batch whose arrays exist on the device only (device-side parse): what Engine.match / mlp3d /
+    triangulate need of a DeviceBatch.  `download()` brings the arrays back as a PackedBatch (tests)."""
+
+    def __init__(self, arena, V, J, n_frames, n_heads, n_edge_nodes, max_heads_in_a_frame):
+        import ctypes as C
+
+        from . import lib as L
+        self.arena, self.V, self.J = arena, V, J
+        self.n_frames, self.n_heads, self.n_edge_nodes = int(n_frames), int(n_heads), int(n_edge_nodes)
+        self._max_heads = int(max_heads_in_a_frame)
+        self.host = None
+        s = L.mpe_batch()
+        s.n_frames, s.n_heads, s.n_edge_nodes = self.n_frames, self.n_heads, self.n_edge_nodes
+        for name, _ in ARRAYS:
+            setattr(s, 'd_' + name, C.c_void_p(arena.ptr(name)))
+        self.struct = s
+
+    def max_heads_per_frame(self):
+        return self._max_heads
+
+    def download(self):
+        raw = self.arena.buf.cpu().numpy()
+        B, H, V, J = self.n_frames, self.n_heads, self.V, self.J
+
+        def arr(name, n):
+            off, _, dt = self.arena.offsets[name]
+            return raw[off: off + n * np.dtype(dt).itemsize].view(dt).copy()
+        pb = PackedBatch(V, J)
+        pb.n_frames = B
+        pb.frame_head_off, pb.frame_en_off = arr('frame_head_off', B + 1), arr('frame_en_off', B + 1)
+        pb.slot_cam, pb.slot_n = arr('slot_cam', B * V).reshape(B, V), arr('slot_n', B * V).reshape(B, V)
+        pb.head_cam, pb.skeleton_index = arr('head_cam', H), arr('skeleton_index', H)
+        pb.joint_mask, pb.tri_mask = arr('joint_mask', H), arr('tri_mask', H)
+        pb.xy, pb.vp = arr('xy', H * J * 2).reshape(H, J, 2), arr('vp', H * J * 2).reshape(H, J, 2)
+        return pb
+
+
 def pack_json_into(text, params, arena, frame_start=0, frame_step=1, max_frames=0, n_threads=0):
     """Native packer straight into a host CapacityArena (page-locked for the production path):
     returns a PackedBatch whose arrays are VIEWS of the arena (valid until the arena is packed into

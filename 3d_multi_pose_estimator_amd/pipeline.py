@@ -11,7 +11,8 @@ import torch
 
 from . import lib as L
 from .calibration import Calibration
-from .packing import CapacityArena, DeviceBatch, JsonIndex, PackedBatch, pack_frames, pack_json, pack_json_into
+from .packing import (CapacityArena, DeviceBatch, JsonIndex, JsonStage, NeedsHostParser, PackedBatch, ParsedOnDevice, pack_frames,
+                      pack_json, pack_json_into, stage_json_window)
 
 
 def _f32p(a):
@@ -130,7 +131,7 @@ class Engine:
         """Native (C++) packer: JSON text of a list of frames -> PackedBatch."""
         return pack_json(text, self.params, frame_start, frame_step, max_frames, n_threads)
 
-    def stream_json(self, text, chunk_frames=None, mode='mlp', frame_step=1, n_threads=0):
+    def stream_json(self, text, chunk_frames=None, mode='mlp', frame_step=1, n_threads=0, parser='device'):
         """Frame JSON (bytes, the reference's wire format) -> 3D poses, chunk by chunk, with the
         host side off the critical path: the native packer parses chunk i+1 straight into a
         page-locked arena (worker thread; the C call releases the GIL) while chunk i is copied to
@@ -138,13 +139,23 @@ class Engine:
         page-locked memory.  Yields (PackedBatch view, poses [B,Pcap,J,3], n_persons [B]) per chunk.
         LIFETIME: the yielded view and arrays are valid until the next `next()` on the generator only --
         resuming it starts the parse of a later chunk into the arena behind the view (two host arenas)
-        and the result arrays of the slot are rewritten one chunk after that.  Copy what you keep."""
+        and the result arrays of the slot are rewritten one chunk after that.  Copy what you keep.
+
+        parser = 'device' (default): the host keeps the first level of the format only (frame extents, camera
+        keys, the extent of every skeleton STRING: stage_json_window) and the strings are parsed ON THE DEVICE
+        (csrc/jsonparse.hip) on a side stream while the previous chunk computes; the first element yielded is
+        then a ParsedOnDevice (n_frames, n_heads, ...; `.download()` for the arrays).  A chunk holding a shape
+        the device parser leaves to the host (literals, nested values, numbers beyond the exact fast path)
+        is packed by the host packer instead -- same arrays either way.  parser = 'host': the round-2 path."""
         from concurrent.futures import ThreadPoolExecutor
         if isinstance(text, str):
             text = text.encode()
         B = int(chunk_frames or self.max_frames)
         if B > self.max_frames:
             raise ValueError('chunk of %d frames exceeds max_frames=%d' % (B, self.max_frames))
+        if parser == 'device':
+            yield from self._stream_json_device(text, B, mode, frame_step, n_threads)
+            return
         H = B * self.hpf
         host = [CapacityArena(self.V, self.J, B, H, 'pinned') for _ in range(2)]
         dev = [CapacityArena(self.V, self.J, B, H, self.device) for _ in range(2)]
@@ -200,6 +211,251 @@ class Engine:
         finally:
             pool.shutdown(wait=True)
             index.close()
+
+    def _stream_json_device(self, text, B, mode, frame_step, n_threads):
+        from concurrent.futures import ThreadPoolExecutor
+        H = B * self.hpf
+        # page-locked staging and the device arenas are kept with the engine: allocating and pinning ~150 MB per call
+        # cost more than parsing a few windows
+        cache = self.__dict__.setdefault('_json_bufs', {})
+        if B not in cache:
+            cache[B] = ([self.json_device_buffers(B) for _ in range(2)], {})
+        bufs, fb = cache[B]                                 # fb: host-packer fallback buffers, made on first use
+        out_dt = torch.float32 if mode == 'mlp' else torch.float64
+        out = [(torch.empty((B, self.pcap, self.J, 3), dtype=out_dt).pin_memory(),
+                torch.empty((B,), dtype=torch.int32).pin_memory()) for _ in range(2)]
+        done = [None, None]
+        cur = torch.cuda.current_stream(self.device)
+        # high priority: the few small parse kernels must not queue behind every large GEMM launch of the chunk that is computing
+        s_parse = torch.cuda.Stream(self.device, priority=-1)
+        s_m, s_d = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+        pool = ThreadPoolExecutor(1)
+        index = JsonIndex(text)
+
+        def stage(i):
+            try:
+                return stage_json_window(index, self.params, bufs[i & 1]['host'], frame_start=i * B * frame_step, frame_step=frame_step,
+                                         max_frames=B, n_threads=n_threads)
+            except NeedsHostParser:
+                return None
+            except ValueError as e:
+                if 'too small' in str(e):                    # an unusually long window: let the host packer size it
+                    return None
+                raise
+
+        def host_pack(i, k):
+            if not fb:
+                fb['host'] = CapacityArena(self.V, self.J, B, H, 'pinned')
+                fb['dev'] = [CapacityArena(self.V, self.J, B, H, self.device) for _ in range(2)]
+                fb['db'] = [None, None]
+            pb = pack_json_into(index, self.params, fb['host'], frame_start=i * B * frame_step, frame_step=frame_step, max_frames=B,
+                                n_threads=n_threads)
+            if pb.n_frames == 0:
+                return None
+            self.check_capacity(pb)
+            import copy
+            keep = copy.copy(pb)
+            for name in ('frame_head_off', 'frame_en_off', 'slot_cam', 'slot_n', 'head_cam', 'skeleton_index', 'joint_mask', 'tri_mask', 'xy', 'vp'):
+                setattr(keep, name, np.array(getattr(pb, name)))      # the one host arena is reused by the next fallback
+            if fb['db'][k] is None:
+                fb['db'][k] = DeviceBatch(keep, self.device, arena=fb['dev'][k])
+            db = fb['db'][k].rebind(keep)
+            fb['dev'][k].buf.copy_(fb['host'].buf, non_blocking=True)
+            cur.synchronize()                                  # the pinned arena is free again (rare path)
+            return db
+        import os
+        import time
+        timing = [] if os.environ.get('MPE_JSON_TIMING') else None
+        gpu_ev = []
+        # Copy engines serve their requests in order: a D2H of results queued behind the kernels of chunk i-1 would hold up
+        # the H2D of chunk i's strings until those kernels are done (measured: 6.4 ms instead of 0.57 ms).  So the results of
+        # chunk i-1 are copied out only AFTER the upload of chunk i has been queued.
+        res = [None, None]                                   # (poses, n_persons, n) of the slot, still on the device
+
+        def copy_out(k):
+            if res[k] is None:
+                return
+            poses_, n_persons_, n_ = res[k]
+            with torch.cuda.stream(s_d):                   # behind the 3D stage that produced them
+                out[k][0][:n_].copy_(poses_, non_blocking=True)
+                out[k][1][:n_].copy_(n_persons_, non_blocking=True)
+                done[k] = torch.cuda.Event()
+                done[k].record()
+            res[k] = None
+        try:
+            fut = pool.submit(stage, 0)
+            i = 0
+            pending = None
+            while True:
+                t_a = time.perf_counter()
+                st = fut.result()
+                t_b = time.perf_counter()
+                k = i & 1
+                db = None
+                if st is not None:
+                    nf, ne, used = st
+                    if nf == 0:
+                        break
+                    with torch.cuda.stream(s_parse):
+                        if done[k] is not None:
+                            s_parse.wait_event(done[k])          # the arena of this slot: chunk i-2 has computed
+                        if timing is not None:
+                            ev_p0 = torch.cuda.Event(enable_timing=True)
+                            ev_p0.record()
+                            bufs[k]['ev_h2d'] = torch.cuda.Event(enable_timing=True)
+                        self.parse_json_device(bufs[k], nf, ne, used)
+                        if timing is not None:
+                            ev_p1 = torch.cuda.Event(enable_timing=True)
+                            ev_p1.record()
+                    copy_out(k ^ 1)                          # results of chunk i-1, behind this chunk's upload in the copy queue
+                    # the other staging buffer is free (its copy finished when chunk i-1's totals arrived)
+                    nxt = pool.submit(stage, i + 1) if nf == B else None
+                    t_c = time.perf_counter()
+                    db = self.finish_parse(bufs[k])
+                    t_d = time.perf_counter()
+                    if db is not None:
+                        if db.max_heads_per_frame() > self.hpf:
+                            raise ValueError('a frame holds %d skeletons, capacity is %d (raise max_persons_per_camera / '
+                                             'max_heads_per_frame)' % (db.max_heads_per_frame(), self.hpf))
+                        s_m.wait_event(bufs[k]['ready'])
+                else:
+                    nxt = None
+                if db is None:                                  # this window goes through the host packer
+                    copy_out(k ^ 1)
+                    if done[k] is not None:
+                        done[k].synchronize()
+                    db = host_pack(i, k)
+                    if db is None:
+                        break
+                    if nxt is None and db.n_frames == B:
+                        nxt = pool.submit(stage, i + 1)
+                n_here = db.n_frames
+                if timing is not None:
+                    ev_c0 = torch.cuda.Event(enable_timing=True)
+                    ev_c0.record()
+                # engine mode as in run_pipelined: the matching stage and the 3D stage on their own streams, so the matching
+                # of this chunk overlaps the 3D stage of the previous one
+                if db.host is not None:
+                    s_m.wait_stream(cur)                     # host-packed window: its upload went over the caller's stream
+                with torch.cuda.stream(s_m):
+                    _, persons, n_persons = self.match(db, want_scores=False)
+                    ev_m = torch.cuda.Event()
+                    ev_m.record()
+                with torch.cuda.stream(s_d):
+                    s_d.wait_event(ev_m)
+                    poses = (self.mlp3d(db, persons, n_persons) if mode == 'mlp' else self.triangulate(db, persons, n_persons))[0]
+                for t_ in (persons, n_persons):
+                    t_.record_stream(s_d)
+                res[k] = (poses, n_persons, n_here)
+                done[k] = None
+                if timing is not None and st is not None:
+                    ev_c1 = torch.cuda.Event(enable_timing=True)
+                    ev_c1.record()
+                    gpu_ev.append((ev_p0, ev_p1, ev_c0, ev_c1, bufs[k]['ev_h2d']))
+                t_e = time.perf_counter()
+                if pending is not None:
+                    pk, pinfo, pn = pending
+                    copy_out(pk)
+                    done[pk].synchronize()
+                    if timing is not None and st is not None:
+                        timing.append((t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, time.perf_counter() - t_e))
+                    yield pinfo, out[pk][0][:pn].numpy(), out[pk][1][:pn].numpy()
+                pending = (k, db if db.host is None else db.host, n_here)
+                if nxt is None:
+                    break
+                fut = nxt
+                i += 1
+            if pending is not None:
+                pk, pinfo, pn = pending
+                copy_out(pk)
+                done[pk].synchronize()
+                yield pinfo, out[pk][0][:pn].numpy(), out[pk][1][:pn].numpy()
+        finally:
+            pool.shutdown(wait=True)
+            for s_ in (s_parse, s_m, s_d):
+                cur.wait_stream(s_)
+            torch.cuda.synchronize(self.device)
+            index.close()
+            if timing and len(timing) > 2:
+                import sys
+                m = np.array(timing[1:]).mean(axis=0) * 1e3
+                print('stream_json(device) per window, ms: wait staging %.2f | queue parse %.2f | wait parse %.2f | launch compute %.2f | '
+                      'wait previous results %.2f' % tuple(m), file=sys.stderr)
+                base = gpu_ev[2][0]
+                for w in range(2, min(7, len(gpu_ev))):
+                    p0, p1, c0, c1, h = gpu_ev[w]
+                    print('  window %d on the GPU clock, ms: H2D %.2f .. %.2f, parse kernels .. %.2f | compute %.2f .. %.2f'
+                          % (w, base.elapsed_time(p0), base.elapsed_time(h), base.elapsed_time(p1), base.elapsed_time(c0), base.elapsed_time(c1)), file=sys.stderr)
+
+    # ---- device-side parse -----------------------------------------------
+    def json_device_buffers(self, max_frames, text_cap=None):
+        """Buffers of one in-flight window of the device-side parse: pinned + device staging, the device
+        arena the arrays are parsed into, scratch and the totals (device + pinned mirror)."""
+        B = int(max_frames)
+        H = B * self.hpf
+        if text_cap is None:
+            text_cap = B * self.V * (64 + 96 * self.J * max(1, self.hpf // self.V) * 2)      # ~2x a full camera string
+        text_cap = (int(text_cap) + 255) // 256 * 256
+        return {'host': JsonStage(self.V, B, text_cap, 'pinned'), 'dev': JsonStage(self.V, B, text_cap, self.device),
+                'arena': CapacityArena(self.V, self.J, B, H, self.device),
+                'kcap': self.hpf,
+                'scratch': torch.empty(int(self.lib.mpe_json_scratch_bytes(B * self.V, self.hpf, self.J)), dtype=torch.uint8, device=self.device),
+                'totals': torch.zeros(4, dtype=torch.int32, device=self.device),
+                'totals_host': torch.zeros(4, dtype=torch.int32).pin_memory(), 'ready': torch.cuda.Event()}
+
+    def parse_json_device(self, bufs, n_frames, n_entries, used_bytes):
+        """Queue (current stream): staging H2D (one copy of the used prefix) -> mpe_json_parse_device -> totals
+        D2H into pinned memory; records bufs['ready'].  `finish_parse` turns the totals into a batch."""
+        bufs['dev'].buf[:used_bytes].copy_(bufs['host'].buf[:used_bytes], non_blocking=True)
+        if bufs.get('ev_h2d') is not None:
+            bufs['ev_h2d'].record()
+        arena = bufs['arena']
+        out = L.mpe_batch()
+        for name in ('frame_head_off', 'frame_en_off', 'slot_cam', 'slot_n', 'head_cam', 'joint_mask', 'tri_mask', 'xy', 'vp'):
+            setattr(out, 'd_' + name, C.c_void_p(arena.ptr(name)))
+        dev = bufs['dev']
+        self._chk(self.lib.mpe_json_parse_device(self.ctx, self._stream(), C.c_void_p(dev.ptr('text')), C.c_void_p(dev.ptr('entries')),
+                                                 C.c_void_p(dev.ptr('frame_entry_off')), n_entries, n_frames, arena.max_heads,
+                                                 bufs['kcap'], _ptr(bufs['scratch']), bufs['scratch'].numel(), C.byref(out),
+                                                 C.c_void_p(arena.ptr('skeleton_index')), _ptr(bufs['totals'])))
+        bufs['totals_host'].copy_(bufs['totals'], non_blocking=True)
+        bufs['ready'].record()
+        bufs['n_frames'] = n_frames
+
+    def finish_parse(self, bufs):
+        """Wait for the parse of `bufs` and return the batch (ParsedOnDevice), or None if the window holds
+        something the device parser leaves to the host packer (status bit 0) -- the caller then packs it
+        on the host.  More heads than the arena holds raises like the host packer does."""
+        bufs['ready'].synchronize()
+        n_heads, n_en, status, max_h = (int(x) for x in bufs['totals_host'].tolist())
+        if status & 2:
+            raise ValueError('device-side parse: %d skeletons exceed the arena capacity %d' % (n_heads, bufs['arena'].max_heads))
+        if status & 1:
+            return None
+        return ParsedOnDevice(bufs['arena'], self.V, self.J, bufs['n_frames'], n_heads, n_en, max_h)
+
+    def pack_json_device(self, text, frame_start=0, frame_step=1, max_frames=0, n_threads=0):
+        """One window of a document through the device-side parser (tests, one-off calls): JSON bytes ->
+        ParsedOnDevice, or None where the host packer has to take over."""
+        index = text if isinstance(text, JsonIndex) else JsonIndex(text)
+        try:
+            B = int(max_frames) if max_frames > 0 else self.max_frames
+            if B > self.max_frames:
+                raise ValueError('window of %d frames exceeds max_frames=%d' % (B, self.max_frames))
+            size = len(index.text)
+            bufs = self.json_device_buffers(B, text_cap=size + 16 * B * self.V + 256)
+            try:
+                nf, ne, used = stage_json_window(index, self.params, bufs['host'], frame_start, frame_step, B, n_threads)
+            except NeedsHostParser:
+                return None
+            self.parse_json_device(bufs, nf, ne, used)
+            pd = self.finish_parse(bufs)
+            if pd is not None:
+                pd.keep = bufs
+            return pd
+        finally:
+            if index is not text:
+                index.close()
 
     def run_pipelined(self, batches, mode='mlp'):
         """Batches (DeviceBatch or PackedBatch) -> (poses, n_persons, persons) per batch, in order, with

@@ -90,7 +90,7 @@ def parse_args(argv=None):
     ap.add_argument('--profile-steps', type=int, default=24,
                     help='single-stream steps after the timed region with HIP event pairs around the GEMM launches '
                          '(kernel-level roofline); 0 = skip')
-    ap.add_argument('--json-steps', type=int, default=8,
+    ap.add_argument('--json-steps', type=int, default=24,
                     help='batches of the json_inclusive region (wire-format JSON bytes -> poses in pinned host memory); 0 = skip')
     ap.add_argument('--no-io', action='store_true', help='skip the second (pinned host -> poses in pinned host) timed region')
     ap.add_argument('--no-profile', action='store_true', help='no per-GEMM HIP events (roofline comes out null)')
@@ -538,8 +538,10 @@ def json_inclusive(args, torch, eng, wire, B, uniq):
     """SURVEY.md §8 f1 as a timed region: the reference's wire format -- one JSON document, a list of frames, per
     camera [json string of the skeleton list, timestamp, 'no_image', bodies_3D]
     (panoptic_conversor/get_joints_from_panoptic_model_multi.py:231-236,287) -- as BYTES in host memory ->
-    Engine.stream_json (native packer into a page-locked arena, one H2D copy per batch, match + 3D stage, D2H of the
-    poses into pinned memory; the parse of batch i+1 overlaps the device work of batch i)."""
+    Engine.stream_json: the host walks the first level only (frame extents by a parallel scan, camera keys, the extent of
+    every skeleton string) and copies the strings into a page-locked buffer; one H2D copy per batch; the second level is
+    parsed ON THE DEVICE (csrc/jsonparse.hip) on a side stream while the previous batch computes; match + 3D stage; D2H of
+    the poses into pinned memory."""
     n_steps = args.json_steps
     one = [wire[i % uniq] for i in range(B)]
     body = json.dumps(one)[1:-1]
@@ -559,8 +561,10 @@ def json_inclusive(args, torch, eng, wire, B, uniq):
         threads = os.cpu_count()
     return {'value': got / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / n_steps, 'steps': n_steps,
             'json_bytes_per_step': len(text) // n_steps, 'json_gb_per_s': len(text) / dt / 1e9, 'host_threads_available': threads,
-            'what': 'wire-format frame JSON bytes in host memory -> native packer (page-locked arena) -> H2D -> match + 3D stage '
-                    '-> D2H of poses into pinned host memory; parse of batch i+1 overlapped with the device work of batch i'}
+            'parser': 'device (csrc/jsonparse.hip); host: frame extents + string extents only',
+            'what': 'wire-format frame JSON bytes in host memory -> first level on the host (parallel frame scan, skeleton strings '
+                    'copied to a page-locked buffer) -> H2D -> second level parsed on the device -> match + 3D stage -> D2H of '
+                    'poses into pinned host memory; batch i+1 is parsed while batch i computes'}
 
 
 def pmc_traffic():

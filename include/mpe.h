@@ -41,7 +41,8 @@ typedef enum {
     MPE_ERR_CAPACITY = -2,      /* batch exceeds the capacity given to mpe_create     */
     MPE_ERR_STATE = -3,         /* weights not uploaded yet                           */
     MPE_ERR_HIP = -4,           /* a HIP runtime call failed                          */
-    MPE_ERR_NOMEM = -5
+    MPE_ERR_NOMEM = -5,
+    MPE_ERR_UNSUPPORTED = -6    /* input the device-side parser leaves to the host parser */
 } mpe_status;
 
 typedef struct mpe_ctx mpe_ctx;
@@ -278,6 +279,35 @@ int mpe_pack_indexed_into(mpe_json_index *ix, const char *const *camera_names, i
                           const mpe_pack_dst *dst, int32_t *n_frames, int32_t *n_heads, int32_t *n_edge_nodes);
 void mpe_packed_free(mpe_packed *pk);
 const char *mpe_pack_last_error(void);
+
+/* ---- device-side second-level parse (csrc/jsonparse.hip) -----------------------------
+ * The host keeps the first level of the wire format only: mpe_json_stage_window walks the frames of a window
+ * (extents from the index) down to the camera entries, records for every configured camera the extent of the
+ * STRING that holds its skeleton list (frame dict key order: graph_generator.py:583-601) and copies those
+ * strings, 16-byte aligned, into `text_dst` -- one page-locked buffer that travels to the device in one copy.
+ * mpe_json_parse_device parses the strings there into the arrays of `out` (device pointers; capacities as for
+ * mpe_pack_dst) and `d_skeleton_index`, replacing json.loads per camera + load_people_view_graph
+ * (graph_generator.py:573-605) like the host packer, whose arrays it reproduces bit for bit.
+ *   skeletons_per_string_cap  rows of the staging arena per string (a string with more skeleton objects goes to the host)
+ *   d_scratch  mpe_json_scratch_bytes(n_entries, skeletons_per_string_cap, n_joints) bytes of device memory
+ *   d_totals   [4]: n_heads, n_edge_nodes, status (0 ok, bit 0: a string needs the host parser, bit 1: more
+ *              heads than head_cap), largest number of heads in a frame
+ * MPE_ERR_UNSUPPORTED from the staging call and a non-zero status both mean: pack this window with
+ * mpe_pack_indexed_into (the host parser defines the accepted language and the error messages). */
+typedef struct {
+    int32_t frame, cam;            /* frame of the window, camera index (position in camera_names) */
+    uint32_t begin, end;           /* the string's body in the staged text                         */
+} mpe_json_entry;
+int mpe_json_stage_window(mpe_json_index *ix, const char *const *camera_names, int32_t n_cameras, int32_t frame_start,
+                          int32_t frame_step, int32_t max_frames, int32_t n_threads, char *text_dst, size_t text_cap,
+                          mpe_json_entry *entries, int32_t entry_cap, int32_t *frame_entry_off, int32_t *n_frames,
+                          int32_t *n_entries, size_t *text_bytes);
+size_t mpe_json_scratch_bytes(int32_t n_entries_cap, int32_t skeletons_per_string_cap, int32_t n_joints);
+int mpe_json_parse_device(mpe_ctx *ctx, void *stream, const char *d_text, const mpe_json_entry *d_entries,
+                          const int32_t *d_frame_entry_off, int32_t n_entries, int32_t n_frames, int32_t head_cap,
+                          int32_t skeletons_per_string_cap, void *d_scratch, size_t scratch_bytes, const mpe_batch *out,
+                          int32_t *d_skeleton_index, int32_t *d_totals);
+
 
 /* Timing probe for bench.py: average duration (ms) of the dominant GEMM launches measured
  * with HIP events on the launch stream during the last mpe_match_batch / mpe_mlp3d_batch

@@ -412,6 +412,74 @@ def test_json_index_windows_equal_one_shot(calib):
     packing.JsonIndex(text).close()
 
 
+def test_parallel_frame_scan_equals_serial_scan(calib, monkeypatch):
+    """mpe_json_index cuts a large document at guessed frame boundaries and scans the parts concurrently; every
+    guess is verified by the scanner that reaches it.  Right guesses, WRONG guesses (the boundary pattern inside
+    nested ground-truth lists, i.e. at another depth) and a document damaged behind a verified boundary must all
+    give exactly what the serial scan gives."""
+    import json
+    packing = pkg('packing')
+    if not os.path.exists(pkg('lib').LIB_PATH):
+        pytest.skip('library not built')
+    _, frames = load_case('c2_5x4_messy')
+    base = []
+    for i in range(260):
+        f = json.loads(json.dumps(frames[i % len(frames)]))
+        for cam in f:
+            # ground truth with the frame-boundary byte pattern "]]}, {" at depth 3
+            f[cam] = [f[cam][0], float(i), 'no_image', [{'0': [[i, 1.5]]}, {'1': [[2.5, i]]}, {'-1': [[0, 0]]}] * 6]
+        base.append(f)
+    text = json.dumps(base * 8).encode()
+    assert len(text) > (5 << 20) and b']]}, {"' in text
+    V, J = len(calib.params.used_cameras_skeleton_matching), len(calib.params.joint_list)
+
+    def windows(threads, doc):
+        monkeypatch.setenv('MPE_SCAN_THREADS', str(threads))
+        ix = packing.JsonIndex(doc)
+        try:
+            out = []
+            arena = packing.CapacityArena(V, J, 500, 500 * 40, 'host')
+            start = 0
+            while True:
+                pb = packing.pack_json_into(ix, calib.params, arena, frame_start=start, max_frames=500)
+                if pb.n_frames == 0:
+                    break
+                out.append((pb.n_frames, pb.frame_head_off.copy(), pb.xy.copy(), pb.slot_cam.copy()))
+                start += pb.n_frames
+                if pb.n_frames < 500:
+                    break
+            return out
+        finally:
+            ix.close()
+    ref = windows(1, text)
+    assert sum(w[0] for w in ref) == len(base) * 8
+    for threads in (2, 4, 7):
+        got = windows(threads, text)
+        assert len(got) == len(ref)
+        for a, b in zip(ref, got):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    # a document cut off in its last eighth: the windows in front of the damage are served, the one that reaches it
+    # fails -- with the same number of windows served as under the serial scan
+    cut = text[:len(text) - len(text) // 8]
+    served = []
+    for threads in (1, 4):
+        monkeypatch.setenv('MPE_SCAN_THREADS', str(threads))
+        ix = packing.JsonIndex(cut)
+        try:
+            arena = packing.CapacityArena(V, J, 500, 500 * 40, 'host')
+            n_ok, start = 0, 0
+            with pytest.raises(ValueError):
+                while True:
+                    pb = packing.pack_json_into(ix, calib.params, arena, frame_start=start, max_frames=500)
+                    assert pb.n_frames == 500
+                    n_ok += 1
+                    start += 500
+            served.append(n_ok)
+        finally:
+            ix.close()
+    assert served[0] == served[1] >= 2
+
+
 def test_frame_scanner_fuzz_simd_and_scalar():
     """The frame scanner's byte searches (AVX2 where the CPU has it, scalar otherwise) on random
     documents with escaped quotes, backslash runs and brackets inside strings: all frames found,

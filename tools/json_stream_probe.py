@@ -1,0 +1,27 @@
+"""Engine.stream_json alone in a fresh process (few streams alive): frames/s and, with MPE_JSON_TIMING=1, the per-window
+timeline.  python tools/json_stream_probe.py [frames] [chunk] [parser]"""
+import importlib, json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = '3d_multi_pose_estimator_amd'
+syn = importlib.import_module(PKG + '.synthetic'); cal = importlib.import_module(PKG + '.calibration')
+par = importlib.import_module(PKG + '.parameters'); pipeline = importlib.import_module(PKG + '.pipeline')
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16000
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+parser = sys.argv[3] if len(sys.argv) > 3 else 'device'
+calib = cal.Calibration(par.parameters)
+uniq = [syn.make_frame(calib, i, syn.FrameSpec(persons=4))[0] for i in range(200)]
+body = json.dumps([uniq[i % 200] for i in range(chunk)])[1:-1]
+text = ('[' + ','.join([body] * (n // chunk)) + ']').encode()
+warm = ('[' + ','.join([body] * 2) + ']').encode()
+eng = pipeline.Engine(par.parameters, calib, max_frames=chunk, max_persons_per_camera=4)
+eng.load_gat(syn.gat_state_dict(7, 902, logit_gain=25.0, logit_shift=0.948), syn.gat_params(902))
+eng.load_mlp(syn.mlp_state_dict(11, 1260))
+sum(len(nn) for _, _, nn in eng.stream_json(warm, chunk_frames=chunk, parser=parser))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+got = sum(len(nn) for _, _, nn in eng.stream_json(text, chunk_frames=chunk, parser=parser))
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print('%s parser: %d frames, %.1f frames/s, %.2f ms per %d-frame window, %.2f GB/s of JSON' % (parser, got, got / dt, 1e3 * dt / (n // chunk), chunk, len(text) / dt / 1e9))
