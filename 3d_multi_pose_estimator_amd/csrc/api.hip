@@ -140,7 +140,7 @@ struct GemmProf {
 int linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, const Linear &L, float *C, int ldc, int m,
            const int32_t *d_m, bool leaky, float slope, bool acc64 = false, const int32_t *a_rows = nullptr,
            const int32_t *c_rows = nullptr, double flop_override = -1.0, const AttnCoef *coef = nullptr,
-           bool *coef_done = nullptr) {
+           bool *coef_done = nullptr, bool out_half = false) {
     if (coef_done) *coef_done = false;
     if (m <= 0) return MPE_OK;
     if (lda < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", lda, L.ldw);
@@ -148,7 +148,7 @@ int linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, const Linear &L
     GemmProf gp(ctx, s, flop_override >= 0.0 ? flop_override : (d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim),
                 host_m ? 0 : L.out_dim, host_m ? 0 : L.in_dim);
     HIPCHK(ctx, launch_linear(s, A, lda, L.w, L.ldw, L.b, C, ldc, m, d_m, L.out_dim, L.ldw, leaky, slope, acc64, a_rows,
-                              c_rows, coef, coef_done));
+                              c_rows, coef, coef_done, out_half));
     return MPE_OK;
 }
 
@@ -170,7 +170,8 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
         // the threshold (0 = never), mpe_set_precision(ctx, 1, .) extends it to every GAT GEMM.
         static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
         const bool acc64 = ctx->gat_acc64 || (mink > 0 && L.in_dim > mink);
-        return linear(ctx, s, A, lda, L, C, ldc, m, d_m, leaky, slope, acc64, a_rows, c_rows, flop_override, coef, coef_done);
+        // out_half here = the fp16-attention mode (fp32 MFMA GEMM, result rows stored as fp16)
+        return linear(ctx, s, A, lda, L, C, ldc, m, d_m, leaky, slope, acc64, a_rows, c_rows, flop_override, coef, coef_done, out_half);
     }
     if (m <= 0) return MPE_OK;
     int rc = ensure_bf16_weights(ctx, &L);
@@ -366,7 +367,8 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
     const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints;
     const int n_nodes = b->n_heads + b->n_edge_nodes;
     const bool red = ctx->gat_reduced;
-    const int ld_ft = red ? 2 * ctx->act_ld : ctx->act_ld;   // fp16 rows keep the byte stride of the fp32 rows
+    const bool half_rows = red || ctx->gat_attn_fp16;        // ft2 as fp16 rows for the attention stage
+    const int ld_ft = half_rows ? 2 * ctx->act_ld : ctx->act_ld;   // fp16 rows keep the byte stride of the fp32 rows
     int rc;
     // fc2 also emits the attention coefficients a1|a2 from its epilogue when the layer's shape allows
     const AttnCoef coef{g.attn_l, g.attn_r, ctx->a12, g.heads, g.out_dim};
@@ -378,7 +380,7 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
                              true, ctx->gat_alpha, false)))
             return rc;
         if ((rc = gat_linear(ctx, s, ctx->hdense, ctx->feat_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
-                             0.f, red, nullptr, nullptr, -1.0, cp, &done)))
+                             0.f, half_rows, nullptr, nullptr, -1.0, cp, &done)))
             return rc;
         a->ft2 = ctx->act[2];
         *n_rows_ft2 = n_nodes;
@@ -405,7 +407,7 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
                                     true, ctx->gat_alpha, false)))
             return rc;
         if ((rc = gat_linear(ctx, s, ctx->h0, ctx->feat_ld, g.fc2, ctx->act[1], ld_ft, b->n_heads, nullptr, false,
-                             0.f, red, nullptr, nullptr, -1.0, cp, &done)))
+                             0.f, half_rows, nullptr, nullptr, -1.0, cp, &done)))
             return rc;
         a->ft2 = ctx->act[1];
         *n_rows_ft2 = b->n_heads;
@@ -416,7 +418,7 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
                              true, ctx->gat_alpha, false)))
             return rc;
         if ((rc = gat_linear(ctx, s, ctx->act[1], ctx->act_ld, g.fc2, ctx->act[2], ld_ft, n_nodes, nullptr, false,
-                             0.f, red, nullptr, nullptr, -1.0, cp, &done)))
+                             0.f, half_rows, nullptr, nullptr, -1.0, cp, &done)))
             return rc;
         a->ft2 = ctx->act[2];
         *n_rows_ft2 = n_nodes;
@@ -432,8 +434,9 @@ AggArgs gat_agg_args(const mpe_ctx *ctx, int l) {
     a.out_dim = g.out_dim;
     a.alpha = ctx->gat_alpha;
     a.out_slope = ctx->gat_hidden_slope;
-    a.ft_half = ctx->gat_reduced ? 1 : 0;
-    a.ld = ctx->gat_reduced ? 2 * ctx->act_ld : ctx->act_ld;
+    const bool half_rows = ctx->gat_reduced || ctx->gat_attn_fp16;
+    a.ft_half = half_rows ? 1 : 0;
+    a.ld = half_rows ? 2 * ctx->act_ld : ctx->act_ld;
     a.a12 = ctx->a12;
     return a;
 }
@@ -471,9 +474,9 @@ int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en,
                                      (size_t)ld_feats * sizeof(float), (size_t)ctx->gat[0].in_dim * sizeof(float),
                                      n_nodes, hipMemcpyDeviceToDevice, s));
     } else if (ctx->l0_grouped) {
-        HIPCHK(ctx, launch_head_features(s, ctx->d_cfg, *b, J, ctx->xc, ctx->l0_ld, 0, 0, false));
+        HIPCHK(ctx, launch_head_features(s, ctx->d_cfg, *b, J, ctx->xc, ctx->l0_ld, 0, 0, false, ctx->cam_count, V));
         HIPCHK(ctx, launch_group_heads(s, b->n_heads, V, b->d_head_cam, ctx->cam_count, ctx->cam_list,
-                                       ctx->cfg.max_heads));
+                                       ctx->cfg.max_heads, true));
     } else {
         HIPCHK(ctx, launch_head_features(s, ctx->d_cfg, *b, J, ctx->x0, ctx->feat_ld, 0, 0, true));
     }
@@ -801,7 +804,8 @@ int mpe_edge_softmax_aggregate(mpe_ctx *ctx, void *stream, const mpe_batch *b, i
     DeviceGuard dg(ctx);
     if ((rc = ensure_gat_workspace(ctx))) return rc;
     if (layer < 0 || layer >= ctx->gat_layers) return fail(ctx, MPE_ERR_INVALID, "GAT layer index %d out of range", layer);
-    if (ctx->gat_reduced) return fail(ctx, MPE_ERR_STATE, "mpe_edge_softmax_aggregate takes fp32 rows (reduced mode is on)");
+    if (ctx->gat_reduced || ctx->gat_attn_fp16)
+        return fail(ctx, MPE_ERR_STATE, "mpe_edge_softmax_aggregate takes fp32 rows (a reduced-precision mode is on)");
     const GatLayer &g = ctx->gat[layer];
     const int hd = g.heads * g.out_dim;
     if ((rc = stage_layer_checks(ctx, b, layer, d_ft2, ld_ft2, hd, d_out, ld_out, hd))) return rc;
@@ -973,10 +977,11 @@ int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
     if (!ctx) return MPE_ERR_INVALID;
     DeviceGuard dg(ctx);
-    if (gat_acc64 < 0 || gat_acc64 > 2 || mlp_acc64 < 0 || mlp_acc64 > 2)
-        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0|1|2, MLP 0|1|2");
+    if (gat_acc64 < 0 || gat_acc64 > 3 || mlp_acc64 < 0 || mlp_acc64 > 2)
+        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0|1|2|3, MLP 0|1|2");
     ctx->gat_acc64 = gat_acc64 == 1;
     ctx->gat_reduced = gat_acc64 == 2;
+    ctx->gat_attn_fp16 = gat_acc64 == 3;
     ctx->mlp_acc64 = mlp_acc64 == 1;
     ctx->mlp_bf16 = mlp_acc64 == 2;
     return MPE_OK;

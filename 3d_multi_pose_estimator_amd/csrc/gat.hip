@@ -97,8 +97,12 @@ hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *no
 __global__ void k_head_features(const DevCfg *__restrict__ cfg, int n_heads, int J,
                                 const int32_t *__restrict__ head_cam, const uint32_t *__restrict__ joint_mask,
                                 const double *__restrict__ xy, const float *__restrict__ vp,
-                                float *__restrict__ feat, int ld_feat, int dense) {
+                                float *__restrict__ feat, int ld_feat, int dense, int32_t *__restrict__ zero_counts,
+                                int n_zero) {
 #pragma clang fp contract(off)
+    // the per-camera head counts of k_group_heads (the next launch) start from zero: cleared here instead of by a
+    // memset node of their own
+    if (zero_counts && blockIdx.x == 0 && (int)threadIdx.x < n_zero) zero_counts[threadIdx.x] = 0;
     const int h = blockIdx.x;
     if (h >= n_heads) return;
     __shared__ float s_f[MPE_MAX_JOINTS * 10];
@@ -158,10 +162,10 @@ __global__ void k_head_features(const DevCfg *__restrict__ cfg, int n_heads, int
 }
 
 hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
-                                int ld_feat, int, int, bool dense) {
-    if (b.n_heads <= 0) return hipSuccess;
+                                int ld_feat, int, int, bool dense, int32_t *zero_counts, int n_zero) {
+    if (b.n_heads <= 0) return zero_counts ? hipMemsetAsync(zero_counts, 0, (size_t)n_zero * sizeof(int32_t), s) : hipSuccess;
     hipLaunchKernelGGL(k_head_features, dim3(b.n_heads), dim3(128), 0, s, cfg, b.n_heads, J, b.d_head_cam,
-                       b.d_joint_mask, b.d_xy, b.d_vp, feat, ld_feat, dense ? 1 : 0);
+                       b.d_joint_mask, b.d_xy, b.d_vp, feat, ld_feat, dense ? 1 : 0, zero_counts, n_zero);
     return hipGetLastError();
 }
 
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(1024) void k_group_heads(int n_heads, const int32_t
 }
 
 hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *head_cam, int32_t *cam_count,
-                              int32_t *cam_list, int list_stride) {
-    hipError_t e = hipMemsetAsync(cam_count, 0, (size_t)V * sizeof(int32_t), s);
+                              int32_t *cam_list, int list_stride, bool counts_zeroed) {
+    hipError_t e = counts_zeroed ? hipSuccess : hipMemsetAsync(cam_count, 0, (size_t)V * sizeof(int32_t), s);
     if (e != hipSuccess || n_heads <= 0) return e;
     hipLaunchKernelGGL(k_group_heads, dim3((n_heads + 1023) / 1024), dim3(1024), 0, s, n_heads, head_cam, cam_count,
                        cam_list, list_stride);

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
                                                        const float *__restrict__ attn_r = nullptr,
                                                        float *__restrict__ a12 = nullptr,
                                                        const int32_t *__restrict__ grp_count = nullptr, int n_grp = 0,
-                                                       int grp_stride = 0, long w_grp_stride = 0) {
+                                                       int grp_stride = 0, long w_grp_stride = 0, int out_half = 0) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];   // 2 stages of (128 + 16 NTT) rows x 128 B
     constexpr int ROWF = 32;                   // floats per tile row (dense)
     constexpr int W_OFF = GEMM_BM * ROWF;      // weight rows follow the activation rows
@@ -511,15 +511,22 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
                 }
             }
             if (m >= M) continue;
-            if (tune_prio & 64) {              // ABLATION (timing only): no result stores
-                asm volatile("" ::"v"(v));
+            const int mo = c_rows ? c_rows[m] : m;
+            if (out_half) {                    // fp16 rows for the attention stage (configs[4]); ldc counts halves
+                _Float16 *dh = reinterpret_cast<_Float16 *>(C) + (size_t)mo * ldc + nb;
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                if (nb + 3 < n) {
+                    *reinterpret_cast<h4 *>(dh) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < n) dh[i] = (_Float16)v[i];
+                }
                 continue;
             }
-            const int mo = c_rows ? c_rows[m] : m;
             float *dst = C + (size_t)mo * ldc + nb;
             if (nb + 3 < n) {
-                if (tune_prio & 256) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));   // EXPERIMENT
-                else *reinterpret_cast<f32x4 *>(dst) = v;
+                *reinterpret_cast<f32x4 *>(dst) = v;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(256) void k_linear_skinny(const float *__restrict__
                                                         int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
                                                         int k_pad, float slope, int nt16,
                                                         const int32_t *__restrict__ a_rows,
-                                                        const int32_t *__restrict__ c_rows) {
+                                                        const int32_t *__restrict__ c_rows, int out_half) {
     int M = m_cap;
     if (d_m) {
         int dm = *d_m;
@@ -643,6 +650,13 @@ __global__ __launch_bounds__(256) void k_linear_skinny(const float *__restrict__
         for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
     }
     const int mo = c_rows ? c_rows[m] : m;
+    if (out_half) {
+        _Float16 *dh = reinterpret_cast<_Float16 *>(C) + (size_t)mo * ldc + nb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (nb + i < n) dh[i] = (_Float16)v[i];
+        return;
+    }
     float *dst = C + (size_t)mo * ldc + nb;
     if (nb + 3 < n) {
         *reinterpret_cast<f32x4 *>(dst) = v;
@@ -670,7 +684,7 @@ __global__ __launch_bounds__(64 * KS) void k_linear_skinny_ks(const float *__res
                                                              int ldc, int m_cap, const int32_t *__restrict__ d_m,
                                                              int n, int k_pad, float slope, int nt16,
                                                              const int32_t *__restrict__ a_rows,
-                                                             const int32_t *__restrict__ c_rows) {
+                                                             const int32_t *__restrict__ c_rows, int out_half) {
     extern __shared__ __attribute__((aligned(16))) float s_part[];       // [nk][64 lanes][4]
     int M = m_cap;
     if (d_m) {
@@ -732,7 +746,8 @@ __global__ __launch_bounds__(64 * KS) void k_linear_skinny_ks(const float *__res
     float v = (float)(run + (double)bias[nb]);
     if (LEAKY) v = v > 0.f ? v : v * slope;
     const int mo = c_rows ? c_rows[m] : m;
-    C[(size_t)mo * ldc + nb] = v;
+    if (out_half) reinterpret_cast<_Float16 *>(C)[(size_t)mo * ldc + nb] = (_Float16)v;
+    else C[(size_t)mo * ldc + nb] = v;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -979,13 +994,14 @@ struct DmaLaunch {
     const int32_t *grp_count = nullptr;
     int n_grp = 0, grp_stride = 0;
     long w_grp_stride = 0;
+    int out_half = 0;          // fc2 of a graph-attention layer in the fp16-attention mode: C holds fp16 rows, ldc in halves
 };
 
 template <bool L, bool A64, int N, bool A12, int NL>
 static void launch_dma(hipStream_t s, int grid, const DmaLaunch &a) {
     hipLaunchKernelGGL((k_linear_dma<L, A64, N, A12, NL>), dim3(grid), dim3(256 + 64 * NL), dma_lds_bytes(N), s, a.A, a.lda, a.W,
                        a.ldw, a.bias, a.C, a.ldc, a.m_cap, a.d_m, a.n, a.k_pad, a.slope, a.ntn, a.n_major, a.a_rows, a.c_rows,
-                       a.attn_l, a.attn_r, a.a12, a.grp_count, a.n_grp, a.grp_stride, a.w_grp_stride);
+                       a.attn_l, a.attn_r, a.a12, a.grp_count, a.n_grp, a.grp_stride, a.w_grp_stride, a.out_half);
 }
 
 static bool gemm_loader_waves_on() {
@@ -1029,7 +1045,7 @@ hipError_t launch_linear_grouped(hipStream_t s, const float *A, int lda, const f
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64, const int32_t *a_rows, const int32_t *c_rows,
-                         const AttnCoef *coef, bool *coef_done) {
+                         const AttnCoef *coef, bool *coef_done, bool out_half) {
     if (coef_done) *coef_done = false;
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
@@ -1060,17 +1076,17 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
         dim3 kgrid((unsigned)waves16), kblock(512);
         if (leaky)
             hipLaunchKernelGGL((k_linear_skinny_ks<true, 8>), kgrid, kblock, shm, s, A, lda, W, ldw, bias, C, ldc, m_cap,
-                               d_m, n, k_pad, slope, nt16, a_rows, c_rows);
+                               d_m, n, k_pad, slope, nt16, a_rows, c_rows, out_half ? 1 : 0);
         else
             hipLaunchKernelGGL((k_linear_skinny_ks<false, 8>), kgrid, kblock, shm, s, A, lda, W, ldw, bias, C, ldc, m_cap,
-                               d_m, n, k_pad, slope, nt16, a_rows, c_rows);
+                               d_m, n, k_pad, slope, nt16, a_rows, c_rows, out_half ? 1 : 0);
         return hipGetLastError();
     }
     if ((waves16 <= skinny_waves || narrow) && !(tune & 8)) {
         dim3 sgrid((unsigned)((waves16 + 3) / 4)), sblock(256);
 #define MPE_LAUNCH_SK(L_, A_)                                                                                  \
     hipLaunchKernelGGL((k_linear_skinny<L_, A_>), sgrid, sblock, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, \
-                       k_pad, slope, nt16, a_rows, c_rows)
+                       k_pad, slope, nt16, a_rows, c_rows, out_half ? 1 : 0)
         if (leaky && acc64) MPE_LAUNCH_SK(true, true);
         else if (leaky) MPE_LAUNCH_SK(true, false);
         else if (acc64) MPE_LAUNCH_SK(false, true);
@@ -1078,7 +1094,7 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
 #undef MPE_LAUNCH_SK
         return hipGetLastError();
     }
-    if ((tune & 8) && !a_rows && !c_rows) {     // MPE_GEMM_TUNE=8: the register-staged kernel of round 1 (A/B)
+    if ((tune & 8) && !a_rows && !c_rows && !out_half) {     // MPE_GEMM_TUNE=8: the register-staged kernel of round 1 (A/B)
         dim3 grid(ntm * ntn), block(256);
 #define MPE_LAUNCH(L_, A_)                                                                                   \
     hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
@@ -1102,6 +1118,7 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
         dma_attr.set();
     }
     DmaLaunch a{A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, 0, n_major, a_rows, c_rows};
+    a.out_half = out_half ? 1 : 0;
     // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile)
     if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !force_bn) {
         a.ntn = (n + 79) / 80;

@@ -26,6 +26,8 @@
 // than the staging arena has rows for -- raises a status bit and the caller packs that window with the
 // host packer, which remains the definition of the accepted language and of the error messages.
 // tests/test_gpu_json.py: the arrays equal the host packer's bit for bit.
+#include <cstdlib>
+
 #include "el_double.h"
 #include "mpe_internal.h"
 
@@ -237,47 +239,51 @@ __global__ __launch_bounds__(64) void k_json_braces(const char *__restrict__ tex
     }
 }
 
-// thread (entry, k): skeleton k of the string; also the list syntax around it
-__global__ __launch_bounds__(64) void k_json_skeleton(const char *__restrict__ text, const mpe_json_entry *__restrict__ entries,
-                                                       int n_entries, int kcap, int J, const SkExt *__restrict__ ext,
-                                                       const int32_t *__restrict__ n_sk, uint32_t *__restrict__ r_jm,
-                                                       uint32_t *__restrict__ r_tm, double *__restrict__ r_xy, float *__restrict__ r_vp,
-                                                       int32_t *__restrict__ totals) {
-    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-    const int e = (int)(gid / kcap), k = (int)(gid - (long)e * kcap);
-    if (e >= n_entries) return;
-    const int cnt = n_sk[e];
-    if (k >= (cnt > 0 ? cnt : 1)) return;
-    const mpe_json_entry en = entries[e];
-    const char *t = text + en.begin;
-    const int n = (int)(en.end - en.begin);
-    bool ok = true;
-    if (cnt == 0) {
-        // "[]" with blanks
-        JCur c(t, 0, n);
-        c.ws();
-        ok = c.ch() == '[';
-        ++c.i;
-        c.ws();
-        ok = ok && c.ch() == ']';
-        ++c.i;
-        c.ws();
-        ok = ok && c.i == n;
-    } else {
-        const SkExt *my = ext + (size_t)e * kcap;
-        const int b = my[k].b, en_ = my[k].e;
-        ok = b < en_ && en_ <= n;
-        if (ok && k == 0) ok = gap_is(t, n, 0, b, '[');
-        if (ok) {
-            const size_t r = (size_t)e * kcap + k;
-            uint32_t jm = 0, tm = 0;
-            ok = walk_skeleton(t, b, en_, J, &jm, &tm, r_xy + r * J * 2, r_vp + r * J * 2);
-            r_jm[r] = ok ? jm : 0;
-            r_tm[r] = tm;
+// thread (entry, k): skeleton k of the string; also the list syntax around it.  The (entry, k) pairs are walked k-major
+// (gid = k * n_entries + entry): strings hold a few skeletons each, far fewer than the capacity kcap, so the live pairs are
+// the first n_entries * (a few) indices and whole waves are either live or skip at once; grid-stride over a capped grid
+// (side_grid below) because the kernel shares the GPU with the previous window's GEMMs.
+__global__ __launch_bounds__(256) void k_json_skeleton(const char *__restrict__ text, const mpe_json_entry *__restrict__ entries,
+                                                        int n_entries, int kcap, int J, const SkExt *__restrict__ ext,
+                                                        const int32_t *__restrict__ n_sk, uint32_t *__restrict__ r_jm,
+                                                        uint32_t *__restrict__ r_tm, double *__restrict__ r_xy, float *__restrict__ r_vp,
+                                                        int32_t *__restrict__ totals) {
+    const long total = (long)n_entries * kcap;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(gid / n_entries), e = (int)(gid - (long)k * n_entries);
+        const int cnt = n_sk[e];
+        if (k >= (cnt > 0 ? cnt : 1)) continue;
+        const mpe_json_entry en = entries[e];
+        const char *t = text + en.begin;
+        const int n = (int)(en.end - en.begin);
+        bool ok = true;
+        if (cnt == 0) {
+            // "[]" with blanks
+            JCur c(t, 0, n);
+            c.ws();
+            ok = c.ch() == '[';
+            ++c.i;
+            c.ws();
+            ok = ok && c.ch() == ']';
+            ++c.i;
+            c.ws();
+            ok = ok && c.i == n;
+        } else {
+            const SkExt *my = ext + (size_t)e * kcap;
+            const int b = my[k].b, en_ = my[k].e;
+            ok = b < en_ && en_ <= n;
+            if (ok && k == 0) ok = gap_is(t, n, 0, b, '[');
+            if (ok) {
+                const size_t r = (size_t)e * kcap + k;
+                uint32_t jm = 0, tm = 0;
+                ok = walk_skeleton(t, b, en_, J, &jm, &tm, r_xy + r * J * 2, r_vp + r * J * 2);
+                r_jm[r] = ok ? jm : 0;
+                r_tm[r] = tm;
+            }
+            if (ok) ok = k + 1 < cnt ? (my[k + 1].b >= en_ && gap_is(t, n, en_, my[k + 1].b, ',')) : gap_is(t, n, en_, n, ']');
         }
-        if (ok) ok = k + 1 < cnt ? (my[k + 1].b >= en_ && gap_is(t, n, en_, my[k + 1].b, ',')) : gap_is(t, n, en_, n, ']');
+        if (!ok) atomicOr(&totals[2], JS_FALLBACK);
     }
-    if (!ok) atomicOr(&totals[2], JS_FALLBACK);
 }
 
 // per frame: slot tables, heads and edge-nodes; exclusive prefix sums over the frames; head base per entry
@@ -352,29 +358,31 @@ __global__ __launch_bounds__(1024) void k_json_layout(const mpe_json_entry *__re
 }
 
 // staging rows of the non-empty skeletons -> batch arrays in head order
-__global__ __launch_bounds__(64) void k_json_compact(const mpe_json_entry *__restrict__ entries, int n_entries, int kcap, int J,
+__global__ __launch_bounds__(256) void k_json_compact(const mpe_json_entry *__restrict__ entries, int n_entries, int kcap, int J,
                                                       const int32_t *__restrict__ n_sk, const uint32_t *__restrict__ r_jm,
                                                       const uint32_t *__restrict__ r_tm, const double *__restrict__ r_xy,
                                                       const float *__restrict__ r_vp, const int32_t *__restrict__ head_base,
                                                       const int32_t *__restrict__ totals, int32_t *__restrict__ head_cam,
                                                       int32_t *__restrict__ skeleton_index, uint32_t *__restrict__ joint_mask,
                                                       uint32_t *__restrict__ tri_mask, double *__restrict__ xy, float *__restrict__ vp) {
-    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-    const int e = (int)(gid / kcap), k = (int)(gid - (long)e * kcap);
-    if (e >= n_entries || totals[2] != JS_OK) return;
-    if (k >= n_sk[e]) return;
-    const size_t r = (size_t)e * kcap + k;
-    if (!r_jm[r]) return;
-    int rank = 0;
-    for (int q = 0; q < k; ++q) rank += r_jm[(size_t)e * kcap + q] != 0;
-    const size_t h = (size_t)head_base[e] + rank;
-    head_cam[h] = entries[e].cam;
-    skeleton_index[h] = k;
-    joint_mask[h] = r_jm[r];
-    tri_mask[h] = r_tm[r];
-    for (int q = 0; q < J * 2; ++q) {
-        xy[h * J * 2 + q] = r_xy[r * J * 2 + q];
-        vp[h * J * 2 + q] = r_vp[r * J * 2 + q];
+    if (totals[2] != JS_OK) return;
+    const long total = (long)n_entries * kcap;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(gid / n_entries), e = (int)(gid - (long)k * n_entries);
+        if (k >= n_sk[e]) continue;
+        const size_t r = (size_t)e * kcap + k;
+        if (!r_jm[r]) continue;
+        int rank = 0;
+        for (int q = 0; q < k; ++q) rank += r_jm[(size_t)e * kcap + q] != 0;
+        const size_t h = (size_t)head_base[e] + rank;
+        head_cam[h] = entries[e].cam;
+        skeleton_index[h] = k;
+        joint_mask[h] = r_jm[r];
+        tri_mask[h] = r_tm[r];
+        for (int q = 0; q < J * 2; ++q) {
+            xy[h * J * 2 + q] = r_xy[r * J * 2 + q];
+            vp[h * J * 2 + q] = r_vp[r * J * 2 + q];
+        }
     }
 }
 
@@ -388,6 +396,17 @@ extern "C" size_t mpe_json_scratch_bytes(int32_t n_entries_cap, int32_t skeleton
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     return up(e * 4) + up(e * 4) + up(rows * sizeof(SkExt)) + up(rows * 4) + up(rows * 4) + up(rows * (size_t)n_joints * 2 * 8) +
            up(rows * (size_t)n_joints * 2 * 4);
+}
+
+// Grid of the two thread-per-skeleton kernels.  They run beside the previous window's GEMMs (pipeline.py), so the grid is
+// capped: one skeleton is ~1.4 KB of serial byte work per thread and the kernel's duration is that latency, not the
+// number of workgroups -- measured with Engine.stream_json, 24 windows of 1000 frames (20 000 skeletons each): cap 16 ->
+// 44.0k frames/s, 48 -> 88.6k, 128 -> 132.4k, uncapped (79 workgroups... of 256 threads would do; "uncapped" = one thread
+// per skeleton slot) -> 122.6k.  MPE_JSON_WGS overrides the cap.
+static unsigned side_grid(long threads) {
+    static const long cap = getenv("MPE_JSON_WGS") ? atol(getenv("MPE_JSON_WGS")) : 128;
+    const long want = (threads + 255) / 256;
+    return (unsigned)(want < cap ? want : (cap > 0 ? cap : 1));
 }
 
 extern "C" int mpe_json_parse_device(mpe_ctx *ctx, void *stream, const char *d_text, const mpe_json_entry *d_entries,
@@ -420,16 +439,14 @@ extern "C" int mpe_json_parse_device(mpe_ctx *ctx, void *stream, const char *d_t
     if (n_frames == 0) return MPE_OK;
     if (n_entries > 0) {
         hipLaunchKernelGGL(k_json_braces, dim3((unsigned)n_entries), dim3(64), 0, s, d_text, d_entries, n_entries, kcap, ext, n_sk, d_totals);
-        const long threads = (long)n_entries * kcap;
-        hipLaunchKernelGGL(k_json_skeleton, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, d_text, d_entries, n_entries, kcap, J, ext,
+        hipLaunchKernelGGL(k_json_skeleton, dim3(side_grid((long)n_entries * kcap)), dim3(256), 0, s, d_text, d_entries, n_entries, kcap, J, ext,
                            n_sk, r_jm, r_tm, r_xy, r_vp, d_totals);
     }
     hipLaunchKernelGGL(k_json_layout, dim3(1), dim3(1024), 0, s, d_entries, d_frame_entry_off, n_frames, V, kcap, n_sk, r_jm, head_cap,
                        const_cast<int32_t *>(out->d_frame_head_off), const_cast<int32_t *>(out->d_frame_en_off),
                        const_cast<int32_t *>(out->d_slot_cam), const_cast<int32_t *>(out->d_slot_n), head_base, d_totals);
     if (n_entries > 0) {
-        const long threads = (long)n_entries * kcap;
-        hipLaunchKernelGGL(k_json_compact, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, d_entries, n_entries, kcap, J, n_sk, r_jm,
+        hipLaunchKernelGGL(k_json_compact, dim3(side_grid((long)n_entries * kcap)), dim3(256), 0, s, d_entries, n_entries, kcap, J, n_sk, r_jm,
                            r_tm, r_xy, r_vp, head_base, d_totals, const_cast<int32_t *>(out->d_head_cam), d_skeleton_index,
                            const_cast<uint32_t *>(out->d_joint_mask), const_cast<uint32_t *>(out->d_tri_mask),
                            const_cast<double *>(out->d_xy), const_cast<float *>(out->d_vp));

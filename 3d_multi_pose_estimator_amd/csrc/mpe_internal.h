@@ -90,6 +90,7 @@ struct mpe_ctx {
     bool mlp_bf16 = false;         // reduced precision: bf16 MFMA for the MLP GEMMs
     bool gat_acc64 = false;
     bool gat_reduced = false;      // reduced precision: bf16 MFMA GEMMs + fp16 feature rows in the attention stage
+    bool gat_attn_fp16 = false;    // configs[4] as BASELINE words it: fp16 feature rows (ft2) in the attention stage, GEMMs stay fp32
     mpe::Linear mlp[MPE_MAX_MLP_LAYERS];
     bool mlp_ready[MPE_MAX_MLP_LAYERS] = {};
     // workspace (sized at create / grown when weights define the widths)
@@ -146,7 +147,7 @@ struct AttnCoef {              // fc2 of a graph-attention layer: also emit a1|a
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64, const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr,
-                         const AttnCoef *coef = nullptr, bool *coef_done = nullptr);
+                         const AttnCoef *coef = nullptr, bool *coef_done = nullptr, bool out_half = false);
 // one launch for `n_grp` GEMMs that share the activation / result buffers: group g takes the rows
 // row_lists[g * grp_stride + 0 .. grp_count[g]) (device-side counts) and the weights W + g * w_grp_stride
 hipError_t launch_linear_grouped(hipStream_t s, const float *A, int lda, const float *W, int ldw, long w_grp_stride,
@@ -154,7 +155,7 @@ hipError_t launch_linear_grouped(hipStream_t s, const float *A, int lda, const f
                                  const int32_t *row_lists, int grp_stride, int n, int k_pad, bool leaky, float slope);
 bool linear_uses_tile_kernel(int m_cap, int n);
 hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *head_cam, int32_t *cam_count,
-                              int32_t *cam_list, int list_stride);
+                              int32_t *cam_list, int list_stride, bool counts_zeroed = false);
 
 hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsigned short *Wb, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad,
@@ -168,7 +169,8 @@ hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *no
 // entries of the per-frame in-edge source table of the heads, or 0 when frames of that capacity do not get one
 size_t head_src_entries(int max_heads_per_frame, int V);
 hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
-                                int ld_feat, int col0, int stride_cam, bool dense);
+                                int ld_feat, int col0, int stride_cam, bool dense, int32_t *zero_counts = nullptr,
+                                int n_zero = 0);
 hipError_t launch_attn_coef(hipStream_t s, const float *ft2, int ld, int n_rows, int heads, int out_dim,
                             const float *attn_l, const float *attn_r, float *a12, int ft_half = 0);
 struct AggArgs {

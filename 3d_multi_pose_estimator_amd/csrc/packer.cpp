@@ -728,6 +728,11 @@ struct mpe_json_index {
     std::vector<std::unique_ptr<Part>> parts;
     std::atomic<bool> abort_parts{false};
 
+    bool scanning() {
+        std::lock_guard<std::mutex> lk(mu);
+        return !done && !failed;
+    }
+
     void plan_parts(const char *b, const char *e, int P) {
         const size_t len = (size_t)(e - b);
         if (P < 2 || len < ((size_t)4 << 20) || sc.single) return;
@@ -838,6 +843,14 @@ static thread_local std::string g_pack_error;
 // Worker threads when the caller does not say: the CPUs this process may actually use -- the smaller of
 // the hardware threads, the affinity mask and the cgroup CPU quota (a container on a 256-thread host is
 // often limited to a few cores; 256 runnable parsers then only starve the scan thread).
+static int default_threads();
+// threads of the document scan: MPE_SCAN_THREADS, else a quarter of the CPUs this process may use (the rest parse / stage)
+static int scan_threads() {
+    if (const char *ev = getenv("MPE_SCAN_THREADS")) return atoi(ev) > 0 ? atoi(ev) : 1;
+    const int hw = default_threads();
+    return hw >= 16 ? 4 : hw >= 6 ? 2 : 1;
+}
+
 static int default_threads() {
     static const int n = [] {
         int hw = (int)std::thread::hardware_concurrency();
@@ -1103,13 +1116,7 @@ int mpe_json_index_create(const char *json, size_t len, mpe_json_index **out) {
     }
     {
         // scan threads: MPE_SCAN_THREADS, else a quarter of the CPUs this process may use (the rest parse / stage)
-        int P = 1;
-        if (const char *ev = getenv("MPE_SCAN_THREADS")) P = atoi(ev);
-        else {
-            const int hw = default_threads();
-            P = hw >= 16 ? 4 : hw >= 6 ? 2 : 1;
-        }
-        ix->plan_parts(json, json + len, P);
+        ix->plan_parts(json, json + len, scan_threads());
     }
     ix->th = std::thread([ix] { ix->run(); });
     *out = ix;
@@ -1175,7 +1182,11 @@ int mpe_json_stage_window(mpe_json_index *ix, const char *const *camera_names, i
     std::vector<std::string> errs((size_t)B);
     std::atomic<int> next{0};
     std::atomic<bool> failed{false}, unsupported{false};
-    int nt = n_threads > 0 ? n_threads : default_threads();
+    // staging runs beside the document scan and the caller's own thread: under a cgroup CPU quota the sum must stay below it,
+    // or the kernel parks the whole process for the rest of the 100 ms period (measured on a 16-CPU share: 16 staging + 4 scan
+    // threads -> nr_throttled 10 in 24 windows, windows of 50 ms; json_inclusive 115k-146k frames/s from run to run)
+    int nt = n_threads > 0 ? n_threads : default_threads() - (ix->scanning() ? scan_threads() : 0) - 2;
+    if (nt < 1) nt = 1;
     if (nt > B) nt = B > 0 ? B : 1;
     auto run = [&](auto &&body) {
         next = 0;

@@ -332,7 +332,7 @@ class Engine:
                 n_here = db.n_frames
                 if timing is not None:
                     ev_c0 = torch.cuda.Event(enable_timing=True)
-                    ev_c0.record()
+                    ev_c0.record(s_m)
                 # engine mode as in run_pipelined: the matching stage and the 3D stage on their own streams, so the matching
                 # of this chunk overlaps the 3D stage of the previous one
                 if db.host is not None:
@@ -350,7 +350,7 @@ class Engine:
                 done[k] = None
                 if timing is not None and st is not None:
                     ev_c1 = torch.cuda.Event(enable_timing=True)
-                    ev_c1.record()
+                    ev_c1.record(s_d)
                     gpu_ev.append((ev_p0, ev_p1, ev_c0, ev_c1, bufs[k]['ev_h2d']))
                 t_e = time.perf_counter()
                 if pending is not None:
@@ -381,6 +381,9 @@ class Engine:
                 m = np.array(timing[1:]).mean(axis=0) * 1e3
                 print('stream_json(device) per window, ms: wait staging %.2f | queue parse %.2f | wait parse %.2f | launch compute %.2f | '
                       'wait previous results %.2f' % tuple(m), file=sys.stderr)
+                worst = np.array(timing[1:]).max(axis=0) * 1e3
+                print('  slowest window of each, ms:            wait staging %.2f | queue parse %.2f | wait parse %.2f | launch compute %.2f | '
+                      'wait previous results %.2f' % tuple(worst), file=sys.stderr)
                 base = gpu_ev[2][0]
                 for w in range(2, min(7, len(gpu_ev))):
                     p0, p1, c0, c1, h = gpu_ev[w]
@@ -638,12 +641,13 @@ class Engine:
         self._chk(self.lib.mpe_dlt_pairs(self.ctx, self._stream(), _ptr(pts), _ptr(cams), n, _ptr(out)))
         return out
 
-    def set_precision(self, gat_acc64=False, mlp_acc64=True, mlp_bf16=False, gat_reduced=False):
-        """GAT: plain fp32 MFMA chain / f64 running sums / reduced (bf16 MFMA GEMMs + fp16 feature
-        rows in the attention stage); MLP: fp32 / f64 running sums (default, parity) / bf16 MFMA.
-        The reduced modes are BASELINE configs[4]; they are never used on the parity path."""
-        self._chk(self.lib.mpe_set_precision(self.ctx, 2 if gat_reduced else int(gat_acc64),
-                                             2 if mlp_bf16 else int(mlp_acc64)))
+    def set_precision(self, gat_acc64=False, mlp_acc64=True, mlp_bf16=False, gat_reduced=False, attn_fp16=False):
+        """GAT: plain fp32 MFMA chain / f64 running sums / `attn_fp16` (BASELINE configs[4] as worded: the transformed
+        features ft2 travel to the attention stage as fp16 rows, the GEMMs stay fp32) / `gat_reduced` (additionally
+        bf16 MFMA for fc1/fc2); MLP: fp32 / f64 running sums (default, parity) / bf16 MFMA.  The reduced modes are
+        never used on the parity path."""
+        gat = 2 if gat_reduced else 3 if attn_fp16 else int(gat_acc64)
+        self._chk(self.lib.mpe_set_precision(self.ctx, gat, 2 if mlp_bf16 else int(mlp_acc64)))
 
     def linear(self, x, w, b, slope=None, acc64=False):
         """act(x @ w.T + b) through the MFMA GEMM (parity tests). x device [m,k]; w,b host."""

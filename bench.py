@@ -81,6 +81,9 @@ def parse_args(argv=None):
     ap.add_argument('--reduced', action='store_true',
                     help='configs[4] precision (NOT the parity path): bf16 MFMA for the GAT and MLP GEMMs, fp16 '
                          'feature rows in the attention stage')
+    ap.add_argument('--cfg4', action='store_true',
+                    help='BASELINE configs[4] precision as worded (NOT the parity path): fp16 feature rows in the attention '
+                         'stage (GAT GEMMs stay fp32) + bf16 MFMA for the MLP GEMMs')
     ap.add_argument('--preset', default='PANOPTIC', choices=['PANOPTIC', 'ARPLAB', 'RING23'],
                     help='camera rig; RING23 = the 23-view stress rig of BASELINE.json configs[4] (fp32 here)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse)')
@@ -90,7 +93,7 @@ def parse_args(argv=None):
     ap.add_argument('--profile-steps', type=int, default=24,
                     help='single-stream steps after the timed region with HIP event pairs around the GEMM launches '
                          '(kernel-level roofline); 0 = skip')
-    ap.add_argument('--json-steps', type=int, default=24,
+    ap.add_argument('--json-steps', type=int, default=48,
                     help='batches of the json_inclusive region (wire-format JSON bytes -> poses in pinned host memory); 0 = skip')
     ap.add_argument('--no-io', action='store_true', help='skip the second (pinned host -> poses in pinned host) timed region')
     ap.add_argument('--no-profile', action='store_true', help='no per-GEMM HIP events (roofline comes out null)')
@@ -274,6 +277,8 @@ def run_rank(args):
         eng.set_precision(False, False, mlp_bf16=True)
     if args.reduced:
         eng.set_precision(False, False, mlp_bf16=True, gat_reduced=True)
+    if args.cfg4:
+        eng.set_precision(False, False, mlp_bf16=True, attn_fp16=True)
     pb = eng.pack(frames)
     eng.check_capacity(pb)
     db = eng.to_device(pb)
@@ -380,13 +385,14 @@ def run_rank(args):
 
     persons_per_frame = float(n_persons.float().mean().item()) if B else 0.0
     value = total * args.steps / elapsed
-    reduced = args.reduced or args.bf16_mlp
+    reduced = args.reduced or args.bf16_mlp or args.cfg4
     out = {
         'metric': 'frames/sec (5-view Panoptic, 4 persons) at 1/2/4/8 GPUs; MPJPE vs ref',
         'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
         'vs_baseline': None,
-        'dtype': 'bf16 GEMMs / f16 attention rows' if args.reduced else ('bf16 (MLP) / f32' if args.bf16_mlp else 'f32'),
+        'dtype': 'bf16 GEMMs / f16 attention rows' if args.reduced else 'f32 GAT GEMMs / f16 attention rows / bf16 MLP' if args.cfg4
+                 else ('bf16 (MLP) / f32' if args.bf16_mlp else 'f32'),
         'data': 'synthetic',
         'config': {'workload': ('%s: %d-view x %d-person, GAT match + %s, %s'
                                 % ('c2 Panoptic' if args.preset == 'PANOPTIC' else args.preset, V, args.persons,
@@ -555,16 +561,30 @@ def json_inclusive(args, torch, eng, wire, B, uniq):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert got == n_steps * B
-    try:
-        threads = len(os.sched_getaffinity(0))
-    except AttributeError:
-        threads = os.cpu_count()
+    threads = usable_cpus()
     return {'value': got / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / n_steps, 'steps': n_steps,
             'json_bytes_per_step': len(text) // n_steps, 'json_gb_per_s': len(text) / dt / 1e9, 'host_threads_available': threads,
             'parser': 'device (csrc/jsonparse.hip); host: frame extents + string extents only',
             'what': 'wire-format frame JSON bytes in host memory -> first level on the host (parallel frame scan, skeleton strings '
                     'copied to a page-locked buffer) -> H2D -> second level parsed on the device -> match + 3D stage -> D2H of '
                     'poses into pinned host memory; batch i+1 is parsed while batch i computes'}
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask cut by the cgroup CPU quota (a GPU box shows 256 CPUs and
+    grants 16; an MKL pool sized to the 256 is throttled by the kernel for most of every 100 ms period)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            q, per = fh.read().split()[:2]
+        if q != 'max' and int(per) > 0:
+            n = max(1, min(n, int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def pmc_traffic():
@@ -610,13 +630,19 @@ def cpu_baseline_and_parity(args, np, torch, calib, params, lo, device):
     try:
         eng.load_gat(gat_sd, prm)
         eng.load_mlp(mlp_sd)
-        onp.run_frame(frames[0], calib, gat_sd, prm, mlp_sd, mode=args.mode)       # warm up
-        res = []
-        t0 = time.perf_counter()
-        for i in range(n):
-            res.append(onp.run_frame(frames[i], calib, gat_sd, prm, mlp_sd, mode=args.mode))
-        dt = time.perf_counter() - t0
-        base = {'value': n / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+        had = torch.get_num_threads()
+        cores = min(had, usable_cpus())
+        torch.set_num_threads(cores)
+        try:
+            onp.run_frame(frames[0], calib, gat_sd, prm, mlp_sd, mode=args.mode)       # warm up
+            res = []
+            t0 = time.perf_counter()
+            for i in range(n):
+                res.append(onp.run_frame(frames[i], calib, gat_sd, prm, mlp_sd, mode=args.mode))
+            dt = time.perf_counter() - t0
+        finally:
+            torch.set_num_threads(had)
+        base = {'value': n / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
                 'sample': '%d frames of the workload\'s shape (%d views x %d persons), per-frame loop as in the reference '
                           '(torch-CPU GEMMs)' % (n, V, spec.persons)}
         db = eng.to_device(eng.pack(frames))

@@ -122,7 +122,10 @@ int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_d
  * bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~3 significant digits; not parity).
  * GAT mode 2 is the other half of that config: fc1/fc2 on the bf16 MFMA and the transformed
  * features (ft2) stored as fp16 rows for the attention stage (coefficients, softmax and sums
- * stay fp32; the layer-0 edge-node constants stay fp32). */
+ * stay fp32; the layer-0 edge-node constants stay fp32).  GAT mode 3 is configs[4] as BASELINE.json words it
+ * ("fp16 GATv2 attention + bf16 MLP" with MLP mode 2): only the ft2 rows are fp16 -- fc2 stores them from its fp32
+ * results, the attention coefficients a1/a2 still come from the fp32 values in the GEMM epilogue -- and fc1/fc2 stay
+ * on the fp32 MFMA. */
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64);
 
 /* ---- batch entry points ---------------------------------------------------------------

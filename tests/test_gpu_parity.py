@@ -690,5 +690,9 @@ def test_random_frame_shapes_vs_oracle(preset, n):
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
-    assert rep['clusters_equal'] + rep['explained'] + rep['graphless'] == n and rep['clusters_equal'] >= n // 3
+    assert rep['clusters_equal'] + rep['explained'] + rep['graphless'] == n
+    # measured (profiles/r02_shape_fuzz.json, r03): every frame with a graph equal, at most one explained by the deciding-gap
+    # rule per few hundred frames; a regression to "mostly explained" must fail
+    with_graph = n - rep['graphless']
+    assert rep['explained'] <= max(2, with_graph // 25), rep
     assert rep['native_packer_same_bits']

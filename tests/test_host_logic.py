@@ -556,3 +556,22 @@ def test_fused_attention_window_isa(tmp_path):
             for m in re.finditer(r'v\[(\d+):(\d+)\]', l):          # address pairs of the pieces must not be a destination
                 assert not any(int(m.group(1)) <= d <= int(m.group(2)) for d in dst), (k, l, dst)
         assert not re.search(r'scratch_|buffer_(load|store)', body), (k, 'scratch access in the kernel')
+
+
+def test_eisel_lemire_against_strtod(tmp_path):
+    """csrc/el_double.h (the exact decimal -> binary64 conversion the device-side JSON parser uses) built for the host
+    and run against glibc strtod on two million tokens: pixel-coordinate doubles in 17- and 15-digit form, random
+    full-range doubles, 19-digit significands with exponents around the table range, near-halfway cases, fixed
+    edge cases.  Every token the fast path ACCEPTS must give strtod's bits; declined tokens go to the host."""
+    import shutil
+    import subprocess
+    gxx = shutil.which('g++')
+    if not gxx:
+        pytest.skip('g++ not available')
+    exe = str(tmp_path / 'el_double_test')
+    subprocess.run([gxx, '-O2', '-I', os.path.join(ROOT, '3d_multi_pose_estimator_amd', 'csrc'),
+                    os.path.join(ROOT, 'tests', 'native', 'el_double_test.cpp'), '-o', exe], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe, '350000'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r'tested (\d+) declined (\d+) bad (\d+)', r.stdout)
+    assert m and int(m.group(3)) == 0 and int(m.group(1)) > 2000000 and int(m.group(2)) < int(m.group(1)) // 2
