@@ -712,21 +712,28 @@ struct mpe_json_index {
     bool done = false, failed = false, stop = false;
     std::string err;
     // Speculative parallel scan.  The serial scan (6-8 GB/s) was the ceiling of the JSON path once the second
-    // level moved to the device.  The document is cut at P - 1 guessed frame boundaries (the byte pattern that
-    // closes a camera entry and a frame and opens the next: `]]}, {"`, else `}, {"`); part k > 0 is scanned by its
-    // own thread from its guess as if it were at the top level.  The scanner of part k - 1 VERIFIES the guess when
-    // it gets there: arriving at that '{' between frames (depth 0) it stops and part k's frames follow; arriving
-    // at any other depth the guess was wrong (e.g. inside the ground-truth lists), part k's frames are dropped and
-    // the scanner goes on through part k's range.  The published sequence is therefore exactly the serial
-    // one; a bad guess only costs speed.
+    // level moved to the device.  The document is cut into parts of ~16 MB at guessed frame boundaries (the byte
+    // pattern that closes a camera entry and a frame and opens the next: `]]}, {"`, else `}, {"`); helper threads take
+    // the parts IN ORDER and scan each from its guess as if it were at the top level.  The scanner of the part before
+    // VERIFIES the guess when it gets there: arriving at that '{' between frames (depth 0) it stops and the part's
+    // frames follow; arriving at any other depth the guess was wrong (e.g. inside the ground-truth lists), the part's
+    // frames are dropped and the scanner goes on through its range.  The published sequence is therefore exactly the
+    // serial one; a bad guess only costs speed.  Parts are small and taken in order so that the FRONT of the document
+    // is known at P times the serial rate too: a streaming reader (Engine.stream_json) consumes windows from the
+    // front, and with P contiguous quarters its first quarter arrived at the serial rate (measured: the first 11 of 48
+    // windows 6-9 ms apart, the rest 5.65 ms).
     struct Part {
         FrameScanner sc;
         const char *open = nullptr;
-        std::thread th;
         bool ok = true;
+        bool fin = false;                     // guarded by pmu
     };
     std::vector<std::unique_ptr<Part>> parts;
+    std::vector<std::thread> helpers;
+    std::atomic<size_t> next_part{0};
     std::atomic<bool> abort_parts{false};
+    std::mutex pmu;
+    std::condition_variable pcv;
 
     bool scanning() {
         std::lock_guard<std::mutex> lk(mu);
@@ -736,16 +743,24 @@ struct mpe_json_index {
     void plan_parts(const char *b, const char *e, int P) {
         const size_t len = (size_t)(e - b);
         if (P < 2 || len < ((size_t)4 << 20) || sc.single) return;
+        size_t chunk = (size_t)16 << 20;
+        if (const char *ev = getenv("MPE_SCAN_CHUNK_KB")) {
+            const long v = atol(ev);
+            if (v >= 64) chunk = (size_t)v << 10;
+        }
+        size_t n = len / chunk;
+        if (n < (size_t)P) n = (size_t)P;
+        chunk = len / n;
         std::vector<const char *> opens;
-        for (int k = 1; k < P; ++k) {
-            const char *from = b + len / (size_t)P * (size_t)k;
-            const size_t reach = len / (size_t)P / 2;
+        for (size_t k = 1; k < n; ++k) {
+            const char *from = b + chunk * k;
+            const size_t reach = chunk / 2;
             const char *open = nullptr;
-            const char *hit = static_cast<const char *>(memmem(from, (size_t)(e - from), "]]}, {\"", 7));
-            if (hit && (size_t)(hit - from) < reach) open = hit + 5;
+            const char *hit = static_cast<const char *>(memmem(from, reach + 7 < (size_t)(e - from) ? reach + 7 : (size_t)(e - from), "]]}, {\"", 7));
+            if (hit) open = hit + 5;
             else {
-                hit = static_cast<const char *>(memmem(from, (size_t)(e - from), "}, {\"", 5));
-                if (hit && (size_t)(hit - from) < reach) open = hit + 3;
+                hit = static_cast<const char *>(memmem(from, reach + 5 < (size_t)(e - from) ? reach + 5 : (size_t)(e - from), "}, {\"", 5));
+                if (hit) open = hit + 3;
             }
             if (open && (opens.empty() || open > opens.back())) opens.push_back(open);
         }
@@ -757,14 +772,24 @@ struct mpe_json_index {
             pt->sc.begin_at(b, opens[k], e);
             pt->sc.stops.assign(opens.begin() + (long)k + 1, opens.end());
         }
-        for (auto &up : parts) {
-            Part *pt = up.get();
-            pt->th = std::thread([this, pt] {
-                while (!pt->sc.finished && !abort_parts.load()) {
-                    if (!pt->sc.extend(pt->sc.ext.size() + 256)) {       // malformed FROM THIS GUESS: decided by the verifier
-                        pt->ok = false;
-                        return;
+        const int n_helpers = (int)parts.size() < P - 1 ? (int)parts.size() : P - 1;
+        for (int h = 0; h < n_helpers; ++h) {
+            helpers.emplace_back([this] {
+                for (;;) {
+                    const size_t k = next_part.fetch_add(1);
+                    if (k >= parts.size() || abort_parts.load()) return;
+                    Part *pt = parts[k].get();
+                    while (!pt->sc.finished && !abort_parts.load()) {
+                        if (!pt->sc.extend(pt->sc.ext.size() + 256)) {       // malformed FROM THIS GUESS: decided by the verifier
+                            pt->ok = false;
+                            break;
+                        }
                     }
+                    {
+                        std::lock_guard<std::mutex> lk(pmu);
+                        pt->fin = true;
+                    }
+                    pcv.notify_all();
                 }
             });
         }
@@ -789,7 +814,11 @@ struct mpe_json_index {
                     // reached a later part's guess between two frames: the guess was right, that part's frames follow
                     for (auto &up : parts)
                         if (up->open == cur->met_at) {
-                            if (up->th.joinable()) up->th.join();
+                            {
+                                std::unique_lock<std::mutex> lk(pmu);
+                                pcv.wait(lk, [&] { return up->fin || abort_parts.load(); });
+                            }
+                            if (abort_parts.load()) return;
                             if (!up->ok) e2 = up->sc.err;              // malformed from a verified boundary on
                             else {
                                 cur = &up->sc;
@@ -831,10 +860,14 @@ struct mpe_json_index {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
         }
-        abort_parts = true;
+        {
+            std::lock_guard<std::mutex> lk(pmu);
+            abort_parts = true;
+        }
+        pcv.notify_all();
         if (th.joinable()) th.join();
-        for (auto &pt : parts)
-            if (pt && pt->th.joinable()) pt->th.join();
+        for (auto &h : helpers)
+            if (h.joinable()) h.join();
     }
 };
 
@@ -1164,6 +1197,7 @@ int mpe_json_stage_window(mpe_json_index *ix, const char *const *camera_names, i
         return MPE_ERR_INVALID;
     }
     std::vector<std::string> cams(camera_names, camera_names + n_cameras);
+    const auto tt0 = std::chrono::steady_clock::now();
     // the window's frame extents (the background scan publishes them in order)
     std::vector<std::pair<const char *, const char *>> sel;
     for (int i = 0; i < max_frames; ++i) {
@@ -1178,6 +1212,7 @@ int mpe_json_stage_window(mpe_json_index *ix, const char *const *camera_names, i
         sel.push_back(ext);
     }
     const int B = (int)sel.size();
+    const auto tt1 = std::chrono::steady_clock::now();
     std::vector<std::vector<StrExtent>> per((size_t)B);
     std::vector<std::string> errs((size_t)B);
     std::atomic<int> next{0};
@@ -1220,6 +1255,7 @@ int mpe_json_stage_window(mpe_json_index *ix, const char *const *camera_names, i
         g_pack_error = "mpe_json_stage_window: a frame needs the host parser (skeleton list not a string, or more camera entries than cameras)";
         return MPE_ERR_UNSUPPORTED;
     }
+    const auto tt2 = std::chrono::steady_clock::now();
     // text offsets (16-byte aligned strings), entry table
     size_t off = 0;
     int ne = 0;
@@ -1249,6 +1285,12 @@ int mpe_json_stage_window(mpe_json_index *ix, const char *const *camera_names, i
             ++k;
         }
     });
+    if (getenv("MPE_STAGE_TIMING")) {
+        const auto tt3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "stage window: %d threads | frame extents %.2f ms | first level %.2f ms | layout + copy %.2f ms\n", nt, ms(tt0, tt1),
+                ms(tt1, tt2), ms(tt2, tt3));
+    }
     *n_frames = B;
     *n_entries = ne;
     *text_bytes = off;

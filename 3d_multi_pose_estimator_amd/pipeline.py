@@ -139,7 +139,9 @@ class Engine:
         page-locked memory.  Yields (PackedBatch view, poses [B,Pcap,J,3], n_persons [B]) per chunk.
         LIFETIME: the yielded view and arrays are valid until the next `next()` on the generator only --
         resuming it starts the parse of a later chunk into the arena behind the view (two host arenas)
-        and the result arrays of the slot are rewritten one chunk after that.  Copy what you keep.
+        and the result arrays of the slot are rewritten one chunk after that.  With the device parser the
+        page-locked result buffers belong to the ENGINE (kept across calls: pinning them costs more than a
+        window), so arrays from an earlier call are rewritten by the next call as well.  Copy what you keep.
 
         parser = 'device' (default): the host keeps the first level of the format only (frame extents, camera
         keys, the extent of every skeleton STRING: stage_json_window) and the strings are parsed ON THE DEVICE
@@ -214,23 +216,30 @@ class Engine:
 
     def _stream_json_device(self, text, B, mode, frame_step, n_threads):
         from concurrent.futures import ThreadPoolExecutor
+        import time
+        t_call = time.perf_counter()
         H = B * self.hpf
-        # page-locked staging and the device arenas are kept with the engine: allocating and pinning ~150 MB per call
-        # cost more than parsing a few windows
+        # page-locked staging, the device arenas, the page-locked result buffers and the streams are kept with the engine:
+        # allocating and pinning ~150 MB per call cost more than parsing a few windows
         cache = self.__dict__.setdefault('_json_bufs', {})
         if B not in cache:
-            cache[B] = ([self.json_device_buffers(B) for _ in range(2)], {})
-        bufs, fb = cache[B]                                 # fb: host-packer fallback buffers, made on first use
+            # s_parse has high priority: the few small parse kernels must not queue behind every large GEMM launch of the
+            # chunk that is computing
+            cache[B] = ([self.json_device_buffers(B) for _ in range(2)], {}, {},
+                        (torch.cuda.Stream(self.device, priority=-1), torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)))
+        bufs, fb, outs, (s_parse, s_m, s_d) = cache[B]      # fb: host-packer fallback buffers, made on first use
         out_dt = torch.float32 if mode == 'mlp' else torch.float64
-        out = [(torch.empty((B, self.pcap, self.J, 3), dtype=out_dt).pin_memory(),
-                torch.empty((B,), dtype=torch.int32).pin_memory()) for _ in range(2)]
+        if mode not in outs:
+            outs[mode] = [(torch.empty((B, self.pcap, self.J, 3), dtype=out_dt).pin_memory(),
+                           torch.empty((B,), dtype=torch.int32).pin_memory()) for _ in range(2)]
+        out = outs[mode]
         done = [None, None]
         cur = torch.cuda.current_stream(self.device)
-        # high priority: the few small parse kernels must not queue behind every large GEMM launch of the chunk that is computing
-        s_parse = torch.cuda.Stream(self.device, priority=-1)
-        s_m, s_d = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+        for s_ in (s_parse, s_m, s_d):
+            s_.wait_stream(cur)
         pool = ThreadPoolExecutor(1)
         index = JsonIndex(text)
+        t_setup = time.perf_counter() - t_call
 
         def stage(i):
             try:
@@ -264,7 +273,6 @@ class Engine:
             cur.synchronize()                                  # the pinned arena is free again (rare path)
             return db
         import os
-        import time
         timing = [] if os.environ.get('MPE_JSON_TIMING') else None
         gpu_ev = []
         # Copy engines serve their requests in order: a D2H of results queued behind the kernels of chunk i-1 would hold up
@@ -379,6 +387,8 @@ class Engine:
             if timing and len(timing) > 2:
                 import sys
                 m = np.array(timing[1:]).mean(axis=0) * 1e3
+                print('stream_json(device): buffers, streams and the frame index ready after %.2f ms; first window staged after %.2f ms'
+                      % (1e3 * t_setup, 1e3 * timing[0][0] + 1e3 * t_setup), file=sys.stderr)
                 print('stream_json(device) per window, ms: wait staging %.2f | queue parse %.2f | wait parse %.2f | launch compute %.2f | '
                       'wait previous results %.2f' % tuple(m), file=sys.stderr)
                 worst = np.array(timing[1:]).max(axis=0) * 1e3

@@ -453,8 +453,11 @@ def test_parallel_frame_scan_equals_serial_scan(calib, monkeypatch):
             ix.close()
     ref = windows(1, text)
     assert sum(w[0] for w in ref) == len(base) * 8
-    for threads in (2, 4, 7):
+    for threads, chunk_kb in ((2, None), (4, None), (7, None), (3, 256), (4, 64)):      # few large parts; many small ones taken in order
+        if chunk_kb:
+            monkeypatch.setenv('MPE_SCAN_CHUNK_KB', str(chunk_kb))
         got = windows(threads, text)
+        monkeypatch.delenv('MPE_SCAN_CHUNK_KB', raising=False)
         assert len(got) == len(ref)
         for a, b in zip(ref, got):
             assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])

@@ -21,7 +21,16 @@ eng.load_mlp(syn.mlp_state_dict(11, 1260))
 sum(len(nn) for _, _, nn in eng.stream_json(warm, chunk_frames=chunk, parser=parser))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-got = sum(len(nn) for _, _, nn in eng.stream_json(text, chunk_frames=chunk, parser=parser))
+got, stamps = 0, []
+for _, _, nn in eng.stream_json(text, chunk_frames=chunk, parser=parser):
+    got += len(nn)
+    stamps.append(time.perf_counter() - t0)
+t_last = time.perf_counter() - t0
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+if os.environ.get('MPE_JSON_TIMING'):
+    gaps = [b - a for a, b in zip(stamps, stamps[1:])]
+    print('first window out after %.2f ms; between windows: median %.2f ms, slowest %.2f ms; after the last window %.2f ms'
+          % (1e3 * stamps[0], 1e3 * sorted(gaps)[len(gaps) // 2], 1e3 * max(gaps), 1e3 * (dt - stamps[-1])))
+    print('gaps, ms: ' + ' '.join('%.1f' % (1e3 * g) for g in gaps))
 print('%s parser: %d frames, %.1f frames/s, %.2f ms per %d-frame window, %.2f GB/s of JSON' % (parser, got, got / dt, 1e3 * dt / (n // chunk), chunk, len(text) / dt / 1e9))
