@@ -418,7 +418,7 @@ def run_rank(args):
     if rank == 0:
         out['roofline'] = roofline(args, prof, elapsed, total, world, V, J, args.persons, reduced)
         # the CPU baseline and the parity sample are taken on rank 0 at N = 1 only
-        base, par_ = (None, None) if distributed else cpu_baseline_and_parity(args, np, torch, calib, params, lo, device)
+        base, par_ = (None, None) if world > 1 else cpu_baseline_and_parity(args, np, torch, calib, params, lo, device)
         out['cpu_baseline'] = base
         out['parity'] = par_
         print(json.dumps(out), flush=True)
