@@ -354,6 +354,23 @@ def run_rank(args):
 
     elapsed, (poses, n_persons) = timed(lambda i: step(), args.steps)
 
+    # the exchange once more, checked: every rank finds its own shard, bit for bit, at its place in what it received
+    gathered_ok = None
+    if distributed:
+        for s_ in (s_match, s_3d):
+            if s_ is not None:
+                torch.cuda.current_stream(device).wait_stream(s_)
+        gp, gn = gather(poses, n_persons)
+        mine = slice(rank * cap, rank * cap + B)
+        ok = bool(torch.equal(gn[mine], n_persons[:B]))
+        if ok and B:
+            live = torch.arange(poses.shape[1], device=device)[None, :] < n_persons[:B, None].to(torch.int64)
+            bits = torch.int32 if poses.dtype == torch.float32 else torch.int64          # NaN joints (DLT) compare as bits
+            ok = bool(torch.equal(gp[mine][live].contiguous().view(bits), poses[:B][live].contiguous().view(bits)))
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        gathered_ok = bool(t.item())
+
     # ---- kernel-level pass: one stream, HIP event pairs around the GEMM launches of every n-th step ----
     prof = None
     if not args.no_profile and args.profile_steps > 0:
@@ -403,6 +420,7 @@ def run_rank(args):
                    'heads_per_batch': pb.n_heads, 'edge_nodes_per_batch': pb.n_edge_nodes,
                    'persons_found_per_frame': persons_per_frame, 'parallelism': 'frame-shard x%d' % world,
                    'world_size_seen': dist.get_world_size() if distributed else 1,
+                   'gathered_equal_local': gathered_ok,
                    'backend': (args.backend + (' (RCCL)' if args.backend == 'nccl' else '')) if distributed else None,
                    'launcher': 'bench.py spawn' if os.environ.get('MPE_BENCH_SPAWNED') else ('torchrun' if distributed else 'single'),
                    'inputs': 'value: packed 2D skeletons resident in HBM, poses left in HBM (bench contract); '

@@ -49,6 +49,8 @@ def test_rank_body_under_a_forced_process_group_matches_the_plain_run():
         assert d['parity']['clusters_exact_frac'] == 1.0 and d['parity']['sample_frames'] == 4
     assert plain['config']['backend'] is None and plain['config']['world_size_seen'] == 1
     assert forced['config']['backend'] == 'nccl (RCCL)' and forced['config']['world_size_seen'] == 1
+    # the rank body gathers once more after the timed region and compares its own shard inside what it received
+    assert plain['config']['gathered_equal_local'] is None and forced['config']['gathered_equal_local'] is True
     # the all-gather of 256 frames of poses is microseconds of a ~1.5 ms step; a forced group that serialised or
     # re-synchronised the step would show as a large drop
     assert forced['value'] >= 0.8 * plain['value'], (forced['value'], plain['value'])
