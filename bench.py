@@ -59,7 +59,7 @@ PKG = '3d_multi_pose_estimator_amd'
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_HBM_TBS = 8.0
-TRAFFIC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+TRAFFIC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
 def parse_args(argv=None):
@@ -536,7 +536,9 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
     flop_per_step = prof['gemm_flop'] / sampled
     step_tf = flop_per_step / (elapsed / args.steps) / 1e12      # per GPU: every rank runs its own shard
     return {
-        'kernel': 'mpe::k_linear_dma (fp32 MFMA 16x16x4 GEMM; K stages by LDS-DMA from loader waves, fused bias + LeakyReLU)',
+        'kernel': 'mpe::k_linear_dma (fp32 MFMA 16x16x4 GEMM; K stages by LDS-DMA from loader waves, fused bias + LeakyReLU); the '
+                  'launches counted are ALL mpe_linear launches of a step: 17 of k_linear_dma + the two narrow outputs of the last '
+                  'GAT layer on k_linear_skinny / k_linear_skinny_ks (0.07 ms of 4.7 ms); compare with rocprofv3 over k_linear*',
         'bound': 'mfma',
         'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': src,

@@ -38,8 +38,8 @@ import csv, json
 for tag in ('default', 'streams1'):
     d = json.load(open('$O/bench_%s_under_rocprof.json' % tag)); r = d['roofline']
     rows = list(csv.DictReader(open('$O/stats%s/run_kernel_stats.csv' % ('2' if tag == 'default' else '1'))))
-    g = [x for x in rows if 'k_linear_dma' in x['Name']]
-    print(tag, 'under rocprof: value', round(d['value'], 1), '| live HIP events: GEMM avg launch', round(r['avg_launch_ms'], 5), 'ms | rocprof k_linear_dma avg',
+    g = [x for x in rows if 'k_linear' in x['Name']]
+    print(tag, 'under rocprof: value', round(d['value'], 1), '| live HIP events: GEMM avg launch', round(r['avg_launch_ms'], 5), 'ms | rocprof k_linear_* avg',
           round(sum(float(x['TotalDurationNs']) for x in g) / sum(int(x['Calls']) for x in g) / 1e6, 5), 'ms over', sum(int(x['Calls']) for x in g), 'launches')
 PY
 fi
