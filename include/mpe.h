@@ -117,7 +117,7 @@ int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_d
 /* Accumulation mode of the fp32 MFMA GEMMs.  0 = one fp32 MFMA chain over the whole K
  * (fastest); 1 = every 32-deep K stage is flushed into f64 running sums, so a dot product
  * carries about one rounding, like a blocked CPU sgemm.  Defaults: GAT 0, MLP 1 (the MLP's
- * K is up to 3072 and its 3D output is held to the 1e-3 mm parity bound).  MLP mode 2 is the
+ * K is up to 3072 and its 3D output is compared with the reference at the micrometre level: DESIGN.md section 5).  MLP mode 2 is the
  * reduced-precision variant of BASELINE.json configs[4]: weights and staged activations in
  * bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~3 significant digits; not parity).
  * GAT mode 2 is the other half of that config: fc1/fc2 on the bf16 MFMA and the transformed

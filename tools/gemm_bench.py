@@ -25,7 +25,7 @@ for m, k, n, name in shapes:
         def run():
             eng._chk(eng.lib.mpe_linear(eng.ctx, eng._stream(), C.c_void_p(x.data_ptr()), ldw.value, dw, ldw.value, db,
                                         C.c_void_p(y.data_ptr()), ldc, m, None, n, k, flags, 0.1))
-        for _ in range(3): run()
+        for _ in range(3 if flags & 2 else 40): run()          # the first launches of a process see the clock still ramping
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 10
