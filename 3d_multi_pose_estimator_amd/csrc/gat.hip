@@ -1139,6 +1139,12 @@ static int agg_vec(const AggArgs &a) {
     return 1;
 }
 
+// fp16 rows in the general kernels: 8 columns per thread (one 16-byte load) or 4 (8-byte loads, twice the threads per row)
+static bool half_vec8() {
+    static const bool v = !(getenv("MPE_HALF_VEC") && atoi(getenv("MPE_HALF_VEC")) == 4);
+    return v;
+}
+
 constexpr size_t FUSED_LDS_LIMIT = 160 * 1024;      // all of a CU's LDS (one workgroup per CU at the limit)
 
 hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
@@ -1209,7 +1215,7 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
         const int hd4 = (a.heads * a.out_dim + 3) / 4 * 4;
         const bool wide = !a.score_mode && !a.ft_half && a.ld % 4 == 0 && a.ld_out % 4 == 0 && hd4 <= a.ld && hd4 <= a.ld_out &&
                           !a.en_const_ft2;
-        if (vec == 4 && a.ft_half && a.out_dim % 8 == 0) MPE_EN(8);    // fp16 rows: 8 columns = one 16-byte load
+        if (vec == 4 && a.ft_half && a.out_dim % 8 == 0 && half_vec8()) MPE_EN(8);    // fp16 rows: 8 columns = one 16-byte load
         else if (vec == 4 || wide) MPE_EN(4);
         else if (vec == 2) MPE_EN(2);
         else MPE_EN(1);
@@ -1238,7 +1244,7 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
     hipLaunchKernelGGL(k_aggregate_heads<V_>, dim3(grid), dim3(256), shm, s, b.n_heads, V, max_deg,         \
                        b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a, head_src,       \
                        max_heads_per_frame + 1)
-        if (vec == 4 && a.ft_half && a.out_dim % 8 == 0) MPE_HEADS(8);
+        if (vec == 4 && a.ft_half && a.out_dim % 8 == 0 && half_vec8()) MPE_HEADS(8);
         else if (vec == 4) MPE_HEADS(4);
         else if (vec == 2) MPE_HEADS(2);
         else MPE_HEADS(1);

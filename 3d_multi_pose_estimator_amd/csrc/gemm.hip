@@ -442,6 +442,42 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
                                                // is done reading the other buffer
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const int cur = (kt & 1) * STAGE;
+        if (tune_prio & 16) {
+            // EXPERIMENT: weight fragments one step ahead in registers.  The compiler's own schedule of the loop below
+            // reads one weight fragment, waits for it (lgkmcnt(0)), issues its 8 MFMAs, reads the next: every fragment's
+            // LDS latency is exposed to this wave.  Here fragment nt + 1 (and the first one of the second half, with
+            // its activation fragments) is requested BEFORE the MFMAs of fragment nt; the sched_barrier keeps the
+            // request above them.  Per accumulator the order of the k steps is unchanged: same bits.
+            f32x4 af[MT], wf_cur;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + c0]);
+            wf_cur = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[0] + c0]);
+#pragma unroll
+            for (int st = 0; st < 2 * NTT; ++st) {
+                const int nt = st % NTT, hh = st / NTT;
+                f32x4 wf_nxt = wf_cur, af_nxt[MT];
+                const bool more = st + 1 < 2 * NTT;
+                const bool flip = more && nt + 1 == NTT;               // the next step starts the second half
+                if (more) wf_nxt = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[(st + 1) % NTT] + ((st + 1) / NTT ? c1 : c0)]);
+                if (flip) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) af_nxt[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + c1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf_cur[s], af[mt][s], acc[nt][mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                wf_cur = wf_nxt;
+                if (flip) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) af[mt] = af_nxt[mt];
+                }
+                (void)hh;
+            }
+        } else {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int co = hh ? c1 : c0;
@@ -457,6 +493,7 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
+        }
         }
         if (ACC64) {
 #pragma unroll

@@ -216,6 +216,7 @@ class Engine:
 
     def _stream_json_device(self, text, B, mode, frame_step, n_threads):
         from concurrent.futures import ThreadPoolExecutor
+        import os
         import time
         t_call = time.perf_counter()
         H = B * self.hpf
@@ -226,8 +227,17 @@ class Engine:
             # s_parse has high priority: the few small parse kernels must not queue behind every large GEMM launch of the
             # chunk that is computing
             cache[B] = ([self.json_device_buffers(B) for _ in range(2)], {}, {},
-                        (torch.cuda.Stream(self.device, priority=-1), torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)))
+                        (torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_PARSE_PRIO', '-1'))),
+                         torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_COMPUTE_PRIO', '0'))),
+                         torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_COMPUTE_PRIO', '0')))))
         bufs, fb, outs, (s_parse, s_m, s_d) = cache[B]      # fb: host-packer fallback buffers, made on first use
+        if os.environ.get('MPE_JSON_STREAMS', '1') == '1':
+            # ONE compute stream beside the parse stream.  Measured (48 windows of 1000 frames): with the matching of
+            # window i+1 overlapping the 3D stage of window i on a second compute stream -- what run_pipelined does for
+            # resident batches -- the parse kernels, the H2D and two compute streams share the CUs three ways and a window
+            # takes 6.1-6.5 ms; with one compute stream 5.55-5.75 ms (whether two torch streams overlap at all depends on
+            # which hardware queues HIP maps them to: alone in a process they happened to share one, inside bench.py not)
+            s_d = s_m
         out_dt = torch.float32 if mode == 'mlp' else torch.float64
         if mode not in outs:
             outs[mode] = [(torch.empty((B, self.pcap, self.J, 3), dtype=out_dt).pin_memory(),
@@ -272,7 +282,6 @@ class Engine:
             fb['dev'][k].buf.copy_(fb['host'].buf, non_blocking=True)
             cur.synchronize()                                  # the pinned arena is free again (rare path)
             return db
-        import os
         timing = [] if os.environ.get('MPE_JSON_TIMING') else None
         gpu_ev = []
         # Copy engines serve their requests in order: a D2H of results queued behind the kernels of chunk i-1 would hold up

@@ -397,7 +397,7 @@ def run_rank(args):
     if not args.no_io:
         io = io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, timed, distributed, total)
     jsn = None
-    if not args.no_io and args.json_steps > 0 and not distributed:
+    if (not args.no_io or os.environ.get('MPE_BENCH_JSON_WITHOUT_IO')) and args.json_steps > 0 and not distributed:
         jsn = json_inclusive(args, torch, eng, wire, B, uniq)
 
     persons_per_frame = float(n_persons.float().mean().item()) if B else 0.0
@@ -576,11 +576,14 @@ def json_inclusive(args, torch, eng, wire, B, uniq):
     mode = args.mode
     assert sum(len(n) for _, _, n in eng.stream_json(warm, chunk_frames=B, mode=mode)) == 2 * B
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    got = sum(len(n) for _, _, n in eng.stream_json(text, chunk_frames=B, mode=mode))
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert got == n_steps * B
+    for rep in range(int(os.environ.get('MPE_BENCH_JSON_REPEAT', '1'))):        # > 1: diagnostics (each repeat on stderr), the last one counts
+        t0 = time.perf_counter()
+        got = sum(len(n) for _, _, n in eng.stream_json(text, chunk_frames=B, mode=mode))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert got == n_steps * B
+        if os.environ.get('MPE_BENCH_JSON_REPEAT'):
+            print('json_inclusive repeat %d: %.1f frames/s' % (rep, got / dt), file=sys.stderr)
     threads = usable_cpus()
     return {'value': got / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / n_steps, 'steps': n_steps,
             'json_bytes_per_step': len(text) // n_steps, 'json_gb_per_s': len(text) / dt / 1e9, 'host_threads_available': threads,
