@@ -12,6 +12,11 @@ LIB_PATH = os.path.join(_HERE, 'libmpe_hip.so')
 if os.environ.get('MPE_LIB_VARIANT'):      # diagnostics: an experiment build beside the product library (csrc/Makefile `exp`)
     LIB_PATH = os.path.join(_HERE, 'libmpe_hip_%s.so' % os.environ['MPE_LIB_VARIANT'])
 
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The engine's pipelines keep 3-4 streams busy
+# (parse / copy / matching / 3D) beside whatever the application has; two of them on one queue serialise (pipeline.py:
+# _make_json_streams has the measurement).  Effective only if HIP has not initialised yet; an explicit setting wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 MPE_MAX_CAMERAS = 32
 MPE_MAX_JOINTS = 32
 MPE_ERR_UNSUPPORTED = -6

@@ -5,6 +5,7 @@ PyTorch is plumbing here (device memory, current stream); every computation on t
 a HIP kernel behind the C ABI of include/mpe.h.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -74,11 +75,64 @@ class Engine:
             raise L.MpeError(rc, 'mpe_create failed')
         self.gat_dims = None
         self.mlp_out = None
+        self._made_with = dict(params=self.params, calib=self.calib, max_frames=self.max_frames, max_heads_per_frame=self.hpf,
+                               max_persons_per_camera=max_persons_per_camera, device=str(self.device), threshold=threshold)
+        self._state = {}                 # what was loaded / set, so that sibling() can repeat it
+        self._siblings = []
+        self._json_streams = None
+        if os.environ.get('MPE_JSON_STREAMS_EARLY', '0') == '1':           # diagnostics (see _make_json_streams)
+            self._make_json_streams()
+
+    def _make_json_streams(self):
+        """The three streams of the JSON pipeline (parse; matching / 3D compute), made at the first stream_json call.
+        Compute at high priority, parse at normal: the parse kernels of window i+1 take the slots the GEMMs of window i
+        leave.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); with the 6-9 streams of
+        an application that also pipelines its copies, the parse stream and the compute stream can land on one queue
+        and then serialise (measured inside bench.py: 145-159 k or 171 k frames/s depending on the order in which streams
+        were first used).  lib.py therefore asks for 8 hardware queues (GPU_MAX_HW_QUEUES=8, only if the variable is not
+        set and before HIP initialises): 170.5-170.7 k in 5 of 5 runs."""
+        if self._json_streams is None:
+            self._json_streams = (torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_PARSE_PRIO', '0'))),
+                                  torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_COMPUTE_PRIO', '-1'))),
+                                  torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_COMPUTE_PRIO', '-1'))))
+            for s_ in self._json_streams:
+                with torch.cuda.stream(s_):
+                    torch.zeros(8, device=self.device).add_(1)
+        return self._json_streams
 
     def close(self):
+        for e in getattr(self, '_siblings', []):
+            e.close()
+        self._siblings = []
         if getattr(self, 'ctx', None):
             self.lib.mpe_destroy(self.ctx)
             self.ctx = None
+
+    def sibling(self, k=1):
+        """The k-th further context with the same configuration, weights, precision mode and threshold (own workspace,
+        124 MB of weights again).  A context is one dependent chain of ~45 kernels per batch; two contexts that take
+        turns on the batches (run_pipelined(contexts=2), stream_json(contexts=2), bench.py) keep two such chains in
+        flight and fill each other's launch tails: 195.6 k against 186-189 k frames/s for one context with its two stages
+        on two streams (tools/two_engines.py, MPE_ALTERNATE=1).  Results are bit-identical: same kernels, same data."""
+        while len(self._siblings) < k:
+            e = Engine(**self._made_with)
+            st = self._state
+            if 'gat' in st:
+                e.load_gat(*st['gat'])
+            if 'mlp' in st:
+                e.load_mlp(*st['mlp'])
+            if 'precision' in st:
+                e.set_precision(*st['precision'])
+            if 'threshold' in st:
+                e.set_threshold(st['threshold'])
+            if 'gat_output' in st:
+                e.set_gat_output(st['gat_output'])
+            self._siblings.append(e)
+        return self._siblings[k - 1]
+
+    def contexts(self, n):
+        """[self, sibling(1), ..., sibling(n - 1)]"""
+        return [self] + [self.sibling(k) for k in range(1, int(n))]
 
     def __del__(self):
         try:
@@ -94,6 +148,9 @@ class Engine:
         """state_dict: reference names ``layers.{l}.{fc1,fc2}.{weight,bias}``, ``attn_l/r``
         (numpy or torch); prm: contents of skeleton_matching.prms."""
         sd = {k: _np32(v) for k, v in state_dict.items()}
+        self._state['gat'] = (sd, prm)
+        for e in self._siblings:
+            e.load_gat(sd, prm)
         n_layers = int(prm['gnn_layers'])
         heads = list(prm['heads']) + [1]
         slope = prm.get('nonlinearity', 0.01)
@@ -115,6 +172,9 @@ class Engine:
 
     def load_mlp(self, state_dict, slope=0.1):
         sd = {k: _np32(v) for k, v in state_dict.items()}
+        self._state['mlp'] = (sd, slope)
+        for e in self._siblings:
+            e.load_mlp(sd, slope)
         keys = sorted({int(k.split('.')[1]) for k in sd})
         self._chk(self.lib.mpe_set_mlp_params(self.ctx, len(keys), float(slope)))
         for n, k in enumerate(keys):
@@ -131,7 +191,7 @@ class Engine:
         """Native (C++) packer: JSON text of a list of frames -> PackedBatch."""
         return pack_json(text, self.params, frame_start, frame_step, max_frames, n_threads)
 
-    def stream_json(self, text, chunk_frames=None, mode='mlp', frame_step=1, n_threads=0, parser='device'):
+    def stream_json(self, text, chunk_frames=None, mode='mlp', frame_step=1, n_threads=0, parser='device', contexts=1):
         """Frame JSON (bytes, the reference's wire format) -> 3D poses, chunk by chunk, with the
         host side off the critical path: the native packer parses chunk i+1 straight into a
         page-locked arena (worker thread; the C call releases the GIL) while chunk i is copied to
@@ -148,7 +208,8 @@ class Engine:
         (csrc/jsonparse.hip) on a side stream while the previous chunk computes; the first element yielded is
         then a ParsedOnDevice (n_frames, n_heads, ...; `.download()` for the arrays).  A chunk holding a shape
         the device parser leaves to the host (literals, nested values, numbers beyond the exact fast path)
-        is packed by the host packer instead -- same arrays either way.  parser = 'host': the round-2 path."""
+        is packed by the host packer instead -- same arrays either way.  parser = 'host': the round-2 path.
+        contexts = 2 (device parser only): windows take turns on two contexts (sibling()), two windows in flight."""
         from concurrent.futures import ThreadPoolExecutor
         if isinstance(text, str):
             text = text.encode()
@@ -156,7 +217,7 @@ class Engine:
         if B > self.max_frames:
             raise ValueError('chunk of %d frames exceeds max_frames=%d' % (B, self.max_frames))
         if parser == 'device':
-            yield from self._stream_json_device(text, B, mode, frame_step, n_threads)
+            yield from self._stream_json_device(text, B, mode, frame_step, n_threads, contexts)
             return
         H = B * self.hpf
         host = [CapacityArena(self.V, self.J, B, H, 'pinned') for _ in range(2)]
@@ -214,7 +275,7 @@ class Engine:
             pool.shutdown(wait=True)
             index.close()
 
-    def _stream_json_device(self, text, B, mode, frame_step, n_threads):
+    def _stream_json_device(self, text, B, mode, frame_step, n_threads, contexts=1):
         from concurrent.futures import ThreadPoolExecutor
         import os
         import time
@@ -224,20 +285,20 @@ class Engine:
         # allocating and pinning ~150 MB per call cost more than parsing a few windows
         cache = self.__dict__.setdefault('_json_bufs', {})
         if B not in cache:
-            # s_parse has high priority: the few small parse kernels must not queue behind every large GEMM launch of the
-            # chunk that is computing
-            cache[B] = ([self.json_device_buffers(B) for _ in range(2)], {}, {},
-                        (torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_PARSE_PRIO', '-1'))),
-                         torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_COMPUTE_PRIO', '0'))),
-                         torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_COMPUTE_PRIO', '0')))))
+            cache[B] = ([self.json_device_buffers(B) for _ in range(2)], {}, {}, self._make_json_streams())
         bufs, fb, outs, (s_parse, s_m, s_d) = cache[B]      # fb: host-packer fallback buffers, made on first use
-        if os.environ.get('MPE_JSON_STREAMS', '1') == '1':
-            # ONE compute stream beside the parse stream.  Measured (48 windows of 1000 frames): with the matching of
-            # window i+1 overlapping the 3D stage of window i on a second compute stream -- what run_pipelined does for
-            # resident batches -- the parse kernels, the H2D and two compute streams share the CUs three ways and a window
-            # takes 6.1-6.5 ms; with one compute stream 5.55-5.75 ms (whether two torch streams overlap at all depends on
-            # which hardware queues HIP maps them to: alone in a process they happened to share one, inside bench.py not)
-            s_d = s_m
+        K = 2 if int(contexts) >= 2 else 1                   # two window slots, so at most two contexts taking turns
+        engs = self.contexts(K)
+        if K == 2:
+            # window i on context i & 1, each context on its own stream: two windows in flight fill each other's tails
+            lanes = [(s_m, s_m), (s_d, s_d)]
+        elif os.environ.get('MPE_JSON_STREAMS', '1') == '1':
+            # ONE compute stream beside the parse stream: a second compute stream (matching of window i+1 beside the 3D stage
+            # of window i, what run_pipelined does for resident batches) measured the same or worse here -- the parse kernels
+            # already fill what the GEMMs leave
+            lanes = [(s_m, s_m), (s_m, s_m)]
+        else:
+            lanes = [(s_m, s_d), (s_m, s_d)]
         out_dt = torch.float32 if mode == 'mlp' else torch.float64
         if mode not in outs:
             outs[mode] = [(torch.empty((B, self.pcap, self.J, 3), dtype=out_dt).pin_memory(),
@@ -293,7 +354,7 @@ class Engine:
             if res[k] is None:
                 return
             poses_, n_persons_, n_ = res[k]
-            with torch.cuda.stream(s_d):                   # behind the 3D stage that produced them
+            with torch.cuda.stream(lanes[k][1]):           # behind the 3D stage that produced them
                 out[k][0][:n_].copy_(poses_, non_blocking=True)
                 out[k][1][:n_].copy_(n_persons_, non_blocking=True)
                 done[k] = torch.cuda.Event()
@@ -334,7 +395,7 @@ class Engine:
                         if db.max_heads_per_frame() > self.hpf:
                             raise ValueError('a frame holds %d skeletons, capacity is %d (raise max_persons_per_camera / '
                                              'max_heads_per_frame)' % (db.max_heads_per_frame(), self.hpf))
-                        s_m.wait_event(bufs[k]['ready'])
+                        lanes[k][0].wait_event(bufs[k]['ready'])
                 else:
                     nxt = None
                 if db is None:                                  # this window goes through the host packer
@@ -349,25 +410,26 @@ class Engine:
                 n_here = db.n_frames
                 if timing is not None:
                     ev_c0 = torch.cuda.Event(enable_timing=True)
-                    ev_c0.record(s_m)
-                # engine mode as in run_pipelined: the matching stage and the 3D stage on their own streams, so the matching
-                # of this chunk overlaps the 3D stage of the previous one
+                    ev_c0.record(lanes[k][0])
+                eng, (l_m, l_d) = engs[k % K], lanes[k]
                 if db.host is not None:
-                    s_m.wait_stream(cur)                     # host-packed window: its upload went over the caller's stream
-                with torch.cuda.stream(s_m):
-                    _, persons, n_persons = self.match(db, want_scores=False)
+                    l_m.wait_stream(cur)                     # host-packed window: its upload went over the caller's stream
+                with torch.cuda.stream(l_m):
+                    _, persons, n_persons = eng.match(db, want_scores=False)
                     ev_m = torch.cuda.Event()
                     ev_m.record()
-                with torch.cuda.stream(s_d):
-                    s_d.wait_event(ev_m)
-                    poses = (self.mlp3d(db, persons, n_persons) if mode == 'mlp' else self.triangulate(db, persons, n_persons))[0]
-                for t_ in (persons, n_persons):
-                    t_.record_stream(s_d)
+                with torch.cuda.stream(l_d):
+                    if l_d is not l_m:
+                        l_d.wait_event(ev_m)
+                    poses = (eng.mlp3d(db, persons, n_persons) if mode == 'mlp' else eng.triangulate(db, persons, n_persons))[0]
+                if l_d is not l_m:
+                    for t_ in (persons, n_persons):
+                        t_.record_stream(l_d)
                 res[k] = (poses, n_persons, n_here)
                 done[k] = None
                 if timing is not None and st is not None:
                     ev_c1 = torch.cuda.Event(enable_timing=True)
-                    ev_c1.record(s_d)
+                    ev_c1.record(l_d)
                     gpu_ev.append((ev_p0, ev_p1, ev_c0, ev_c1, bufs[k]['ev_h2d']))
                 t_e = time.perf_counter()
                 if pending is not None:
@@ -479,50 +541,61 @@ class Engine:
             if index is not text:
                 index.close()
 
-    def run_pipelined(self, batches, mode='mlp'):
-        """Batches (DeviceBatch or PackedBatch) -> (poses, n_persons, persons) per batch, in order, with
-        the two stages on their own streams: the matching stage of batch i+1 (GAT workspace) runs while
-        the 3D stage of batch i (MLP workspace / DLT) is still in flight -- the two workspaces are
-        disjoint, and concurrent kernels fill the tails of each other's dependent launch chains (+4-5 %
-        throughput at 1000-frame batches).  Results are the same bits as match() + mlp3d() / triangulate()
-        called one after the other.  Each result is yielded once its 3D stage has finished."""
-        s_match, s_3d = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+    def run_pipelined(self, batches, mode='mlp', contexts=1):
+        """Batches (DeviceBatch or PackedBatch) -> (poses, n_persons, persons) per batch, in order.
+
+        contexts == 1: the two stages on their own streams: the matching stage of batch i+1 (GAT workspace) runs while
+        the 3D stage of batch i (MLP workspace / DLT) is still in flight -- the two workspaces are disjoint, and
+        concurrent kernels fill the tails of each other's dependent launch chains (+2-5 % throughput at 1000-frame
+        batches).  contexts == K > 1: K contexts (sibling()) take turns on the batches, each on its own stream, so K whole
+        batches are in flight (195.6 k against 186-189 k frames/s at K = 2; K = 3: 194.7 k).  Either way the results are
+        the same bits as match() + mlp3d() / triangulate() called one after the other.  Each result is yielded once its
+        3D stage has finished (with K contexts: when K - 1 later batches have been queued)."""
+        K = max(1, int(contexts))
+        engs = self.contexts(K)
+        two = K == 1
+        s_match = [torch.cuda.Stream(self.device) for _ in range(K)]
+        s_3d = [torch.cuda.Stream(self.device)] if two else s_match
         cur = torch.cuda.current_stream(self.device)
-        pending = None
+        pending = []
         try:
-            for b in batches:
+            for i, b in enumerate(batches):
+                e, sm, sd = engs[i % K], s_match[i % K], s_3d[i % K]
                 db = self.to_device(b)
                 # whatever produced this batch (an upload the iterator queued on the current stream) is ordered
                 # before its matching stage -- per batch, not once in front of the loop
-                s_match.wait_stream(cur)
-                with torch.cuda.stream(s_match):
-                    _, persons, n_persons = self.match(db, want_scores=False)
+                sm.wait_stream(cur)
+                with torch.cuda.stream(sm):
+                    _, persons, n_persons = e.match(db, want_scores=False)
                     ev = torch.cuda.Event()
-                    ev.record(s_match)
-                with torch.cuda.stream(s_3d):
-                    s_3d.wait_event(ev)
-                    poses = (self.mlp3d(db, persons, n_persons) if mode == 'mlp' else self.triangulate(db, persons, n_persons))[0]
+                    ev.record(sm)
+                with torch.cuda.stream(sd):
+                    if two:
+                        sd.wait_event(ev)
+                    poses = (e.mlp3d(db, persons, n_persons) if mode == 'mlp' else e.triangulate(db, persons, n_persons))[0]
                     done = torch.cuda.Event()
-                    done.record(s_3d)
+                    done.record(sd)
                 # tensors allocated on one stream and consumed on another: the allocator must not hand
                 # their memory out again before the consumer is done
-                for t_ in (persons, n_persons):
-                    t_.record_stream(s_3d)
-                prev, pending = pending, (done, poses, n_persons, persons, db)   # db: keeps the batch alive while it is in flight
-                if prev is not None:
+                if two:
+                    for t_ in (persons, n_persons):
+                        t_.record_stream(sd)
+                pending.append((done, poses, n_persons, persons, db))   # db: keeps the batch alive while it is in flight
+                if len(pending) > K:
+                    prev = pending.pop(0)
                     prev[0].synchronize()
                     yield prev[1:]
-            if pending is not None:
-                last, pending = pending, None
+            while pending:
+                last = pending.pop(0)
                 last[0].synchronize()
                 yield last[1:]
         finally:
             # also on early exit (the consumer closed the generator): nothing of ours is still running on
             # the side streams when the caller's stream goes on, and nothing in flight is freed under them
-            cur.wait_stream(s_match)
-            cur.wait_stream(s_3d)
-            if pending is not None:
-                pending[0].synchronize()
+            for s_ in set(s_match + s_3d):
+                cur.wait_stream(s_)
+            for p_ in pending:
+                p_[0].synchronize()
 
     def to_device(self, pb):
         if isinstance(pb, DeviceBatch):
@@ -571,6 +644,9 @@ class Engine:
     def set_gat_output(self, sigmoid=True):
         """Last-layer activation: sigmoid (deployed model) or identity (final_activation=None)."""
         self._chk(self.lib.mpe_set_gat_output(self.ctx, 1 if sigmoid else 2))
+        self._state['gat_output'] = bool(sigmoid)
+        for e in self._siblings:
+            e.set_gat_output(sigmoid)
 
     def gat_layer(self, db, layer, x, activation=0):
         """One GraphAttention2 layer + the activation GAT2.forward applies (mpe_gat_layer).
@@ -597,6 +673,9 @@ class Engine:
 
     def set_threshold(self, thr):
         self._chk(self.lib.mpe_set_threshold(self.ctx, float(thr)))
+        self._state['threshold'] = float(thr)
+        for e in self._siblings:
+            e.set_threshold(thr)
 
     def cluster(self, db, scores):
         B = db.n_frames
@@ -667,6 +746,9 @@ class Engine:
         never used on the parity path."""
         gat = 2 if gat_reduced else 3 if attn_fp16 else int(gat_acc64)
         self._chk(self.lib.mpe_set_precision(self.ctx, gat, 2 if mlp_bf16 else int(mlp_acc64)))
+        self._state['precision'] = (gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16)
+        for e in self._siblings:
+            e.set_precision(gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16)
 
     def linear(self, x, w, b, slope=None, acc64=False):
         """act(x @ w.T + b) through the MFMA GEMM (parity tests). x device [m,k]; w,b host."""

@@ -20,8 +20,10 @@ all ranks receive all T results (distributed.all_gather_results).
 What is timed.  `value` = whole-job frames/s with the packed 2D skeletons already resident in HBM
 when the timed region starts and the poses left in HBM (barrier + synchronize on both sides, max
 over ranks; the bench contract's definition -- a PCIe-inclusive rate is never `value`).  The engine
-runs in its default mode: the matching stage of step i+1 on one stream while the 3D stage of step i
-is still in flight on another (`--streams 2`, Engine.run_pipelined; `--streams 1` = one stream).
+runs in its default mode: two contexts (own workspace, same weights: Engine.sibling) take turns on the
+steps, each on its own stream, so two whole steps are in flight and fill each other's launch tails
+(`--contexts 2`, Engine.run_pipelined(contexts=2)).  `--contexts 1 --streams 2` = one context with the
+matching stage of step i+1 beside the 3D stage of step i; `--contexts 1 --streams 1` = one stream.
 Further timed regions, reported BESIDE `value`:
   io_inclusive    SURVEY.md §8(d) as worded: packed batch in pinned host memory -> one H2D copy ->
                   compute -> D2H of poses and person counts into pinned memory, double-buffered
@@ -90,6 +92,9 @@ def parse_args(argv=None):
     ap.add_argument('--streams', type=int, default=2, choices=[1, 2],
                     help='2 (default engine mode) = software pipeline across steps: matching of batch i+1 overlaps the 3D '
                          'stage of batch i on a second stream; 1 = everything on one stream')
+    ap.add_argument('--contexts', type=int, default=2,
+                    help='2 (default engine mode): two contexts (own workspace, same weights) take turns on the steps, one stream '
+                         'each, so two whole steps are in flight; 1 = one context (--streams then says how its stages run)')
     ap.add_argument('--profile-steps', type=int, default=24,
                     help='single-stream steps after the timed region with HIP event pairs around the GEMM launches '
                          '(kernel-level roofline); 0 = skip')
@@ -203,6 +208,7 @@ def launch_ranks(args, count_fn=visible_gpu_count, popen=subprocess.Popen):
 # --------------------------------------------------------------------------------------------
 
 def run_rank(args):
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before HIP initialises: one hardware queue per stream of the pipelines (lib.py)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -283,15 +289,23 @@ def run_rank(args):
     eng.check_capacity(pb)
     db = eng.to_device(pb)
     torch.cuda.synchronize(device)
+    if os.environ.get('MPE_BENCH_JSON_EARLY'):          # diagnostics: the JSON pipeline's streams and buffers made before any other stream
+        list(eng.stream_json(json.dumps(wire[:2]).encode(), chunk_frames=B, mode=args.mode))
+        torch.cuda.synchronize(device)
 
-    s_match = torch.cuda.Stream(device) if args.streams == 2 else None
-    s_3d = torch.cuda.Stream(device) if args.streams == 2 else None
+    K = max(1, args.contexts)
+    engs = eng.contexts(K)              # K > 1: further contexts with the same weights and precision mode (Engine.sibling)
+    ctx_streams = [torch.cuda.Stream(device) for _ in range(K)] if K > 1 else []
+    s_match = torch.cuda.Stream(device) if (K == 1 and args.streams == 2) else None
+    s_3d = torch.cuda.Stream(device) if (K == 1 and args.streams == 2) else None
     keep = []          # tensors produced on one stream and consumed on another stay referenced
+    step_no = [0]
 
-    def stage3d(batch, persons, n_persons):
+    def stage3d(batch, persons, n_persons, e=None):
+        e = e or eng
         if args.mode == 'mlp':
-            return eng.mlp3d(batch, persons, n_persons)[0]
-        return eng.triangulate(batch, persons, n_persons)[0]
+            return e.mlp3d(batch, persons, n_persons)[0]
+        return e.triangulate(batch, persons, n_persons)[0]
 
     def gather(poses, n_persons):
         """The path's only exchange: every rank receives the poses of all shards."""
@@ -306,6 +320,18 @@ def run_rank(args):
         return poses, n_persons
 
     def step():
+        if K > 1:
+            # the batch is read-only input: both contexts work from the same resident arrays, each in its own workspace
+            k = step_no[0] % K
+            step_no[0] += 1
+            with torch.cuda.stream(ctx_streams[k]):
+                _, persons, n_persons = engs[k].match(db, want_scores=False)
+                poses = stage3d(db, persons, n_persons, engs[k])
+                gather(poses, n_persons)
+            keep.append((persons, n_persons, poses))
+            if len(keep) > 2 * K:
+                keep.pop(0)
+            return poses, n_persons
         if args.streams != 2:
             return step_single()
         # the two stages use disjoint workspace, so matching of the next step may run
@@ -347,8 +373,11 @@ def run_rank(args):
             dt = float(t.item())
         return dt, out
 
-    step()                       # initialisation (workspace, LDS attributes, communicator): not a warmup step
-    eng.sync_status()
+    for _ in range(K):           # initialisation (workspace, LDS attributes, communicator) of every context: not a warmup step
+        step()
+    torch.cuda.synchronize(device)
+    for e in engs:
+        e.sync_status()
     for _ in range(args.warmup):
         step()
 
@@ -357,7 +386,7 @@ def run_rank(args):
     # the exchange once more, checked: every rank finds its own shard, bit for bit, at its place in what it received
     gathered_ok = None
     if distributed:
-        for s_ in (s_match, s_3d):
+        for s_ in [s_match, s_3d] + ctx_streams:
             if s_ is not None:
                 torch.cuda.current_stream(device).wait_stream(s_)
         gp, gn = gather(poses, n_persons)
@@ -375,7 +404,7 @@ def run_rank(args):
     prof = None
     if not args.no_profile and args.profile_steps > 0:
         every = max(1, args.profile_every)
-        for s_ in (s_match, s_3d):
+        for s_ in [s_match, s_3d] + ctx_streams:
             if s_ is not None:
                 torch.cuda.current_stream(device).wait_stream(s_)
         for _ in range(3):
@@ -395,10 +424,10 @@ def run_rank(args):
     # ---- contract form: pinned host -> H2D -> compute -> D2H into pinned host, double-buffered ----
     io = None
     if not args.no_io:
-        io = io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, timed, distributed, total)
+        io = io_inclusive(args, torch, dist, packing, engs, pb, device, stage3d, gather, timed, distributed, total)
     jsn = None
     if (not args.no_io or os.environ.get('MPE_BENCH_JSON_WITHOUT_IO')) and args.json_steps > 0 and not distributed:
-        jsn = json_inclusive(args, torch, eng, wire, B, uniq)
+        jsn = json_inclusive(args, torch, eng, wire, B, uniq, K)
 
     persons_per_frame = float(n_persons.float().mean().item()) if B else 0.0
     value = total * args.steps / elapsed
@@ -426,8 +455,11 @@ def run_rank(args):
                    'inputs': 'value: packed 2D skeletons resident in HBM, poses left in HBM (bench contract); '
                              'io_inclusive: pinned host -> poses in pinned host (SURVEY 8(d) as worded); '
                              'json_inclusive: wire-format JSON bytes -> poses in pinned host (SURVEY 8 f1)',
-                   'streams': args.streams,
-                   'engine_mode': 'two-stream pipeline across steps (default)' if args.streams == 2 else 'single stream',
+                   'contexts': K, 'streams': args.streams if K == 1 else 1,
+                   'engine_mode': ('%d contexts (own workspace, same weights) taking turns on the steps, one stream each: %d steps in '
+                                   'flight (default)' % (K, K)) if K > 1
+                                  else ('one context, matching of step i+1 beside the 3D stage of step i on two streams' if args.streams == 2
+                                        else 'one context, one stream'),
                    'mlp_accumulate': 'bf16 mfma (reduced precision)' if reduced else ('f32' if args.fast_mlp else 'f32 mfma + f64 running sums'),
                    'weights': 'deterministic hash init (no checkpoint offline)'},
         'io_inclusive': io,
@@ -447,7 +479,7 @@ def run_rank(args):
     return 0
 
 
-def io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, timed, distributed, total):
+def io_inclusive(args, torch, dist, packing, engs, pb, device, stage3d, gather, timed, distributed, total):
     """SURVEY.md §8(d) metric as written: from compact 2D keypoints in host pinned memory to 3D
     poses back in host pinned memory.  Two buffer sets; the H2D of step i+1 and the D2H of step
     i-1 run on two copy streams while step i computes."""
@@ -461,14 +493,25 @@ def io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, t
     back_s = torch.cuda.Stream(device)              # D2H of the previous results (its own stream: behind the
                                                     # compute of step i it must not hold up the H2D of step i+1)
     comp_s = torch.cuda.current_stream(device)
-    # engine mode as in the main region: with --streams 2 the matching stage and the 3D stage run on their own streams
-    two = args.streams == 2 and not distributed
-    m_s = torch.cuda.Stream(device) if two else comp_s
-    d_s = torch.cuda.Stream(device) if two else comp_s
+    # engine mode as in the main region: buffer set i & 1 belongs to context i & 1 (one stream each); with one context and
+    # --streams 2 the matching stage and the 3D stage run on their own streams
+    K = len(engs)
+    two = K == 1 and args.streams == 2 and not distributed
+    lanes = []
+    for k in range(2):
+        if K > 1:
+            st = torch.cuda.Stream(device) if k < K else lanes[k % K][0]
+            lanes.append((st, st))
+        elif two:
+            lanes.append(lanes[0] if lanes else (torch.cuda.Stream(device), torch.cuda.Stream(device)))
+        else:
+            lanes.append((comp_s, comp_s))
     first = [True, True]
 
     def step(i):
         b = sets[i & 1]
+        eng = engs[(i & 1) % K]
+        m_s, d_s = lanes[i & 1]
         with torch.cuda.stream(copy_s):
             if not first[i & 1]:
                 copy_s.wait_event(b['done'])            # the batch buffer is free once step i-2 has computed
@@ -482,8 +525,9 @@ def io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, t
             ev = torch.cuda.Event()
             ev.record(m_s)
         with torch.cuda.stream(d_s):
-            d_s.wait_event(ev)
-            poses = stage3d(b['db'], persons, n_persons)
+            if d_s is not m_s:
+                d_s.wait_event(ev)
+            poses = stage3d(b['db'], persons, n_persons, eng)
             poses, n_persons = gather(poses, n_persons)
             b['done'].record(d_s)
         for t_ in (persons, n_persons, poses):
@@ -504,8 +548,9 @@ def io_inclusive(args, torch, dist, packing, eng, pb, device, stage3d, gather, t
     for i in range(max(2, args.warmup)):
         step(i)
     dt, _ = timed(step, args.steps)
-    for s_ in (m_s, d_s, back_s, copy_s):
-        comp_s.wait_stream(s_)
+    for s_ in {x for lane in lanes for x in lane} | {back_s, copy_s}:
+        if s_ is not comp_s:
+            comp_s.wait_stream(s_)
     return {'value': total * args.steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / args.steps,
             'h2d_bytes_per_step': int(pinned.nbytes),
             'd2h_bytes_per_step': int(sum(t.numel() * t.element_size() for t in sets[0]['host'])),
@@ -560,7 +605,7 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
     }
 
 
-def json_inclusive(args, torch, eng, wire, B, uniq):
+def json_inclusive(args, torch, eng, wire, B, uniq, contexts=1):
     """SURVEY.md §8 f1 as a timed region: the reference's wire format -- one JSON document, a list of frames, per
     camera [json string of the skeleton list, timestamp, 'no_image', bodies_3D]
     (panoptic_conversor/get_joints_from_panoptic_model_multi.py:231-236,287) -- as BYTES in host memory ->
@@ -574,11 +619,11 @@ def json_inclusive(args, torch, eng, wire, B, uniq):
     text = ('[' + ','.join([body] * n_steps) + ']').encode()
     warm = ('[' + ','.join([body] * 2) + ']').encode()
     mode = args.mode
-    assert sum(len(n) for _, _, n in eng.stream_json(warm, chunk_frames=B, mode=mode)) == 2 * B
+    assert sum(len(n) for _, _, n in eng.stream_json(warm, chunk_frames=B, mode=mode, contexts=contexts)) == 2 * B
     torch.cuda.synchronize()
     for rep in range(int(os.environ.get('MPE_BENCH_JSON_REPEAT', '1'))):        # > 1: diagnostics (each repeat on stderr), the last one counts
         t0 = time.perf_counter()
-        got = sum(len(n) for _, _, n in eng.stream_json(text, chunk_frames=B, mode=mode))
+        got = sum(len(n) for _, _, n in eng.stream_json(text, chunk_frames=B, mode=mode, contexts=contexts))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert got == n_steps * B
@@ -590,7 +635,8 @@ def json_inclusive(args, torch, eng, wire, B, uniq):
             'parser': 'device (csrc/jsonparse.hip); host: frame extents + string extents only',
             'what': 'wire-format frame JSON bytes in host memory -> first level on the host (parallel frame scan, skeleton strings '
                     'copied to a page-locked buffer) -> H2D -> second level parsed on the device -> match + 3D stage -> D2H of '
-                    'poses into pinned host memory; batch i+1 is parsed while batch i computes'}
+                    'poses into pinned host memory; batch i+1 is parsed while batch i computes'
+                    + ('; batches take turns on %d contexts' % contexts if contexts > 1 else '')}
 
 
 def usable_cpus():

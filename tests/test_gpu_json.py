@@ -208,11 +208,14 @@ def test_stream_json_device_parser_equals_host_parser():
             for info, poses, n in eng.stream_json(text, chunk_frames=16, parser=parser):
                 out.append((info.n_frames, poses.copy(), n.copy()))
             return out
-        a, b = run('host'), run('device')
-        assert [x[0] for x in a] == [x[0] for x in b] == [16, 16, 16, 16, 6]
-        for (_, p1, n1), (_, p2, n2) in zip(a, b):
-            assert np.array_equal(n1, n2)
-            for f in range(len(n1)):
-                assert np.array_equal(p1[f, :n1[f]], p2[f, :n1[f]])
+        def run2():
+            return [(info.n_frames, poses.copy(), n.copy()) for info, poses, n in eng.stream_json(text, chunk_frames=16, contexts=2)]
+        a, b, c2 = run('host'), run('device'), run2()          # c2: windows take turns on two contexts
+        assert [x[0] for x in a] == [x[0] for x in b] == [x[0] for x in c2] == [16, 16, 16, 16, 6]
+        for other in (b, c2):
+            for (_, p1, n1), (_, p2, n2) in zip(a, other):
+                assert np.array_equal(n1, n2)
+                for f in range(len(n1)):
+                    assert np.array_equal(p1[f, :n1[f]], p2[f, :n1[f]])
     finally:
         eng.close()

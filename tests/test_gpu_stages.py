@@ -743,10 +743,33 @@ def test_run_pipelined_gives_the_same_bits_as_sequential_calls():
         assert np.array_equal(n1, n2) and np.array_equal(q1, q2)
         for f in range(len(n1)):
             assert np.array_equal(p1[f, :n1[f]], p2[f, :n1[f]])
+    # several contexts taking turns on the batches (Engine.sibling: own workspace, same weights): same bits again,
+    # with the lazily uploading iterator too; a precision mode set afterwards reaches the siblings
+    for K in (2, 3):
+        for src in (batches, lazy()):
+            gotk = [(p.cpu().numpy(), n.cpu().numpy(), q.cpu().numpy()) for p, n, q, _ in eng.run_pipelined(src, contexts=K)]
+            assert len(gotk) == len(want)
+            for (p1, n1, q1), (p2, n2, q2) in zip(want, gotk):
+                assert np.array_equal(n1, n2) and np.array_equal(q1, q2)
+                for f in range(len(n1)):
+                    assert np.array_equal(p1[f, :n1[f]], p2[f, :n1[f]])
+    assert len(eng._siblings) == 2
+    eng.set_precision(False, False)
+    try:
+        plain = []
+        for db in batches:
+            _, persons, n_persons = eng.match(db, want_scores=False)
+            plain.append(eng.mlp3d(db, persons, n_persons)[0].cpu().numpy())
+        for w, (p, n, q, _) in zip(plain, eng.run_pipelined(batches, contexts=2)):
+            assert np.array_equal(w, p.cpu().numpy())
+    finally:
+        eng.set_precision()
     # closing the generator early must leave nothing running on the side streams
-    gen = eng.run_pipelined(batches)
-    first = next(gen)
-    gen.close()
-    torch.cuda.synchronize()
-    assert np.array_equal(first[1].cpu().numpy(), want[0][1])
+    for K in (1, 2):
+        gen = eng.run_pipelined(batches, contexts=K)
+        first = next(gen)
+        gen.close()
+        torch.cuda.synchronize()
+        assert np.array_equal(first[1].cpu().numpy(), want[0][1])
     eng.close()
+    assert eng._siblings == []

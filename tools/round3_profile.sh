@@ -1,5 +1,5 @@
 # The GPU-box command list behind profiles/r03_*.  Two calls (gpurun's limit is 20 minutes each):
-#   bash tools/round3_profile.sh A   tests, smoke, default bench (two streams / one stream) plain and under rocprofv3
+#   bash tools/round3_profile.sh A   tests, smoke, default bench (two contexts / one context on one stream) plain and under rocprofv3
 #                                    --kernel-trace --stats, the two PMC traffic passes, the SQ passes of the GEMM
 #   bash tools/round3_profile.sh B   the other shapes (tri, 5x10, configs[3] shard, 23x10 fp32 / as worded / reduced, one
 #                                    frame), the JSON path, GEMM per-shape and K sweep, the checkers
@@ -16,14 +16,15 @@ if [ "$1" = A ]; then
   grep -q "Memory access fault" $O/gputest.log && exit 1
   timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
   timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1; show default
-  timeout -k 10 300 python bench.py --streams 1 --json-steps 0 > $O/bench_streams1.json 2>> $O/bench_default.err || exit 1; show streams1
+  timeout -k 10 300 python bench.py --contexts 1 --streams 1 --json-steps 0 > $O/bench_streams1.json 2>> $O/bench_default.err || exit 1; show streams1
+  timeout -k 10 300 python bench.py --contexts 1 --streams 2 --json-steps 0 > $O/bench_contexts1_streams2.json 2>> $O/bench_default.err || exit 1; show contexts1_streams2
   cd /tmp; export TMPDIR=/tmp
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o run -- python3 $R/bench.py --json-steps 0 > $O/bench_default_under_rocprof.json 2> $O/stats2.err; echo "stats (two streams) rc $?"
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o run -- python3 $R/bench.py --streams 1 --json-steps 0 --no-io --cpu-sample 0 > $O/bench_streams1_under_rocprof.json 2> $O/stats1.err; echo "stats (one stream) rc $?"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o run -- python3 $R/bench.py --json-steps 0 > $O/bench_default_under_rocprof.json 2> $O/stats2.err; echo "stats (default: two contexts) rc $?"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o run -- python3 $R/bench.py --contexts 1 --streams 1 --json-steps 0 --no-io --cpu-sample 0 > $O/bench_streams1_under_rocprof.json 2> $O/stats1.err; echo "stats (one stream) rc $?"
   rm -f $O/stats*/run_kernel_trace.csv
-  for C in FETCH_SIZE WRITE_SIZE; do timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc -o $C -- python3 $R/bench.py --streams 1 --steps 3 --warmup 1 --cpu-sample 0 --no-io --json-steps 0 --no-profile > /dev/null 2> $O/$C.err; echo "$C rc $?"; done
+  for C in FETCH_SIZE WRITE_SIZE; do timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc -o $C -- python3 $R/bench.py --contexts 1 --streams 1 --steps 3 --warmup 1 --cpu-sample 0 --no-io --json-steps 0 --no-profile > /dev/null 2> $O/$C.err; echo "$C rc $?"; done
   python3 $R/tools/pmc_traffic.py $O/pmc/FETCH_SIZE_counter_collection.csv $O/pmc/WRITE_SIZE_counter_collection.csv $O/pmc_traffic.json
-  B="python3 $R/bench.py --streams 1 --steps 3 --warmup 1 --cpu-sample 0 --no-io --no-profile --json-steps 0"
+  B="python3 $R/bench.py --contexts 1 --streams 1 --steps 3 --warmup 1 --cpu-sample 0 --no-io --no-profile --json-steps 0"
   P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
   P2="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE"
   P3="SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_BANK_CONFLICT"
@@ -53,7 +54,7 @@ if [ "$1" = B ]; then
   timeout -k 10 300 python bench.py --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 --json-steps 0 --reduced > $O/bench_ring96_reduced.json 2>> $O/bench_b.err; show ring96_reduced
   timeout -k 10 300 python bench.py --frames 1 --cpu-sample 0 --steps 200 --warmup 20 --json-steps 0 > $O/bench_1frame.json 2>> $O/bench_b.err; show 1frame
   cd /tmp; export TMPDIR=/tmp
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ring96 -o run -- python3 $R/bench.py --streams 1 --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 --json-steps 0 --no-io > /dev/null 2> $O/stats_ring96.err; echo "ring96 stats rc $?"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ring96 -o run -- python3 $R/bench.py --contexts 1 --streams 1 --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 --json-steps 0 --no-io > /dev/null 2> $O/stats_ring96.err; echo "ring96 stats rc $?"
   rm -f $O/stats_ring96/run_kernel_trace.csv
   cd $R
   for i in 1 2; do MPE_JSON_TIMING=1 timeout -k 10 300 python tools/json_stream_probe.py 48000 1000 device >> $O/json_stream_probe.txt 2>&1; done

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c4; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for tag in fp32 cfg4; do
   extra=""; [ $tag = cfg4 ] && extra="--cfg4"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$tag -o run -- python3 $R/bench.py --streams 1 --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 --json-steps 0 --no-io $extra > $O/bench_$tag.json 2> $O/$tag.err || { tail -3 $O/$tag.err; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$tag -o run -- python3 $R/bench.py --contexts 1 --streams 1 --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 --json-steps 0 --no-io $extra > $O/bench_$tag.json 2> $O/$tag.err || { tail -3 $O/$tag.err; exit 1; }
   rm -f $O/$tag/run_kernel_trace.csv
 done
 python3 - <<PY

@@ -2,7 +2,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ks; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --streams 1 --steps 100 --warmup 10 --cpu-sample 0 --no-io --json-steps 0 > $O/bench_s1_under_rocprof.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --contexts 1 --streams 1 --steps 100 --warmup 10 --cpu-sample 0 --no-io --json-steps 0 > $O/bench_s1_under_rocprof.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
 rm -f $O/stats/run_kernel_trace.csv
 python3 - <<PY
 import csv, json

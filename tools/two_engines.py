@@ -5,6 +5,7 @@ and put the memory-bound attention under the MFMA-bound GEMMs of the other share
     python tools/two_engines.py [K ...]      (default: 1 2 3 4)
 """
 import importlib, json, os, sys, time
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -29,13 +30,39 @@ for K in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
         e.load_gat(gat, prm); e.load_mlp(mlp)
         engs.append(e); dbs.append(e.to_device(e.pack(frames[k * per:(k + 1) * per]))); streams.append(torch.cuda.Stream())
 
+    two = bool(os.environ.get('MPE_TWO_STREAMS'))           # every engine with its own matching / 3D stream pair, as bench.py's default mode
+    streams3d = [torch.cuda.Stream() for _ in range(K)] if two else streams
+
     def step():
         res = []
-        for e, db, s in zip(engs, dbs, streams):
+        for e, db, s, s3 in zip(engs, dbs, streams, streams3d):
             with torch.cuda.stream(s):
                 _, persons, n_persons = e.match(db, want_scores=False)
+                ev = torch.cuda.Event(); ev.record(s)
+            with torch.cuda.stream(s3):
+                s3.wait_event(ev)
                 res.append(e.mlp3d(db, persons, n_persons)[0])
+            for t_ in (persons, n_persons):
+                t_.record_stream(s3)
         return res
+    alt = bool(os.environ.get('MPE_ALTERNATE'))             # every engine holds the WHOLE batch; step i runs on engine i % K
+    if alt:
+        for e in engs:
+            e.close()
+        engs, dbs = [], []
+        for k in range(K):
+            e = pipeline.Engine(par.parameters, calib, max_frames=total, max_persons_per_camera=4)
+            e.load_gat(gat, prm); e.load_mlp(mlp)
+            engs.append(e); dbs.append(e.to_device(e.pack(frames)))
+        per = total // K                                    # so that the frames/s formula below counts `total` frames per step
+        counter = [0]
+
+        def step():
+            k = counter[0] % K
+            counter[0] += 1
+            with torch.cuda.stream(streams[k]):
+                _, persons, n_persons = engs[k].match(dbs[k], want_scores=False)
+                return [engs[k].mlp3d(dbs[k], persons, n_persons)[0]]
     for _ in range(10):
         step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
