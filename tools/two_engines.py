@@ -60,6 +60,16 @@ for K in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
         def step():
             k = counter[0] % K
             counter[0] += 1
+            if two:
+                with torch.cuda.stream(streams[k]):
+                    _, persons, n_persons = engs[k].match(dbs[k], want_scores=False)
+                    ev = torch.cuda.Event(); ev.record(streams[k])
+                with torch.cuda.stream(streams3d[k]):
+                    streams3d[k].wait_event(ev)
+                    out = [engs[k].mlp3d(dbs[k], persons, n_persons)[0]]
+                for t_ in (persons, n_persons):
+                    t_.record_stream(streams3d[k])
+                return out
             with torch.cuda.stream(streams[k]):
                 _, persons, n_persons = engs[k].match(dbs[k], want_scores=False)
                 return [engs[k].mlp3d(dbs[k], persons, n_persons)[0]]
