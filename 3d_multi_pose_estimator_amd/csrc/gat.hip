@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
                                                       const int32_t *__restrict__ en_off,
                                                       const int32_t *__restrict__ node_off,
                                                       const int32_t *__restrict__ en_frame,
-                                                      const int32_t *__restrict__ en_pair, AggArgs a, int hmax, int f_lo, int f_hi) {
+                                                      const int32_t *__restrict__ en_pair, AggArgs a, int hmax) {
 #pragma clang fp contract(off)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     __shared__ float s_w[EN_ROWS][16][3];           // softmax weights of (h1, h2, self) per attention head
@@ -540,11 +540,8 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
     __shared__ long s_dst[EN_ROWS];                 // output row
     const int hd = a.heads * a.out_dim, heads = a.heads;
     const int per_row = (hd + VEC - 1) / VEC;       // a VEC-column group may straddle two attention heads
-    // f_hi >= 0: the rows of frames [f_lo, f_hi) only (chunked launches, launch_aggregate); the grid is sized by capacity
-    const int m_begin = f_hi >= 0 ? en_off[f_lo] : 0, m_end = f_hi >= 0 ? en_off[f_hi] : n_en;
-    const int m0 = m_begin + blockIdx.x * EN_ROWS;
-    if (m0 >= m_end) return;
-    const int rows = min(EN_ROWS, m_end - m0);
+    const int m0 = blockIdx.x * EN_ROWS;
+    const int rows = min(EN_ROWS, n_en - m0);
     const bool l0 = a.en_const_ft2 != nullptr;
     for (int i = threadIdx.x; i < rows * heads; i += blockDim.x) {
         const int r = i / heads, hh = i - r * heads;
@@ -630,11 +627,9 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_aggregate_heads(
     int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
     const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off,
-    const int32_t *__restrict__ head_frame, AggArgs a, const uint16_t *__restrict__ head_src, int src_stride, int f_lo, int f_hi) {
+    const int32_t *__restrict__ head_frame, AggArgs a, const uint16_t *__restrict__ head_src, int src_stride) {
 #pragma clang fp contract(off)
     extern __shared__ float s_dyn[];
-    const int h_begin = f_hi >= 0 ? head_off[f_lo] : 0, h_end = f_hi >= 0 ? head_off[f_hi] : n_heads;
-    if (h_begin + (int)blockIdx.x * AGG_ROWS >= h_end) return;
     const int heads = a.heads, hd = a.heads * a.out_dim;
     float *s_w = s_dyn;                                                          // [AGG_ROWS][heads][max_deg]
     int *s_src = reinterpret_cast<int *>(s_w + (size_t)AGG_ROWS * heads * max_deg);   // [AGG_ROWS][max_deg]
@@ -644,7 +639,7 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool l0 = a.en_const_ft2 != nullptr;
     const int r_own = wave & (AGG_ROWS - 1), half = wave / AGG_ROWS;      // row of this wave, which half of the heads
-    const int gh = h_begin + blockIdx.x * AGG_ROWS + r_own;
+    const int gh = blockIdx.x * AGG_ROWS + r_own;
     int deg = 0, f = 0, hb = 0, H = 0, v = 0;
     int32_t nb = 0;
     const int32_t *sn = slot_n;
@@ -652,7 +647,7 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
     tp.start = s_topo + r_own * (V + 1 + V * V);
     tp.base = tp.start + V + 1;
     bool live = false;
-    if (gh < h_end) {
+    if (gh < n_heads) {
         f = head_frame[gh];
         hb = head_off[f];
         H = head_off[f + 1] - hb;
@@ -1205,78 +1200,55 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
     return launch_aggregate(s, b, V, max_heads_per_frame, node_off, head_frame, en_frame, en_pair, a2, head_src);
 }
 
-// Frames per launch pair of the general attention kernels.  One launch over the whole batch streams every edge-node row
-// three times from HBM (its own pass, then once for each of its two heads, a whole batch later: 3.1 GB per pass at
-// 23 x 10 x 96 frames, nothing survives in the 256 MB Infinity Cache).  Launched for a few frames at a time -- edge-node
-// kernel, then head kernel, same stream -- the head kernel finds the rows its frames' edge-node kernel just read.
-static int attn_chunk_frames(const mpe_batch &b, const AggArgs &a, int m_cap) {
-    const char *ev = getenv("MPE_ATTN_CHUNK");                  // read per call: tests toggle it
-    if (ev && atoi(ev) >= 0) return atoi(ev);                   // 0 = one launch over the whole batch
-    // default: as many frames as put ~64 MB of ft2 + output rows in flight, chunking only when the batch is several such chunks
-    const double per_frame = (double)m_cap * a.heads * a.out_dim * (a.ft_half ? 2 : 4) * 2;
-    int f = (int)(64e6 / (per_frame > 1 ? per_frame : 1));
-    if (f < 1) f = 1;
-    return b.n_frames >= 3 * f ? f : 0;
-}
-
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                             const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
                             const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src) {
     const int vec = agg_vec(a);
     if (!head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
-    const long hm = max_heads_per_frame;
-    const int m_cap = (int)(hm * hm * (V - 1) / (2 * V) + 1);     // most edge-nodes a frame of hm heads can have (even spread over V cameras)
-    const int chunk = a.score_mode ? 0 : attn_chunk_frames(b, a, m_cap);
-    int max_deg = max_heads_per_frame + 1;
-    if (max_deg < 3) max_deg = 3;
-    const size_t shm = (size_t)AGG_ROWS * ((size_t)a.heads * max_deg + max_deg + (V + 1) + (size_t)V * V) * sizeof(float);
-    const bool do_heads = b.n_heads > 0 && (!a.score_mode || a.out_heads);
-    if (do_heads && shm > 64 * 1024) {
-        static PerDeviceFlag attr;
-        if (!attr.test()) {
-            hipError_t e = hipSuccess;
-            const void *fns[4] = {reinterpret_cast<const void *>(k_aggregate_heads<8>), reinterpret_cast<const void *>(k_aggregate_heads<4>),
-                                  reinterpret_cast<const void *>(k_aggregate_heads<2>), reinterpret_cast<const void *>(k_aggregate_heads<1>)};
-            for (const void *fn : fns)
-                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_LIMIT);
-            if (e != hipSuccess) return e;
-            attr.set();
-        }
-    }
-    const int hd4 = (a.heads * a.out_dim + 3) / 4 * 4;
-    // the edge-node kernel takes 16-byte groups whatever the head width (a group may straddle two
-    // heads), as long as the rounded-up row fits the row strides
-    const bool wide = !a.score_mode && !a.ft_half && a.ld % 4 == 0 && a.ld_out % 4 == 0 && hd4 <= a.ld && hd4 <= a.ld_out &&
-                      !a.en_const_ft2;
-    const bool half8 = vec == 4 && a.ft_half && a.out_dim % 8 == 0 && half_vec8();      // fp16 rows: 8 columns = one 16-byte load
-    const int n_chunks = chunk > 0 ? (b.n_frames + chunk - 1) / chunk : 1;
-    for (int c = 0; c < n_chunks; ++c) {
-        const int f_lo = chunk > 0 ? c * chunk : 0, f_hi = chunk > 0 ? (f_lo + chunk < b.n_frames ? f_lo + chunk : b.n_frames) : -1;
-        if (b.n_edge_nodes > 0) {
-            const unsigned blocks = chunk > 0 ? (unsigned)(((long)(f_hi - f_lo) * m_cap + EN_ROWS - 1) / EN_ROWS)
-                                              : (unsigned)((b.n_edge_nodes + EN_ROWS - 1) / EN_ROWS);
+    if (b.n_edge_nodes > 0) {
+        const unsigned blocks = (unsigned)((b.n_edge_nodes + EN_ROWS - 1) / EN_ROWS);
 #define MPE_EN(V_)                                                                                      \
     hipLaunchKernelGGL(k_aggregate_en<V_>, dim3(blocks), dim3(256), 0, s, b.n_edge_nodes, b.d_frame_head_off, \
-                       b.d_frame_en_off, node_off, en_frame, en_pair, a, max_heads_per_frame, f_lo, f_hi)
-            if (half8) MPE_EN(8);
-            else if (vec == 4 || wide) MPE_EN(4);
-            else if (vec == 2) MPE_EN(2);
-            else MPE_EN(1);
+                       b.d_frame_en_off, node_off, en_frame, en_pair, a, max_heads_per_frame)
+        // the edge-node kernel takes 16-byte groups whatever the head width (a group may straddle two
+        // heads), as long as the rounded-up row fits the row strides
+        const int hd4 = (a.heads * a.out_dim + 3) / 4 * 4;
+        const bool wide = !a.score_mode && !a.ft_half && a.ld % 4 == 0 && a.ld_out % 4 == 0 && hd4 <= a.ld && hd4 <= a.ld_out &&
+                          !a.en_const_ft2;
+        if (vec == 4 && a.ft_half && a.out_dim % 8 == 0 && half_vec8()) MPE_EN(8);    // fp16 rows: 8 columns = one 16-byte load
+        else if (vec == 4 || wide) MPE_EN(4);
+        else if (vec == 2) MPE_EN(2);
+        else MPE_EN(1);
 #undef MPE_EN
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (b.n_heads > 0 && (!a.score_mode || a.out_heads)) {
+        int max_deg = max_heads_per_frame + 1;
+        if (max_deg < 3) max_deg = 3;
+        const size_t shm = (size_t)AGG_ROWS * ((size_t)a.heads * max_deg + max_deg + (V + 1) + (size_t)V * V) * sizeof(float);
+        if (shm > 64 * 1024) {
+            static PerDeviceFlag attr;
+            if (!attr.test()) {
+                hipError_t e = hipSuccess;
+                const void *fns[4] = {reinterpret_cast<const void *>(k_aggregate_heads<8>), reinterpret_cast<const void *>(k_aggregate_heads<4>),
+                                      reinterpret_cast<const void *>(k_aggregate_heads<2>), reinterpret_cast<const void *>(k_aggregate_heads<1>)};
+                for (const void *fn : fns)
+                    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_LIMIT);
+                if (e != hipSuccess) return e;
+                attr.set();
+            }
         }
-        if (do_heads) {
-            const int grid = chunk > 0 ? (int)(((long)(f_hi - f_lo) * max_heads_per_frame + AGG_ROWS - 1) / AGG_ROWS)
-                                       : (b.n_heads + AGG_ROWS - 1) / AGG_ROWS;
+        const int grid = (b.n_heads + AGG_ROWS - 1) / AGG_ROWS;
 #define MPE_HEADS(V_)                                                                                   \
     hipLaunchKernelGGL(k_aggregate_heads<V_>, dim3(grid), dim3(256), shm, s, b.n_heads, V, max_deg,         \
                        b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a, head_src,       \
-                       max_heads_per_frame + 1, f_lo, f_hi)
-            if (half8) MPE_HEADS(8);
-            else if (vec == 4) MPE_HEADS(4);
-            else if (vec == 2) MPE_HEADS(2);
-            else MPE_HEADS(1);
+                       max_heads_per_frame + 1)
+        if (vec == 4 && a.ft_half && a.out_dim % 8 == 0 && half_vec8()) MPE_HEADS(8);
+        else if (vec == 4) MPE_HEADS(4);
+        else if (vec == 2) MPE_HEADS(2);
+        else MPE_HEADS(1);
 #undef MPE_HEADS
-        }
     }
     return hipGetLastError();
 }

@@ -530,17 +530,6 @@ def test_attention_paths_give_identical_bits(monkeypatch):
                         switch('MPE_FUSED_NO_OVERLAP', not overlap)
                         sc, sh = eng.gat_scores(db, heads=True)
                         res[(fused, epi, table, overlap)] = (sc.cpu().numpy(), sh.cpu().numpy())
-        # ... and the general pair may be launched for a few frames at a time (launch_aggregate, MPE_ATTN_CHUNK: the head
-        # kernel then finds the rows its frames' edge-node kernel just read in the Infinity Cache): ragged chunk sizes, a
-        # chunk larger than the batch, and the whole batch in one launch (0)
-        switch('MPE_NO_FUSED_ATTENTION', True)
-        switch('MPE_NO_COEF_EPILOGUE', False)
-        switch('MPE_NO_HEAD_SRC_TABLE', False)
-        for chunk in (0, 1, 7, 32, 500):
-            monkeypatch.setenv('MPE_ATTN_CHUNK', str(chunk))
-            sc, sh = eng.gat_scores(db, heads=True)
-            res[('general, frames per launch', chunk)] = (sc.cpu().numpy(), sh.cpu().numpy())
-        monkeypatch.delenv('MPE_ATTN_CHUNK', raising=False)
         ref = res[(True, True, True, True)]
         for key, (sc, sh) in res.items():
             assert np.array_equal(sc, ref[0]) and np.array_equal(sh, ref[1]), key
