@@ -578,3 +578,17 @@ def test_eisel_lemire_against_strtod(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r'tested (\d+) declined (\d+) bad (\d+)', r.stdout)
     assert m and int(m.group(3)) == 0 and int(m.group(1)) > 2000000 and int(m.group(2)) < int(m.group(1)) // 2
+
+
+def test_lib_asks_for_eight_hardware_queues_unless_told_otherwise():
+    """lib.py sets GPU_MAX_HW_QUEUES=8 before HIP initialises (two busy streams of a pipeline on one of HIP's default four
+    hardware queues serialise: DESIGN.md 7.2) and never overrides an explicit setting."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import importlib; importlib.import_module('3d_multi_pose_estimator_amd.lib'); "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'))" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.strip() == '8'
+    env['GPU_MAX_HW_QUEUES'] = '2'
+    assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.strip() == '2'
+
