@@ -197,7 +197,8 @@ class Engine:
         page-locked arena (worker thread; the C call releases the GIL) while chunk i is copied to
         the device in ONE transfer and runs mpe_match_batch + the 3D stage; results come back into
         page-locked memory.  Yields (PackedBatch view, poses [B,Pcap,J,3], n_persons [B]) per chunk.
-        LIFETIME: the yielded view and arrays are valid until the next `next()` on the generator only --
+        LIFETIME: the yielded view and arrays are valid until the next `next()` on the generator only (with contexts = 2
+        there are four buffer sets instead of two and two windows in flight; the rule is the same) --
         resuming it starts the parse of a later chunk into the arena behind the view (two host arenas)
         and the result arrays of the slot are rewritten one chunk after that.  With the device parser the
         page-locked result buffers belong to the ENGINE (kept across calls: pinning them costs more than a
@@ -287,7 +288,13 @@ class Engine:
         if B not in cache:
             cache[B] = ([self.json_device_buffers(B) for _ in range(2)], {}, {}, self._make_json_streams())
         bufs, fb, outs, (s_parse, s_m, s_d) = cache[B]      # fb: host-packer fallback buffers, made on first use
-        K = 2 if int(contexts) >= 2 else 1                   # two window slots, so at most two contexts taking turns
+        K = 2 if int(contexts) >= 2 else 1                   # contexts taking turns on the windows (two compute streams exist)
+        # Window slots (staging + arena + result buffers): S = 2 K.  Window i is parsed into slot i % S while the K windows
+        # before it compute; with only K slots the parse of window i would have to wait for the compute of window i - K --
+        # its own context -- to let go of the arena, and the context would idle for the length of a parse (2.5 ms of 5.5)
+        S = 2 * K
+        while len(bufs) < S:
+            bufs.append(self.json_device_buffers(B))
         engs = self.contexts(K)
         if K == 2:
             # window i on context i & 1, each context on its own stream: two windows in flight fill each other's tails
@@ -296,15 +303,16 @@ class Engine:
             # ONE compute stream beside the parse stream: a second compute stream (matching of window i+1 beside the 3D stage
             # of window i, what run_pipelined does for resident batches) measured the same or worse here -- the parse kernels
             # already fill what the GEMMs leave
-            lanes = [(s_m, s_m), (s_m, s_m)]
+            lanes = [(s_m, s_m)]
         else:
-            lanes = [(s_m, s_d), (s_m, s_d)]
+            lanes = [(s_m, s_d)]
         out_dt = torch.float32 if mode == 'mlp' else torch.float64
-        if mode not in outs:
-            outs[mode] = [(torch.empty((B, self.pcap, self.J, 3), dtype=out_dt).pin_memory(),
-                           torch.empty((B,), dtype=torch.int32).pin_memory()) for _ in range(2)]
+        outs.setdefault(mode, [])
+        while len(outs[mode]) < S:
+            outs[mode].append((torch.empty((B, self.pcap, self.J, 3), dtype=out_dt).pin_memory(),
+                               torch.empty((B,), dtype=torch.int32).pin_memory()))
         out = outs[mode]
-        done = [None, None]
+        done = [None] * S
         cur = torch.cuda.current_stream(self.device)
         for s_ in (s_parse, s_m, s_d):
             s_.wait_stream(cur)
@@ -314,7 +322,7 @@ class Engine:
 
         def stage(i):
             try:
-                return stage_json_window(index, self.params, bufs[i & 1]['host'], frame_start=i * B * frame_step, frame_step=frame_step,
+                return stage_json_window(index, self.params, bufs[i % S]['host'], frame_start=i * B * frame_step, frame_step=frame_step,
                                          max_frames=B, n_threads=n_threads)
             except NeedsHostParser:
                 return None
@@ -323,7 +331,12 @@ class Engine:
                     return None
                 raise
 
-        def host_pack(i, k):
+        def host_pack(i):
+            # rare path: everything that is in flight finishes first (the two fallback arenas and the context are then free)
+            for j in range(S):
+                copy_out(j)
+            torch.cuda.synchronize(self.device)
+            k = i & 1
             if not fb:
                 fb['host'] = CapacityArena(self.V, self.J, B, H, 'pinned')
                 fb['dev'] = [CapacityArena(self.V, self.J, B, H, self.device) for _ in range(2)]
@@ -348,13 +361,13 @@ class Engine:
         # Copy engines serve their requests in order: a D2H of results queued behind the kernels of chunk i-1 would hold up
         # the H2D of chunk i's strings until those kernels are done (measured: 6.4 ms instead of 0.57 ms).  So the results of
         # chunk i-1 are copied out only AFTER the upload of chunk i has been queued.
-        res = [None, None]                                   # (poses, n_persons, n) of the slot, still on the device
+        res = [None] * S                                     # (poses, n_persons, n, lane) of the slot, still on the device
 
         def copy_out(k):
             if res[k] is None:
                 return
-            poses_, n_persons_, n_ = res[k]
-            with torch.cuda.stream(lanes[k][1]):           # behind the 3D stage that produced them
+            poses_, n_persons_, n_, lane_ = res[k]
+            with torch.cuda.stream(lane_):                 # behind the 3D stage that produced them
                 out[k][0][:n_].copy_(poses_, non_blocking=True)
                 out[k][1][:n_].copy_(n_persons_, non_blocking=True)
                 done[k] = torch.cuda.Event()
@@ -363,12 +376,12 @@ class Engine:
         try:
             fut = pool.submit(stage, 0)
             i = 0
-            pending = None
+            pending = []
             while True:
                 t_a = time.perf_counter()
                 st = fut.result()
                 t_b = time.perf_counter()
-                k = i & 1
+                k = i % S                                   # slot of this window
                 db = None
                 if st is not None:
                     nf, ne, used = st
@@ -376,7 +389,7 @@ class Engine:
                         break
                     with torch.cuda.stream(s_parse):
                         if done[k] is not None:
-                            s_parse.wait_event(done[k])          # the arena of this slot: chunk i-2 has computed
+                            s_parse.wait_event(done[k])          # the arena of this slot: window i - S has computed
                         if timing is not None:
                             ev_p0 = torch.cuda.Event(enable_timing=True)
                             ev_p0.record()
@@ -385,8 +398,8 @@ class Engine:
                         if timing is not None:
                             ev_p1 = torch.cuda.Event(enable_timing=True)
                             ev_p1.record()
-                    copy_out(k ^ 1)                          # results of chunk i-1, behind this chunk's upload in the copy queue
-                    # the other staging buffer is free (its copy finished when chunk i-1's totals arrived)
+                    copy_out((i - 1) % S)                    # results of window i-1, behind this window's upload in the copy queue
+                    # the next staging buffer is free (its copy finished when the totals of window i+1-S arrived)
                     nxt = pool.submit(stage, i + 1) if nf == B else None
                     t_c = time.perf_counter()
                     db = self.finish_parse(bufs[k])
@@ -395,14 +408,11 @@ class Engine:
                         if db.max_heads_per_frame() > self.hpf:
                             raise ValueError('a frame holds %d skeletons, capacity is %d (raise max_persons_per_camera / '
                                              'max_heads_per_frame)' % (db.max_heads_per_frame(), self.hpf))
-                        lanes[k][0].wait_event(bufs[k]['ready'])
+                        lanes[i % K][0].wait_event(bufs[k]['ready'])
                 else:
                     nxt = None
                 if db is None:                                  # this window goes through the host packer
-                    copy_out(k ^ 1)
-                    if done[k] is not None:
-                        done[k].synchronize()
-                    db = host_pack(i, k)
+                    db = host_pack(i)
                     if db is None:
                         break
                     if nxt is None and db.n_frames == B:
@@ -410,8 +420,8 @@ class Engine:
                 n_here = db.n_frames
                 if timing is not None:
                     ev_c0 = torch.cuda.Event(enable_timing=True)
-                    ev_c0.record(lanes[k][0])
-                eng, (l_m, l_d) = engs[k % K], lanes[k]
+                    ev_c0.record(lanes[i % K][0])
+                eng, (l_m, l_d) = engs[i % K], lanes[i % K]
                 if db.host is not None:
                     l_m.wait_stream(cur)                     # host-packed window: its upload went over the caller's stream
                 with torch.cuda.stream(l_m):
@@ -425,27 +435,27 @@ class Engine:
                 if l_d is not l_m:
                     for t_ in (persons, n_persons):
                         t_.record_stream(l_d)
-                res[k] = (poses, n_persons, n_here)
+                res[k] = (poses, n_persons, n_here, l_d)
                 done[k] = None
                 if timing is not None and st is not None:
                     ev_c1 = torch.cuda.Event(enable_timing=True)
                     ev_c1.record(l_d)
                     gpu_ev.append((ev_p0, ev_p1, ev_c0, ev_c1, bufs[k]['ev_h2d']))
                 t_e = time.perf_counter()
-                if pending is not None:
-                    pk, pinfo, pn = pending
+                pending.append((k, db if db.host is None else db.host, n_here))
+                if len(pending) > K:                          # K windows stay in flight; the oldest one is handed out
+                    pk, pinfo, pn = pending.pop(0)
                     copy_out(pk)
                     done[pk].synchronize()
                     if timing is not None and st is not None:
                         timing.append((t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, time.perf_counter() - t_e))
                     yield pinfo, out[pk][0][:pn].numpy(), out[pk][1][:pn].numpy()
-                pending = (k, db if db.host is None else db.host, n_here)
                 if nxt is None:
                     break
                 fut = nxt
                 i += 1
-            if pending is not None:
-                pk, pinfo, pn = pending
+            while pending:
+                pk, pinfo, pn = pending.pop(0)
                 copy_out(pk)
                 done[pk].synchronize()
                 yield pinfo, out[pk][0][:pn].numpy(), out[pk][1][:pn].numpy()
