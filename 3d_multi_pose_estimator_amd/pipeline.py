@@ -289,10 +289,10 @@ class Engine:
             cache[B] = ([self.json_device_buffers(B) for _ in range(2)], {}, {}, self._make_json_streams())
         bufs, fb, outs, (s_parse, s_m, s_d) = cache[B]      # fb: host-packer fallback buffers, made on first use
         K = 2 if int(contexts) >= 2 else 1                   # contexts taking turns on the windows (two compute streams exist)
-        # Window slots (staging + arena + result buffers): S = 2 K.  Window i is parsed into slot i % S while the K windows
-        # before it compute; with only K slots the parse of window i would have to wait for the compute of window i - K --
-        # its own context -- to let go of the arena, and the context would idle for the length of a parse (2.5 ms of 5.5)
-        S = 2 * K
+        # Window slots (staging + arena + result buffers): S = K + 2 -- K windows computing, one parsed and about to compute,
+        # one being uploaded and parsed (the loop below queues the parse one window ahead).  A slot is reused when its window
+        # has been handed out.
+        S = K + 2
         while len(bufs) < S:
             bufs.append(self.json_device_buffers(B))
         engs = self.contexts(K)
@@ -358,9 +358,9 @@ class Engine:
             return db
         timing = [] if os.environ.get('MPE_JSON_TIMING') else None
         gpu_ev = []
-        # Copy engines serve their requests in order: a D2H of results queued behind the kernels of chunk i-1 would hold up
-        # the H2D of chunk i's strings until those kernels are done (measured: 6.4 ms instead of 0.57 ms).  So the results of
-        # chunk i-1 are copied out only AFTER the upload of chunk i has been queued.
+        # Copy engines serve their requests in order: a D2H of results queued behind kernels that are still running holds up the
+        # H2D of a later window's strings until those kernels are done (measured: 6.4 ms instead of 0.57 ms).  So the results of
+        # a window are queued for copy-out only after the upload of the window that is parsed next.
         res = [None] * S                                     # (poses, n_persons, n, lane) of the slot, still on the device
 
         def copy_out(k):
@@ -373,55 +373,79 @@ class Engine:
                 done[k] = torch.cuda.Event()
                 done[k].record()
             res[k] = None
+        # The loop runs the PARSE ONE WINDOW AHEAD of the compute: in iteration i the upload and the parse kernels of window
+        # i+1 are queued first, then the host waits for the totals of window i (queued an iteration ago, so they are there or
+        # nearly), launches its compute and hands out the results of window i-K.  Queued in the same iteration as its own
+        # compute, a parse was on the host's critical path for its whole duration beside K computes (3 ms of a 5.5 ms window).
+        futs, pev = {}, {}
+
+        def queue(i):
+            """Stage result of window i -> its upload + parse on the parse stream.  ('dev', frames) | ('host', B) | ('end', 0)"""
+            t0_ = time.perf_counter()
+            st = futs.pop(i).result()
+            t1_ = time.perf_counter()
+            if st is None:
+                return ('host', B, t1_ - t0_, 0.0)
+            nf, ne, used = st
+            if nf == 0:
+                return ('end', 0, t1_ - t0_, 0.0)
+            k = i % S
+            assert res[k] is None, 'window slot reused before its results were handed out'
+            with torch.cuda.stream(s_parse):
+                if done[k] is not None:
+                    s_parse.wait_event(done[k])          # the arena of this slot: window i - S has computed and its results are out
+                if timing is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    bufs[k]['ev_h2d'] = torch.cuda.Event(enable_timing=True)
+                self.parse_json_device(bufs[k], nf, ne, used)
+                if timing is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    pev[i] = (e0, e1, bufs[k]['ev_h2d'])
+            return ('dev', nf, t1_ - t0_, time.perf_counter() - t1_)
+
+        def may_continue(w):
+            return w[0] == 'host' or (w[0] == 'dev' and w[1] == B)
         try:
-            fut = pool.submit(stage, 0)
+            futs[0] = pool.submit(stage, 0)
+            w_cur = queue(0)
+            if may_continue(w_cur):
+                futs[1] = pool.submit(stage, 1)
             i = 0
             pending = []
-            while True:
-                t_a = time.perf_counter()
-                st = fut.result()
-                t_b = time.perf_counter()
+            while w_cur[0] != 'end':
                 k = i % S                                   # slot of this window
+                w_nxt = ('end', 0, 0.0, 0.0)
+                if i + 1 in futs:
+                    w_nxt = queue(i + 1)
+                    if may_continue(w_nxt):
+                        futs[i + 2] = pool.submit(stage, i + 2)   # into the staging buffer of window i + 2 - S, uploaded long ago
+                t_c = time.perf_counter()
                 db = None
-                if st is not None:
-                    nf, ne, used = st
-                    if nf == 0:
-                        break
-                    with torch.cuda.stream(s_parse):
-                        if done[k] is not None:
-                            s_parse.wait_event(done[k])          # the arena of this slot: window i - S has computed
-                        if timing is not None:
-                            ev_p0 = torch.cuda.Event(enable_timing=True)
-                            ev_p0.record()
-                            bufs[k]['ev_h2d'] = torch.cuda.Event(enable_timing=True)
-                        self.parse_json_device(bufs[k], nf, ne, used)
-                        if timing is not None:
-                            ev_p1 = torch.cuda.Event(enable_timing=True)
-                            ev_p1.record()
-                    copy_out((i - 1) % S)                    # results of window i-1, behind this window's upload in the copy queue
-                    # the next staging buffer is free (its copy finished when the totals of window i+1-S arrived)
-                    nxt = pool.submit(stage, i + 1) if nf == B else None
-                    t_c = time.perf_counter()
+                if w_cur[0] == 'dev':
                     db = self.finish_parse(bufs[k])
-                    t_d = time.perf_counter()
                     if db is not None:
                         if db.max_heads_per_frame() > self.hpf:
                             raise ValueError('a frame holds %d skeletons, capacity is %d (raise max_persons_per_camera / '
                                              'max_heads_per_frame)' % (db.max_heads_per_frame(), self.hpf))
                         lanes[i % K][0].wait_event(bufs[k]['ready'])
-                else:
-                    nxt = None
+                t_d = time.perf_counter()
+                from_device = db is not None
                 if db is None:                                  # this window goes through the host packer
                     db = host_pack(i)
                     if db is None:
                         break
-                    if nxt is None and db.n_frames == B:
-                        nxt = pool.submit(stage, i + 1)
                 n_here = db.n_frames
+                eng, (l_m, l_d) = engs[i % K], lanes[i % K]
+                # the results of window i-K (same context, same stream) leave the device BEFORE this window's kernels are queued
+                # behind them on that stream; this window's upload is already in the copy queue, the next one's comes an
+                # iteration later, when window i-K has long finished (copy engines serve in order)
+                if len(pending) >= K:
+                    copy_out(pending[0][0])
                 if timing is not None:
                     ev_c0 = torch.cuda.Event(enable_timing=True)
-                    ev_c0.record(lanes[i % K][0])
-                eng, (l_m, l_d) = engs[i % K], lanes[i % K]
+                    ev_c0.record(l_m)
                 if db.host is not None:
                     l_m.wait_stream(cur)                     # host-packed window: its upload went over the caller's stream
                 with torch.cuda.stream(l_m):
@@ -437,22 +461,22 @@ class Engine:
                         t_.record_stream(l_d)
                 res[k] = (poses, n_persons, n_here, l_d)
                 done[k] = None
-                if timing is not None and st is not None:
+                if timing is not None and from_device and i in pev:
                     ev_c1 = torch.cuda.Event(enable_timing=True)
                     ev_c1.record(l_d)
-                    gpu_ev.append((ev_p0, ev_p1, ev_c0, ev_c1, bufs[k]['ev_h2d']))
+                    gpu_ev.append(pev.pop(i)[:2] + (ev_c0, ev_c1) + (bufs[k]['ev_h2d'],))
                 t_e = time.perf_counter()
                 pending.append((k, db if db.host is None else db.host, n_here))
                 if len(pending) > K:                          # K windows stay in flight; the oldest one is handed out
                     pk, pinfo, pn = pending.pop(0)
-                    copy_out(pk)
+                    copy_out(pk)                              # (already queued above)
                     done[pk].synchronize()
-                    if timing is not None and st is not None:
-                        timing.append((t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, time.perf_counter() - t_e))
+                    if timing is not None:
+                        timing.append((w_nxt[2], w_nxt[3], t_d - t_c, t_e - t_d, time.perf_counter() - t_e))
                     yield pinfo, out[pk][0][:pn].numpy(), out[pk][1][:pn].numpy()
-                if nxt is None:
+                if n_here < B:
                     break
-                fut = nxt
+                w_cur = w_nxt
                 i += 1
             while pending:
                 pk, pinfo, pn = pending.pop(0)
@@ -460,6 +484,8 @@ class Engine:
                 done[pk].synchronize()
                 yield pinfo, out[pk][0][:pn].numpy(), out[pk][1][:pn].numpy()
         finally:
+            for f_ in list(futs.values()):
+                f_.cancel()
             pool.shutdown(wait=True)
             for s_ in (s_parse, s_m, s_d):
                 cur.wait_stream(s_)
