@@ -481,45 +481,67 @@ def run_rank(args):
 
 def io_inclusive(args, torch, dist, packing, engs, pb, device, stage3d, gather, timed, distributed, total):
     """SURVEY.md §8(d) metric as written: from compact 2D keypoints in host pinned memory to 3D
-    poses back in host pinned memory.  Two buffer sets; the H2D of step i+1 and the D2H of step
-    i-1 run on two copy streams while step i computes."""
+    poses back in host pinned memory.  K + 2 buffer sets; the H2D of step i+1 and the D2H of step
+    i-1 run on two copy streams while step i (and, with K contexts, step i-1) computes."""
     pinned = packing.BatchArena(pb, 'pinned').fill(pb)
+    K = len(engs)
+    # Buffer sets: K steps computing + the one uploaded ahead + the one whose results are leaving.  The copy engines serve
+    # H2D and D2H requests in ONE order: a D2H queued behind kernels that are still running holds up every upload queued
+    # after it.  With K contexts the upload of step i must not wait for step i-1's results (step i-1 is still computing when
+    # step i wants to start), so uploads run one step AHEAD and the D2H of step i-1 is queued after the launch of step i.
+    NS = K + 2
     sets = []
-    for _ in range(2):
+    for _ in range(NS):
         arena = packing.BatchArena(pb, device)
         sets.append({'db': packing.DeviceBatch(pb, device, arena=arena), 'h2d': torch.cuda.Event(),
-                     'done': torch.cuda.Event(), 'd2h': torch.cuda.Event(), 'out': None, 'host': None})
-    copy_s = torch.cuda.Stream(device)              # H2D of the next batch
-    back_s = torch.cuda.Stream(device)              # D2H of the previous results (its own stream: behind the
-                                                    # compute of step i it must not hold up the H2D of step i+1)
+                     'done': torch.cuda.Event(), 'd2h': torch.cuda.Event(), 'out': None, 'host': None, 'used': False, 'sent': False})
+    copy_s = torch.cuda.Stream(device)              # H2D of the batches
+    back_s = torch.cuda.Stream(device)              # D2H of the results
     comp_s = torch.cuda.current_stream(device)
-    # engine mode as in the main region: buffer set i & 1 belongs to context i & 1 (one stream each); with one context and
-    # --streams 2 the matching stage and the 3D stage run on their own streams
-    K = len(engs)
+    # engine mode as in the main region: step g on context g % K (one stream each); with one context and --streams 2 the
+    # matching stage and the 3D stage run on their own streams
     two = K == 1 and args.streams == 2 and not distributed
     lanes = []
-    for k in range(2):
+    for k in range(K):
         if K > 1:
-            st = torch.cuda.Stream(device) if k < K else lanes[k % K][0]
+            st = torch.cuda.Stream(device)
             lanes.append((st, st))
         elif two:
-            lanes.append(lanes[0] if lanes else (torch.cuda.Stream(device), torch.cuda.Stream(device)))
+            lanes.append((torch.cuda.Stream(device), torch.cuda.Stream(device)))
         else:
             lanes.append((comp_s, comp_s))
-    first = [True, True]
+    state = {'g': 0, 'uploaded': 0, 'pending': None}
 
-    def step(i):
-        b = sets[i & 1]
-        eng = engs[(i & 1) % K]
-        m_s, d_s = lanes[i & 1]
+    def upload(g):
+        b = sets[g % NS]
         with torch.cuda.stream(copy_s):
-            if not first[i & 1]:
-                copy_s.wait_event(b['done'])            # the batch buffer is free once step i-2 has computed
+            if b['used']:
+                copy_s.wait_event(b['done'])            # the batch buffer is free once step g - NS has computed
             b['db'].upload(pinned)
             b['h2d'].record(copy_s)
+
+    def results_out(g):
+        b = sets[g % NS]
+        poses, n_persons, _ = b['out']
+        with torch.cuda.stream(back_s):
+            back_s.wait_event(b['done'])
+            b['host'][0].copy_(poses, non_blocking=True)
+            b['host'][1].copy_(n_persons, non_blocking=True)
+            b['d2h'].record(back_s)
+        b['sent'] = True
+
+    def step(i, last=False):
+        g = state['g']
+        state['g'] += 1
+        while state['uploaded'] <= g + 1:               # this step's batch (first call) and the next one
+            upload(state['uploaded'])
+            state['uploaded'] += 1
+        b = sets[g % NS]
+        eng = engs[g % K]
+        m_s, d_s = lanes[g % K]
         m_s.wait_event(b['h2d'])
-        if not first[i & 1]:
-            d_s.wait_event(b['d2h'])                    # step i-2's results have left the output tensors
+        if b['sent']:
+            d_s.wait_event(b['d2h'])                    # step g - NS's results have left the output tensors
         with torch.cuda.stream(m_s):
             _, persons, n_persons = eng.match(b['db'], want_scores=False)
             ev = torch.cuda.Event()
@@ -530,6 +552,7 @@ def io_inclusive(args, torch, dist, packing, engs, pb, device, stage3d, gather, 
             poses = stage3d(b['db'], persons, n_persons, eng)
             poses, n_persons = gather(poses, n_persons)
             b['done'].record(d_s)
+        b['used'] = True
         for t_ in (persons, n_persons, poses):
             t_.record_stream(d_s)
             t_.record_stream(back_s)
@@ -537,17 +560,17 @@ def io_inclusive(args, torch, dist, packing, engs, pb, device, stage3d, gather, 
             b['host'] = (torch.empty(poses.shape, dtype=poses.dtype).pin_memory(),
                          torch.empty(n_persons.shape, dtype=n_persons.dtype).pin_memory())
         b['out'] = (poses, n_persons, persons)          # keep the tensors alive until their D2H is done
-        with torch.cuda.stream(back_s):
-            back_s.wait_event(b['done'])
-            b['host'][0].copy_(poses, non_blocking=True)
-            b['host'][1].copy_(n_persons, non_blocking=True)
-            b['d2h'].record(back_s)
-        first[i & 1] = False
+        if state['pending'] is not None:
+            results_out(state['pending'])               # step g-1: behind this step's (and the next step's) upload in the copy queue
+        state['pending'] = g
+        if last:                                        # the region ends with every result in host memory
+            results_out(g)
+            state['pending'] = None
         return poses, n_persons
 
     for i in range(max(2, args.warmup)):
         step(i)
-    dt, _ = timed(step, args.steps)
+    dt, _ = timed(lambda i: step(i, i == args.steps - 1), args.steps)
     for s_ in {x for lane in lanes for x in lane} | {back_s, copy_s}:
         if s_ is not comp_s:
             comp_s.wait_stream(s_)
@@ -555,7 +578,7 @@ def io_inclusive(args, torch, dist, packing, engs, pb, device, stage3d, gather, 
             'h2d_bytes_per_step': int(pinned.nbytes),
             'd2h_bytes_per_step': int(sum(t.numel() * t.element_size() for t in sets[0]['host'])),
             'what': 'packed batch in pinned host memory -> one H2D copy -> match + 3D stage -> D2H of poses and '
-                    'n_persons into pinned host memory; double-buffered, H2D and D2H on their own streams'}
+                    'n_persons into pinned host memory; %d buffer sets, uploads one step ahead, H2D and D2H on their own streams' % NS}
 
 
 def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
