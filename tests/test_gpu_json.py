@@ -219,3 +219,64 @@ def test_stream_json_device_parser_equals_host_parser():
                     assert np.array_equal(p1[f, :n1[f]], p2[f, :n1[f]])
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('contexts', [1, 2])
+def test_stream_json_window_edges(contexts):
+    """The look-ahead loop of Engine.stream_json (parse of window i+1 queued before the compute of window i, K + 2 window
+    slots, K windows in flight) at its edges: a document that ends exactly on a window boundary, one shorter than a
+    window, an empty list, host-packed windows at the very start and the very end, and a consumer that stops early.
+    Reference for every case: the host parser's stream."""
+    e = env('panoptic')
+    syn = pkg('synthetic')
+    eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=8, max_persons_per_camera=6)
+    try:
+        eng.load_gat(*e.gat)
+        eng.load_mlp(e.mlp)
+        frames = [syn.make_frame(e.calib, 8800 + i, syn.FrameSpec(persons=1 + i % 4))[0] for i in range(40)]
+
+        def literal(f):                        # a shape the device parser hands back: `valid` = true
+            f = json.loads(json.dumps(f))
+            cam = next(c for c in f if json.loads(f[c][0]))
+            sk = json.loads(f[cam][0])
+            key = next(k for k in sk[0] if k != 'ID')
+            sk[0][key][3] = True
+            f[cam][0] = json.dumps(sk)
+            return f
+
+        def run(doc, parser, **kw):
+            return [(info.n_frames, poses.copy(), n.copy()) for info, poses, n in eng.stream_json(doc, chunk_frames=8, parser=parser, **kw)]
+
+        def same(a, b):
+            assert [x[0] for x in a] == [x[0] for x in b]
+            for (_, p1, n1), (_, p2, n2) in zip(a, b):
+                assert np.array_equal(n1, n2)
+                for f in range(len(n1)):
+                    assert np.array_equal(p1[f, :n1[f]], p2[f, :n1[f]])
+        cases = {
+            'exact multiple': frames[:32],
+            'one short window': frames[:5],
+            'one full window': frames[:8],
+            'host-packed first window': [literal(frames[0])] + frames[1:20],
+            'host-packed last window': frames[:19] + [literal(frames[19])],
+            'host-packed windows back to back': frames[:8] + [literal(frames[8])] + frames[9:16] + [literal(frames[16])] + frames[17:30],
+        }
+        for name, fr in cases.items():
+            doc = json.dumps(fr)
+            want = run(doc, 'host')
+            assert sum(x[0] for x in want) == len(fr), name
+            same(want, run(doc, 'device', contexts=contexts))
+        assert run('[]', 'device', contexts=contexts) == []
+        # a consumer that stops after the first window: nothing is left running, the next call starts clean
+        doc = json.dumps(frames)
+        gen = eng.stream_json(doc, chunk_frames=8, contexts=contexts)
+        first = next(gen)
+        keep = (first[0].n_frames, first[1].copy(), first[2].copy())
+        gen.close()
+        torch.cuda.synchronize()
+        again = run(doc, 'device', contexts=contexts)
+        same([keep], again[:1])
+        same(run(doc, 'host'), again)
+    finally:
+        eng.close()
+
