@@ -1,5 +1,5 @@
 """Engine.stream_json alone in a fresh process (few streams alive): frames/s and, with MPE_JSON_TIMING=1, the per-window
-timeline.  python tools/json_stream_probe.py [frames] [chunk] [parser] [repeats]
+timeline.  python tools/json_stream_probe.py [frames] [chunk] [parser] [repeats] [contexts]
 `repeats` > 1 runs the same call again in the same process: the first call of a fresh process finds a cool GPU."""
 import importlib, json, os, sys, time
 import torch
@@ -11,6 +11,8 @@ par = importlib.import_module(PKG + '.parameters'); pipeline = importlib.import_
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16000
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 parser = sys.argv[3] if len(sys.argv) > 3 else 'device'
+contexts = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+kw = {'contexts': contexts} if parser == 'device' else {}
 calib = cal.Calibration(par.parameters)
 uniq = [syn.make_frame(calib, i, syn.FrameSpec(persons=4))[0] for i in range(200)]
 body = json.dumps([uniq[i % 200] for i in range(chunk)])[1:-1]
@@ -29,12 +31,12 @@ if os.environ.get('MPE_PROBE_RESIDENT'):                 # a resident batch thro
     for _ in range(30):
         _, pp, nn_ = eng.match(db, want_scores=False); eng.mlp3d(db, pp, nn_)
     torch.cuda.synchronize()
-sum(len(nn) for _, _, nn in eng.stream_json(warm, chunk_frames=chunk, parser=parser))
+sum(len(nn) for _, _, nn in eng.stream_json(warm, chunk_frames=chunk, parser=parser, **kw))
 torch.cuda.synchronize()
 for rep in range(int(sys.argv[4]) if len(sys.argv) > 4 else 1):
   t0 = time.perf_counter()
   got, stamps = 0, []
-  for _, _, nn in eng.stream_json(text, chunk_frames=chunk, parser=parser):
+  for _, _, nn in eng.stream_json(text, chunk_frames=chunk, parser=parser, **kw):
       got += len(nn)
       stamps.append(time.perf_counter() - t0)
   t_last = time.perf_counter() - t0
