@@ -612,7 +612,10 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': src,
         'launches': prof['gemm_launches'], 'avg_launch_ms': prof['gemm_ms'] / max(1, prof['gemm_launches']),
         'measured': 'HIP events around every GEMM launch of %d sampled steps of a single-stream pass (%d steps) after the '
-                    'timed region' % (sampled, args.profile_steps),
+                    'timed region; rocprofv3 --kernel-trace --stats agrees with it on the one-context one-stream command '
+                    '(`bench.py --contexts 1 --streams 1`, profiles/r03_bench_streams1_kernel_stats.csv); with two contexts in '
+                    'flight the kernels of two steps overlap and a launch\'s duration as rocprofv3 sees it is ~1.9x longer, which '
+                    'is why the kernel-level figure comes from this pass' % (sampled, args.profile_steps),
         'sampled_steps': sampled, 'flop_per_step': flop_per_step,
         'gemm_share_of_single_stream_step': (gemm_s / sampled) / (prof['single_stream_ms_per_step'] * 1e-3),
         'single_stream_ms_per_step': prof['single_stream_ms_per_step'],
