@@ -1220,7 +1220,7 @@ int mpe_json_stage_window(mpe_json_index *ix, const char *const *camera_names, i
     // staging runs beside the document scan and the caller's own thread: under a cgroup CPU quota the sum must stay below it,
     // or the kernel parks the whole process for the rest of the 100 ms period (measured on a 16-CPU share: 16 staging + 4 scan
     // threads -> nr_throttled 10 in 24 windows, windows of 50 ms; json_inclusive 115k-146k frames/s from run to run)
-    int nt = n_threads > 0 ? n_threads : default_threads() - (ix->scanning() ? scan_threads() : 0) - 2;
+    int nt = n_threads > 0 ? n_threads : default_threads() - (ix->scanning() ? scan_threads() : 0) - 4;   // the caller's thread, its staging worker, the HIP runtime's
     if (nt < 1) nt = 1;
     if (nt > B) nt = B > 0 ? B : 1;
     auto run = [&](auto &&body) {
