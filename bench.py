@@ -98,7 +98,7 @@ def parse_args(argv=None):
     ap.add_argument('--profile-steps', type=int, default=24,
                     help='single-stream steps after the timed region with HIP event pairs around the GEMM launches '
                          '(kernel-level roofline); 0 = skip')
-    ap.add_argument('--json-steps', type=int, default=48,
+    ap.add_argument('--json-steps', type=int, default=96,
                     help='batches of the json_inclusive region (wire-format JSON bytes -> poses in pinned host memory); 0 = skip')
     ap.add_argument('--no-io', action='store_true', help='skip the second (pinned host -> poses in pinned host) timed region')
     ap.add_argument('--no-profile', action='store_true', help='no per-GEMM HIP events (roofline comes out null)')
