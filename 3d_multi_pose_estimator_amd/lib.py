@@ -145,6 +145,12 @@ def load():
         raise ImportError('%s is missing: build it with `python __graft_entry__.py` or '
                           '`make -C 3d_multi_pose_estimator_amd/csrc` (hipcc, gfx950). '
                           'There is no CPU fallback.' % LIB_PATH)
+    # torch first, if it is there: libmpe_hip.so needs libamdhip64, and a process that already has the system's copy loaded
+    # when torch later brings its own talks to two HIP runtimes at once (device tensors of one, kernels of the other)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
