@@ -15,7 +15,8 @@ if os.environ.get('MPE_LIB_VARIANT'):      # diagnostics: an experiment build be
 # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The engine's pipelines keep 3-4 streams busy
 # (parse / copy / matching / 3D) beside whatever the application has; two of them on one queue serialise (pipeline.py:
 # _make_json_streams has the measurement).  Effective only if HIP has not initialised yet; an explicit setting wins.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+if os.environ.get('MPE_SET_HW_QUEUES', '1') != '0':      # opt out: MPE_SET_HW_QUEUES=0 leaves the host application's environment alone
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 MPE_MAX_CAMERAS = 32
 MPE_MAX_JOINTS = 32
@@ -136,6 +137,19 @@ SYMBOLS = {
 _lib = None
 
 
+def hip_runtimes_mapped():
+    """Real paths of every libamdhip64 mapped into this process (Linux: /proc/self/maps)."""
+    paths = set()
+    try:
+        with open('/proc/self/maps') as fh:
+            for line in fh:
+                if 'libamdhip64' in line:
+                    paths.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    return sorted(paths)
+
+
 def load():
     """Return the loaded library; raise if it has not been built (no fallback)."""
     global _lib
@@ -152,6 +166,12 @@ def load():
     except ImportError:
         pass
     lib = C.CDLL(LIB_PATH)
+    rts = hip_runtimes_mapped()
+    if len(rts) > 1:
+        # device memory of one runtime, kernels of the other: every later call would fail with an opaque MPE_ERR_HIP (-4)
+        raise ImportError('two HIP runtimes are mapped into this process (%s): something loaded a libamdhip64 before torch '
+                          'brought its own.  Import torch (or this package) BEFORE anything that dlopens the system HIP '
+                          'runtime, e.g. before ctypes.CDLL(%r).' % (', '.join(rts), LIB_PATH))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res

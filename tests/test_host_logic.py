@@ -592,3 +592,75 @@ def test_lib_asks_for_eight_hardware_queues_unless_told_otherwise():
     env['GPU_MAX_HW_QUEUES'] = '2'
     assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.strip() == '2'
 
+    env['MPE_SET_HW_QUEUES'] = '0'
+    del env['GPU_MAX_HW_QUEUES']
+    assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.strip() == 'None'
+
+
+def test_build_then_load_in_one_process_maps_one_hip_runtime():
+    """Round 3 lost a GPU run to this: build() dlopen-ed libmpe_hip.so for its symbol check BEFORE torch was imported, which
+    bound the process to the system's libamdhip64; smoke() in the same process then ran on two HIP runtimes and mpe_create
+    failed with -4.  build() now checks the symbols in a child and lib.load() imports torch first and refuses to go on
+    with two runtimes mapped.  CPU-runnable: the maps of the process tell."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, importlib; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g\n"
+        "g.build()\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "assert 'libmpe_hip' not in maps and 'libamdhip64' not in maps, 'build() mapped a HIP library into its own process'\n"
+        "lib = importlib.import_module('3d_multi_pose_estimator_amd.lib')\n"
+        "lib.load()\n"
+        "rts = lib.hip_runtimes_mapped()\n"
+        "assert len(rts) == 1, rts\n"
+        "import torch\n"
+        "assert len(lib.hip_runtimes_mapped()) == 1, lib.hip_runtimes_mapped()\n"
+        "print('ok', rts[0])\n" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'ok ' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # the failure mode itself: the system runtime first, then the package -> a clear ImportError, not -4 later
+    sys_hip = '/opt/rocm/lib/libamdhip64.so'
+    if os.path.exists(sys_hip):
+        code2 = ("import ctypes, sys, importlib; sys.path.insert(0, %r); ctypes.CDLL(%r)\n"
+                 "lib = importlib.import_module('3d_multi_pose_estimator_amd.lib')\n"
+                 "try:\n    lib.load()\nexcept ImportError as e:\n    print('refused:', e); sys.exit(0)\n"
+                 "print('runtimes', lib.hip_runtimes_mapped()); sys.exit(0 if len(lib.hip_runtimes_mapped()) == 1 else 3)" % (ROOT, sys_hip))
+        r2 = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, timeout=300)
+        assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+
+
+def test_build_stamp_forces_a_rebuild_when_sources_change(tmp_path, monkeypatch):
+    """build() must not trust objects that merely travel with the tree: a source hash that differs from the stamp (or no
+    stamp) turns the call into `make -B`.  The make itself is stubbed out here; the decision is what is tested."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    g = importlib.import_module('__graft_entry__')
+    calls = []
+    monkeypatch.setattr(g.subprocess, 'check_call', lambda cmd, **kw: calls.append(list(cmd)))
+    csrc = os.path.join(ROOT, '3d_multi_pose_estimator_amd', 'csrc')
+    stamp, mode = os.path.join(csrc, '.build_stamp'), os.path.join(csrc, '.build_mode')
+    keep = {p: (open(p).read() if os.path.exists(p) else None) for p in (stamp, mode)}
+    try:
+        with open(stamp, 'w') as fh:
+            fh.write('0000000000000000\n')
+        g.build()
+        assert '-B' in calls[0] and open(mode).read().startswith('clean ')
+        assert open(stamp).read().strip() == g.source_hash()
+        calls.clear()
+        if os.path.exists(os.path.join(ROOT, '3d_multi_pose_estimator_amd', 'libmpe_hip.so')):
+            g.build()
+            assert '-B' not in calls[0] and open(mode).read().startswith('reused ')
+        calls.clear()
+        monkeypatch.setattr(g, 'source_hash', lambda: 'feedfacefeedface')
+        g.build()
+        assert '-B' in calls[0]
+    finally:
+        for p, v in keep.items():
+            if v is None:
+                if os.path.exists(p):
+                    os.remove(p)
+            else:
+                with open(p, 'w') as fh:
+                    fh.write(v)
