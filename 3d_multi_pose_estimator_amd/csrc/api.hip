@@ -106,8 +106,11 @@ int check_batch(mpe_ctx *ctx, const mpe_batch *b) {
         return fail(ctx, MPE_ERR_CAPACITY, "batch (%d frames, %d heads, %d edge-nodes) exceeds capacity (%d, %d, %d)",
                     b->n_frames, b->n_heads, b->n_edge_nodes, ctx->cfg.max_frames, ctx->cfg.max_heads,
                     ctx->cfg.max_edge_nodes);
-    if (b->n_frames > 0 && (!b->d_frame_head_off || !b->d_frame_en_off || !b->d_slot_cam || !b->d_slot_n))
+    if (b->n_frames > 0 && (!b->d_frame_head_off || !b->d_frame_en_off || (!b->d_en_pair && (!b->d_slot_cam || !b->d_slot_n))))
         return fail(ctx, MPE_ERR_INVALID, "batch offset tables missing");
+    if (b->d_en_pair && ctx->x_m_cap <= 0)
+        return fail(ctx, MPE_ERR_UNSUPPORTED, "explicit edge-node lists need max_heads_per_frame <= 1024 and node ids that fit 16 bits "
+                    "(max_heads_per_frame = %d)", ctx->cfg.max_heads_per_frame);
     if (b->n_heads > 0 && (!b->d_head_cam || !b->d_joint_mask || !b->d_tri_mask || !b->d_xy || !b->d_vp))
         return fail(ctx, MPE_ERR_INVALID, "batch skeleton arrays missing");
     return MPE_OK;
@@ -445,13 +448,16 @@ int gat_attention(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, const 
     const GatLayer &g = ctx->gat[l];
     HIPCHK(ctx, launch_gat_attention(s, *b, ctx->cfg.n_cameras, ctx->cfg.max_heads_per_frame, ctx->node_off,
                                      ctx->head_frame, ctx->en_frame, ctx->en_pair, g.attn_l, g.attn_r, ctx->a12, a,
-                                     n_rows_ft2, ctx->head_src));
+                                     n_rows_ft2, ctx->head_src, explicit_deg_cap(ctx->cfg.max_heads_per_frame), ctx->x_m_cap));
     return MPE_OK;
 }
 
 int gat_topology(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b) {
+    if (b->d_en_pair && (size_t)b->n_frames * ctx->cfg.max_heads_per_frame * explicit_deg_cap(ctx->cfg.max_heads_per_frame) > ctx->head_src_cap)
+        return fail(ctx, MPE_ERR_CAPACITY, "in-edge table too small for %d frames with explicit edge-node lists", b->n_frames);
     HIPCHK(ctx, launch_topology(s, *b, ctx->cfg.n_cameras, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair,
-                                ctx->cfg.max_heads_per_frame, ctx->d_status, ctx->head_src));
+                                ctx->cfg.max_heads_per_frame, ctx->d_status, ctx->head_src,
+                                explicit_deg_cap(ctx->cfg.max_heads_per_frame), ctx->x_m_cap));
     return MPE_OK;
 }
 
@@ -570,11 +576,19 @@ int mpe_create(const mpe_config *cfg, mpe_ctx **out) {
         if ((rc = dev_alloc(ctx, &ctx->en_frame, (size_t)cfg->max_edge_nodes))) break;
         if ((rc = dev_alloc(ctx, &ctx->en_pair, (size_t)cfg->max_edge_nodes * 2))) break;
         if ((rc = dev_alloc(ctx, &ctx->node_off, (size_t)cfg->max_frames + 1))) break;
-        if (head_src_entries(cfg->max_heads_per_frame, cfg->n_cameras) &&
-            (rc = dev_alloc(ctx, &ctx->head_src, head_src_entries(cfg->max_heads_per_frame, cfg->n_cameras) * cfg->max_frames,
-                            false)))
-            break;
         ctx->cl_keys_per_frame = cluster_keys_per_frame(cfg->max_heads_per_frame);
+        {
+            // in-edge source table of the heads: implicit topology [hmax][hmax + 1] per frame; explicit edge-node lists
+            // (mpe_batch::d_en_pair) [hmax][2 hmax], available while a frame's node ids fit the table's 16 bits.  A frame
+            // of an explicit list may hold as many edge-nodes as the clustering scratch has keys.
+            const size_t hm = (size_t)cfg->max_heads_per_frame;
+            const bool x_ok = hm <= 1024 && hm + ctx->cl_keys_per_frame <= 65535;
+            ctx->x_m_cap = x_ok ? (int)ctx->cl_keys_per_frame : 0;
+            size_t per = head_src_entries(cfg->max_heads_per_frame, cfg->n_cameras);
+            if (x_ok && hm * explicit_deg_cap(cfg->max_heads_per_frame) > per) per = hm * explicit_deg_cap(cfg->max_heads_per_frame);
+            ctx->head_src_cap = per * cfg->max_frames;
+            if (per && (rc = dev_alloc(ctx, &ctx->head_src, ctx->head_src_cap, false))) break;
+        }
         ctx->cl_scratch_per_frame = cluster_scratch_per_frame(cfg->max_heads_per_frame);
         if ((rc = dev_alloc(ctx, &ctx->cl_keys, ctx->cl_keys_per_frame * cfg->max_frames, false))) break;
         if ((rc = dev_alloc(ctx, &ctx->cl_scratch, ctx->cl_scratch_per_frame * cfg->max_frames, false))) break;
@@ -745,9 +759,12 @@ int mpe_sync_status(mpe_ctx *ctx, void *stream) {
     HIPCHK(ctx, hipMemcpyAsync(&st, ctx->d_status, sizeof st, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof st, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
+    if (st & 2)
+        return fail(ctx, MPE_ERR_INVALID, "an explicit edge-node list held a pair outside its frame (or h1 == h2), or repeated pairs "
+                    "beyond the in-degree capacity 2 * max_heads_per_frame; such pairs were replaced / dropped");
     if (st & 1)
-        return fail(ctx, MPE_ERR_CAPACITY, "a frame holds more than max_heads_per_frame = %d skeletons; its scores are "
-                    "zero and it produced no persons", ctx->cfg.max_heads_per_frame);
+        return fail(ctx, MPE_ERR_CAPACITY, "a frame holds more than max_heads_per_frame = %d skeletons (or, with an explicit edge-node list, more "
+                    "than %d edge-nodes); its scores are zero and it produced no persons", ctx->cfg.max_heads_per_frame, ctx->x_m_cap);
     return MPE_OK;
 }
 

@@ -73,10 +73,101 @@ size_t head_src_entries(int max_heads_per_frame, int V) {
     return nodes <= 65535 ? h * (h + 1) : 0;
 }
 
+// Explicit edge-node lists (mpe_batch::d_en_pair): the graphs of process_training (graph_generator.py:672-810, one
+// edge-node per ORDERED head pair, heads grouped by person) or any other pair list.  One workgroup per frame: the
+// caller's pairs are checked and copied into the context's table (a pair outside [0, H) or with h1 == h2 is replaced
+// by a memory-safe one and raises status bit 1 << 1), then the in-edge sources of every head are listed in ascending
+// edge-node order -- head h: (h,h), then every X whose pair holds h; that is ascending edge id, the reference's
+// creation order (:632-651) -- into the same per-frame table the implicit mode uses, here [hmax][deg_cap].  A head
+// with more than deg_cap - 1 edge-nodes (only possible with repeated pairs) loses the surplus and raises bit 1 << 1;
+// a frame with more than hmax heads or m_cap edge-nodes gets an all-0xFFFF table and raises bit 0 (skipped downstream).
+constexpr int XT_CHUNK = 2048;
+__global__ __launch_bounds__(256) void k_topology_explicit(int n_frames, const int32_t *__restrict__ head_off,
+                                                           const int32_t *__restrict__ en_off,
+                                                           const int32_t *__restrict__ pairs_in,
+                                                           int32_t *__restrict__ node_off, int32_t *__restrict__ head_frame,
+                                                           int32_t *__restrict__ en_frame, int32_t *__restrict__ en_pair,
+                                                           uint16_t *__restrict__ head_src, int hmax, int deg_cap, int m_cap,
+                                                           int32_t *__restrict__ status) {
+    __shared__ uint32_t s_pr[XT_CHUNK];
+    const int f = blockIdx.x, t = threadIdx.x;
+    const int h0 = head_off[f], H = head_off[f + 1] - h0;
+    const int e0 = en_off[f], M = en_off[f + 1] - e0;
+    const bool ok = H <= hmax && M <= m_cap;
+    if (t == 0) {
+        node_off[f] = h0 + e0;
+        if (f == n_frames - 1) node_off[n_frames] = head_off[n_frames] + en_off[n_frames];
+        if (!ok && status) atomicOr(status, 1);
+    }
+    for (int i = t; i < H; i += blockDim.x) head_frame[h0 + i] = f;
+    int flag = 0;
+    uint16_t *tab = head_src + (size_t)f * hmax * deg_cap;
+    // one thread per head row of the table; deg = entries written so far
+    int deg_a[4];                                   // rows t, t + 256, ... (hmax < 1024 in explicit mode: checked by the caller)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = t + r * 256;
+        deg_a[r] = 0;
+        if (ok && h < H && h < hmax) {
+            tab[(size_t)h * deg_cap] = (uint16_t)h;
+            deg_a[r] = 1;
+        }
+    }
+    for (int c0 = 0; c0 < M; c0 += XT_CHUNK) {
+        const int cn = min(XT_CHUNK, M - c0);
+        __syncthreads();
+        for (int i = t; i < cn; i += blockDim.x) {
+            const size_t m = (size_t)e0 + c0 + i;
+            int h1 = pairs_in[2 * m], h2 = pairs_in[2 * m + 1];
+            if (h1 < 0 || h1 >= H || h2 < 0 || h2 >= H || h1 == h2) {
+                flag = 2;
+                h1 = 0;
+                h2 = H > 1 ? 1 : 0;
+            }
+            en_frame[m] = f;
+            en_pair[2 * m] = h1;
+            en_pair[2 * m + 1] = h2;
+            s_pr[i] = ((uint32_t)h1 << 16) | (uint32_t)h2;
+        }
+        __syncthreads();
+        if (!ok) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = t + r * 256;
+            if (h >= H || h >= hmax) continue;
+            uint16_t *row = tab + (size_t)h * deg_cap;
+            int deg = deg_a[r];
+            for (int i = 0; i < cn; ++i) {
+                const uint32_t pr = s_pr[i];
+                if ((int)(pr >> 16) == h || (int)(pr & 0xFFFFu) == h) {
+                    if (deg < deg_cap) row[deg++] = (uint16_t)(H + c0 + i);
+                    else flag = 2;
+                }
+            }
+            deg_a[r] = deg;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = t + r * 256;
+        if (h >= hmax) continue;
+        uint16_t *row = tab + (size_t)h * deg_cap;
+        for (int e = deg_a[r]; e < deg_cap; ++e) row[e] = 0xFFFF;
+    }
+    if (flag && status) atomicOr(status, flag);
+}
+
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
                            int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status,
-                           uint16_t *head_src) {
+                           uint16_t *head_src, int x_deg_cap, int x_m_cap) {
     if (b.n_frames <= 0) return hipSuccess;
+    if (b.d_en_pair) {
+        if (!head_src || x_deg_cap <= 0 || max_heads_per_frame > 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_topology_explicit, dim3(b.n_frames), dim3(256), 0, s, b.n_frames, b.d_frame_head_off,
+                           b.d_frame_en_off, b.d_en_pair, node_off, head_frame, en_frame, en_pair, head_src,
+                           max_heads_per_frame, x_deg_cap, x_m_cap, status);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_topology, dim3(b.n_frames), dim3(128), 0, s, b.n_frames, V, b.d_frame_head_off,
                        b.d_frame_en_off, b.d_slot_n, node_off, head_frame, en_frame, en_pair, max_heads_per_frame,
                        status);
@@ -627,7 +718,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_aggregate_heads(
     int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
     const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off,
-    const int32_t *__restrict__ head_frame, AggArgs a, const uint16_t *__restrict__ head_src, int src_stride) {
+    const int32_t *__restrict__ head_frame, AggArgs a, const uint16_t *__restrict__ head_src, int src_stride, int hmax) {
 #pragma clang fp contract(off)
     extern __shared__ float s_dyn[];
     const int heads = a.heads, hd = a.heads * a.out_dim;
@@ -651,7 +742,7 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
         f = head_frame[gh];
         hb = head_off[f];
         H = head_off[f + 1] - hb;
-        live = H <= max_deg - 1;                // frames beyond max_heads_per_frame are skipped (flagged by k_topology)
+        live = H <= hmax;                       // frames beyond max_heads_per_frame are skipped (flagged by k_topology)
         v = gh - hb;
         nb = node_off[f];
         sn = slot_n + (size_t)f * V;
@@ -662,7 +753,7 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
         if (head_src) {
             // in-edge sources from the per-frame table (0xFFFF behind the in-degree); both waves of a
             // row derive the in-degree, the first one fills the LDS list
-            const uint16_t *tab = head_src + ((size_t)f * (src_stride - 1) + v) * src_stride;
+            const uint16_t *tab = head_src + ((size_t)f * hmax + v) * src_stride;
             int *src = s_src + r_own * max_deg;
             int dg = 0;
             for (int e = lane; e < src_stride; e += 64) {
@@ -760,8 +851,8 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
 // activated output slice -- ft2 is read once and nothing else touches HBM.
 // ---------------------------------------------------------------------------------------
 // floats of the small LDS tables of k_gat_fused, rounded up to 1 KiB (the feature image follows)
-__host__ __device__ inline size_t fused_tables_floats(int hmax, int V, int n_cap, int m_cap) {
-    const size_t deg = (size_t)hmax + 1;
+__host__ __device__ inline size_t fused_tables_floats(int hmax, int max_deg, int V, int n_cap, int m_cap) {
+    const size_t deg = (size_t)max_deg;
     const size_t n = 2 * (size_t)n_cap + 2 * hmax * deg + (size_t)m_cap * 4 + (V + 1) + (size_t)V * V + MPE_MAX_CAMERAS + hmax;
     return (n + 255) & ~(size_t)255;
 }
@@ -782,7 +873,7 @@ __device__ __forceinline__ void lds_barrier_raw() { asm volatile("s_waitcnt lgkm
 constexpr int FUSED_PIECES = 8;     // LDS-DMA pieces per wave of the overlapped staging (8 x 4 x 1 KiB = 32 KiB image)
 
 template <int VEC, int G>
-__global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap, int m_cap,
+__global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int hmax, int n_cap, int m_cap,
                                                    const int32_t *__restrict__ head_off,
                                                    const int32_t *__restrict__ en_off,
                                                    const int32_t *__restrict__ slot_n,
@@ -805,7 +896,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     const int eb = en_off[f], M = en_off[f + 1] - eb;
     const int N = H + M, nb = node_off[f];
     if (M <= 0) return;                             // frames without a graph produce nothing
-    if (H > max_deg - 1 || N > n_cap || M > m_cap) {
+    if (H > hmax || N > n_cap || M > m_cap) {
         // frame beyond max_heads_per_frame (k_topology raised the status flag): defined output
         if (a.score_mode)
             for (int m = threadIdx.x; m < M; m += blockDim.x) a.out[(size_t)eb + m] = 0.f;
@@ -817,15 +908,15 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     float *s_a1 = s_dyn;                            // [n_cap]
     float *s_a2 = s_a1 + n_cap;                     // [n_cap]
     float *s_wh = s_a2 + n_cap;                     // [hmax][max_deg] softmax weights of heads
-    int *s_src = reinterpret_cast<int *>(s_wh + (size_t)(max_deg - 1) * max_deg);   // [hmax][max_deg]
-    int *s_pair = s_src + (size_t)(max_deg - 1) * max_deg;                          // [m_cap] h1 << 16 | h2
+    int *s_src = reinterpret_cast<int *>(s_wh + (size_t)hmax * max_deg);            // [hmax][max_deg]
+    int *s_pair = s_src + (size_t)hmax * max_deg;                                   // [m_cap] h1 << 16 | h2
     float *s_wen = reinterpret_cast<float *>(s_pair + m_cap);                       // [m_cap][3] softmax weights of edge-nodes
     FrameTopo tp;
     tp.start = reinterpret_cast<int *>(s_wen + (size_t)m_cap * 3);                  // [V + 1]
     tp.base = tp.start + V + 1;                     // [V * V]
     int *s_sn = tp.base + V * V;                    // [V] heads per camera slot of this frame
     int *s_deg = s_sn + MPE_MAX_CAMERAS;            // [hmax] in-degree of the heads
-    float *s_ft = s_dyn + fused_tables_floats(max_deg - 1, V, n_cap, m_cap);         // [n_cap][Dp]
+    float *s_ft = s_dyn + fused_tables_floats(hmax, max_deg, V, n_cap, m_cap);       // [n_cap][Dp]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool l0 = a.en_const_ft2 != nullptr;
     const int c0 = hh * D;
@@ -852,12 +943,12 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
         const int total = N * DV;
         const size_t row0 = (size_t)(l0 ? hb : nb);
         const int tn = t < N ? t : N - 1, tm = t < M ? t : M - 1;
-        const int n_src2 = (max_deg - 1) * max_deg / 2;          // dwords (entry pairs) of the frame's source table
+        const int n_src2 = hmax * max_deg / 2;                   // dwords (entry pairs) of the frame's source table
         const int ts = t < n_src2 ? t : n_src2 - 1;
         const float *pr_ = (l0 && tn >= H) ? a.en_const_a : a.a12 + (row0 + tn) * 32;
         const float *p1 = pr_ + hh, *p2 = pr_ + 16 + hh;
         const int32_t *pe = en_pair + 2 * (size_t)(eb + tm);
-        const uint32_t *ps = reinterpret_cast<const uint32_t *>(head_src + (size_t)f * (max_deg - 1) * max_deg) + ts;
+        const uint32_t *ps = reinterpret_cast<const uint32_t *>(head_src + (size_t)f * hmax * max_deg) + ts;
         const float *src[FUSED_PIECES];
 #pragma unroll
         for (int u = 0; u < FUSED_PIECES; ++u) {
@@ -982,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     for (int m = t; m < M; m += blockDim.x)
         s_pair[m] = (en_pair[2 * (size_t)(eb + m)] << 16) | en_pair[2 * (size_t)(eb + m) + 1];
     if (head_src) {
-        const uint16_t *tab = head_src + (size_t)f * (max_deg - 1) * max_deg;
+        const uint16_t *tab = head_src + (size_t)f * hmax * max_deg;
         for (int i = t; i < H * max_deg; i += blockDim.x) {
             const int u = tab[i];
             s_src[i] = u == 0xFFFF ? -1 : u;
@@ -1113,23 +1204,22 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int n_cap
     }
 }
 
-// LDS bytes of k_gat_fused for frames of up to `hmax` heads
-static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_cap) {
-    const int mc = hmax * hmax * (V - 1) / (2 * V) + 1;
+// LDS bytes of k_gat_fused for frames of up to `hmax` heads.  Implicit topology: at most hmax^2 (V-1) / 2V edge-nodes
+// and hmax + 1 in-edges per head; explicit pair lists (x_m_cap > 0): the caller's caps.
+static size_t fused_lds_bytes(int hmax, int V, int out_dim, int *n_cap, int *m_cap, int *max_deg, int x_deg_cap, int x_m_cap) {
+    const int mc = x_m_cap > 0 ? x_m_cap : hmax * hmax * (V - 1) / (2 * V) + 1;
     const int nc = hmax + mc;
+    const int deg = x_m_cap > 0 ? x_deg_cap : hmax + 1;
     const int Dp = out_dim;
     size_t image = (size_t)nc * Dp + 256;
     if (out_dim % 4 == 0 && image < (size_t)FUSED_PIECES * 1024)
         image = (size_t)FUSED_PIECES * 1024;                                           // overlapped staging issues whole pieces
-    const size_t bytes = (fused_tables_floats(hmax, V, nc, mc) + image) * sizeof(float);
+    const size_t bytes = (fused_tables_floats(hmax, deg, V, nc, mc) + image) * sizeof(float);
     *n_cap = nc;
     *m_cap = mc;
+    *max_deg = deg;
     return bytes;
 }
-
-hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
-                            const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
-                            const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src);
 
 static int agg_vec(const AggArgs &a) {
     if (!a.score_mode && a.ld % 4 == 0 && a.ld_out % 4 == 0) {
@@ -1150,20 +1240,23 @@ constexpr size_t FUSED_LDS_LIMIT = 160 * 1024;      // all of a CU's LDS (one wo
 hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                                 const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
                                 const int32_t *en_pair, const float *attn_l, const float *attn_r, float *a12,
-                                const AggArgs &a, int n_rows_ft2, const uint16_t *head_src) {
-    int n_cap, m_cap;
-    if (getenv("MPE_NO_HEAD_SRC_TABLE")) head_src = nullptr;                // read per call: tests toggle it
-    const size_t shm = fused_lds_bytes(max_heads_per_frame, V, a.out_dim, &n_cap, &m_cap);
+                                const AggArgs &a, int n_rows_ft2, const uint16_t *head_src, int x_deg_cap, int x_m_cap) {
+    int n_cap, m_cap, max_deg;
+    const bool xpl = b.d_en_pair != nullptr;              // explicit pair list: the in-edge sources exist as a table only
+    if (xpl && (!head_src || x_m_cap <= 0)) return hipErrorInvalidValue;
+    if (!xpl) x_deg_cap = x_m_cap = 0;
+    if (!xpl && getenv("MPE_NO_HEAD_SRC_TABLE")) head_src = nullptr;       // read per call: tests toggle it
+    const size_t shm = fused_lds_bytes(max_heads_per_frame, V, a.out_dim, &n_cap, &m_cap, &max_deg, x_deg_cap, x_m_cap);
     const bool no_fuse = getenv("MPE_NO_FUSED_ATTENTION") != nullptr;       // read per call: tests toggle it
     if (shm <= FUSED_LDS_LIMIT && !no_fuse && b.n_frames > 0) {
         const int vec = agg_vec(a);
-        // lane-group width of the head softmax: the in-degree of a head is at most max_heads_per_frame
-        const int grp = max_heads_per_frame + 1 <= 16 ? 16 : max_heads_per_frame + 1 <= 32 ? 32 : 64;
+        // lane-group width of the head softmax: the largest in-degree a head can have
+        const int grp = max_deg <= 16 ? 16 : max_deg <= 32 ? 32 : 64;
         // overlapped staging: coefficients from the GEMM, fp32 rows of 16-byte chunks, tables of at most one
         // entry per thread, image of at most FUSED_PIECES x 256 chunks
-        if (!head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
+        if (!xpl && !head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
         // (the source table then travels as at most one dword = two entries per thread)
-        const int overlap = (vec == 4 && a.a12_ready && !a.ft_half && n_cap <= 256 && m_cap <= 256 && head_src &&
+        const int overlap = (!xpl && vec == 4 && a.a12_ready && !a.ft_half && n_cap <= 256 && m_cap <= 256 && head_src &&
                              max_heads_per_frame * (max_heads_per_frame + 1) <= 512 &&
                              n_cap * (a.out_dim / 4) <= FUSED_PIECES * 256 && !getenv("MPE_FUSED_NO_OVERLAP")) ? 1 : 0;
         const void *fn = nullptr;
@@ -1175,7 +1268,7 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
             if (e_ != hipSuccess) return e_;                                                                  \
         }                                                                                                     \
         hipLaunchKernelGGL((k_gat_fused<V_, G_>), dim3(b.n_frames * a.heads), dim3(256), shm, s, V,            \
-                           max_heads_per_frame + 1, n_cap, m_cap, b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, \
+                           max_deg, max_heads_per_frame, n_cap, m_cap, b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, \
                            node_off, en_pair, attn_l, attn_r, a, overlap, head_src);                          \
     } while (0)
 #define MPE_FUSED_G(V_)                     \
@@ -1197,14 +1290,16 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
         hipError_t e = launch_attn_coef(s, a.ft2, a.ld, n_rows_ft2, a.heads, a.out_dim, attn_l, attn_r, a12, a.ft_half);
         if (e != hipSuccess) return e;
     }
-    return launch_aggregate(s, b, V, max_heads_per_frame, node_off, head_frame, en_frame, en_pair, a2, head_src);
+    return launch_aggregate(s, b, V, max_heads_per_frame, node_off, head_frame, en_frame, en_pair, a2, head_src, x_deg_cap);
 }
 
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                             const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
-                            const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src) {
+                            const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src, int x_deg_cap) {
     const int vec = agg_vec(a);
-    if (!head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
+    const bool xpl = b.d_en_pair != nullptr;
+    if (xpl && (!head_src || x_deg_cap <= 0)) return hipErrorInvalidValue;
+    if (!xpl && !head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
     if (b.n_edge_nodes > 0) {
         const unsigned blocks = (unsigned)((b.n_edge_nodes + EN_ROWS - 1) / EN_ROWS);
 #define MPE_EN(V_)                                                                                      \
@@ -1224,7 +1319,8 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
         if (e != hipSuccess) return e;
     }
     if (b.n_heads > 0 && (!a.score_mode || a.out_heads)) {
-        int max_deg = max_heads_per_frame + 1;
+        const int src_stride = xpl ? x_deg_cap : max_heads_per_frame + 1;     // row stride of the in-edge source table
+        int max_deg = src_stride;
         if (max_deg < 3) max_deg = 3;
         const size_t shm = (size_t)AGG_ROWS * ((size_t)a.heads * max_deg + max_deg + (V + 1) + (size_t)V * V) * sizeof(float);
         if (shm > 64 * 1024) {
@@ -1243,7 +1339,7 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
 #define MPE_HEADS(V_)                                                                                   \
     hipLaunchKernelGGL(k_aggregate_heads<V_>, dim3(grid), dim3(256), shm, s, b.n_heads, V, max_deg,         \
                        b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, a, head_src,       \
-                       max_heads_per_frame + 1)
+                       src_stride, max_heads_per_frame)
         if (vec == 4 && a.ft_half && a.out_dim % 8 == 0 && half_vec8()) MPE_HEADS(8);
         else if (vec == 4) MPE_HEADS(4);
         else if (vec == 2) MPE_HEADS(2);

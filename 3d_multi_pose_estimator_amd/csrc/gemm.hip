@@ -359,6 +359,28 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
             if (tune_prio & 8) return;         // ABLATION (timing only, wrong data): no staging at all
             const int koff = kt * GEMM_BK;
             float *base = lds + buf * STAGE;
+            if constexpr ((tune_prio & 32) != 0 && NA_L == 4 && (NW_L == 2 || NW_L == 3)) {
+                // ABLATION (timing only, wrong data): the same requests as plain register loads -- same addresses, same
+                // bytes through TA / TCP / L2, but nothing is written into LDS.  The loads AND their wait are one asm
+                // statement with early-clobber outputs: a destination register is never free for the compiler to reuse
+                // while its load is in flight (a first form without the wait inside faulted: the landing load overwrote a
+                // reused address register).  The loader therefore waits here instead of in front of the next barrier.
+                f32x4 v0, v1, v2, v3, v4, v5, v6;
+                const float *w2 = lw[NW_L - 1] + koff;
+                asm volatile(
+                    "global_load_dwordx4 %0, %7, off\n\t"
+                    "global_load_dwordx4 %1, %8, off\n\t"
+                    "global_load_dwordx4 %2, %9, off\n\t"
+                    "global_load_dwordx4 %3, %10, off\n\t"
+                    "global_load_dwordx4 %4, %11, off\n\t"
+                    "global_load_dwordx4 %5, %12, off\n\t"
+                    "global_load_dwordx4 %6, %13, off\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6)
+                    : "v"(la[0] + koff), "v"(la[1] + koff), "v"(la[2] + koff), "v"(la[3] + koff), "v"(lw[0] + koff), "v"(lw[1] + koff), "v"(w2)
+                    : "memory");
+                return;
+            }
 #pragma unroll
             for (int g = 0; g < NA_L; ++g)
                 __builtin_amdgcn_global_load_lds((glb_void *)(la[g] + koff), (lds_void *)(base + (li * NA_L + g) * 8 * ROWF), 16, 0, 0);

@@ -115,7 +115,10 @@ struct mpe_ctx {
     int32_t *head_frame = nullptr; // [max_heads]
     int32_t *en_frame = nullptr;   // [max_edge_nodes]
     int32_t *en_pair = nullptr;    // [max_edge_nodes][2] frame-local head ids
-    uint16_t *head_src = nullptr;  // [max_frames][hmax][hmax + 1] in-edge sources of the heads (small frames only)
+    uint16_t *head_src = nullptr;  // [max_frames][hmax][hmax + 1] in-edge sources of the heads (small frames only); explicit
+                                   // pair lists: [n_frames][hmax][2 hmax] in the same allocation
+    size_t head_src_cap = 0;       // entries allocated
+    int x_m_cap = 0;               // explicit pair lists: edge-nodes a frame may hold (0 = mode unavailable on this context)
     int32_t *node_off = nullptr;   // [max_frames+1]
     uint64_t *cl_keys = nullptr;   // clustering scratch
     int32_t *cl_scratch = nullptr;
@@ -165,7 +168,9 @@ hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsi
 // gat.hip
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
                            int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status,
-                           uint16_t *head_src);
+                           uint16_t *head_src, int x_deg_cap = 0, int x_m_cap = 0);
+// explicit pair lists (mpe_batch::d_en_pair): row stride of the in-edge source table = largest in-degree of a head
+inline int explicit_deg_cap(int max_heads_per_frame) { return 2 * max_heads_per_frame; }
 // entries of the per-frame in-edge source table of the heads, or 0 when frames of that capacity do not get one
 size_t head_src_entries(int max_heads_per_frame, int V);
 hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, float *feat,
@@ -191,12 +196,13 @@ struct AggArgs {
 };
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                             const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
-                            const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src);
+                            const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src, int x_deg_cap = 0);
 
 hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                                 const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
                                 const int32_t *en_pair, const float *attn_l, const float *attn_r, float *a12,
-                                const AggArgs &a, int n_rows_ft2, const uint16_t *head_src);
+                                const AggArgs &a, int n_rows_ft2, const uint16_t *head_src, int x_deg_cap = 0,
+                                int x_m_cap = 0);
 
 // cluster.hip
 size_t cluster_keys_per_frame(int max_heads_per_frame);

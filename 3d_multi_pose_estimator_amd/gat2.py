@@ -4,7 +4,7 @@
 ``skeleton_matching.tch`` state dict loads unchanged) and call convention
 ``model(feats, g) -> N x 1 x 1`` (reference gat2.py:91-149), but forward() is one call into
 libmpe_hip.so (mpe_gat_forward): fp32 MFMA GEMMs for fc1/fc2, wavefront-level edge softmax and
-aggregation on the implicit topology.  Dropout and the residual branch are inactive in the
+aggregation on the implicit topology (or the explicit edge-node list of a generated scene, graph_generator.py:672-810).  Dropout and the residual branch are inactive in the
 deployed model (train_skeleton_matching.py:49-52) and are rejected if requested.
 """
 import torch
@@ -63,9 +63,9 @@ class GAT2(nn.Module):
     def _state_version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def _ensure_engine(self):
+    def _ensure_engine(self, n_graphs=1):
         ver = self._state_version()
-        if self._engine is not None and ver == self._version:
+        if self._engine is not None and ver == self._version and self._engine.max_frames >= n_graphs:
             return self._engine
         slope = getattr(self.activation, 'negative_slope', None)
         if not isinstance(self.activation, nn.LeakyReLU) or slope is None:
@@ -74,7 +74,7 @@ class GAT2(nn.Module):
             raise NotImplementedError('final activation must be nn.Sigmoid or None')
         if self._engine is not None:
             self._engine.close()
-        eng = runtime.new_engine()
+        eng = runtime.new_engine(max_frames=max(1, n_graphs))      # a batch of graphs = a batch of frames of the engine
         sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
         for l, layer in enumerate(self.layers):         # bias=False models: zero biases
             for fc in ('fc1', 'fc2'):
@@ -88,7 +88,7 @@ class GAT2(nn.Module):
 
     def forward(self, inputs, g):
         self.set_g(g)
-        eng = self._ensure_engine()
+        eng = self._ensure_engine(getattr(g, 'batch_size', 1))
         db = g.device_batch(eng)
         own = g.ndata.get('h') if 'h' in g.ndata else None
         feats = None
@@ -99,4 +99,12 @@ class GAT2(nn.Module):
                 feats = inputs
         eng.set_gat_output(sigmoid=self.final_activation is not None)     # None: raw logits (gat2.py:146-148)
         sc, sh = eng.gat_scores(db, heads=True, feats=feats)
-        return torch.cat([sh, sc]).reshape(-1, 1, 1)
+        eng.sync_status()                  # a graph beyond the engine's per-frame capacity raises here instead of scoring 0
+        if getattr(g, 'batch_size', 1) == 1:
+            return torch.cat([sh, sc]).reshape(-1, 1, 1)
+        # a batch of graphs (graph_generator.batch = the reference's dgl.batch): node order graph by graph, heads then edge-nodes
+        parts, h0, e0 = [], 0, 0
+        for H, M in zip(g.batch_num_heads, g.batch_num_edge_nodes):
+            parts += [sh[h0:h0 + H], sc[e0:e0 + M]]
+            h0, e0 = h0 + H, e0 + M
+        return torch.cat(parts).reshape(-1, 1, 1)

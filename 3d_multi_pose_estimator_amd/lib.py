@@ -53,6 +53,7 @@ class mpe_batch(C.Structure):
         ('d_frame_head_off', C.c_void_p), ('d_frame_en_off', C.c_void_p), ('d_slot_cam', C.c_void_p),
         ('d_slot_n', C.c_void_p), ('d_head_cam', C.c_void_p), ('d_joint_mask', C.c_void_p),
         ('d_tri_mask', C.c_void_p), ('d_xy', C.c_void_p), ('d_vp', C.c_void_p),
+        ('d_en_pair', C.c_void_p),      # optional explicit edge-node list (process_training topology); NULL = implicit
     ]
 
 

@@ -33,6 +33,7 @@ class PackedBatch:
         self.vp = None
         self.skeleton_index = None     # [n_heads] position in the camera's original list
         self.jsons_for_head = None     # optional: list (per frame) of {head id: skeleton dict}
+        self.en_pair = None            # optional [n_edge_nodes][2] int32: EXPLICIT edge-node list (mpe_batch::d_en_pair)
 
     @property
     def n_heads(self):
@@ -49,6 +50,15 @@ class PackedBatch:
 
     def max_heads_per_frame(self):
         return int(np.max(np.diff(self.frame_head_off))) if self.n_frames else 0
+
+    def max_edge_nodes_per_frame(self):
+        return int(np.max(np.diff(self.frame_en_off))) if self.n_frames else 0
+
+    def pairs(self, f):
+        """(h1, h2) of every edge-node of frame f, in edge-node order."""
+        if self.en_pair is not None:
+            return self.en_pair[int(self.frame_en_off[f]):int(self.frame_en_off[f + 1])]
+        return pairs_of_frame(self.slot_n[f])
 
     def to(self, device):
         return DeviceBatch(self, device)
@@ -312,9 +322,16 @@ class DeviceBatch:
                 'joint_mask': up(pb.joint_mask.view(np.int32)), 'tri_mask': up(pb.tri_mask.view(np.int32)),
                 'xy': up(pb.xy), 'vp': up(pb.vp),
             }
+            if pb.en_pair is not None:
+                ep = np.ascontiguousarray(pb.en_pair, np.int32).reshape(-1, 2)
+                if ep.shape[0] != pb.n_edge_nodes:
+                    raise ValueError('en_pair holds %d pairs, frame_en_off says %d' % (ep.shape[0], pb.n_edge_nodes))
+                self.t['en_pair'] = up(ep if ep.size else np.zeros((1, 2), np.int32))
             for k, v in self.t.items():
                 setattr(s, 'd_' + k, C.c_void_p(v.data_ptr()))
         else:
+            if pb.en_pair is not None:
+                raise ValueError('arena-backed batches carry the implicit topology only')
             for name, _ in ARRAYS:
                 setattr(s, 'd_' + name, C.c_void_p(arena.ptr(name)))
         self.struct = s
@@ -350,6 +367,27 @@ def parse_skeletons(frame_cam_entry):
     return json.loads(sk) if isinstance(sk, (str, bytes)) else sk
 
 
+def skeleton_arrays(sk, J):
+    """One skeleton dict {joint id: [id, x, y, valid, prob], optional "ID"} -> (joint mask, triangulation mask,
+    xy [J,2] f64, vp [J,2] f32); mask 0 = no joint key (the reference drops such skeletons, graph_generator.py:590-591)."""
+    xy = np.zeros((J, 2), np.float64)
+    vp = np.zeros((J, 2), np.float32)
+    m = 0
+    t = 0
+    for key, val in sk.items():
+        if key == 'ID':
+            continue
+        j = int(key)
+        if j < 0 or j >= J:
+            raise ValueError('joint id %r out of range' % key)
+        m |= 1 << j
+        if val[0] > 0.:
+            t |= 1 << j
+        xy[j, 0], xy[j, 1] = val[1], val[2]
+        vp[j, 0], vp[j, 1] = val[3], val[4]
+    return m, t, xy, vp
+
+
 def pack_frames(frames, params, keep_json=False):
     """frames: list of {cam: [json string of skeleton list, ...]} -> PackedBatch."""
     sm = list(params.used_cameras_skeleton_matching)
@@ -377,21 +415,7 @@ def pack_frames(frames, params, keep_json=False):
             c = sm.index(cam)
             n_here = 0
             for idx, sk in enumerate(parse_skeletons(frame[cam])):
-                xy = np.zeros((J, 2), np.float64)
-                vp = np.zeros((J, 2), np.float32)
-                m = 0
-                t = 0
-                for key, val in sk.items():
-                    if key == 'ID':
-                        continue
-                    j = int(key)
-                    if j < 0 or j >= J:
-                        raise ValueError('joint id %r out of range' % key)
-                    m |= 1 << j
-                    if val[0] > 0.:
-                        t |= 1 << j
-                    xy[j, 0], xy[j, 1] = val[1], val[2]
-                    vp[j, 0], vp[j, 1] = val[3], val[4]
+                m, t, xy, vp = skeleton_arrays(sk, J)
                 if m == 0:
                     continue
                 head_cam.append(c)
@@ -483,3 +507,120 @@ def pack_json(text, params, frame_start=0, frame_step=1, max_frames=0, n_threads
         return pb
     finally:
         lib.mpe_packed_free(handle)
+
+
+def generated_scene(views, params):
+    """Node and edge-node order of ONE graph of MergedMultipleHumansDataset.process_training (reference
+    graph_generator.py:697-797; what mode='test_generated' of test/sm_metrics_without_gt.py:108 builds).  `views` = the
+    sampled single-person frames ({cam: [json string of the skeleton list, ...]}) of the scene.
+
+    Heads: view after view (person-major), inside a view in the dict's camera order and list order, skipping skeletons
+    without a joint key (load_people_view_graph, :573-605).  Per view and camera the skeleton with the most joints is the
+    person's (first one on ties, :723), the others are spurious (:724-726).  Edge-nodes, one per ORDERED pair of heads of
+    different cameras: per person its own heads (label 1, :749-760), then its heads x every other person's (label 0,
+    :762-774), then its heads x the spurious ones (:776-786); after all persons the spurious x spurious pairs (:788-797).
+    Returns dict(heads=[(camera name, index in its list, skeleton dict)], pairs [M,2] int32, labels [M] f64)."""
+    sm = list(params.used_cameras_skeleton_matching)
+    heads, people, spurious = [], [], []
+    for view in views:
+        person = []
+        for cam in view:
+            if cam not in sm:
+                continue
+            ids, nj = [], []
+            for idx, sk in enumerate(parse_skeletons(view[cam])):
+                n = sum(1 for k in sk if k != 'ID')
+                if n == 0:
+                    continue
+                ids.append(len(heads))
+                nj.append(n)
+                heads.append((cam, idx, sk))
+            if nj:
+                good = max(enumerate(nj), key=lambda x: x[1])[0]
+                spurious += [(h, cam) for h in ids if h != ids[good]]
+                person.append((ids[good], cam))
+        people.append(person)
+    pairs, labels = [], []
+
+    def link(group1, group2, label):
+        for h1, c1 in group1:
+            for h2, c2 in group2:
+                if c1 == c2:
+                    continue
+                pairs.append((h1, h2))
+                labels.append(label)
+    for ip, person in enumerate(people):
+        link(person, person, 1.0)
+        for io, other in enumerate(people):
+            if io != ip:
+                link(person, other, 0.0)
+        link(person, spurious, 0.0)
+    link(spurious, spurious, 0.0)
+    return {'heads': heads, 'pairs': np.array(pairs, np.int32).reshape(-1, 2), 'labels': np.array(labels, np.float64)}
+
+
+def pack_scenes(scenes, params, keep_json=False):
+    """[generated_scene(...)] -> PackedBatch with an explicit edge-node list (one frame per scene)."""
+    sm = list(params.used_cameras_skeleton_matching)
+    V, J = len(sm), len(params.joint_list)
+    B = len(scenes)
+    pb = PackedBatch(V, J)
+    pb.n_frames = B
+    head_off = np.zeros(B + 1, np.int32)
+    en_off = np.zeros(B + 1, np.int32)
+    head_cam, jmask, tmask, skidx, xy_rows, vp_rows, pairs = [], [], [], [], [], [], []
+    jsons = [] if keep_json else None
+    for f, sc in enumerate(scenes):
+        for cam, idx, sk in sc['heads']:
+            m, t, xy, vp = skeleton_arrays(sk, J)
+            head_cam.append(sm.index(cam))
+            jmask.append(m)
+            tmask.append(t)
+            skidx.append(idx)
+            xy_rows.append(xy)
+            vp_rows.append(vp)
+        if keep_json:
+            jsons.append({i: h[2] for i, h in enumerate(sc['heads'])})
+        head_off[f + 1] = head_off[f] + len(sc['heads'])
+        en_off[f + 1] = en_off[f] + len(sc['pairs'])
+        pairs.append(np.asarray(sc['pairs'], np.int32).reshape(-1, 2))
+    n = len(head_cam)
+    pb.frame_head_off, pb.frame_en_off = head_off, en_off
+    pb.slot_cam = np.full((B, V), -1, np.int32)
+    pb.slot_n = np.zeros((B, V), np.int32)
+    pb.head_cam = np.array(head_cam, np.int32).reshape(n)
+    pb.joint_mask = np.array(jmask, np.uint32).reshape(n)
+    pb.tri_mask = np.array(tmask, np.uint32).reshape(n)
+    pb.skeleton_index = np.array(skidx, np.int32).reshape(n)
+    pb.xy = np.stack(xy_rows).reshape(n, J, 2) if n else np.zeros((0, J, 2), np.float64)
+    pb.vp = np.stack(vp_rows).reshape(n, J, 2) if n else np.zeros((0, J, 2), np.float32)
+    pb.en_pair = np.concatenate(pairs).reshape(-1, 2) if pairs else np.zeros((0, 2), np.int32)
+    pb.jsons_for_head = jsons
+    return pb
+
+
+def concat_packed(batches):
+    """Frames of several PackedBatch objects back to back (the engine's frame batch = what dgl.batch is to the
+    reference, train_skeleton_matching.py:67-84).  All explicit or all implicit."""
+    first = batches[0]
+    explicit = first.en_pair is not None
+    if any((b.en_pair is not None) != explicit or b.V != first.V or b.J != first.J for b in batches):
+        raise ValueError('cannot batch graphs of different kinds')
+    pb = PackedBatch(first.V, first.J)
+    pb.n_frames = sum(b.n_frames for b in batches)
+
+    def offs(name):
+        out, base = [np.zeros(1, np.int32)], 0
+        for b in batches:
+            a = np.asarray(getattr(b, name), np.int32)
+            out.append(a[1:] + base)
+            base += int(a[-1])
+        return np.concatenate(out).astype(np.int32)
+    pb.frame_head_off, pb.frame_en_off = offs('frame_head_off'), offs('frame_en_off')
+    for name in ('slot_cam', 'slot_n', 'head_cam', 'joint_mask', 'tri_mask', 'skeleton_index', 'xy', 'vp'):
+        setattr(pb, name, np.concatenate([np.asarray(getattr(b, name)) for b in batches]))
+    if explicit:
+        pb.en_pair = np.concatenate([np.asarray(b.en_pair, np.int32).reshape(-1, 2) for b in batches])
+    if all(b.jsons_for_head is not None for b in batches):
+        pb.jsons_for_head = [j for b in batches for j in b.jsons_for_head]
+    return pb

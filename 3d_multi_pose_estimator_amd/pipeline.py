@@ -22,7 +22,7 @@ def _f32p(a):
 
 class Engine:
     def __init__(self, params=None, calib=None, max_frames=1024, max_heads_per_frame=None,
-                 max_persons_per_camera=4, device='cuda:0', threshold=0.5):
+                 max_persons_per_camera=4, device='cuda:0', threshold=0.5, max_edge_nodes_per_frame=None):
         from .parameters import parameters as default_params
         self.params = params or default_params
         self.calib = calib or Calibration(self.params)
@@ -43,6 +43,10 @@ class Engine:
         self.pcap = max(1, hpf // max(1, p.min_number_of_views))
         # largest edge-node count of a frame with `hpf` heads (even spread over V cameras)
         m_frame = hpf * hpf * (self.V - 1) // (2 * self.V) + 1
+        # batches with an explicit edge-node list (process_training graphs: one edge-node per ORDERED head pair) hold up to
+        # explicit_m_cap(hpf) edge-nodes per frame; `max_edge_nodes_per_frame` sizes the batch totals for them
+        if max_edge_nodes_per_frame:
+            m_frame = max(m_frame, int(max_edge_nodes_per_frame))
         self._keep = {
             'Kinv': np.ascontiguousarray(self.calib.Kinv32[cal_idx].reshape(-1), np.float32),
             'K': np.ascontiguousarray(self.calib.K32[cal_idx].reshape(-1), np.float32),
@@ -75,8 +79,10 @@ class Engine:
             raise L.MpeError(rc, 'mpe_create failed')
         self.gat_dims = None
         self.mlp_out = None
+        self.m_frame = m_frame
         self._made_with = dict(params=self.params, calib=self.calib, max_frames=self.max_frames, max_heads_per_frame=self.hpf,
-                               max_persons_per_camera=max_persons_per_camera, device=str(self.device), threshold=threshold)
+                               max_persons_per_camera=max_persons_per_camera, device=str(self.device), threshold=threshold,
+                               max_edge_nodes_per_frame=max_edge_nodes_per_frame)
         self._state = {}                 # what was loaded / set, so that sibling() can repeat it
         self._siblings = []
         self._json_streams = None
@@ -651,6 +657,20 @@ class Engine:
         if pb.V != self.V or pb.J != self.J:
             raise ValueError('batch packed for %d cameras x %d joints, engine built for %d x %d'
                              % (pb.V, pb.J, self.V, self.J))
+        if getattr(pb, 'en_pair', None) is not None and pb.n_frames:
+            cap = explicit_m_cap(self.hpf)
+            if cap == 0:
+                raise ValueError('explicit edge-node lists need max_heads_per_frame <= 1024 and 16-bit node ids (capacity %d)' % self.hpf)
+            if pb.max_edge_nodes_per_frame() > cap:
+                raise ValueError('a graph holds %d edge-nodes, an engine with max_heads_per_frame = %d takes %d per frame'
+                                 % (pb.max_edge_nodes_per_frame(), self.hpf, cap))
+            if pb.n_edge_nodes > self.max_frames * self.m_frame:
+                raise ValueError('batch of %d edge-nodes exceeds the capacity %d (max_edge_nodes_per_frame)'
+                                 % (pb.n_edge_nodes, self.max_frames * self.m_frame))
+            ep = np.asarray(pb.en_pair).reshape(-1, 2)
+            H = np.repeat(np.diff(pb.frame_head_off), np.diff(pb.frame_en_off))
+            if ep.size and (ep.min() < 0 or (ep >= H[:, None]).any() or (ep[:, 0] == ep[:, 1]).any()):
+                raise ValueError('explicit edge-node list: a pair lies outside its frame or joins a head with itself')
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -819,6 +839,15 @@ class Engine:
         ms, fl, n, tot = C.c_double(), C.c_double(), C.c_int64(), C.c_double()
         self._chk(self.lib.mpe_profile_read(self.ctx, C.byref(ms), C.byref(fl), C.byref(n), C.byref(tot)))
         return {'gemm_ms': ms.value, 'gemm_flop': fl.value, 'gemm_launches': n.value}
+
+
+def explicit_m_cap(max_heads_per_frame):
+    """Edge-nodes a frame of an explicit edge-node list may hold on a context of that capacity (include/mpe.h: the power of
+    two >= max(512, hmax^2 / 2 + 1), the clustering scratch; 0 = mode unavailable)."""
+    need, n = max_heads_per_frame * max_heads_per_frame // 2 + 1, 512
+    while n < need:
+        n <<= 1
+    return n if max_heads_per_frame <= 1024 and max_heads_per_frame + n <= 65535 else 0
 
 
 def _np32(v):

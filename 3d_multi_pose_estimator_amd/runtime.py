@@ -21,16 +21,23 @@ def device():
 
 
 def new_engine(params=None, calib=None, max_frames=1):
-    from .pipeline import Engine
+    from .parameters import parameters as default_params
+    from .pipeline import Engine, explicit_m_cap
+    p = params or default_params
+    hpf = len(p.used_cameras_skeleton_matching) * max_persons_per_camera()
+    # the mirrors also take the graphs of mode='test_generated' (explicit edge-node lists: up to explicit_m_cap per graph)
     return Engine(params, calib, max_frames=max_frames, max_persons_per_camera=max_persons_per_camera(),
-                  device=device())
+                  device=device(), max_edge_nodes_per_frame=explicit_m_cap(hpf) or None)
 
 
-def shared_engine(params=None, calib=None):
-    """Weight-less engine keyed by the calibration it was built from."""
+def shared_engine(params=None, calib=None, max_frames=1):
+    """Weight-less engine keyed by the calibration it was built from; rebuilt larger when a batch of graphs needs more
+    frames than it has."""
     key = 'default' if calib is None else _calib_key(calib)
+    if key in _shared and _shared[key].max_frames < max_frames:
+        _shared.pop(key).close()
     if key not in _shared:
-        _shared[key] = new_engine(params, calib)
+        _shared[key] = new_engine(params, calib, max_frames=max(1, int(max_frames)))
     return _shared[key]
 
 

@@ -11,6 +11,8 @@ def get_person_proposal_from_network_output(outputs, subgraph, indices, nodes_ca
     """Same arguments and result as the reference (:12-132): a list of
     ``{camera_name: head id or None}`` over ``used_cameras_skeleton_matching``.  `outputs` may
     be a tensor or a Python list of per-node scores; only edge-node entries are read."""
+    if getattr(subgraph, 'batch_size', 1) != 1:
+        raise ValueError('one graph per call (the reference function walks one graph, skeleton_matching_utils.py:33-55)')
     eng = runtime.shared_engine()
     db = subgraph.device_batch(eng)
     if type(outputs) is list:
@@ -25,6 +27,7 @@ def get_person_proposal_from_network_output(outputs, subgraph, indices, nodes_ca
         raise RuntimeError('engine / parameters mismatch')
     eng.set_threshold(CLASSIFICATION_THRESHOLD)
     persons, n_persons = eng.cluster(db, scores)
+    eng.sync_status()
     n = int(n_persons[0])
     rows = persons[0, :n].cpu().tolist()
     cams = list(parameters.used_cameras_skeleton_matching)

@@ -94,6 +94,17 @@ typedef struct {
     const uint32_t *d_tri_mask;      /* [n_heads] bit j: present and values[0] > 0      */
     const double *d_xy;              /* [n_heads][J][2] pixel x,y (values[1], values[2])*/
     const float *d_vp;               /* [n_heads][J][2] values[3] (valid), values[4]    */
+    /* Optional EXPLICIT edge-node list, NULL = the implicit one of process_test (every cross-slot head pair once,
+     * graph_generator.py:854-864).  [n_edge_nodes][2] frame-local head ids (h1, h2) of edge-node m, frames back to back
+     * as d_frame_en_off says; edge-node X = (h1,h2) carries the edges (h1,X),(X,h1),(h2,X),(X,h2),(X,X) in that order
+     * (add_edge_node_to_graph, :627-656).  This is the topology of MergedMultipleHumansDataset.process_training
+     * (:672-810; mode 'test_generated' of test/sm_metrics_without_gt.py:108): heads grouped by person instead of by
+     * camera slot and one edge-node per ORDERED head pair -- or any other pair list.  The heads may then come in any
+     * order; d_slot_cam / d_slot_n are not read and may be NULL.  Per-frame limits, checked on the device and reported by
+     * mpe_sync_status: heads <= max_heads_per_frame, edge-nodes <= the power of two >= max(512, max_heads_per_frame^2 / 2 + 1),
+     * every pair inside its frame with h1 != h2 (else MPE_ERR_INVALID).  Available on contexts with
+     * max_heads_per_frame <= 1024 whose per-frame node ids fit 16 bits (MPE_ERR_UNSUPPORTED otherwise). */
+    const int32_t *d_en_pair;
 } mpe_batch;
 
 /* ---- lifetime ------------------------------------------------------------------------ */
@@ -207,7 +218,7 @@ int mpe_edge_softmax_aggregate(mpe_ctx *ctx, void *stream, const mpe_batch *b, i
  * than the per-frame LDS / scratch budget) is detected on the device: its scores come back as
  * zeros, it yields n_persons = 0, and a sticky status bit is raised.  mpe_sync_status
  * synchronises `stream`, returns MPE_ERR_CAPACITY if any batch since the last call contained
- * such a frame (MPE_OK otherwise) and clears the bit.  Limits that mpe_create enforces:
+ * such a frame (MPE_ERR_INVALID if an explicit edge-node list held a bad pair; MPE_OK otherwise) and clears the bits.  Limits that mpe_create enforces:
  * max_heads_per_frame < 32768, n_cameras <= 32, n_joints <= 32, attention heads <= 16. */
 int mpe_sync_status(mpe_ctx *ctx, void *stream);
 

@@ -68,12 +68,34 @@ def graph(data, num_nodes=None, idtype=torch.int64):
 
 
 def batch(graphs):
-    raise NotImplementedError('dgl.batch is training-only; not part of the oracle')
+    """dgl.batch: one graph holding the input graphs as disjoint components, nodes and edges relabelled in input order
+    (node i of graph k becomes i + the node count of graphs 0..k-1), node / edge data concatenated.  Called by the collate
+    functions of train_skeleton_matching.py:67-84 and test/sm_metrics_without_gt.py:46-64."""
+    src, dst, base = [], [], 0
+    for g in graphs:
+        src.append(g._src.long() + base)
+        dst.append(g._dst.long() + base)
+        base += g._n
+    out = DGLGraph(torch.cat(src), torch.cat(dst), base, graphs[0].idtype)
+    for k in graphs[0].ndata:
+        out.ndata[k] = torch.cat([g.ndata[k] for g in graphs], dim=0)
+    for k in graphs[0].edata:
+        out.edata[k] = torch.cat([g.edata[k] for g in graphs], dim=0)
+    out._batch_num_nodes = [g._n for g in graphs]
+    return out
 
 
 def save_graphs(path, graphs, labels=None):
-    raise NotImplementedError
+    """dgl.save_graphs: persist a list of graphs (graph_generator.py:895).  Stand-in format: torch.save of plain tensors."""
+    torch.save([{'src': g._src, 'dst': g._dst, 'n': g._n, 'idtype': g.idtype, 'ndata': dict(g.ndata), 'edata': dict(g.edata)}
+                for g in graphs], path)
 
 
 def load_graphs(path):
-    raise NotImplementedError
+    out = []
+    for d in torch.load(path):
+        g = DGLGraph(d['src'], d['dst'], d['n'], d['idtype'])
+        g.ndata.update(d['ndata'])
+        g.edata.update(d['edata'])
+        out.append(g)
+    return out, {}
