@@ -9,6 +9,9 @@ third-party stand-ins of oracle/shims first on sys.path) on four committed singl
     labels, edge_nodes_indices, nodes_camera, the non-zero block of every head row,
   * the reference model's scores on every graph and the two proposal lists the script derives per graph (from the scores,
     :131, and from the labels-as-scores, :147) -- recomputed after the run with the script's own objects,
+  * the scores and proposals of a SECOND weight set on the same graphs (the hash weights of the frame fixtures, through a
+    second instance of the reference's GAT2): the hand-built matcher network is steep (its own fp32 scores sit up to 3e-3 from
+    the float64 network on head nodes), the hash network is where the 2e-5 score bound of the frame fixtures applies,
 
 in tests/golden/generated/.  The single-person files are cut out of synthetic 4-person frames (every person keeps its
 identity code in the `prob` field, which the hand-built matcher network reads; some frames carry a spurious skeleton, a
@@ -36,6 +39,7 @@ PKG = '3d_multi_pose_estimator_amd'
 SEED = 20260104
 LENGTHS = (16, 14, 12, 10)
 GAT_NOISE_SEED, GAT_NOISE = 5, 1e-4
+HASH_GAT = {'seed': 7, 'logit_gain': 25.0, 'logit_shift': 0.698}       # the weights of the frame fixtures (tests/golden/meta.json)
 
 
 def build_files(calib, syn):
@@ -76,6 +80,13 @@ sys.argv = ['sm_metrics_without_gt.py', '--testfiles'] + %(files)r + ['--modelsd
 random.seed(%(seed)d)
 g = runpy.run_path(%(script)r, run_name='__main__')
 ds, model, fn = g['test_dataset'], g['model'], g['get_person_proposal_from_network_output']
+# a second, well-conditioned weight set on the same graphs (hash weights: scores spread over (0, 1), fp32 noise ~1e-5),
+# through the reference's GAT2 built the way the script builds its own (:88-92)
+params = g['params']
+model2 = g['GAT'](None, params['gnn_layers'], params['num_feats'], params['n_classes'], params['num_hidden'], params['heads'],
+                  params['nonlinearity'], params['final_activation'], params['in_drop'], params['attn_drop'], params['alpha'],
+                  params['residual'], bias=True)
+model2.load_state_dict(torch.load(%(hash_tch)r))
 out = []
 for i in range(len(ds)):
     graph, labels, indices, nodes_camera = ds[i]
@@ -85,6 +96,11 @@ for i in range(len(ds)):
     feats = graph.ndata['h']
     scores = torch.squeeze(model(feats.float(), graph))
     idx = torch.squeeze(indices)
+    model2.g = graph
+    for layer in model2.layers:
+        layer.g = graph
+    scores_hash = torch.squeeze(model2(feats.float(), graph))
+    est_hash = fn(scores_hash, graph, idx, nodes_camera, None, 0.5)
     est = fn(scores, graph, idx, nodes_camera, None, 0.5)
     lab = [0.] * graph.number_of_nodes()
     for (j, v) in zip(idx, torch.squeeze(labels).tolist()):
@@ -92,7 +108,8 @@ for i in range(len(ds)):
     gt = fn(lab, graph, idx, nodes_camera, None, 0.5)
     src, dst = graph.edges()
     out.append({'src': src.numpy(), 'dst': dst.numpy(), 'labels': labels.numpy(), 'indices': indices.numpy(),
-                'nodes_camera': nodes_camera, 'scores': scores.numpy(), 'est': est, 'gt': gt, 'feats': feats.numpy()})
+                'nodes_camera': nodes_camera, 'scores': scores.numpy(), 'est': est, 'gt': gt, 'feats': feats.numpy(),
+                'scores_hash': scores_hash.numpy(), 'est_hash': est_hash})
 pickle.dump(out, open(%(dump)r, 'wb'))
 '''
 
@@ -123,8 +140,12 @@ def main():
         gh.GAT_NOISE_SEED, gh.GAT_NOISE = GAT_NOISE_SEED, GAT_NOISE
         gh.save_models(mdir, syn, V, J)
         dump = os.path.join(layout, 'graphs.pkl')
+        import torch
+        hash_tch = os.path.join(layout, 'hash_gat.tch')
+        torch.save({k: torch.from_numpy(v) for k, v in syn.gat_state_dict(HASH_GAT['seed'], 2 + V * J * 10, logit_gain=HASH_GAT['logit_gain'],
+                                                                          logit_shift=HASH_GAT['logit_shift']).items()}, hash_tch)
         code = CHILD % {'paths': [SHIMS, os.path.join(REF, 'skeleton_matching'), os.path.join(REF, 'utils'), REF], 'files': names,
-                        'mdir': mdir, 'seed': SEED, 'script': os.path.join(REF, 'test', 'sm_metrics_without_gt.py'), 'dump': dump}
+                        'mdir': mdir, 'seed': SEED, 'hash_tch': hash_tch, 'script': os.path.join(REF, 'test', 'sm_metrics_without_gt.py'), 'dump': dump}
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
         res = subprocess.run([sys.executable, '-c', code], cwd=os.path.join(layout, 'test'), env=env, capture_output=True, text=True)
         if res.returncode != 0:
@@ -155,12 +176,13 @@ def main():
         arrays['labels_%d' % i] = g['labels'].reshape(-1).astype(np.float64)
         arrays['indices_%d' % i] = g['indices'].reshape(-1).astype(np.int64)
         arrays['scores_%d' % i] = g['scores'].astype(np.float32)
+        arrays['scores_hash_%d' % i] = g['scores_hash'].astype(np.float32)
         arrays['head_cam_%d' % i] = cam_idx
         arrays['head_blocks_%d' % i] = head_blocks.astype(np.float32)
-        meta.append({'H': H, 'N': N, 'nodes_camera': g['nodes_camera'], 'est': g['est'], 'gt': g['gt']})
+        meta.append({'H': H, 'N': N, 'nodes_camera': g['nodes_camera'], 'est': g['est'], 'gt': g['gt'], 'est_hash': g['est_hash']})
     np.savez_compressed(os.path.join(OUT, 'generated_graphs.npz'), **arrays)
     report = {'printed': printed, 'seed': SEED, 'n_graphs': len(graphs), 'files': [os.path.basename(n) for n in names],
-              'gat': {'kind': 'matcher', 'noise_seed': GAT_NOISE_SEED, 'noise_bound': GAT_NOISE}, 'graphs': meta,
+              'gat': {'kind': 'matcher', 'noise_seed': GAT_NOISE_SEED, 'noise_bound': GAT_NOISE}, 'hash_gat': HASH_GAT, 'graphs': meta,
               'numpy': np.__version__, 'python': sys.version.split()[0]}
     with open(os.path.join(OUT, 'generated_expected.json'), 'w') as fh:
         json.dump(report, fh, indent=1)

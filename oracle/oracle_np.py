@@ -590,3 +590,143 @@ def run_frame(frame, calib, gat_sd, gat_prm, mlp_sd=None, mode='mlp'):
     elif mode == 'tri':
         res['tri'] = [triangulate_person(person_skeletons(p, g['jsons_for_head'], sm), calib) for p in persons]
     return res
+
+
+# --------------------------------------------------------------------------------------
+# scenes composed from single-person files: mode='test_generated'
+# (graph_generator.py:526-536, 672-810; consumer test/sm_metrics_without_gt.py:95-170)
+# --------------------------------------------------------------------------------------
+
+def generated_dataset_scenes(files_data, probabilities, limit, rng=None):
+    """The sampling of MergedMultipleHumansDataset(list_of_files, probabilities, limit, mode='test_generated').
+
+    Constructor (graph_generator.py:526-536): per file the frame indices 0..n-1, shuffled with `random.shuffle` (the
+    module-level generator: `rng` = the `random` module, seeded by the caller).  process_training's sample_and_remove
+    (:674-693): up to `limit` times draw num_people = randint(1, n_files), take the num_people files with the largest
+    probabilities (np.argpartition(p, -k)[-k:], in that order) and pop the LAST shuffled index of each; the first file that
+    has run dry ends the sampling for good (`return`, :688-689).  Yields lists of single-person frames."""
+    import random as _random
+    rng = rng or _random
+    indices = []
+    for data in files_data:
+        idx = list(range(len(data)))
+        rng.shuffle(idx)
+        indices.append(idx)
+    scenes = []
+    for _ in range(limit):
+        if all(len(d) == 0 for d in files_data):
+            break
+        k = rng.randint(1, len(files_data))
+        chosen = np.argpartition(np.array(probabilities), -k)[-k:]
+        views = []
+        for f in chosen:
+            if not indices[f]:
+                return scenes
+            views.append(files_data[f][indices[f].pop()])
+        if views:
+            scenes.append(views)
+    return scenes
+
+
+def generated_graph(views, calib):
+    """One graph of process_training (graph_generator.py:697-810) from the sampled single-person frames `views`.
+
+    Nodes: per view (person) its heads in camera-dict order and list order (load_people_view_graph, :573-605), ids offset
+    by the heads of the views before it (:731).  Per view and camera the head with the most joints is the person's, the
+    rest are spurious (:718-726).  Edge-nodes (each with the five edges of add_edge_node_to_graph, :627-656) for ORDERED
+    head pairs of different cameras, in this order: per person -- own x own (label 1, :749-760), own x every other
+    person's (0, :762-774), own x spurious (0, :776-786) -- then spurious x spurious (0, :788-797).  Returns None when no
+    edge-node exists (:799)."""
+    params = calib.params
+    heads_all, people, spurious, total = [], [], [], 0
+    for view in views:
+        pf = parse_frame(view, params)
+        person = []
+        for cam, ids in pf['slots']:
+            if not ids:
+                continue
+            nj = [sum(1 for k in pf['heads'][h][2] if k != 'ID') for h in ids]
+            best = 0
+            for i in range(1, len(nj)):          # max(enumerate(...), key=joints): the first of the largest
+                if nj[i] > nj[best]:
+                    best = i
+            for i, h in enumerate(ids):
+                if i == best:
+                    person.append((h + total, cam))
+                else:
+                    spurious.append((h + total, cam))
+        people.append(person)
+        heads_all += pf['heads']
+        total += len(pf['heads'])
+    H = total
+    src, dst = list(range(H)), list(range(H))
+    pairs, labels = [], []
+
+    def edge_nodes(a, b, label):
+        for h1, c1 in a:
+            for h2, c2 in b:
+                if c1 == c2:
+                    continue
+                X = H + len(pairs)
+                src.extend([h1, X, h2, X, X])
+                dst.extend([X, h1, X, h2, X])
+                pairs.append((h1, h2))
+                labels.append(label)
+    for ip, person in enumerate(people):
+        edge_nodes(person, person, 1.0)
+        for io, other in enumerate(people):
+            if io != ip:
+                edge_nodes(person, other, 0.0)
+        edge_nodes(person, spurious, 0.0)
+    edge_nodes(spurious, spurious, 0.0)
+    if not pairs:
+        return None
+    N = H + len(pairs)
+    F = 2 + len(params.used_cameras_skeleton_matching) * len(params.joint_list) * J_FEATS
+    feats = torch.zeros([N, F])
+    for h, (cam, _, sk) in enumerate(heads_all):
+        feats[h] = head_row(sk, cam, calib)[0][0]
+    feats[H:, 1] = 1.0
+    return {'N': N, 'H': H, 'src': np.array(src, np.int32), 'dst': np.array(dst, np.int32),
+            'pairs': np.array(pairs, np.int32).reshape(-1, 2), 'feats': feats, 'labels': np.array(labels, np.float64),
+            'edge_nodes_indices': np.arange(H, N, dtype=np.int64),
+            'nodes_camera': [h[0] for h in heads_all] + [''] * (N - H)}
+
+
+def proposal_labels(persons, H):
+    """One label per head: index of the first proposal that holds it, or the number of proposals
+    (test/sm_metrics_without_gt.py:133-141, 149-157)."""
+    out = []
+    for h in range(H):
+        idx = len(persons)
+        for p, members in enumerate(persons):
+            if h in members:
+                idx = p
+                break
+        out.append(idx)
+    return out
+
+
+def sm_without_gt(graphs, score_fn, params, thr=0.5):
+    """The loop of test/sm_metrics_without_gt.py:112-170 over `graphs` (generated_graph dicts): proposals from the model's
+    scores (score_fn(graph) -> N scores) and from the labels used as scores (:143-147), adjusted Rand index / homogeneity /
+    completeness / V-measure averaged over the graphs.  Returns the four means and the per-graph proposals."""
+    from sklearn.metrics import adjusted_rand_score, homogeneity_completeness_v_measure
+    sm = list(params.used_cameras_skeleton_matching)
+    tot = {'rand score': 0.0, 'homogeneity': 0.0, 'completeness': 0.0, 'v_measure': 0.0}
+    per_graph = []
+    for g in graphs:
+        H = g['H']
+        head_cam = [sm.index(c) for c in g['nodes_camera'][:H]]
+        scores = np.asarray(score_fn(g), np.float32).reshape(-1)[H:]
+        est = cluster(scores, g['pairs'], H, head_cam, len(sm), params.min_number_of_views, thr)
+        gt = cluster(g['labels'].astype(np.float32), g['pairs'], H, head_cam, len(sm), params.min_number_of_views, thr)
+        l_est, l_gt = proposal_labels(est, H), proposal_labels(gt, H)
+        tot['rand score'] += adjusted_rand_score(l_gt, l_est)
+        hom, com, v = homogeneity_completeness_v_measure(l_gt, l_est)
+        tot['homogeneity'] += hom
+        tot['completeness'] += com
+        tot['v_measure'] += v
+        per_graph.append({'est': est, 'gt': gt})
+    n = max(1, len(graphs))
+    return {k: v / n for k, v in tot.items()}, per_graph

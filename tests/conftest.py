@@ -148,3 +148,32 @@ def harness_model_files(out_dir, inputs):
     torch.save({'model_state_dict': {k: torch.from_numpy(v) for k, v in mlp.items()}},
                os.path.join(mdir, 'pose_estimator.pytorch'))
     return mdir
+
+
+def generated_fixture():
+    """tests/golden/generated/: what /root/reference/test/sm_metrics_without_gt.py built and printed on the four committed
+    single-person files with `random` seeded (oracle/gen_generated_golden.py) -> (expected dict, arrays, file paths,
+    probabilities_set of the script, :99-104)."""
+    d = os.path.join(GOLDEN, 'generated')
+    with open(os.path.join(d, 'generated_expected.json')) as fh:
+        exp = json.load(fh)
+    arr = np.load(os.path.join(d, 'generated_graphs.npz'))
+    files = [os.path.join(d, f) for f in exp['files']]
+    lengths = []
+    for f in files:
+        with open(f) as fh:
+            lengths.append(len(json.load(fh)))
+    probs = [0.8] + [0.8 * n / lengths[0] for n in lengths[1:]]
+    return exp, arr, files, probs
+
+
+def generated_gat_weights(exp):
+    syn = pkg('synthetic')
+    par = pkg('parameters').parameters
+    V, J = len(par.used_cameras_skeleton_matching), len(par.joint_list)
+    nf = 2 + V * J * 10
+    return syn.matcher_gat_state_dict(nf, V, J, noise_seed=exp['gat']['noise_seed'], noise_bound=exp['gat']['noise_bound']), syn.gat_params(nf)
+
+
+def proposals_as_rows(proposals, cams):
+    return [[-1 if d[c] is None else int(d[c]) for c in cams] for d in proposals]

@@ -1,0 +1,308 @@
+"""GPU: SURVEY.md §8 f4 / the second half of f2 -- the graphs of mode='test_generated' (graph_generator.py:672-810: heads grouped
+by person, one edge-node per ORDERED head pair) through the explicit edge-node lists of the C ABI (mpe_batch::d_en_pair),
+against what /root/reference/test/sm_metrics_without_gt.py built, scored, clustered and printed on the committed
+single-person files (tests/golden/generated/, oracle/gen_generated_golden.py)."""
+import importlib
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import env, generated_fixture, generated_gat_weights, harness_model_files, load_case, oracle, pkg, proposals_as_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gen(tmp_path_factory):
+    exp, arr, files, probs = generated_fixture()
+    gg = pkg('graph_generator')
+    cwd = os.getcwd()
+    os.chdir(tmp_path_factory.mktemp('gen'))              # ./cache/ of the dataset
+    try:
+        random.seed(exp['seed'])
+        ds = gg.MergedMultipleHumansDataset(files, probs, limit=1000, mode='test_generated', alt='3', raw_dir='.')
+    finally:
+        os.chdir(cwd)
+    sd, prm = generated_gat_weights(exp)
+    gat2 = pkg('gat2')
+    model = gat2.GAT2(None, prm['gnn_layers'], prm['num_feats'], prm['n_classes'], prm['num_hidden'], prm['heads'],
+                      torch.nn.LeakyReLU(), torch.nn.Sigmoid(), prm['in_drop'], prm['attn_drop'], prm['alpha'], prm['residual'], bias=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return {'exp': exp, 'arr': arr, 'files': files, 'ds': ds, 'model': model, 'gg': gg, 'sd': sd, 'prm': prm}
+
+
+def _engine(gen, max_frames=16, hpf=28):
+    pipeline = pkg('pipeline')
+    e = env()
+    eng = pipeline.Engine(e.params, e.calib, max_frames=max_frames, max_heads_per_frame=hpf, max_edge_nodes_per_frame=512)
+    eng.load_gat(gen['sd'], gen['prm'])
+    return eng
+
+
+def test_reference_loop_of_sm_metrics_without_gt_on_the_mirrors(gen):
+    """The loop body of test/sm_metrics_without_gt.py:112-165 written against the package's mirrors, one graph per call as the
+    reference does it: scores of all N nodes within 2e-5 of the reference model's, the proposals from the scores and from the
+    labels-as-scores bit-exact, and therefore the script's four means to the last digit."""
+    from sklearn.metrics import adjusted_rand_score, homogeneity_completeness_v_measure
+    fn = pkg('skeleton_matching_utils').get_person_proposal_from_network_output
+    exp, arr, ds, model = gen['exp'], gen['arr'], gen['ds'], gen['model']
+    sm = list(env().params.used_cameras_skeleton_matching)
+    tot = np.zeros(4)
+    worst = 0.0
+    for i in range(len(ds)):
+        subgraph, labels, indices, nodes_camera = ds[i]
+        feats = subgraph.ndata['h']
+        all_nodes = subgraph.nodes().tolist()
+        model.g = subgraph
+        for layer in model.layers:
+            layer.g = subgraph
+        outputs = torch.squeeze(model(feats.float(), subgraph))
+        labels = torch.squeeze(labels).to('cpu')
+        indices = torch.squeeze(indices).to('cpu')
+        head_nodes = list(set(all_nodes) - set(indices.tolist()))
+        worst = max(worst, float(np.abs(outputs.cpu().numpy() - arr['scores_%d' % i]).max()))
+        final_output = fn(outputs, subgraph, indices, nodes_camera, None, 0.5)
+        assert proposals_as_rows(final_output, sm) == proposals_as_rows(exp['graphs'][i]['est'], sm), i
+        est = []
+        for h in head_nodes:
+            k = 0
+            for person in final_output:
+                if h in list(person.values()):
+                    break
+                k += 1
+            est.append(k)
+        output_features = [0.] * len(all_nodes)
+        for (j, v) in zip(indices, labels.tolist()):
+            output_features[j] = v
+        final_output = fn(output_features, subgraph, indices, nodes_camera, None, 0.5)
+        assert proposals_as_rows(final_output, sm) == proposals_as_rows(exp['graphs'][i]['gt'], sm), i
+        gt = []
+        for h in head_nodes:
+            k = 0
+            for person in final_output:
+                if h in list(person.values()):
+                    break
+                k += 1
+            gt.append(k)
+        tot += np.array((adjusted_rand_score(gt, est),) + tuple(homogeneity_completeness_v_measure(gt, est)))
+        # the head rows the graph hands out are the reference's
+        blk = feats.shape[1] - 2
+        J10 = arr['head_blocks_%d' % i].shape[1]
+        for h, c in enumerate(arr['head_cam_%d' % i]):
+            np.testing.assert_allclose(feats[h, 2 + c * J10: 2 + (c + 1) * J10].numpy(), arr['head_blocks_%d' % i][h], rtol=0, atol=5e-7)
+        assert blk % J10 == 0
+    # The hand-built matcher network is steep: the REFERENCE'S OWN fp32 scores sit up to 6e-5 (edge-nodes) and 3e-3 (head
+    # nodes, which nothing consumes) from the same network evaluated in float64 on these graphs, so the 2e-5 bound of the frame
+    # fixtures does not apply to it (test_generated_scores_hash_weights_vs_reference holds it on the well-conditioned weights);
+    # here the bound is the one of test_score_noise_against_the_f64_network: the HIP path is at most 2.5 x as far from the
+    # float64 network as torch-CPU is, on the edge-nodes and on the heads.
+    assert worst < 8e-3, worst
+    onp = oracle()
+    record = []
+    for i in range(len(ds)):
+        g = ds[i][0]
+        src, dst = g.edges()
+        model.g = g
+        got = torch.squeeze(model(None, g)).cpu().numpy()
+        # rows of the float64 network = the reference's dense rows (graph.ndata['h'] within 5e-7 of them, asserted above)
+        F = g.ndata['h'].shape[1]
+        feats = torch.zeros((g.H + g.M, F))
+        J10 = arr['head_blocks_%d' % i].shape[1]
+        feats[:g.H, 0] = 1.0
+        feats[g.H:, 1] = 1.0
+        for h, c in enumerate(arr['head_cam_%d' % i]):
+            feats[h, 2 + c * J10: 2 + (c + 1) * J10] = torch.from_numpy(arr['head_blocks_%d' % i][h])
+        ex = onp.gat_forward(gen['sd'], gen['prm'], feats, src.numpy(), dst.numpy(), dtype=torch.float64).numpy()
+        ref = arr['scores_%d' % i]
+        for lo, hi, what in ((g.H, g.H + g.M, 'edge-nodes'), (0, g.H, 'heads')):
+            e_ref, e_gpu = np.abs(ref[lo:hi] - ex[lo:hi]).max(), np.abs(got[lo:hi] - ex[lo:hi]).max()
+            record.append({'graph': i, 'nodes': what, 'e_ref': float(e_ref), 'e_gpu': float(e_gpu)})
+            # per graph: the 2e-5 of the frame fixtures where the reference's own noise is small (a maximum over 20 edge-nodes
+            # of a 5-head graph is a coin toss between two fp32 evaluations), 2.5 x the reference's where it is large
+            assert e_gpu <= max(2.5 * e_ref, 2e-5), (i, what, e_gpu, e_ref)
+    for what in ('edge-nodes', 'heads'):
+        rows = [r for r in record if r['nodes'] == what]
+        assert max(r['e_gpu'] for r in rows) <= 2.5 * max(r['e_ref'] for r in rows), what
+    import json
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'generated_score_noise.json'), 'w') as fh:
+        json.dump(record, fh, indent=1)
+    tot /= len(ds)
+    for v, k in zip(tot, ('rand score', 'homogeneity', 'completeness', 'v_measure')):
+        assert v == exp['printed'][k], (k, v, exp['printed'][k])
+
+
+def test_generated_scores_hash_weights_vs_reference(gen):
+    """The 2e-5 score bound of the frame fixtures on the generated graphs: the well-conditioned hash weights (the ones of
+    tests/golden/*.npz) through the reference's GAT2 on the same 16 graphs (scores_hash_*), against the engine on a batch of all
+    of them; proposals from these scores bit-exact."""
+    syn = pkg('synthetic')
+    exp, arr, ds, gg = gen['exp'], gen['arr'], gen['ds'], gen['gg']
+    e = env()
+    nf = 2 + len(e.params.used_cameras_skeleton_matching) * len(e.params.joint_list) * 10
+    h = exp['hash_gat']
+    pipeline = pkg('pipeline')
+    eng = pipeline.Engine(e.params, e.calib, max_frames=len(ds), max_heads_per_frame=28, max_edge_nodes_per_frame=512)
+    eng.load_gat(syn.gat_state_dict(h['seed'], nf, logit_gain=h['logit_gain'], logit_shift=h['logit_shift']), syn.gat_params(nf))
+    b = gg.batch([ds[i][0] for i in range(len(ds))])
+    db = b.device_batch(eng)
+    sc, sh = eng.gat_scores(db, heads=True)
+    _, persons, n_persons = eng.match(db)
+    eng.sync_status()
+    sc, sh, persons, n_persons = sc.cpu().numpy(), sh.cpu().numpy(), persons.cpu().numpy(), n_persons.cpu().numpy()
+    sm = list(e.params.used_cameras_skeleton_matching)
+    h0 = e0 = 0
+    worst = 0.0
+    for i in range(len(ds)):
+        H, M = ds[i][0].H, ds[i][0].M
+        ref = arr['scores_hash_%d' % i]
+        worst = max(worst, float(np.abs(sh[h0:h0 + H] - ref[:H]).max()), float(np.abs(sc[e0:e0 + M] - ref[H:]).max()))
+        assert persons[i, :n_persons[i]].tolist() == proposals_as_rows(exp['graphs'][i]['est_hash'], sm), i
+        h0, e0 = h0 + H, e0 + M
+    assert worst < 2e-5, worst
+    assert any(len(exp['graphs'][i]['est_hash']) for i in range(len(ds)))
+    eng.close()
+
+
+def test_a_batch_of_graphs_in_one_call_gives_the_per_graph_bits(gen):
+    """The dgl.batch of the reference's collate (train_skeleton_matching.py:67-84) = the engine's frame batch: all 16 graphs in
+    ONE call give, node for node, the bits of 16 one-graph calls, and the same persons."""
+    ds, model, gg = gen['ds'], gen['model'], gen['gg']
+    single = []
+    for i in range(len(ds)):
+        g = ds[i][0]
+        single.append(torch.squeeze(model(None, g)).cpu().numpy())
+    b = gg.batch([ds[i][0] for i in range(len(ds))])
+    assert b.batch_size == len(ds) >= 15
+    out = torch.squeeze(model(None, b)).cpu().numpy()
+    assert out.shape[0] == sum(len(s) for s in single)
+    assert np.array_equal(out, np.concatenate(single))
+    eng = _engine(gen, max_frames=len(ds))
+    db = b.device_batch(eng)
+    scores, persons, n_persons = eng.match(db)
+    eng.sync_status()
+    scores, persons, n_persons = scores.cpu().numpy(), persons.cpu().numpy(), n_persons.cpu().numpy()
+    sm = list(env().params.used_cameras_skeleton_matching)
+    e0 = 0
+    for i in range(len(ds)):
+        H, M = ds[i][0].H, ds[i][0].M
+        assert np.array_equal(scores[e0:e0 + M], single[i][H:])
+        e0 += M
+        want = proposals_as_rows(gen['exp']['graphs'][i]['est'], sm)
+        assert persons[i, :n_persons[i]].tolist() == want, i
+    eng.close()
+
+
+def test_generated_graphs_fused_and_general_attention_give_identical_bits(gen, monkeypatch):
+    ds, gg = gen['ds'], gen['gg']
+    b = gg.batch([ds[i][0] for i in range(len(ds))])
+    eng = _engine(gen, max_frames=len(ds))
+    db = b.device_batch(eng)
+    fused = eng.gat_scores(db, heads=True)
+    fused = [t.cpu().numpy() for t in fused]
+    monkeypatch.setenv('MPE_NO_FUSED_ATTENTION', '1')
+    general = [t.cpu().numpy() for t in eng.gat_scores(db, heads=True)]
+    monkeypatch.delenv('MPE_NO_FUSED_ATTENTION')
+    monkeypatch.setenv('MPE_NO_COEF_EPILOGUE', '1')
+    no_epi = [t.cpu().numpy() for t in eng.gat_scores(db, heads=True)]
+    eng.sync_status()
+    for a, g2, g3 in zip(fused, general, no_epi):
+        assert np.array_equal(a, g2) and np.array_equal(a, g3)
+    eng.close()
+
+
+@pytest.mark.parametrize('name', ['c2_5x4_clean', 'c2_5x4_messy', 'c4_5x10'])
+@pytest.mark.parametrize('general', [False, True])
+def test_explicit_list_equal_to_the_implicit_one_gives_the_implicit_bits(name, general, gat_weights, monkeypatch):
+    """Cross-check of the explicit path against the production path: golden frames packed as usual, and the same frames with
+    the implicit pair list (process_test, graph_generator.py:854-864) handed over EXPLICITLY -- same edge-nodes in the same
+    order, so every score (edge-nodes and heads) and every person must come out bit-identical, on the fused attention
+    kernel and on the general kernels."""
+    import copy
+    pipeline, packing = pkg('pipeline'), pkg('packing')
+    e = env()
+    arr, frames = load_case(name)
+    onp = oracle()
+    frames = [onp.processed_input(f) for f in frames]
+    eng = pipeline.Engine(e.params, e.calib, max_frames=8, max_heads_per_frame=50, max_edge_nodes_per_frame=2048)
+    eng.load_gat(*gat_weights)
+    pb = eng.pack(frames)
+    px = copy.copy(pb)
+    px.en_pair = np.concatenate([packing.pairs_of_frame(pb.slot_n[f]) for f in range(pb.n_frames)]).astype(np.int32).reshape(-1, 2)
+    px.slot_cam = np.full_like(pb.slot_cam, -1)
+    px.slot_n = np.zeros_like(pb.slot_n)                       # not read in explicit mode
+    if general:
+        monkeypatch.setenv('MPE_NO_FUSED_ATTENTION', '1')
+    di, dx = eng.to_device(pb), eng.to_device(px)
+    si, pi, ni = eng.match(di)
+    hi = eng.gat_scores(di, heads=True)[1]
+    sx, pxr, nx = eng.match(dx)
+    hx = eng.gat_scores(dx, heads=True)[1]
+    eng.sync_status()
+    assert np.array_equal(si.cpu().numpy(), sx.cpu().numpy())
+    assert np.array_equal(hi.cpu().numpy(), hx.cpu().numpy())
+    assert np.array_equal(ni.cpu().numpy(), nx.cpu().numpy()) and np.array_equal(pi.cpu().numpy(), pxr.cpu().numpy())
+    eng.close()
+
+
+def test_harness_prints_what_the_reference_script_printed(gen, tmp_path, monkeypatch):
+    """harness/sm_metrics_without_gt.py (scenes in batches of graphs through the engine) with `--seed`: the four numbers
+    /root/reference/test/sm_metrics_without_gt.py printed, and the same proposals per graph."""
+    exp = gen['exp']
+    mdir = harness_model_files(str(tmp_path), {'gat': exp['gat'], 'mlp': {'kind': 'decoder', 'noise_seed': 3, 'noise_bound': 2e-4}})
+    monkeypatch.chdir(tmp_path)
+    m = importlib.import_module('3d_multi_pose_estimator_amd.harness.sm_metrics_without_gt')
+    out = m.main(['--testfiles'] + gen['files'] + ['--modelsdir', mdir, '--datastep', '1', '--batch', '5', '--seed', str(exp['seed'])])
+    assert out['n_data'] == exp['n_graphs']
+    for k, v in exp['printed'].items():
+        assert out[k] == pytest.approx(v, rel=1e-12, abs=1e-12), k
+    sm = list(env().params.used_cameras_skeleton_matching)
+    for i, pg in enumerate(out['per_graph']):
+        assert pg['est'] == proposals_as_rows(exp['graphs'][i]['est'], sm) and pg['gt'] == proposals_as_rows(exp['graphs'][i]['gt'], sm)
+
+
+def test_bad_pairs_and_overfull_graphs_are_refused_not_faulted(gen):
+    """An explicit list is caller data: the host mirror refuses it (ValueError), and the C ABI alone -- reached here by skipping
+    the host check -- makes the pair memory-safe on the device and reports MPE_ERR_INVALID / MPE_ERR_CAPACITY from
+    mpe_sync_status instead of reading outside the frame."""
+    import copy
+    packing, lib = pkg('packing'), pkg('lib')
+    g = gen['ds'][1][0]
+    eng = _engine(gen, max_frames=2, hpf=12)                   # explicit capacity: 512 edge-nodes, 12 heads, in-degree 24
+    good = eng.to_device(g.packed)
+    ref = eng.gat_scores(good).cpu().numpy()
+    eng.sync_status()
+    for bad_pair in ([0, g.H], [-1, 1], [2, 2]):
+        pb = copy.copy(g.packed)
+        pb.en_pair = pb.en_pair.copy()
+        pb.en_pair[3] = bad_pair
+        with pytest.raises(ValueError):
+            eng.to_device(pb)
+        db = packing.DeviceBatch(pb, eng.device)               # the C ABI without the host check
+        eng.gat_scores(db)
+        with pytest.raises(lib.MpeError) as ei:
+            eng.sync_status()
+        assert ei.value.code == -1
+    # the same pair many times: in-degree beyond 2 * max_heads_per_frame
+    pb = copy.copy(g.packed)
+    pb.en_pair = np.tile(np.array([[0, 1]], np.int32), (g.M, 1))
+    eng.gat_scores(packing.DeviceBatch(pb, eng.device))
+    with pytest.raises(lib.MpeError) as ei:
+        eng.sync_status()
+    assert ei.value.code == -1
+    # a graph with more heads than the context takes: host check, then the device's own
+    big = gen['ds'][0][0]
+    assert big.H > 12
+    with pytest.raises(ValueError):
+        eng.to_device(big.packed)
+    sc, persons, n_persons = eng.match(packing.DeviceBatch(big.packed, eng.device))
+    with pytest.raises(lib.MpeError) as ei:
+        eng.sync_status()
+    assert ei.value.code == -2 and int(n_persons[0]) == 0 and not sc.cpu().numpy().any()
+    # and the context still works
+    assert np.array_equal(eng.gat_scores(good).cpu().numpy(), ref)
+    eng.sync_status()
+    eng.close()

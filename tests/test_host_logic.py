@@ -1,6 +1,7 @@
 """CPU tests of the host-side logic: packing order, topology mirror, library symbols,
 frame sharding + all-gather on gloo (world_size 2)."""
 import ctypes
+import json
 import os
 import re
 
@@ -664,3 +665,86 @@ def test_build_stamp_forces_a_rebuild_when_sources_change(tmp_path, monkeypatch)
             else:
                 with open(p, 'w') as fh:
                     fh.write(v)
+
+
+def _generated_dataset(tmp_path, monkeypatch, **kw):
+    import random
+
+    from conftest import generated_fixture
+    exp, arr, files, probs = generated_fixture()
+    gg = pkg('graph_generator')
+    monkeypatch.chdir(tmp_path)                     # the dataset cache goes to ./cache/ (reference :520, 884-917)
+    random.seed(exp['seed'])
+    ds = gg.MergedMultipleHumansDataset(files, probs, limit=1000, mode='test_generated', alt='3', raw_dir='.', **kw)
+    return gg, ds, exp, arr
+
+
+def test_generated_dataset_mirror_builds_the_reference_graphs(tmp_path, monkeypatch):
+    """MergedMultipleHumansDataset(files, probabilities, limit, mode='test_generated') of the package, seeded like
+    the reference run, composes the reference's scenes: per graph the same edge list (one edge-node per ORDERED head pair,
+    heads grouped by person), labels, edge_nodes_indices and nodes_camera as /root/reference built (tests/golden/generated/).
+    Host logic only -- no GPU call."""
+    gg, ds, exp, arr = _generated_dataset(tmp_path, monkeypatch)
+    assert len(ds) == exp['n_graphs']
+    for i in range(len(ds)):
+        g, labels, idx, nodes_camera = ds[i]
+        src, dst = g.edges()
+        assert np.array_equal(src.numpy(), arr['src_%d' % i]) and np.array_equal(dst.numpy(), arr['dst_%d' % i])
+        assert src.dtype == torch.int32 and labels.dtype == torch.float64 and idx.dtype == torch.int64
+        assert labels.shape == (g.M, 1) and idx.shape == (g.M, 1)
+        assert np.array_equal(labels.numpy().reshape(-1), arr['labels_%d' % i])
+        assert np.array_equal(idx.numpy().reshape(-1), arr['indices_%d' % i])
+        assert nodes_camera == exp['graphs'][i]['nodes_camera']
+        assert g.number_of_nodes() == exp['graphs'][i]['N'] and len(g.nodes()) == exp['graphs'][i]['N']
+        assert np.array_equal(g.packed.head_cam, arr['head_cam_%d' % i])
+    # batch() = dgl.batch: nodes and edges relabelled graph by graph
+    b = gg.batch([ds[i][0] for i in range(3)])
+    src, dst = b.edges()
+    off = 0
+    want_s, want_d = [], []
+    for i in range(3):
+        want_s.append(arr['src_%d' % i] + off)
+        want_d.append(arr['dst_%d' % i] + off)
+        off += exp['graphs'][i]['N']
+    assert np.array_equal(src.numpy(), np.concatenate(want_s)) and np.array_equal(dst.numpy(), np.concatenate(want_d))
+    assert b.number_of_nodes() == off and b.batch_size == 3 and b.batch_num_nodes().tolist() == [exp['graphs'][i]['N'] for i in range(3)]
+    # the cache of the reference (graph_generator.py:884-917): a second construction loads it instead of sampling again
+    assert os.path.exists(tmp_path / 'cache' / 'MergedMultipleHumansDataset_test_generated_alt_3_s_1000.bin')
+    ds2 = gg.MergedMultipleHumansDataset(_files_of(exp), [1.0] * 4, limit=1000, mode='test_generated', alt='3')
+    assert len(ds2) == len(ds)
+    for i in range(len(ds)):
+        assert np.array_equal(ds2[i][0].edges()[0].numpy(), arr['src_%d' % i]) and ds2[i][3] == ds[i][3]
+    # debug=True neither reads nor writes it; the training modes are out of scope and say so
+    with pytest.raises(NotImplementedError):
+        gg.MergedMultipleHumansDataset(_files_of(exp), [1.0] * 4, limit=10, mode='train', alt='3')
+    with pytest.raises(NotImplementedError):
+        gg.MergedMultipleHumansDataset(_files_of(exp), [1.0] * 4, limit=10, mode='test_generated', alt='2')
+
+
+def _files_of(exp):
+    return [os.path.join(ROOT, 'tests', 'golden', 'generated', f) for f in exp['files']]
+
+
+def test_generated_scene_order_rules():
+    """packing.generated_scene on a hand-made scene: person blocks before the spurious block, ordered pairs, same-camera pairs
+    skipped, first-of-the-largest as the person's skeleton (graph_generator.py:718-797)."""
+    packing = pkg('packing')
+    par = pkg('parameters').parameters
+
+    def sk(n):
+        return {str(j): [j, 10.0 * j, 5.0, 1, 1] for j in range(n)}
+    a, b, c = par.used_cameras_skeleton_matching[:3]
+    views = [{a: [json.dumps([sk(3), sk(5), sk(5)])], b: [json.dumps([sk(4)])], 'not_a_camera': [json.dumps([sk(2)])]},
+             {b: [json.dumps([{'ID': 1}, sk(2)])], c: [json.dumps([])]}]
+    sc = packing.generated_scene(views, par)
+    assert [(h[0], h[1]) for h in sc['heads']] == [(a, 0), (a, 1), (a, 2), (b, 0), (b, 1)]
+    # person 0 = heads {1 (first of the two 5-joint skeletons), 3}; person 1 = {4}; spurious = {0, 2}
+    want = [(1, 3), (3, 1),                                  # own x own
+            (1, 4),                                          # person 0 x person 1 (3-4 share camera b)
+            (3, 0), (3, 2),                                  # person 0 x spurious (1-0, 1-2 share camera a)
+            (4, 1),                                          # person 1 x person 0
+            (4, 0), (4, 2)]                                  # person 1 x spurious; spurious x spurious: both on camera a
+    assert sc['pairs'].tolist() == [list(p) for p in want]
+    assert sc['labels'].tolist() == [1.0, 1.0, 0, 0, 0, 0, 0, 0]
+    pb = packing.pack_scenes([sc], par)
+    assert pb.n_heads == 5 and pb.n_edge_nodes == 8 and pb.en_pair.shape == (8, 2) and pb.head_cam.tolist() == [0, 0, 0, 1, 1]

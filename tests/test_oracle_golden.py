@@ -1,5 +1,6 @@
 """CPU: the oracle restatement (oracle/oracle_np.py) against the fixtures produced by the
 reference's own files (oracle/gen_golden.py).  This is what pins the oracle."""
+import json
 import os
 
 import numpy as np
@@ -257,3 +258,54 @@ def test_reprojection_bookkeeping_reproduces_reference_report(tmp_path):
             g = got[(kind, cam)]
             assert g[1] == pytest.approx(median, rel=2e-4), (cam, kind, g, median)
             assert abs(np.log10(g[0]) - np.log10(mean)) < 0.5, (cam, kind, g, mean)
+
+
+def test_generated_scenes_oracle_vs_reference_script():
+    """SURVEY §8 f4 / f2: the oracle's restatement of mode='test_generated' (sampling graph_generator.py:526-536, 674-693;
+    graph synthesis :697-810) and of the loop of test/sm_metrics_without_gt.py:112-170 against what the REFERENCE SCRIPT built
+    and printed on the committed single-person files under the same `random` seed: the same 16 scenes, identical edge lists,
+    labels, node cameras and head rows, scores bit-equal (same torch-CPU ops), both proposal lists of every graph, the four
+    printed means to the last digit."""
+    import random
+
+    from conftest import generated_fixture, generated_gat_weights, proposals_as_rows
+    onp = oracle()
+    e = env()
+    exp, arr, files, probs = generated_fixture()
+    data = [json.load(open(f)) for f in files]
+    random.seed(exp['seed'])
+    scenes = onp.generated_dataset_scenes(data, probs, 1000)
+    graphs = [g for g in (onp.generated_graph(v, e.calib) for v in scenes) if g is not None]
+    assert len(graphs) == exp['n_graphs'] >= 15
+    sd, prm = generated_gat_weights(exp)
+    hg = exp['hash_gat']
+    sd2 = pkg('synthetic').gat_state_dict(hg['seed'], prm['num_feats'], logit_gain=hg['logit_gain'], logit_shift=hg['logit_shift'])
+    sm = list(e.params.used_cameras_skeleton_matching)
+    blk = len(e.params.joint_list) * 10
+    for i, g in enumerate(graphs):
+        meta = exp['graphs'][i]
+        assert g['H'] == meta['H'] and g['N'] == meta['N']
+        assert np.array_equal(g['src'], arr['src_%d' % i]) and np.array_equal(g['dst'], arr['dst_%d' % i])
+        assert np.array_equal(g['labels'], arr['labels_%d' % i])
+        assert np.array_equal(g['edge_nodes_indices'], arr['indices_%d' % i])
+        assert g['nodes_camera'] == meta['nodes_camera']
+        rows = np.stack([g['feats'][h, 2 + c * blk: 2 + (c + 1) * blk].numpy() for h, c in enumerate(arr['head_cam_%d' % i])])
+        assert np.array_equal(rows, arr['head_blocks_%d' % i])
+        assert np.count_nonzero(g['feats'].numpy()) == np.count_nonzero(rows) + g['N']      # col 0 / col 1 + the own block only
+        sc = onp.gat_forward(sd, prm, g['feats'], g['src'], g['dst']).numpy()
+        assert np.array_equal(sc, arr['scores_%d' % i])
+        sc2 = onp.gat_forward(sd2, prm, g['feats'], g['src'], g['dst']).numpy()          # the second (hash) weight set
+        assert np.array_equal(sc2, arr['scores_hash_%d' % i])
+        head_cam = [sm.index(c) for c in g['nodes_camera'][:g['H']]]
+        assert onp.cluster(sc2[g['H']:], g['pairs'], g['H'], head_cam, len(sm), e.params.min_number_of_views) == \
+            proposals_as_rows(meta['est_hash'], sm)
+    res, per = onp.sm_without_gt(graphs, lambda g: onp.gat_forward(sd, prm, g['feats'], g['src'], g['dst']).numpy(), e.params)
+    for i, p in enumerate(per):
+        assert p['est'] == proposals_as_rows(exp['graphs'][i]['est'], sm), i
+        assert p['gt'] == proposals_as_rows(exp['graphs'][i]['gt'], sm), i
+    for k, v in exp['printed'].items():
+        assert res[k] == v, (k, res[k], v)
+    # the fixture exercises what it is meant to: spurious heads, a person missing from a camera, ordered pairs
+    assert any(len(set(m['nodes_camera'][:m['H']])) < m['H'] for m in exp['graphs'])
+    pairs = graphs[0]['pairs'].tolist()
+    assert [pairs[0][1], pairs[0][0]] in pairs
