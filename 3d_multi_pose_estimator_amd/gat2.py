@@ -90,12 +90,12 @@ class GAT2(nn.Module):
         self.set_g(g)
         eng = self._ensure_engine(getattr(g, 'batch_size', 1))
         db = g.device_batch(eng)
-        own = g.ndata.get('h') if 'h' in g.ndata else None
+        own = dict.get(g.ndata, 'h')            # the graph's own dense rows, if the caller ever asked for them
         feats = None
         if inputs is not None and (own is None or inputs.data_ptr() != own.data_ptr()):
             # caller-made features: honour them (dense path); the graph's own rows are
             # re-derived on the device from the packed skeletons instead
-            if not (own is not None and inputs.shape == own.shape and torch.equal(inputs.cpu().float(), own)):
+            if not (own is not None and inputs.shape == own.shape and torch.equal(inputs.to(own.device).float(), own)):
                 feats = inputs
         eng.set_gat_output(sigmoid=self.final_activation is not None)     # None: raw logits (gat2.py:146-148)
         sc, sh = eng.gat_scores(db, heads=True, feats=feats)

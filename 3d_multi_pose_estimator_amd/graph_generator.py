@@ -136,27 +136,138 @@ class FrameGraph:
         return torch.tensor(src, dtype=torch.int32), torch.tensor(dst, dtype=torch.int32)
 
     def device_batch(self, engine):
-        key = id(engine)
+        """The graph's arrays on the engine's device: uploaded once per device (the GAT2 / clustering / dataset mirrors
+        each own an engine), capacity checked per engine."""
+        engine.check_capacity(self.packed)
+        key = str(engine.device)
         if key not in self._dev:
-            self._dev[key] = engine.to_device(self.packed)
+            self._dev[key] = self.packed.to(engine.device)
         return self._dev[key]
 
     def _dense_features(self):
+        """graph.ndata['h']: the dense N x F rows (reference :444-508, 629-631), assembled ON THE DEVICE from the featurisation
+        kernel's output (mpe_head_features) -- a tensor on the engine's device, so the callers' `.to(device)` /
+        `.float()` hand the same object back and GAT2.forward recognises the graph's own rows without comparing them."""
         eng = runtime.shared_engine(max_frames=self.batch_size)
-        blk = eng.head_features(self.device_batch(eng)).cpu()      # [H][J][10]
+        blk = eng.head_features(self.device_batch(eng))            # [H][J][10] on the device
         J = blk.shape[1]
         F = 2 + eng.V * J * 10
-        feats = torch.zeros((self.H + self.M, F))
-        off = self.node_offsets()
-        h = 0
-        for f, Hf in enumerate(self.batch_num_heads):
-            feats[off[f]:off[f] + Hf, 0] = 1.0
-            feats[off[f] + Hf:off[f + 1], 1] = 1.0
-            for i in range(Hf):
-                c = int(self.packed.head_cam[h])
-                feats[off[f] + i, 2 + c * J * 10: 2 + (c + 1) * J * 10] = blk[h].reshape(-1)
-                h += 1
+        dev = blk.device
+        feats = torch.zeros((self.H + self.M, F), device=dev)
+        if self.batch_size == 1:
+            H = self.H
+            feats[:H, 0] = 1.0
+            feats[H:, 1] = 1.0
+            head_rows = torch.arange(H, device=dev)
+        else:
+            off = self.node_offsets()
+            hr = np.concatenate([np.arange(off[f], off[f] + h) for f, h in enumerate(self.batch_num_heads)]) if self.H else np.zeros(0, np.int64)
+            head_rows = torch.from_numpy(hr.astype(np.int64)).to(dev)
+            kind = torch.ones(self.H + self.M, dtype=torch.int64, device=dev)
+            kind[head_rows] = 0
+            feats[torch.arange(self.H + self.M, device=dev), kind] = 1.0
+        if self.H:
+            cam = torch.from_numpy(np.ascontiguousarray(self.packed.head_cam, np.int64)).to(dev)
+            cols = (2 + cam * (J * 10)).unsqueeze(1) + torch.arange(J * 10, device=dev).unsqueeze(0)
+            feats[head_rows.unsqueeze(1), cols] = blk.reshape(self.H, J * 10)
         return feats
+
+
+class _LazyHeadJsons(dict):
+    """jsons_for_head of one frame (reference :597-598: head id -> skeleton dict), filled camera by camera on first use:
+    the native packer has already turned the frame into arrays, the Python dicts are only needed by callers that go on to
+    the 3D stage (metrics_from_model.py:250-252)."""
+
+    def __init__(self, frame, packed):
+        super().__init__()
+        self._frame, self._packed, self._done = frame, packed, False
+
+    def _fill(self):
+        if self._done:
+            return
+        self._done = True
+        sm = list(parameters.used_cameras_skeleton_matching)
+        pb = self._packed
+        h = 0
+        for s in range(pb.slot_cam.shape[1]):
+            c, n = int(pb.slot_cam[0, s]), int(pb.slot_n[0, s])
+            if c < 0:
+                continue
+            skeletons = json.loads(self._frame[sm[c]][0]) if n else []
+            for _ in range(n):
+                dict.__setitem__(self, h, skeletons[int(pb.skeleton_index[h])])
+                h += 1
+
+    def json_text(self, h):
+        """'[<skeleton h>]' as json.dumps writes it, cut out of the camera's string instead of serialised again -- what the
+        reference's caller produces with json.dumps([jsons_for_head[h]]) (metrics_from_model.py:250-252) WHEN the camera string
+        was itself written by json.dumps with its default separators (:186-190 does exactly that).  None when the text cannot
+        be cut safely (then the caller's string is rebuilt with json.dumps)."""
+        if not hasattr(self, '_texts'):
+            self._texts = {}
+            sm = list(parameters.used_cameras_skeleton_matching)
+            pb = self._packed
+            k = 0
+            for s in range(pb.slot_cam.shape[1]):
+                c, n = int(pb.slot_cam[0, s]), int(pb.slot_n[0, s])
+                if c < 0 or n == 0:
+                    continue
+                text = self._frame[sm[c]][0]
+                pieces = None
+                # skeleton dicts hold lists of numbers only (no nested dict): '}, {' separates them; an "ID" member may hold anything
+                if text.startswith('[{') and text.endswith('}]') and '"ID"' not in text and '\\' not in text:
+                    pieces = text[2:-2].split('}, {')
+                for _ in range(n):
+                    i = int(pb.skeleton_index[k])
+                    self._texts[k] = '[{' + pieces[i] + '}]' if pieces is not None and i < len(pieces) else None
+                    k += 1
+        return self._texts.get(h)
+
+    def __missing__(self, key):
+        self._fill()
+        if dict.__contains__(self, key):
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        self._fill()
+        return dict.__contains__(self, key)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+
+def _pack_one(frame):
+    """One frame dict -> PackedBatch through the native packer (csrc/packer.cpp: the Python loops over 20 skeletons x 18
+    joints cost more than the frame's kernels); frames it declines (keys outside the configured joints, non-string
+    entries, ...) go through the Python packer, which defines the accepted language and the error messages."""
+    try:
+        from .packing import pack_json
+        if all(isinstance(frame[c][0], str) for c in frame):
+            pb = pack_json(json.dumps([frame]), parameters, n_threads=1)
+            if pb.n_frames == 1:
+                pb.jsons_for_head = [_LazyHeadJsons(frame, pb)]
+                return pb
+    except (ValueError, ImportError, TypeError, KeyError):
+        pass
+    return pack_frames([frame], parameters, keep_json=True)
 
 
 def batch(graphs):
@@ -226,7 +337,7 @@ class MergedMultipleHumansDataset:
             if idx == self.limit:
                 break
             idx += 1
-            packed = pack_frames([json_view], parameters, keep_json=True)
+            packed = _pack_one(json_view)
             self.jsons_for_head = packed.jsons_for_head[0]          # of the last frame seen, as in the reference (:577-578)
             self.skeleton_index = {i: int(v) for i, v in enumerate(packed.skeleton_index)}
             h0, H, e0, M = packed.frame_counts(0)

@@ -314,21 +314,29 @@ class DeviceBatch:
         s = L.mpe_batch()
         s.n_frames, s.n_heads, s.n_edge_nodes = pb.n_frames, pb.n_heads, pb.n_edge_nodes
         if arena is None:
-            def up(a):
-                return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-            self.t = {
-                'frame_head_off': up(pb.frame_head_off), 'frame_en_off': up(pb.frame_en_off),
-                'slot_cam': up(pb.slot_cam), 'slot_n': up(pb.slot_n), 'head_cam': up(pb.head_cam),
-                'joint_mask': up(pb.joint_mask.view(np.int32)), 'tri_mask': up(pb.tri_mask.view(np.int32)),
-                'xy': up(pb.xy), 'vp': up(pb.vp),
-            }
+            # ONE pageable buffer, one H2D copy (the per-frame mirrors upload a batch per call: nine small copies cost more
+            # than the batch's kernels); 256-byte aligned pieces like the arenas
+            parts, off = [], 0
+            names = [(n, dt) for n, dt in ARRAYS]
             if pb.en_pair is not None:
                 ep = np.ascontiguousarray(pb.en_pair, np.int32).reshape(-1, 2)
                 if ep.shape[0] != pb.n_edge_nodes:
                     raise ValueError('en_pair holds %d pairs, frame_en_off says %d' % (ep.shape[0], pb.n_edge_nodes))
-                self.t['en_pair'] = up(ep if ep.size else np.zeros((1, 2), np.int32))
-            for k, v in self.t.items():
-                setattr(s, 'd_' + k, C.c_void_p(v.data_ptr()))
+                names.append(('en_pair', np.int32))
+            offs = {}
+            for name, dt in names:
+                a = np.ascontiguousarray(getattr(pb, name)).reshape(-1)
+                a = a.view(dt) if a.dtype != dt and a.dtype.itemsize == np.dtype(dt).itemsize else a.astype(dt, copy=False)
+                offs[name] = off
+                parts.append((off, a))
+                off += (a.nbytes + 255) // 256 * 256
+            host = np.zeros(max(off, 256), np.uint8)
+            for o, a in parts:
+                host[o:o + a.nbytes] = a.view(np.uint8)
+            self.buf = torch.from_numpy(host).to(self.device)
+            base = self.buf.data_ptr()
+            for name, _ in names:
+                setattr(s, 'd_' + name, C.c_void_p(base + offs[name]))
         else:
             if pb.en_pair is not None:
                 raise ValueError('arena-backed batches carry the implicit topology only')

@@ -31,6 +31,8 @@ class Engine:
         if self.device.type != 'cuda':
             raise RuntimeError('Engine needs a GPU device (there is no CPU fallback)')
         torch.cuda.set_device(self.device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         p = self.params
         sm = list(p.used_cameras_skeleton_matching)
         if sm != list(p.used_cameras) or sm != [c for c in p.camera_names if c in sm]:
@@ -673,7 +675,12 @@ class Engine:
                 raise ValueError('explicit edge-node list: a pair lies outside its frame or joins a head with itself')
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # torch.cuda.current_stream() builds a Stream object (~80 us on the GPU box's host; ten calls per frame in the
+        # one-frame-per-call mirrors); the raw handle is what the C ABI takes
+        try:
+            return C.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index or 0))
+        except AttributeError:
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def match(self, db, want_scores=True):
         """-> (scores[n_edge_nodes] f32 or None, persons[B,Pcap,V] i32, n_persons[B] i32)."""
@@ -699,6 +706,8 @@ class Engine:
 
     def set_gat_output(self, sigmoid=True):
         """Last-layer activation: sigmoid (deployed model) or identity (final_activation=None)."""
+        if self._state.get('gat_output', True) == bool(sigmoid):
+            return
         self._chk(self.lib.mpe_set_gat_output(self.ctx, 1 if sigmoid else 2))
         self._state['gat_output'] = bool(sigmoid)
         for e in self._siblings:
@@ -728,6 +737,8 @@ class Engine:
         self._chk(self.lib.mpe_sync_status(self.ctx, self._stream()))
 
     def set_threshold(self, thr):
+        if self._state.get('threshold', self._made_with['threshold']) == float(thr):
+            return                          # (the C call re-uploads the whole device-side configuration, synchronously)
         self._chk(self.lib.mpe_set_threshold(self.ctx, float(thr)))
         self._state['threshold'] = float(thr)
         for e in self._siblings:

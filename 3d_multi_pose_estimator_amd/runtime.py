@@ -61,3 +61,46 @@ def calibration_from_dicts(params, camera_matrices, distortion_coefficients, pro
         cal.dist[i] = np.asarray(distortion_coefficients[c], np.float64)
         cal.P[i] = np.asarray(projection_matrices[c], np.float64)
     return cal
+
+
+# ---- MLP input rows of a frame's persons, computed in ONE launch --------------------------------------------------------
+# The reference's caller builds one PoseEstimatorDataset per PERSON (metrics_from_model.py:243-277), each from the JSON text
+# of that person's skeletons.  get_person_proposal_from_network_output (the call right before, :214) knows all persons of the
+# frame and has the frame's arrays on the device, so it computes every person's row with one mpe_mlp_input_rows launch and
+# leaves them here, keyed by exactly the strings the caller is about to hand to PoseEstimatorDataset
+# (json.dumps([jsons_for_head[head]]) per camera, :250-252).  A row is a pure function of those strings and the
+# calibration, so an entry can never be stale; PoseEstimatorDataset falls back to its own launch on a miss.
+# MPE_DROPIN_PREFETCH=0 switches the prefetch off.
+_row_cache = {}
+_ROW_CACHE_CAP = 512
+
+
+def prefetch_enabled():
+    return os.environ.get('MPE_DROPIN_PREFETCH', '1') != '0'
+
+
+def prefetch_mlp_rows(eng, db, persons, n_persons, rows, jsons_for_head, cams):
+    """rows: the frame's persons as lists of head ids per camera of `cams` (-1 = none)."""
+    import json
+    used = [c for c in eng.params.used_cameras]
+    r, valid = eng.mlp_input_rows(db, persons, n_persons)
+    n = len(rows)
+    r, valid = r[0, :n].cpu(), valid[0, :n].cpu()
+    if len(_row_cache) > _ROW_CACHE_CAP:
+        _row_cache.clear()
+    text_of = getattr(jsons_for_head, 'json_text', None)
+
+    def text(h):
+        t = text_of(h) if text_of is not None else None
+        return t if t is not None else json.dumps([jsons_for_head[h]])
+    for p, row in enumerate(rows):
+        key = tuple((cam, text(row[cams.index(cam)])) for cam in used if cam in cams and row[cams.index(cam)] >= 0)
+        _row_cache[(_engine_key(eng), key)] = (r[p].clone(), bool(valid[p]))
+
+
+def cached_mlp_row(eng, key):
+    return _row_cache.get((_engine_key(eng), key))
+
+
+def _engine_key(eng):
+    return id(eng.calib)

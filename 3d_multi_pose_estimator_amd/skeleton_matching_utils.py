@@ -31,4 +31,8 @@ def get_person_proposal_from_network_output(outputs, subgraph, indices, nodes_ca
     n = int(n_persons[0])
     rows = persons[0, :n].cpu().tolist()
     cams = list(parameters.used_cameras_skeleton_matching)
+    if jsons_for_head is not None and n and runtime.prefetch_enabled():
+        # the caller goes on to the 3D stage with these persons (metrics_from_model.py:243-277): their MLP input rows in ONE
+        # launch now instead of one launch per person later (runtime.prefetch_mlp_rows)
+        runtime.prefetch_mlp_rows(eng, db, persons, n_persons, rows, jsons_for_head, cams)
     return [{cam: (None if row[c] < 0 else row[c]) for c, cam in enumerate(cams)} for row in rows]

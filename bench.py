@@ -100,6 +100,8 @@ def parse_args(argv=None):
                          '(kernel-level roofline); 0 = skip')
     ap.add_argument('--json-steps', type=int, default=96,
                     help='batches of the json_inclusive region (wire-format JSON bytes -> poses in pinned host memory); 0 = skip')
+    ap.add_argument('--dropin-frames', type=int, default=200,
+                    help="frames of the dropin_loop region (the reference's one-frame-per-call loop over the drop-in mirrors); 0 = skip")
     ap.add_argument('--no-io', action='store_true', help='skip the second (pinned host -> poses in pinned host) timed region')
     ap.add_argument('--no-profile', action='store_true', help='no per-GEMM HIP events (roofline comes out null)')
     ap.add_argument('--profile-every', type=int, default=4,
@@ -429,6 +431,19 @@ def run_rank(args):
     if (not args.no_io or os.environ.get('MPE_BENCH_JSON_WITHOUT_IO')) and args.json_steps > 0 and not distributed:
         jsn = json_inclusive(args, torch, eng, wire, B, uniq, K)
 
+    # ---- the reference's own call pattern: ONE frame per call through the drop-in mirrors (metrics_from_model.py:178-294) ----
+    dropin = None
+    if args.dropin_frames > 0 and not distributed and args.preset == 'PANOPTIC' and args.mode == 'mlp' and not (args.reduced or args.cfg4 or args.bf16_mlp):
+        loop = importlib.import_module(PKG + '.harness.dropin_loop')
+        model_, mlp_ = loop.build_models(gat_sd, prm, mlp_sd)
+        n_dl = args.dropin_frames
+        res = loop.run([wire[i % uniq] for i in range(n_dl + 10)], model_, mlp_, warmup=10, device=device)
+        res.pop('last', None)
+        res['what'] = ("the loop body of the reference's test/metrics_from_model.py:178-294, one frame per call, over the package's "
+                       'mirrors of its symbols (INTEGRATION.md section 2), timed with the reference\'s own two timers; '
+                       'reference_readme_ms = what the reference README quotes for its own path on its authors\' GPU')
+        dropin = res
+
     persons_per_frame = float(n_persons.float().mean().item()) if B else 0.0
     value = total * args.steps / elapsed
     reduced = args.reduced or args.bf16_mlp or args.cfg4
@@ -464,6 +479,7 @@ def run_rank(args):
                    'weights': 'deterministic hash init (no checkpoint offline)'},
         'io_inclusive': io,
         'json_inclusive': jsn,
+        'dropin_loop': dropin,
     }
     if rank == 0:
         out['roofline'] = roofline(args, prof, elapsed, total, world, V, J, args.persons, reduced)
@@ -648,8 +664,11 @@ def json_inclusive(args, torch, eng, wire, B, uniq, contexts=1):
     assert sum(len(n) for _, _, n in eng.stream_json(warm, chunk_frames=B, mode=mode, contexts=contexts)) == 2 * B
     # one untimed pass over the document itself (the warm-up steps of this region): the first pass over freshly built bytes
     # measures the host's page and cache state as much as the pipeline (167-171 k against 180 k for every later pass)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     assert sum(len(n) for _, _, n in eng.stream_json(text, chunk_frames=B, mode=mode, contexts=contexts)) == n_steps * B
     torch.cuda.synchronize()
+    cold = n_steps * B / (time.perf_counter() - t0)       # the FIRST pass over these bytes: what a stream that is read once sees
     for rep in range(int(os.environ.get('MPE_BENCH_JSON_REPEAT', '1'))):        # > 1: diagnostics (each repeat on stderr), the last one counts
         t0 = time.perf_counter()
         got = sum(len(n) for _, _, n in eng.stream_json(text, chunk_frames=B, mode=mode, contexts=contexts))
@@ -659,10 +678,11 @@ def json_inclusive(args, torch, eng, wire, B, uniq, contexts=1):
         if os.environ.get('MPE_BENCH_JSON_REPEAT'):
             print('json_inclusive repeat %d: %.1f frames/s' % (rep, got / dt), file=sys.stderr)
     threads = usable_cpus()
-    return {'value': got / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / n_steps, 'steps': n_steps,
+    return {'value': got / dt, 'value_cold': cold, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / n_steps, 'steps': n_steps,
             'json_bytes_per_step': len(text) // n_steps, 'json_gb_per_s': len(text) / dt / 1e9, 'host_threads_available': threads,
             'parser': 'device (csrc/jsonparse.hip); host: frame extents + string extents only',
-            'warmup': 'one untimed pass over the same document',
+            'warmup': 'value: the second pass over the same document (page and cache state warm); value_cold: the first pass over the '
+                      'freshly built bytes, what a stream that is read once sees',
             'what': 'wire-format frame JSON bytes in host memory -> first level on the host (parallel frame scan, skeleton strings '
                     'copied to a page-locked buffer) -> H2D -> second level parsed on the device -> match + 3D stage -> D2H of '
                     'poses into pinned host memory; batch i+1 is parsed while batch i computes'

@@ -163,3 +163,78 @@ def test_gat2_without_final_activation_returns_logits(dropin):
     probs = torch.squeeze(model(g.ndata['h'].cuda(), g)).cpu().numpy()
     np.testing.assert_allclose(probs, arr['f0_scores'], rtol=0, atol=2e-5)
     np.testing.assert_allclose(torch.sigmoid(logits).numpy(), arr['f0_scores'], rtol=0, atol=2e-5)
+
+
+def test_rows_prefetched_per_frame_equal_the_per_person_rows(dropin, monkeypatch):
+    """The 3D stage of the reference's loop builds one PoseEstimatorDataset per PERSON (metrics_from_model.py:243-277).  The
+    mirrors compute all rows of a frame in ONE mpe_mlp_input_rows launch when the persons are formed (runtime.prefetch_mlp_rows)
+    and serve them by the JSON text the caller hands over; a row served from there is bit-identical to the row the dataset
+    computes itself (MPE_DROPIN_PREFETCH=0), and the invalid-row rule (sum |x| > 1, :287) is the same."""
+    d = dropin
+    parameters = d['parameters']
+    runtime = __import__('importlib').import_module('3d_multi_pose_estimator_amd.runtime')
+    arr, frames = load_case('c2_5x4_messy')
+    checked = 0
+    for input_element in frames:
+        processed_input = {}
+        for cam in input_element:
+            data = json.loads(input_element[cam][0])
+            if data:
+                processed_input[cam] = [json.dumps(data), input_element[cam][1]]
+        scenario = d['MergedMultipleHumansDataset'](processed_input, mode='test', limit=10000, debug=True,
+                                                    alt=parameters.graph_alternative, verbose=False)
+        if not scenario.graphs:
+            continue
+        subgraph = scenario.graphs[0]
+        indices = torch.squeeze(scenario.data['edge_nodes_indices'][0], 1)
+        outputs = torch.squeeze(d['model'](None, subgraph))
+        runtime._row_cache.clear()
+        monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+        final_output = d['get_person_proposal_from_network_output'](outputs, subgraph, indices, scenario.data['nodes_camera'][0],
+                                                                    scenario.jsons_for_head, 0.5)
+        assert len(runtime._row_cache) == len(final_output)
+        for person in final_output:
+            raw_input = {}
+            for camera in parameters.used_cameras:
+                if person[camera] is not None:
+                    raw_input[camera] = [json.dumps([scenario.jsons_for_head[person[camera]]])]
+            monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+            n_before = len(runtime._row_cache)
+            fast = d['PoseEstimatorDataset'](raw_input, parameters.cameras, parameters.joint_list, save=False)
+            assert len(runtime._row_cache) == n_before
+            monkeypatch.setenv('MPE_DROPIN_PREFETCH', '0')
+            slow = d['PoseEstimatorDataset'](raw_input, parameters.cameras, parameters.joint_list, save=False)
+            assert len(fast) == len(slow) == 1
+            assert torch.equal(fast[0][0], slow[0][0])
+            checked += 1
+    monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+    assert checked >= 4
+
+
+def test_dropin_loop_region_gives_the_engine_bits(gat_weights, mlp_weights, calib):
+    """bench.py's `dropin_loop` region (harness/dropin_loop.py = the body of test/metrics_from_model.py:178-294 over the
+    mirrors, one frame per call): it reports both of the reference's timers, and the poses it ends with are, bit for bit, those
+    of the batched engine on the same frame (same kernels: the per-frame row prefetch, the wave-per-tile GEMMs at small M)."""
+    import importlib
+    loop = importlib.import_module('3d_multi_pose_estimator_amd.harness.dropin_loop')
+    syn = importlib.import_module('3d_multi_pose_estimator_amd.synthetic')
+    pipeline = importlib.import_module('3d_multi_pose_estimator_amd.pipeline')
+    par = importlib.import_module('3d_multi_pose_estimator_amd.parameters').parameters
+    sd, prm = gat_weights
+    model, mlp = loop.build_models(sd, prm, mlp_weights)
+    frames = [syn.make_frame(calib, 40 + i, syn.FrameSpec(persons=3 + i % 2, noise_px=1.0))[0] for i in range(8)]
+    out = loop.run(frames, model, mlp, warmup=2)
+    assert out['frames'] == 6 and out['graph_matching_ms'] > 0 and out['pose_3d_ms'] > 0 and out['inside_mirrors_ms'] < out['ms_per_frame']
+    eng = pipeline.Engine(par, calib, max_frames=2, max_persons_per_camera=5)
+    eng.load_gat(sd, prm)
+    eng.load_mlp(mlp_weights)
+    onp = oracle()
+    db = eng.to_device(eng.pack([onp.processed_input(frames[-1])]))
+    _, persons, n_persons = eng.match(db, want_scores=False)
+    poses, valid = eng.mlp3d(db, persons, n_persons)
+    n = int(n_persons[0])
+    assert n == len(out['last']) >= 3
+    want = poses[0, :n].cpu().numpy()
+    got = np.array([[j for j in person] for person in out['last']], np.float32)
+    assert np.array_equal(got, want)
+    eng.close()

@@ -91,8 +91,10 @@ def test_reference_loop_of_sm_metrics_without_gt_on_the_mirrors(gen):
         # the head rows the graph hands out are the reference's
         blk = feats.shape[1] - 2
         J10 = arr['head_blocks_%d' % i].shape[1]
+        fc = feats.cpu()
         for h, c in enumerate(arr['head_cam_%d' % i]):
-            np.testing.assert_allclose(feats[h, 2 + c * J10: 2 + (c + 1) * J10].numpy(), arr['head_blocks_%d' % i][h], rtol=0, atol=5e-7)
+            np.testing.assert_allclose(fc[h, 2 + c * J10: 2 + (c + 1) * J10].numpy(), arr['head_blocks_%d' % i][h], rtol=0, atol=5e-7)
+        assert np.count_nonzero(fc.numpy()) == np.count_nonzero(arr['head_blocks_%d' % i]) + fc.shape[0]
         assert blk % J10 == 0
     # The hand-built matcher network is steep: the REFERENCE'S OWN fp32 scores sit up to 6e-5 (edge-nodes) and 3e-3 (head
     # nodes, which nothing consumes) from the same network evaluated in float64 on these graphs, so the 2e-5 bound of the frame
