@@ -273,13 +273,14 @@ __global__ __launch_bounds__(256) void k_json_skeleton(const char *__restrict__ 
             const int b = my[k].b, en_ = my[k].e;
             ok = b < en_ && en_ <= n;
             if (ok && k == 0) ok = gap_is(t, n, 0, b, '[');
-            if (ok) {
-                const size_t r = (size_t)e * kcap + k;
-                uint32_t jm = 0, tm = 0;
-                ok = walk_skeleton(t, b, en_, J, &jm, &tm, r_xy + r * J * 2, r_vp + r * J * 2);
-                r_jm[r] = ok ? jm : 0;
-                r_tm[r] = tm;
-            }
+            const size_t r = (size_t)e * kcap + k;
+            uint32_t jm = 0, tm = 0;
+            if (ok) ok = walk_skeleton(t, b, en_, J, &jm, &tm, r_xy + r * J * 2, r_vp + r * J * 2);
+            // every path writes its row: a skeleton rejected before the walk must not leave the masks of the PREVIOUS window
+            // in the scratch (k_json_layout would count them as heads and could report a capacity overflow instead of the
+            // hand-over to the host parser)
+            r_jm[r] = ok ? jm : 0;
+            r_tm[r] = ok ? tm : 0;
             if (ok) ok = k + 1 < cnt ? (my[k + 1].b >= en_ && gap_is(t, n, en_, my[k + 1].b, ',')) : gap_is(t, n, en_, n, ']');
         }
         if (!ok) atomicOr(&totals[2], JS_FALLBACK);

@@ -63,8 +63,15 @@ struct Cursor {
     bool inner;        // true while scanning text that sits inside a JSON string (one escape level)
 };
 
+// Whitespace.  Inside a JSON string (`inner`) a line break or tab of the inner document arrives as the two-character
+// escape \n / \t / \r (a pretty-printed skeleton list, json.dumps(..., indent=1), then dumped again): json.loads of the
+// outer document turns it back into whitespace before the inner json.loads sees it, so it is whitespace here too.
 inline void skip_ws(Cursor &c) {
-    while (c.p < c.end && (*c.p == ' ' || *c.p == '\n' || *c.p == '\t' || *c.p == '\r')) ++c.p;
+    while (c.p < c.end) {
+        if (*c.p == ' ' || *c.p == '\n' || *c.p == '\t' || *c.p == '\r') { ++c.p; continue; }
+        if (c.inner && *c.p == '\\' && c.p + 1 < c.end && (c.p[1] == 'n' || c.p[1] == 't' || c.p[1] == 'r')) { c.p += 2; continue; }
+        break;
+    }
 }
 
 // In "inner" mode the text is the body of a JSON string: a quote appears as \" and a
@@ -95,6 +102,65 @@ bool read_string(Cursor &c, std::string *out) {
         if (c.inner && *c.p == '"') return false;   // the enclosing string ended unexpectedly
         if (out) out->push_back(*c.p);
         ++c.p;
+    }
+    return false;
+}
+
+// A key of the OUTER document (a camera name) with JSON's escapes resolved as json.loads resolves them: \" \\ \/ \b \f \n
+// \r \t and \uXXXX (surrogate pairs -> one code point; output UTF-8).  read_string copies the character behind a backslash
+// as it stands, which is right for \" and \\ only: "tracker\u0061" must look up `trackera`, not be dropped as unknown.
+bool read_key(Cursor &c, std::string *out) {
+    if (c.inner || c.p >= c.end || *c.p != '"') return false;
+    ++c.p;
+    out->clear();
+    auto hex4 = [&](const char *q, unsigned *v) {
+        unsigned x = 0;
+        for (int i = 0; i < 4; ++i) {
+            const char h = q[i];
+            x <<= 4;
+            if (h >= '0' && h <= '9') x |= (unsigned)(h - '0');
+            else if (h >= 'a' && h <= 'f') x |= (unsigned)(h - 'a' + 10);
+            else if (h >= 'A' && h <= 'F') x |= (unsigned)(h - 'A' + 10);
+            else return false;
+        }
+        *v = x;
+        return true;
+    };
+    while (c.p < c.end) {
+        const char ch = *c.p;
+        if (ch == '"') { ++c.p; return true; }
+        if (ch != '\\') { out->push_back(ch); ++c.p; continue; }
+        if (c.p + 1 >= c.end) return false;
+        const char e = c.p[1];
+        c.p += 2;
+        switch (e) {
+            case '"': out->push_back('"'); break;
+            case '\\': out->push_back('\\'); break;
+            case '/': out->push_back('/'); break;
+            case 'b': out->push_back('\b'); break;
+            case 'f': out->push_back('\f'); break;
+            case 'n': out->push_back('\n'); break;
+            case 'r': out->push_back('\r'); break;
+            case 't': out->push_back('\t'); break;
+            case 'u': {
+                unsigned cp = 0;
+                if (c.end - c.p < 4 || !hex4(c.p, &cp)) return false;
+                c.p += 4;
+                if (cp >= 0xD800 && cp <= 0xDBFF && c.end - c.p >= 6 && c.p[0] == '\\' && c.p[1] == 'u') {
+                    unsigned lo = 0;
+                    if (hex4(c.p + 2, &lo) && lo >= 0xDC00 && lo <= 0xDFFF) {
+                        cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                        c.p += 6;
+                    }
+                }
+                if (cp < 0x80) out->push_back((char)cp);
+                else if (cp < 0x800) { out->push_back((char)(0xC0 | (cp >> 6))); out->push_back((char)(0x80 | (cp & 0x3F))); }
+                else if (cp < 0x10000) { out->push_back((char)(0xE0 | (cp >> 12))); out->push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out->push_back((char)(0x80 | (cp & 0x3F))); }
+                else { out->push_back((char)(0xF0 | (cp >> 18))); out->push_back((char)(0x80 | ((cp >> 12) & 0x3F))); out->push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out->push_back((char)(0x80 | (cp & 0x3F))); }
+                break;
+            }
+            default: return false;                  // not a JSON escape: json.loads rejects it
+        }
     }
     return false;
 }
@@ -191,6 +257,10 @@ bool read_number(Cursor &c, double *v) {
         if (c.end - c.p >= 4 && !strncmp(c.p, "true", 4)) { *v = 1; c.p += 4; return true; }
         if (c.end - c.p >= 5 && !strncmp(c.p, "false", 5)) { *v = 0; c.p += 5; return true; }
         if (c.end - c.p >= 3 && !strncmp(c.p, "NaN", 3)) { *v = NAN; c.p += 3; return true; }
+        if (c.end - c.p >= 8 && !strncmp(c.p, "Infinity", 8)) { *v = INFINITY; c.p += 8; return true; }
+        if (c.end - c.p >= 9 && !strncmp(c.p, "-Infinity", 9)) { *v = -INFINITY; c.p += 9; return true; }
+        // null where a number may stand: the Python packer stores it into its float arrays as NaN (numpy's conversion of None)
+        if (c.end - c.p >= 4 && !strncmp(c.p, "null", 4)) { *v = NAN; c.p += 4; return true; }
         return false;
     }
     c.p = e;
@@ -312,7 +382,9 @@ bool parse_skeleton(Cursor &c, int J, Head *h, std::string *err) {
                 if (c.p >= c.end) break;
                 if (*c.p == ']') { ++c.p; closed = true; break; }
                 double d;
+                const bool is_null = c.end - c.p >= 4 && !strncmp(c.p, "null", 4);
                 if (!read_number(c, &d)) { *err = "bad number in joint"; return false; }
+                if (n == 0 && is_null) { *err = "joint id is null"; return false; }     // `values[0] > 0.` raises on None (dataset :75)
                 if (n < 5) v[n] = d;
                 ++n;
                 skip_ws(c);
@@ -408,7 +480,7 @@ bool parse_frame(const char *b, const char *e, const std::vector<std::string> &c
     std::string key;
     while (c.p < c.end) {
         skip_ws(c);
-        if (!read_string(c, &key)) { fo->error = "bad camera key"; return false; }
+        if (!read_key(c, &key)) { fo->error = "bad camera key"; return false; }
         skip_ws(c);
         if (c.p >= c.end || *c.p != ':') { fo->error = "missing ':' after camera"; return false; }
         ++c.p;
@@ -469,7 +541,7 @@ bool index_frame(const char *b, const char *e, const std::vector<std::string> &c
     std::string key;
     while (c.p < c.end) {
         skip_ws(c);
-        if (!read_string(c, &key)) { *err = "bad camera key"; return false; }
+        if (!read_key(c, &key)) { *err = "bad camera key"; return false; }
         skip_ws(c);
         if (c.p >= c.end || *c.p != ':') { *err = "missing ':' after camera"; return false; }
         ++c.p;

@@ -215,7 +215,9 @@ class Engine:
         parser = 'device' (default): the host keeps the first level of the format only (frame extents, camera
         keys, the extent of every skeleton STRING: stage_json_window) and the strings are parsed ON THE DEVICE
         (csrc/jsonparse.hip) on a side stream while the previous chunk computes; the first element yielded is
-        then a ParsedOnDevice (n_frames, n_heads, ...; `.download()` for the arrays).  A chunk holding a shape
+        then a ParsedOnDevice (n_frames, n_heads, ...; `.download()` for the arrays; a window that fell back to the host
+        packer yields a PackedBatch there instead -- both carry n_frames / n_heads / n_edge_nodes / frame_counts-style
+        offsets, test with isinstance if you need the host arrays).  A chunk holding a shape
         the device parser leaves to the host (literals, nested values, numbers beyond the exact fast path)
         is packed by the host packer instead -- same arrays either way.  parser = 'host': the round-2 path.
         contexts = 2 (device parser only): windows take turns on two contexts (sibling()), two windows in flight."""
@@ -225,8 +227,19 @@ class Engine:
         B = int(chunk_frames or self.max_frames)
         if B > self.max_frames:
             raise ValueError('chunk of %d frames exceeds max_frames=%d' % (B, self.max_frames))
+        if int(contexts) not in (1, 2):
+            raise ValueError('stream_json takes contexts = 1 or 2 (two compute streams exist; more contexts measured slower, DESIGN 7.1)')
         if parser == 'device':
-            yield from self._stream_json_device(text, B, mode, frame_step, n_threads, contexts)
+            # the page-locked result buffers, the arenas and the streams of the device parser belong to the ENGINE: a second
+            # generator running on it at the same time would overwrite the first one's results
+            if getattr(self, '_json_busy', False):
+                raise RuntimeError('another stream_json(parser="device") generator is still open on this engine; exhaust or close() it '
+                                   'first, or use a second Engine / Engine.sibling()')
+            self._json_busy = True
+            try:
+                yield from self._stream_json_device(text, B, mode, frame_step, n_threads, contexts)
+            finally:
+                self._json_busy = False
             return
         H = B * self.hpf
         host = [CapacityArena(self.V, self.J, B, H, 'pinned') for _ in range(2)]
@@ -556,10 +569,10 @@ class Engine:
         on the host.  More heads than the arena holds raises like the host packer does."""
         bufs['ready'].synchronize()
         n_heads, n_en, status, max_h = (int(x) for x in bufs['totals_host'].tolist())
+        if status & 1:                       # first: a window the device declines is sized (and refused, if need be) by the host packer
+            return None
         if status & 2:
             raise ValueError('device-side parse: %d skeletons exceed the arena capacity %d' % (n_heads, bufs['arena'].max_heads))
-        if status & 1:
-            return None
         return ParsedOnDevice(bufs['arena'], self.V, self.J, bufs['n_frames'], n_heads, n_en, max_h)
 
     def pack_json_device(self, text, frame_start=0, frame_step=1, max_frames=0, n_threads=0):

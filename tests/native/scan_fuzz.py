@@ -27,3 +27,27 @@ for st in range(0,400,64):
 ix.close()
 print('frames', tot, 'simd', not os.environ.get('MPE_PACK_NO_SIMD'))
 assert tot==300
+
+# camera keys spelled with JSON escapes (\\uXXXX for any character, \\/): json.loads resolves them, so must the packer --
+# a key that names a configured camera may never be dropped as unknown
+cams = list(par.parameters.used_cameras_skeleton_matching)
+def spell(name):
+    out = ''
+    for ch in name:
+        r = random.random()
+        out += ('\\u%04x' % ord(ch)) if r < 0.3 else ('\\u%04X' % ord(ch)) if r < 0.4 else ch
+    return out
+def sk():
+    return {str(j): [j, random.random() * 1900, random.random() * 1000, 1, random.random()] for j in random.sample(range(18), random.randint(1, 18))}
+docs, want = [], []
+for _ in range(120):
+    use = random.sample(cams, random.randint(1, len(cams)))
+    body = ', '.join('"%s": [%s, 0.0]' % (spell(c), json.dumps(json.dumps([sk() for _ in range(random.randint(0, 3))]))) for c in use)
+    docs.append('{' + body + '}')
+text = '[' + ', '.join(docs) + ']'
+py = packing.pack_frames(json.loads(text), par.parameters)
+nat = packing.pack_json(text, par.parameters)
+import numpy as np
+for f in ('frame_head_off', 'frame_en_off', 'slot_cam', 'slot_n', 'head_cam', 'skeleton_index', 'joint_mask', 'tri_mask', 'xy', 'vp'):
+    assert np.array_equal(np.asarray(getattr(py, f)), np.asarray(getattr(nat, f))), f
+print('escaped camera keys: %d frames, %d heads, arrays equal to json.loads + the Python packer' % (nat.n_frames, nat.n_heads))

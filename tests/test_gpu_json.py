@@ -280,3 +280,86 @@ def test_stream_json_window_edges(contexts):
     finally:
         eng.close()
 
+
+
+@pytest.mark.parametrize('variant,name', ALL_CASES)
+def test_device_parsed_golden_frames_against_the_reference_fixtures(variant, name):
+    """f1 against the REFERENCE directly (not through the host packer): every golden `*.frames.json` document, in the wire
+    format, parsed on the device; the batch that comes out gives the reference's head rows (5e-7), the reference's scores (2e-5)
+    and the reference's clusters (bit-exact) for every frame -- the fixtures the reference's own files produced
+    (oracle/gen_golden.py)."""
+    e = env(variant)
+    eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=8, max_persons_per_camera=10 if variant == 'panoptic' else 3)
+    try:
+        eng.load_gat(*e.gat)
+        arr, frames = load_case(name, variant)
+        onp = oracle()
+        wire = [onp.processed_input(f) for f in frames]              # what the callers hand over (metrics_from_model.py:182-191)
+        dev = eng.pack_json_device(json.dumps(wire))
+        assert dev is not None and dev.n_frames == len(frames)
+        host = dev.download()
+        feat = eng.head_features(dev).cpu().numpy()
+        scores, persons, n_persons = eng.match(dev)
+        sh = eng.gat_scores(dev, heads=True)[1].cpu().numpy()
+        eng.sync_status()
+        scores, persons, n_persons = scores.cpu().numpy(), persons.cpu().numpy(), n_persons.cpu().numpy()
+        J10 = len(e.params.joint_list) * 10
+        for n in range(len(frames)):
+            p = 'f%d_' % n
+            h0, H, e0, M = host.frame_counts(n)
+            if M == 0:
+                assert (p + 'scores') not in arr.files or len(arr[p + 'scores']) == 0
+                continue
+            want = arr[p + 'scores']
+            assert len(want) == H + M
+            np.testing.assert_allclose(scores[e0:e0 + M], want[H:], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(sh[h0:h0 + H], want[:H], rtol=0, atol=2e-5)
+            dense = np.zeros((H, e.meta['num_feats']), np.float32)
+            rc = arr[p + 'feat_rc']
+            sel = rc[:, 0] < H
+            dense[rc[sel, 0], rc[sel, 1]] = arr[p + 'feat_v'][sel]
+            for h in range(H):
+                c = host.head_cam[h0 + h]
+                np.testing.assert_allclose(feat[h0 + h].reshape(-1), dense[h, 2 + c * J10: 2 + (c + 1) * J10], rtol=0, atol=5e-7)
+            wp = arr[p + 'persons']
+            assert int(n_persons[n]) == len(wp) and np.array_equal(persons[n, :len(wp)], wp)
+            assert list(arr[p + 'nodes_camera'][:H]) == [e.params.used_cameras_skeleton_matching[c] for c in host.head_cam[h0:h0 + H]]
+    finally:
+        eng.close()
+
+
+def test_device_declines_what_only_the_host_dialect_covers():
+    """JSON the device-side parser leaves to the host packer (pretty-printed inner strings = \\n escapes between the members,
+    Infinity, null): the window comes back as "host parser, please", the host packer then gives the Python packer's arrays,
+    and stream_json() delivers the same poses as for the canonical text.  A skeleton rejected BEFORE the member walk must not
+    leave the previous window's rows in the scratch (stale rows used to turn into a spurious capacity error)."""
+    e = env('panoptic')
+    eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=8, max_persons_per_camera=4)
+    packing = pkg('packing')
+    try:
+        eng.load_gat(*e.gat)
+        eng.load_mlp(e.mlp)
+        syn = pkg('synthetic')
+        frames = [syn.make_frame(e.calib, 300 + i)[0] for i in range(6)]
+        canon = json.dumps(frames)
+        pretty = json.dumps([{c: [json.dumps(json.loads(f[c][0]), indent=1)] + f[c][1:] for c in f} for f in frames])
+        # first a FULL window through the device parser (fills the scratch), then the declined one
+        assert eng.pack_json_device(canon) is not None
+        assert eng.pack_json_device(pretty) is None
+        a, b = packing.pack_json(pretty, e.params), packing.pack_json(canon, e.params)
+        same_arrays(a, b)
+        got = [(type(i).__name__, p.copy(), n.copy()) for i, p, n in eng.stream_json(pretty.encode(), chunk_frames=8)]
+        want = [(p.copy(), n.copy()) for _, p, n in eng.stream_json(canon.encode(), chunk_frames=8)]
+        assert [g[0] for g in got] == ['PackedBatch'] and len(want) == 1
+        assert np.array_equal(got[0][2], want[0][1]) and np.array_equal(got[0][1], want[0][0])
+        # two generators on one engine would share the result buffers: refused
+        g1 = eng.stream_json(canon.encode(), chunk_frames=2)
+        next(g1)
+        with pytest.raises(RuntimeError):
+            next(eng.stream_json(canon.encode(), chunk_frames=2))
+        g1.close()
+        assert len(list(eng.stream_json(canon.encode(), chunk_frames=4))) == 2
+        with pytest.raises(ValueError):
+            next(eng.stream_json(canon.encode(), chunk_frames=2, contexts=3))
+    finally:
+        eng.close()

@@ -748,3 +748,60 @@ def test_generated_scene_order_rules():
     assert sc['labels'].tolist() == [1.0, 1.0, 0, 0, 0, 0, 0, 0]
     pb = packing.pack_scenes([sc], par)
     assert pb.n_heads == 5 and pb.n_edge_nodes == 8 and pb.en_pair.shape == (8, 2) and pb.head_cam.tolist() == [0, 0, 0, 1, 1]
+
+
+def test_native_packer_accepts_the_json_dialect_of_python(calib):
+    """The host packer (csrc/packer.cpp) and json.loads + the Python packer on JSON that json.dumps never writes but json.loads
+    accepts: a camera key spelled with escapes ("tracker\\u0061" IS trackera -- it used to be dropped silently as an unknown
+    camera: different arrays, no error), a pretty-printed inner skeleton list (its line breaks arrive as \\n escapes),
+    Infinity / -Infinity / NaN, null where a number may stand (numpy stores None as NaN).  Same arrays or both refuse; and the
+    first-level walk of the device path (mpe_json_stage_window) finds the escaped camera as well."""
+    packing = pkg('packing')
+    P = calib.params
+    sk = [{"0": [0, 100.5, 200.25, 1, 0.9], "5": [5, 10, 20, 0.5, 0.25]}]
+
+    def frame(inner, ts='0.0', extra='"no_image", []'):
+        return '{"trackera": [%s, %s, %s], "trackerb": [%s, 1.0]}' % (json.dumps(inner), ts, extra, json.dumps(inner))
+    canon = json.dumps(sk)
+    docs = {
+        'unicode key': frame(canon).replace('"trackera"', '"tracker\\u0061"'),
+        'unicode key upper hex': frame(canon).replace('"trackerb"', '"\\u0074racker\\u0062"'),
+        'escaped slash in an unknown key': frame(canon).replace('"trackera"', '"tracker\\/a"'),
+        'surrogate pair key': frame(canon).replace('"trackera"', '"\\ud83d\\ude00"'),
+        'pretty inner': frame(json.dumps(sk, indent=1)),
+        'pretty inner, tabs': frame(json.dumps(sk, indent='\t')),
+        'Infinity': frame(canon.replace('0.9', 'Infinity')),
+        '-Infinity': frame(canon.replace('100.5', '-Infinity')),
+        'NaN': frame(canon.replace('0.9', 'NaN')),
+        'null number': frame(canon.replace('0.9', 'null')),
+        'null timestamp and bodies': frame(canon, ts='null', extra='"no_image", null'),
+        'null joint id': frame(canon.replace('[0, 100.5', '[null, 100.5')),
+        'bad escape in a key': frame(canon).replace('"trackera"', '"tracker\\qa"'),
+    }
+    n_same = n_refused = 0
+    for name, body in docs.items():
+        doc = '[' + body + ']'
+        try:
+            py = packing.pack_frames(json.loads(doc), P)
+        except Exception:
+            py = None
+        if py is None:
+            with pytest.raises(ValueError):
+                packing.pack_json(doc, P)
+            n_refused += 1
+            continue
+        nat = packing.pack_json(doc, P)
+        for f in ('frame_head_off', 'frame_en_off', 'slot_cam', 'slot_n', 'head_cam', 'skeleton_index', 'joint_mask', 'tri_mask', 'xy', 'vp'):
+            a, b = np.asarray(getattr(py, f)), np.asarray(getattr(nat, f))
+            assert a.shape == b.shape and np.array_equal(a, b, equal_nan=a.dtype.kind == 'f'), (name, f)
+        n_same += 1
+    assert n_same == 11 and n_refused == 2
+    # first level of the device path: both cameras found although one key is spelled with escapes
+    doc = ('[' + docs['unicode key'] + ']').encode()
+    ix = packing.JsonIndex(doc)
+    try:
+        st = packing.JsonStage(len(P.used_cameras_skeleton_matching), 4, 1 << 16, 'host')
+        nf, ne, used = packing.stage_json_window(ix, P, st, max_frames=4)
+        assert (nf, ne) == (1, 2)
+    finally:
+        ix.close()
