@@ -2,6 +2,9 @@
 #   bash tools/round4_profile.sh C   LDS-pipe / texture-path counters of the GEMM launches: which unit do the
 #                                    MFMA waves of k_linear_dma wait for -- the LDS pipe (DMA writes + fragment reads) or the loader side?
 #   bash tools/round4_profile.sh T   the GPU test suite + smoke
+#   bash tools/round4_profile.sh A   default bench plain and under rocprofv3 --kernel-trace --stats (two contexts / one stream), the two PMC
+#                                    traffic passes
+#   bash tools/round4_profile.sh B   the other shapes (tri, 5x10, configs[3] shard, 23x10 fp32 / as worded / reduced, one frame) + ring96 stats
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4; mkdir -p $O
 cd $R
@@ -26,4 +29,44 @@ if [ "$1" = C ]; then
   done
   python3 $R/tools/pmc_gemm.py $O/pmc_lds.json $O/p4/d_counter_collection.csv $O/p5/d_counter_collection.csv $O/p6/d_counter_collection.csv $O/p7/d_counter_collection.csv $O/p8/d_counter_collection.csv > $O/pmc_lds.txt 2>&1; head -14 $O/pmc_lds.txt
   rm -f $O/*/*_kernel_trace.csv
+fi
+show() { python3 -c "
+import json,sys
+d=json.load(open('$O/bench_$1.json')); r=d.get('roofline') or {}; s=r.get('step') or {}; dl=d.get('dropin_loop') or {}; j=d.get('json_inclusive') or {}
+print('$1', round(d['value'],1), 'frames/s', round(d['ms_per_step'],3),'ms', 'io', d.get('io_inclusive') and round(d['io_inclusive']['value'],1), 'json warm/cold', j.get('value') and round(j['value'],1), j.get('value_cold') and round(j['value_cold'],1), 'gemm', r.get('frac') and round(r['frac'],4), 'step', s.get('frac') and round(s['frac'],4), 'dropin ms/frame', dl.get('ms_per_frame') and round(dl['ms_per_frame'],3))
+"; }
+if [ "$1" = A ]; then
+  cd $R
+  timeout -k 10 500 python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }; show default
+  timeout -k 10 300 python bench.py --contexts 1 --streams 1 --json-steps 0 --dropin-frames 0 > $O/bench_streams1.json 2>> $O/bench_default.err || exit 1; show streams1
+  cd /tmp; export TMPDIR=/tmp
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o run -- python3 $R/bench.py --contexts 1 --streams 1 --json-steps 0 --no-io --cpu-sample 0 --dropin-frames 0 > $O/bench_streams1_under_rocprof.json 2> $O/stats1.err; echo "stats (one stream) rc $?"
+  rm -f $O/stats*/run_kernel_trace.csv
+  for C in FETCH_SIZE WRITE_SIZE; do timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc -o $C -- python3 $R/bench.py --contexts 1 --streams 1 --steps 3 --warmup 1 --cpu-sample 0 --no-io --json-steps 0 --no-profile --dropin-frames 0 > /dev/null 2> $O/$C.err; echo "$C rc $?"; done
+  python3 $R/tools/pmc_traffic.py $O/pmc/FETCH_SIZE_counter_collection.csv $O/pmc/WRITE_SIZE_counter_collection.csv $O/pmc_traffic.json
+  rm -f $O/*/*_kernel_trace.csv
+  python3 - <<PY
+import csv, json
+d = json.load(open('$O/bench_streams1_under_rocprof.json')); r = d['roofline']
+rows = list(csv.DictReader(open('$O/stats1/run_kernel_stats.csv')))
+g = [x for x in rows if 'k_linear' in x['Name']]
+print('under rocprof: value', round(d['value'], 1), '| live HIP events: GEMM avg launch', round(r['avg_launch_ms'], 5), 'ms | rocprof k_linear_* avg',
+      round(sum(float(x['TotalDurationNs']) for x in g) / sum(int(x['Calls']) for x in g) / 1e6, 5), 'ms over', sum(int(x['Calls']) for x in g), 'launches')
+PY
+fi
+if [ "$1" = B ]; then
+  cd $R
+  X="--json-steps 0 --dropin-frames 0"
+  timeout -k 10 300 python bench.py --mode tri --cpu-sample 20 $X > $O/bench_tri.json 2> $O/bench_b.err; show tri
+  timeout -k 10 300 python bench.py --persons 10 --frames 500 --cpu-sample 0 --steps 30 $X > $O/bench_5x10.json 2>> $O/bench_b.err; show 5x10
+  timeout -k 10 300 python bench.py --persons 10 --total-frames 12500 --cpu-sample 0 --steps 5 --warmup 1 $X > $O/bench_c4_shard.json 2>> $O/bench_b.err; show c4_shard
+  timeout -k 10 300 python bench.py --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 $X > $O/bench_ring96.json 2>> $O/bench_b.err; show ring96
+  timeout -k 10 300 python bench.py --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 $X --cfg4 > $O/bench_ring96_cfg4.json 2>> $O/bench_b.err; show ring96_cfg4
+  timeout -k 10 300 python bench.py --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 $X --reduced > $O/bench_ring96_reduced.json 2>> $O/bench_b.err; show ring96_reduced
+  timeout -k 10 300 python bench.py --frames 1 --cpu-sample 0 --steps 200 --warmup 20 $X > $O/bench_1frame.json 2>> $O/bench_b.err; show 1frame
+  cd /tmp; export TMPDIR=/tmp
+  for M in "" "--cfg4"; do
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ring96$M -o run -- python3 $R/bench.py --contexts 1 --streams 1 --preset RING23 --persons 10 --frames 96 --cpu-sample 0 --steps 6 --warmup 2 $X --no-io $M > /dev/null 2> $O/stats_ring96$M.err; echo "ring96 $M stats rc $?"
+  done
+  rm -f $O/stats_ring96*/run_kernel_trace.csv
 fi
