@@ -278,6 +278,11 @@ def main(variant='panoptic'):
 
     if variant in ('panoptic', 'ring23'):
         gen_cluster_cases(ref, meta)
+    if variant == 'arprobot':
+        # this preset is where the two statements above differ from an UNMODIFIED reference run: say so next to the fixtures
+        meta['deviations_from_an_unmodified_reference_run'] = [
+            "MLP input width from len(parameters.used_cameras) (oracle/gen_golden.py), where test/metrics_from_model.py:91 uses len(parameters.cameras): with the camera-subset preset only the former matches the rows PoseEstimatorDataset builds (pose_estimator_dataset_from_json.py:237-285); numerically neutral for the all-camera presets",
+            "the triangulation gather reads person.get(camera) where test/metrics_from_triangulation.py:240 reads person[camera]: with this preset the reference's own statement raises KeyError for the cameras outside used_cameras_skeleton_matching, so these fixtures pin the builder's reading of the script, not an unmodified run"]
     with open(os.path.join(OUT, 'meta.json'), 'w') as fh:
         json.dump(meta, fh, indent=1)
 
