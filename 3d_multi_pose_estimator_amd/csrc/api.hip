@@ -77,6 +77,7 @@ void free_linear(mpe_ctx *ctx, Linear *L) {
     dev_free(ctx, L->w);
     dev_free(ctx, L->b);
     dev_free(ctx, L->w16);
+    dev_free(ctx, L->w3);
     *L = Linear();
 }
 
@@ -121,7 +122,7 @@ struct GemmProf {
     hipStream_t s;
     bool on;
     size_t idx;
-    GemmProf(mpe_ctx *c, hipStream_t st, double flop, int dev_m_n, int dev_m_k) : ctx(c), s(st), on(false), idx(0) {
+    GemmProf(mpe_ctx *c, hipStream_t st, double flop, int dev_m_n, int dev_m_k, int kind = 0) : ctx(c), s(st), on(false), idx(0) {
         if (!c->profiling) return;
         if (c->prof_used == c->prof.size()) {
             ProfileRec r{};
@@ -132,6 +133,7 @@ struct GemmProf {
         c->prof[idx].flop = flop;
         c->prof[idx].dev_n = dev_m_n;
         c->prof[idx].dev_k = dev_m_k;
+        c->prof[idx].kind = kind;
         on = true;
         (void)hipEventRecord(c->prof[idx].start, s);
     }
@@ -323,6 +325,16 @@ int ensure_bf16_weights(mpe_ctx *ctx, Linear *L) {
     int rc = dev_alloc(ctx, &L->w16, wb.size(), false);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpy(L->w16, wb.data(), wb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    return MPE_OK;
+}
+
+// the three bf16 planes of a weight matrix (split on the device from the padded fp32 copy, stream-ordered)
+int ensure_split_weights(mpe_ctx *ctx, hipStream_t s, Linear *L) {
+    if (L->w3) return MPE_OK;
+    const size_t count = (size_t)weight_rows(L->out_dim) * L->ldw;
+    int rc = dev_alloc(ctx, &L->w3, 3 * count, false);
+    if (rc) return rc;
+    HIPCHK(ctx, launch_split_planes(s, L->w, count, L->w3));
     return MPE_OK;
 }
 
@@ -719,6 +731,20 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
     L.in_dim = k;
     L.out_dim = n;
     L.ldw = ldw;
+    if (slope_on & 4) {
+        // split-bf16 arithmetic (gemm_sb16.hip) on caller-provided weights: the planes are made for this call (a stage-level
+        // entry point for tests; the batch entry points keep theirs with the context)
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const size_t count = (size_t)weight_rows(n) * ldw;
+        unsigned short *planes = nullptr;
+        HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&planes), 3 * count * sizeof(unsigned short)));
+        hipError_t e = launch_split_planes(s, d_w, count, planes);
+        if (e == hipSuccess) e = launch_linear_sb16(s, d_a, lda, planes, count, ldw, d_bias, d_c, ldc, m, d_m, n, ldw, (slope_on & 1) != 0, slope);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(planes);
+        HIPCHK(ctx, e);
+        return MPE_OK;
+    }
     return linear(ctx, static_cast<hipStream_t>(stream), d_a, lda, L, d_c, ldc, m, d_m, (slope_on & 1) != 0, slope,
                   (slope_on & 2) != 0);
 }
@@ -909,7 +935,14 @@ static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int 
     for (int l = 0; l < ctx->mlp_layers; ++l) {
         float *out = ctx->mlp_act[l & 1];
         const bool last = l == ctx->mlp_layers - 1;
-        if (ctx->mlp_bf16) {
+        if (ctx->mlp_split) {
+            Linear &L = ctx->mlp[l];
+            if ((rc = ensure_split_weights(ctx, s, &L))) return rc;
+            if (ld_in < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", ld_in, L.ldw);
+            GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0, 1);
+            HIPCHK(ctx, launch_linear_sb16(s, in, ld_in, L.w3, (size_t)weight_rows(L.out_dim) * L.ldw, L.ldw, L.b, out, ctx->mlp_ld_hidden, m,
+                                           d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope));
+        } else if (ctx->mlp_bf16) {
             Linear &L = ctx->mlp[l];
             if ((rc = ensure_bf16_weights(ctx, &L))) return rc;
             if (ld_in < L.ldw16) return fail(ctx, MPE_ERR_INVALID, "bf16 GEMM needs an input stride >= %d", L.ldw16);
@@ -994,13 +1027,14 @@ int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
     if (!ctx) return MPE_ERR_INVALID;
     DeviceGuard dg(ctx);
-    if (gat_acc64 < 0 || gat_acc64 > 3 || mlp_acc64 < 0 || mlp_acc64 > 2)
-        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0|1|2|3, MLP 0|1|2");
+    if (gat_acc64 < 0 || gat_acc64 > 3 || mlp_acc64 < 0 || mlp_acc64 > 3)
+        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0|1|2|3, MLP 0|1|2|3");
     ctx->gat_acc64 = gat_acc64 == 1;
     ctx->gat_reduced = gat_acc64 == 2;
     ctx->gat_attn_fp16 = gat_acc64 == 3;
     ctx->mlp_acc64 = mlp_acc64 == 1;
     ctx->mlp_bf16 = mlp_acc64 == 2;
+    ctx->mlp_split = mlp_acc64 == 3;
     return MPE_OK;
 }
 
@@ -1018,18 +1052,32 @@ int mpe_profile_read(mpe_ctx *ctx, double *gemm_ms, double *gemm_flop, int64_t *
     HIPCHK(ctx, hipDeviceSynchronize());
     int32_t dev_m = 0;
     HIPCHK(ctx, hipMemcpy(&dev_m, ctx->mlp_count, sizeof dev_m, hipMemcpyDeviceToHost));
-    double ms = 0, flop = 0;
+    double ms[2] = {0, 0}, flop[2] = {0, 0};
+    int64_t cnt[2] = {0, 0};
     for (size_t i = 0; i < ctx->prof_used; ++i) {
+        const int k = ctx->prof[i].kind ? 1 : 0;
         float t = 0;
-        if (hipEventElapsedTime(&t, ctx->prof[i].start, ctx->prof[i].stop) == hipSuccess) ms += t;
-        flop += ctx->prof[i].flop;
-        if (ctx->prof[i].dev_n) flop += 2.0 * dev_m * (double)ctx->prof[i].dev_n * ctx->prof[i].dev_k;
+        if (hipEventElapsedTime(&t, ctx->prof[i].start, ctx->prof[i].stop) == hipSuccess) ms[k] += t;
+        flop[k] += ctx->prof[i].flop;
+        if (ctx->prof[i].dev_n) flop[k] += 2.0 * dev_m * (double)ctx->prof[i].dev_n * ctx->prof[i].dev_k;
+        ++cnt[k];
     }
-    if (gemm_ms) *gemm_ms = ms;
-    if (gemm_flop) *gemm_flop = flop;
-    if (gemm_launches) *gemm_launches = (int64_t)ctx->prof_used;
+    if (gemm_ms) *gemm_ms = ms[0];
+    if (gemm_flop) *gemm_flop = flop[0];
+    if (gemm_launches) *gemm_launches = cnt[0];
+    ctx->sb_ms = ms[1];
+    ctx->sb_flop = flop[1];
+    ctx->sb_launches = cnt[1];
     if (total_ms) *total_ms = 0;
     ctx->prof_used = 0;
+    return MPE_OK;
+}
+
+int mpe_profile_read_split(mpe_ctx *ctx, double *ms, double *flop, int64_t *launches) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (ms) *ms = ctx->sb_ms;
+    if (flop) *flop = ctx->sb_flop;
+    if (launches) *launches = ctx->sb_launches;
     return MPE_OK;
 }
 

@@ -1,0 +1,456 @@
+// fp32-accurate nn.Linear on the bf16 matrix pipe ("split-bf16"): C = act(A W^T + b) with every fp32 operand taken as the
+// exact sum of three bf16 numbers, a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = a - a1 - a2: 3 x 8 significant
+// bits), and the six products a_i w_j with i + j <= 4 evaluated on v_mfma_f32_16x16x32_bf16 (16x the rate of the fp32 MFMA;
+// every single product is exact in fp32) into fp32 accumulators that are flushed into f64 running sums every SECOND 32-deep K
+// stage.  What is dropped (a2 w3 + a3 w2 + a3 w3) is below 2^-24 of |a||w| per product.  Measured against exactly evaluated
+// dot products on MLP-shaped operands (tools/sb16_numerics.hip, profiles/r04_sb16_numerics.txt): rms 0.25-0.26 ulp of the
+// result's scale at K = 416 ... 3072 -- the same as the fp32 MFMA chain with a flush per stage that the MLP launches ran on
+// (0.26), with half as many flushes and 6 x 16-cycle instead of 8 x 32-cycle matrix instructions per 16 x 16 x 32 block.
+//
+// Replaces the same reference code as gemm.hip (nn.Linear + LeakyReLU of utils/mlp.py:8-28) for the MLP launches when the
+// context's MLP mode is 3.  Activations stay fp32 in memory and are split in registers by the MFMA waves (88 VALU
+// instructions per stage and wave, hidden behind the other workgroup's MFMAs); the weights are split once (k_split_planes)
+// into three bf16 planes [3][rows][ldw].
+//
+// Three kernels, one arithmetic -- per 16 x 16 output tile and K stage the six MFMAs in the order (a1,w3) (a2,w2) (a1,w2)
+// (a3,w1) (a2,w1) (a1,w1), stages ascending, flush after every odd stage and after the last one -- so a row has the same
+// bits in a batch of one and of a thousand:
+//   k_linear_sb         128 x 64|80 x 32 tiles, 4 MFMA waves + 2 loader waves (LDS-DMA of the fp32 activation tile and the
+//                       three weight planes), double-buffered LDS, one barrier per stage
+//   k_linear_sb_skinny  one wave per 16 x 16 tile, operands streamed from global memory (small batches, narrow outputs)
+//   k_linear_sb_ks      the same with the stage pairs of a tile dealt to eight waves and an ordered f64 reduction through LDS
+#include <cstdlib>
+
+#include "mpe_internal.h"
+
+namespace mpe {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    bf2 v = {(__bf16)lo, (__bf16)hi};                    // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// eight fp32 values -> their three bf16 planes (exact: x = p0 + p1 + p2)
+__device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
+    u32x4 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+        const unsigned u0 = pack2_bf16(a, b);
+        const float ra = a - __uint_as_float(u0 << 16), rb = b - __uint_as_float(u0 & 0xFFFF0000u);
+        const unsigned u1 = pack2_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(u1 << 16), sb = rb - __uint_as_float(u1 & 0xFFFF0000u);
+        q0[j] = u0;
+        q1[j] = u1;
+        q2[j] = pack2_bf16(sa, sb);
+    }
+    p0 = __builtin_bit_cast(bf16x8, q0);
+    p1 = __builtin_bit_cast(bf16x8, q1);
+    p2 = __builtin_bit_cast(bf16x8, q2);
+}
+
+// the six products of one stage, canonical order; a[p], w[p] = plane p (0 = most significant)
+#define SB_STAGE(ACC, A, W)                                                            \
+    do {                                                                               \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[2], (A)[0], ACC, 0, 0, 0);   \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[1], (A)[1], ACC, 0, 0, 0);   \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[1], (A)[0], ACC, 0, 0, 0);   \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[2], ACC, 0, 0, 0);   \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[1], ACC, 0, 0, 0);   \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[0], ACC, 0, 0, 0);   \
+    } while (0)
+
+__device__ __forceinline__ int a_swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }   // gemm.hip: dma_swz
+__device__ __forceinline__ int w_swz(int row) { return (row >> 2) & 3; }                                  // 64-byte rows
+
+constexpr int SB_NL = 2;                              // loader waves (6-wave workgroups: 168 registers at two workgroups per CU)
+constexpr int SB_A_BYTES = GEMM_BM * GEMM_BK * 4;     // 16 KiB: the activation tile, fp32, the image of k_linear_dma
+
+__host__ __device__ constexpr int sb_stage_bytes(int ntt) { return SB_A_BYTES + 3 * ntt * 16 * GEMM_BK * 2; }
+
+template <bool LEAKY, int NTT>
+__global__ __launch_bounds__(256 + 64 * SB_NL, 3) void k_linear_sb(const float *__restrict__ A, int lda,
+                                                                   const unsigned short *__restrict__ W3, size_t w_plane, int ldw,
+                                                                   const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                                   int m_cap, const int32_t *__restrict__ d_m, int n, int k_pad,
+                                                                   float slope, int ntn, int n_major) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    constexpr int STAGE = sb_stage_bytes(NTT);
+    constexpr int WPL = NTT * 16 * GEMM_BK * 2;       // bytes of one weight plane of a stage
+    int M = m_cap;
+    if (d_m) {
+        const int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    const int ntm = (M + GEMM_BM - 1) / GEMM_BM;
+    const int bid = blockIdx.x, nwg = ntm * ntn;
+    if (bid >= nwg) return;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int tm, tn;
+    if (n_major) {
+        constexpr int RB = 8;
+        const int band = swz / (RB * ntn), rem = swz - band * (RB * ntn);
+        const int rows = ntm - band * RB < RB ? ntm - band * RB : RB;
+        tn = rem / rows;
+        tm = band * RB + (rem - tn * rows);
+    } else {
+        tm = swz / ntn;
+        tn = swz - tm * ntn;
+    }
+    const int m0 = tm * GEMM_BM, n0 = tn * NTT * 16;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nk = k_pad / GEMM_BK;
+
+    if (wave >= 4) {
+        // ---- loader waves: 16 activation groups (8 rows x 128 B each) + 3 NTT weight groups (16 rows x 64 B) per stage ----
+        const int li = wave - 4;
+        const int dr = lane >> 3, dp = lane & 7, wr = lane >> 2, wc = lane & 3;
+        __builtin_amdgcn_s_setprio(3);
+        constexpr int NA = 16 / SB_NL;
+        constexpr int NW = 3 * NTT, NWL = (NW + SB_NL - 1) / SB_NL;
+        const float *la[NA];
+        const unsigned short *lw[NWL];
+        int lw_dst[NWL];
+#pragma unroll
+        for (int g = 0; g < NA; ++g) {
+            const int row = (li * NA + g) * 8 + dr;
+            int grow = m0 + row;
+            grow = grow < M ? grow : M - 1;
+            la[g] = A + (size_t)grow * lda + ((dp ^ a_swz(row)) << 2);
+        }
+#pragma unroll
+        for (int g = 0; g < NWL; ++g) {
+            int idx = li + SB_NL * g;
+            idx = idx < NW ? idx : NW - 1;
+            const int p = idx / NTT, grp = idx - p * NTT;
+            const int row = grp * 16 + wr;
+            lw[g] = W3 + p * w_plane + (size_t)(n0 + row) * ldw + ((wc ^ w_swz(row)) << 3);
+            lw_dst[g] = SB_A_BYTES + p * WPL + grp * 1024;
+        }
+        auto fill = [&](int kt, int buf) {
+            unsigned char *base = lds + buf * STAGE;
+            const int koff = kt * GEMM_BK;
+#pragma unroll
+            for (int g = 0; g < NA; ++g)
+                __builtin_amdgcn_global_load_lds((glb_void *)(la[g] + koff), (lds_void *)(base + (li * NA + g) * 8 * 128), 16, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NWL; ++g)
+                if ((g + 1) * SB_NL <= NW || li + SB_NL * g < NW)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(lw[g] + koff), (lds_void *)(base + lw_dst[g]), 16, 0, 0);
+        };
+        fill(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();                       // vmcnt(0): stage kt has landed; the MFMA waves are done with the other buffer
+            if (kt + 1 < nk) fill(kt + 1, (kt + 1) & 1);
+        }
+        return;
+    }
+
+    // ---- MFMA waves: 32 rows x 16 NTT features each ----
+    const int fq = lane >> 4, fr = lane & 15;
+    int a_rd[2], w_rd[NTT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * 128;
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) {
+        const int row = nt * 16 + fr;
+        w_rd[nt] = SB_A_BYTES + row * 64 + ((fq ^ w_swz(row)) << 4);
+    }
+    const int fsw = a_swz(fr);
+    const int c0 = ((fq * 2 + 0) ^ fsw) << 4, c1 = ((fq * 2 + 1) ^ fsw) << 4;      // k = 8 fq .. 8 fq + 7 of the row
+
+    f32x4 acc[NTT][2];
+    double run[NTT][2][4];
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) run[nt][mt][i] = 0.0;
+        }
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        const unsigned char *cur = lds + (kt & 1) * STAGE;
+        bf16x8 ap[2][3];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(cur + a_rd[mt] + c0);
+            const f32x4 x1 = *reinterpret_cast<const f32x4 *>(cur + a_rd[mt] + c1);
+            split8(x0, x1, ap[mt][0], ap[mt][1], ap[mt][2]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+            bf16x8 wp[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wp[p] = *reinterpret_cast<const bf16x8 *>(cur + p * WPL + w_rd[nt]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) SB_STAGE(acc[nt][mt], ap[mt], wp);
+        }
+        if ((kt & 1) || kt == nk - 1) {
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) run[nt][mt][i] += (double)acc[nt][mt][i];
+                    acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) {
+        const int nb = n0 + nt * 16 + fq * 4;
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = m0 + wave * 32 + mt * 16 + fr;
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = (float)(run[nt][mt][i] + (double)bv[i]);
+                if (LEAKY) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+            }
+            if (m >= M) continue;
+            float *dst = C + (size_t)m * ldc + nb;
+            if (nb + 3 < n) {
+                *reinterpret_cast<f32x4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (nb + i < n) dst[i] = v[i];
+            }
+        }
+    }
+}
+
+// ---- one wave per 16 x 16 tile (small batches, narrow outputs): operands streamed from global memory --------------------------
+constexpr int SBS_DEPTH = 4;
+
+struct SbFrag {
+    f32x4 a0, a1;
+    bf16x8 w[3];
+};
+
+__device__ __forceinline__ void sb_load(SbFrag &f, const float *pa, const unsigned short *pw, size_t w_plane, int ko) {
+    f.a0 = *reinterpret_cast<const f32x4 *>(pa + ko);
+    f.a1 = *reinterpret_cast<const f32x4 *>(pa + ko + 4);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f.w[p] = *reinterpret_cast<const bf16x8 *>(pw + p * w_plane + ko);
+}
+
+template <bool LEAKY>
+__global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
+                                                           size_t w_plane, int ldw, const float *__restrict__ bias,
+                                                           float *__restrict__ C, int ldc, int m_cap,
+                                                           const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16) {
+    int M = m_cap;
+    if (d_m) {
+        const int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tm = gw / nt16, tn = gw - tm * nt16;
+    if (tm * 16 >= M) return;                                // no barriers below: waves may leave early
+    const int fq = lane >> 4, fr = lane & 15;
+    int grow = tm * 16 + fr;
+    grow = grow < M ? grow : M - 1;
+    const float *pa = A + (size_t)grow * lda + 8 * fq;       // stage kt: k = 32 kt + 8 fq + {0..7}
+    const unsigned short *pw = W3 + (size_t)(tn * 16 + fr) * ldw + 8 * fq;
+    const int nk = k_pad / GEMM_BK;
+    SbFrag fr_[SBS_DEPTH];
+#pragma unroll
+    for (int d = 0; d < SBS_DEPTH; ++d) sb_load(fr_[d], pa, pw, w_plane, (d < nk ? d : nk - 1) * GEMM_BK);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    double run[4] = {0.0, 0.0, 0.0, 0.0};
+    auto stage = [&](const SbFrag &f, int kt) {
+        bf16x8 ap[3];
+        split8(f.a0, f.a1, ap[0], ap[1], ap[2]);
+        SB_STAGE(acc, ap, f.w);
+        if ((kt & 1) || kt == nk - 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) run[i] += (double)acc[i];
+            acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    int kt0 = 0;
+    for (; kt0 + SBS_DEPTH <= nk; kt0 += SBS_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < SBS_DEPTH; ++d) {
+            stage(fr_[d], kt0 + d);
+            int kn = kt0 + d + SBS_DEPTH;                    // refill the slot in place (clamped: no branch)
+            kn = (kn < nk ? kn : nk - 1) * GEMM_BK;
+            sb_load(fr_[d], pa, pw, w_plane, kn);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < SBS_DEPTH; ++d)
+        if (kt0 + d < nk) stage(fr_[d], kt0 + d);
+    const int m = tm * 16 + fr;
+    if (m >= M) return;
+    const int nb = tn * 16 + fq * 4;
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+    float *dst = C + (size_t)m * ldc + nb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = (float)(run[i] + (double)bv[i]);
+        if (LEAKY) v = v > 0.f ? v : v * slope;
+        if (nb + i < n) dst[i] = v;
+    }
+}
+
+// The stage PAIRS of a tile (= the units between two f64 flushes) dealt round-robin to the KS waves of a workgroup; fp32 pair
+// results parked in LDS, then every element summed over the pairs in pair order in f64: the additions of k_linear_sb in the
+// same order (and exact anyway: fp32 terms in an f64 sum).
+template <bool LEAKY, int KS>
+__global__ __launch_bounds__(64 * KS) void k_linear_sb_ks(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
+                                                          size_t w_plane, int ldw, const float *__restrict__ bias,
+                                                          float *__restrict__ C, int ldc, int m_cap,
+                                                          const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16) {
+    extern __shared__ __attribute__((aligned(16))) float s_part[];       // [pairs][64 lanes][4]
+    int M = m_cap;
+    if (d_m) {
+        const int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    const int tm = blockIdx.x / nt16, tn = blockIdx.x - tm * nt16;
+    if (tm * 16 >= M) return;                                // whole workgroup leaves: no barrier reached
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fq = lane >> 4, fr = lane & 15;
+    int grow = tm * 16 + fr;
+    grow = grow < M ? grow : M - 1;
+    const float *pa = A + (size_t)grow * lda + 8 * fq;
+    const unsigned short *pw = W3 + (size_t)(tn * 16 + fr) * ldw + 8 * fq;
+    const int nk = k_pad / GEMM_BK, npair = (nk + 1) / 2;
+    for (int j = wave; j < npair; j += KS) {
+        SbFrag f0, f1;
+        const int k0 = 2 * j, k1 = 2 * j + 1 < nk ? 2 * j + 1 : nk - 1;
+        sb_load(f0, pa, pw, w_plane, k0 * GEMM_BK);
+        sb_load(f1, pa, pw, w_plane, k1 * GEMM_BK);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 ap[3];
+        split8(f0.a0, f0.a1, ap[0], ap[1], ap[2]);
+        SB_STAGE(acc, ap, f0.w);
+        if (2 * j + 1 < nk) {
+            split8(f1.a0, f1.a1, ap[0], ap[1], ap[2]);
+            SB_STAGE(acc, ap, f1.w);
+        }
+        *reinterpret_cast<f32x4 *>(&s_part[(j * 64 + lane) * 4]) = acc;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= 256) return;
+    double run = 0.0;
+    for (int j = 0; j < npair; ++j) run += (double)s_part[j * 256 + t];  // pair order, as the tile kernel
+    const int el = t >> 2, i = t & 3;                        // element (lane el, component i) of the MFMA tile
+    const int m = tm * 16 + (el & 15), nb = tn * 16 + (el >> 4) * 4 + i;
+    if (m >= M || nb >= n) return;
+    float v = (float)(run + (double)bias[nb]);
+    if (LEAKY) v = v > 0.f ? v : v * slope;
+    C[(size_t)m * ldc + nb] = v;
+}
+
+// fp32 weights [rows][ld] -> three bf16 planes [3][rows][ld]
+__global__ void k_split_planes(const float *__restrict__ w, size_t count, unsigned short *__restrict__ planes) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= count) return;
+    const float a = w[i], b = i + 1 < count ? w[i + 1] : 0.f;
+    const unsigned u0 = pack2_bf16(a, b);
+    const float ra = a - __uint_as_float(u0 << 16), rb = b - __uint_as_float(u0 & 0xFFFF0000u);
+    const unsigned u1 = pack2_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(u1 << 16), sb = rb - __uint_as_float(u1 & 0xFFFF0000u);
+    const unsigned u2 = pack2_bf16(sa, sb);
+    const unsigned us[3] = {u0, u1, u2};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        planes[p * count + i] = (unsigned short)(us[p] & 0xFFFFu);
+        if (i + 1 < count) planes[p * count + i + 1] = (unsigned short)(us[p] >> 16);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsigned short *planes) {
+    if (count == 0) return hipSuccess;
+    const size_t pairs = (count + 1) / 2;
+    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, w, count, planes);
+    return hipGetLastError();
+}
+
+// Same dispatch rules as launch_linear's f64-sum branch (gemm.hip): K split over eight waves / one wave per 16 x 16 tile for
+// small batches and for outputs of at most four 16-wide tiles at any batch size, the tile kernel otherwise.
+hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
+                              const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
+                              float slope) {
+    if (m_cap <= 0 || n <= 0) return hipSuccess;
+    static const int skinny_waves = getenv("MPE_SKINNY_WAVES") ? atoi(getenv("MPE_SKINNY_WAVES")) : 1024;
+    static const int narrow_on = getenv("MPE_GEMM_NARROW") ? atoi(getenv("MPE_GEMM_NARROW")) : 1;
+    const int nt16 = (n + 15) / 16, nk = k_pad / GEMM_BK;
+    const long waves16 = (long)((m_cap + 15) / 16) * nt16;
+    const bool narrow = narrow_on && nt16 <= 4;
+    if ((waves16 <= skinny_waves || narrow) && nk <= 256 && nk >= 8) {
+        const size_t shm = (size_t)((nk + 1) / 2) * 1024;
+        static PerDeviceFlag attr_done;
+        if (!attr_done.test()) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_sb_ks<true, 8>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_sb_ks<false, 8>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done.set();
+        }
+        if (leaky)
+            hipLaunchKernelGGL((k_linear_sb_ks<true, 8>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C,
+                               ldc, m_cap, d_m, n, k_pad, slope, nt16);
+        else
+            hipLaunchKernelGGL((k_linear_sb_ks<false, 8>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C,
+                               ldc, m_cap, d_m, n, k_pad, slope, nt16);
+        return hipGetLastError();
+    }
+    if (waves16 <= skinny_waves || narrow) {
+        const dim3 grid((unsigned)((waves16 + 3) / 4)), block(256);
+        if (leaky)
+            hipLaunchKernelGGL((k_linear_sb_skinny<true>), grid, block, 0, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad,
+                               slope, nt16);
+        else
+            hipLaunchKernelGGL((k_linear_sb_skinny<false>), grid, block, 0, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad,
+                               slope, nt16);
+        return hipGetLastError();
+    }
+    static PerDeviceFlag lds_attr;
+    if (!lds_attr.test()) {
+        hipError_t e = hipSuccess;
+        const void *fns[2] = {reinterpret_cast<const void *>(k_linear_sb<true, 4>), reinterpret_cast<const void *>(k_linear_sb<false, 4>)};
+        for (const void *fn : fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sb_stage_bytes(4));
+        if (e != hipSuccess) return e;
+        lds_attr.set();
+    }
+    const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
+    const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
+    // 64-wide feature tiles only: with 80 the f64 running sums of the wider wave tile do not fit the 168 registers that two
+    // six-wave workgroups per CU leave (the compiler spills); the MLP's layers balance with 64 anyway
+    const int ntn = (n + 63) / 64;
+    const dim3 grid((unsigned)(ntm * ntn)), block(256 + 64 * SB_NL);
+#define MPE_SB(L_, N_)                                                                                                     \
+    hipLaunchKernelGGL((k_linear_sb<L_, N_>), grid, block, 2 * sb_stage_bytes(N_), s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, \
+                       d_m, n, k_pad, slope, ntn, n_major)
+    if (leaky) MPE_SB(true, 4);
+    else MPE_SB(false, 4);
+#undef MPE_SB
+    return hipGetLastError();
+}
+
+}  // namespace mpe

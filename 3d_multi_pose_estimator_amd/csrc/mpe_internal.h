@@ -25,6 +25,7 @@ struct Linear {                // one nn.Linear, zero padded on the device
     float *b = nullptr;        // [weight_rows(out)]
     unsigned short *w16 = nullptr;   // optional bf16 copy [rows][ldw16] (reduced-precision mode)
     int ldw16 = 0;
+    unsigned short *w3 = nullptr;    // optional: the three bf16 planes of w, [3][weight_rows(out)][ldw] (split-bf16 mode, gemm_sb16.hip)
     int in_dim = 0, out_dim = 0, ldw = 0;
 };
 
@@ -62,6 +63,7 @@ struct ProfileRec {
     hipEvent_t start, stop;
     double flop;      // known on the host, or
     int dev_n, dev_k;  // 2 * (device-side row count) * dev_n * dev_k
+    int kind;          // 0 = fp32 MFMA launch (gemm.hip), 1 = split-bf16 launch (gemm_sb16.hip)
 };
 
 }  // namespace mpe
@@ -86,8 +88,9 @@ struct mpe_ctx {
     bool en0_ready = false;
     int mlp_layers = 0;
     float mlp_slope = 0.1f;
-    bool mlp_acc64 = true;         // f64 running sums in the MLP GEMMs (parity mode)
+    bool mlp_acc64 = true;         // fp32 MFMA with f64 running sums per K stage in the MLP GEMMs (MLP mode 1; the parity mode of rounds 1-3)
     bool mlp_bf16 = false;         // reduced precision: bf16 MFMA for the MLP GEMMs
+    bool mlp_split = true;         // DEFAULT (MLP mode 3): fp32-accurate MLP GEMMs on the bf16 MFMA (three bf16 planes per operand, six products, f64 sums every second stage)
     bool gat_acc64 = false;
     bool gat_reduced = false;      // reduced precision: bf16 MFMA GEMMs + fp16 feature rows in the attention stage
     bool gat_attn_fp16 = false;    // configs[4] as BASELINE words it: fp16 feature rows (ft2) in the attention stage, GEMMs stay fp32
@@ -137,6 +140,8 @@ struct mpe_ctx {
     size_t prof_used = 0;
     hipEvent_t tot_start = nullptr, tot_stop = nullptr;
     bool tot_valid = false;
+    double sb_ms = 0, sb_flop = 0;      // the split-bf16 launches of the records last read by mpe_profile_read
+    int64_t sb_launches = 0;
 };
 
 namespace mpe {
@@ -164,6 +169,12 @@ hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsi
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad,
                               bool leaky, float slope, int k_lim = 0, bool out_half = false,
                               const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr);
+
+// gemm_sb16.hip: fp32-accurate nn.Linear on the bf16 MFMA (three bf16 planes per operand, f64 flush every second stage)
+hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsigned short *planes);
+hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
+                              const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
+                              float slope);
 
 // gat.hip
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,

@@ -125,10 +125,13 @@ int mpe_set_mlp_params(mpe_ctx *ctx, int32_t n_layers, float slope);
 int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_dim,
                       const float *w, const float *b);
 
-/* Accumulation mode of the fp32 MFMA GEMMs.  0 = one fp32 MFMA chain over the whole K
- * (fastest); 1 = every 32-deep K stage is flushed into f64 running sums, so a dot product
- * carries about one rounding, like a blocked CPU sgemm.  Defaults: GAT 0, MLP 1 (the MLP's
- * K is up to 3072 and its 3D output is compared with the reference at the micrometre level: DESIGN.md section 5).  MLP mode 2 is the
+/* Arithmetic of the GEMMs.  0 = one fp32 MFMA chain over the whole K; 1 = fp32 MFMA, every 32-deep K stage flushed into f64
+ * running sums, so a dot product carries about one rounding, like a blocked CPU sgemm.  MLP mode 3 (the MLP DEFAULT since round
+ * 4) = the same accuracy class on the bf16 matrix pipe: every fp32 operand is taken as the exact sum of three bf16 numbers, the
+ * six significant partial products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulators flushed into f64 sums every second
+ * stage (csrc/gemm_sb16.hip; measured error against exactly evaluated dot products: that of mode 1 or below, 1.35x faster
+ * launches).  Defaults: GAT 0, MLP 3 (the MLP's K is up to 3072 and its 3D output is compared with the reference at the
+ * micrometre level: DESIGN.md section 5; mode 1 stays selectable).  MLP mode 2 is the
  * reduced-precision variant of BASELINE.json configs[4]: weights and staged activations in
  * bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~3 significant digits; not parity).
  * GAT mode 2 is the other half of that config: fc1/fc2 on the bf16 MFMA and the transformed
@@ -329,6 +332,10 @@ int mpe_json_parse_device(mpe_ctx *ctx, void *stream, const char *d_text, const 
 int mpe_profile_enable(mpe_ctx *ctx, int32_t on);      /* 1 = on, records cleared; 2 = on, records kept (resume); 0 = off (records kept until read) */
 int mpe_profile_read(mpe_ctx *ctx, double *gemm_ms, double *gemm_flop, int64_t *gemm_launches,
                      double *total_ms);
+/* mpe_profile_read reports the launches on the fp32 MFMA (the dominant kernel, k_linear_dma); the split-bf16 launches of the
+ * same records (MLP mode 3: k_linear_sb*, fp32-equivalent FLOPs = 2 M N K, executed on the bf16 MFMA as six products) are kept
+ * apart and read here, after mpe_profile_read. */
+int mpe_profile_read_split(mpe_ctx *ctx, double *ms, double *flop, int64_t *launches);
 
 #ifdef __cplusplus
 }
