@@ -159,6 +159,7 @@ int linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, const Linear &L
 
 unsigned short f32_to_bf16(float f);
 int ensure_bf16_weights(mpe_ctx *ctx, Linear *L);
+int ensure_split_weights(mpe_ctx *ctx, hipStream_t s, Linear *L);
 
 // GEMM of a GAT layer: fp32 MFMA (parity) or, in the reduced-precision mode, bf16 MFMA with an
 // optional fp16 result (`out_half`: C is the same buffer seen as fp16 rows, ldc in halves)
@@ -167,6 +168,22 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
                const int32_t *c_rows = nullptr, double flop_override = -1.0, const AttnCoef *coef = nullptr,
                bool *coef_done = nullptr) {
     if (coef_done) *coef_done = false;
+    if (ctx->gat_split && !ctx->gat_reduced && !out_half && !a_rows && !c_rows && &L != &ctx->gat[0].fc1 && &L != &ctx->gat[0].fc2 &&
+        L.w != ctx->l0_w) {
+        // split-bf16 form (gemm_sb16.hip): fp32-accurate products on the bf16 matrix pipe; f64 sums where the fp32 path has them
+        static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
+        const bool f64 = ctx->gat_acc64 || (mink > 0 && L.in_dim > mink);
+        if (m <= 0) return MPE_OK;
+        int rc = ensure_split_weights(ctx, s, &L);
+        if (rc) return rc;
+        if (lda < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", lda, L.ldw);
+        const bool host_m = !d_m || flop_override >= 0.0;
+        GemmProf gp(ctx, s, flop_override >= 0.0 ? flop_override : (d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim),
+                    host_m ? 0 : L.out_dim, host_m ? 0 : L.in_dim, 1);
+        HIPCHK(ctx, launch_linear_sb16(s, A, lda, L.w3, (size_t)weight_rows(L.out_dim) * L.ldw, L.ldw, L.b, C, ldc, m, d_m, L.out_dim, L.ldw,
+                                       leaky, slope, f64, f64 ? nullptr : coef, coef_done));
+        return MPE_OK;
+    }
     if (!ctx->gat_reduced) {
         // Long sums (K > 512: fc2 of layer 0, K = 902 / 1082, on head rows only -- no measurable cost) always
         // run with f64 running sums: a single fp32 chain of that length was the largest contribution to the
@@ -739,7 +756,8 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
         unsigned short *planes = nullptr;
         HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&planes), 3 * count * sizeof(unsigned short)));
         hipError_t e = launch_split_planes(s, d_w, count, planes);
-        if (e == hipSuccess) e = launch_linear_sb16(s, d_a, lda, planes, count, ldw, d_bias, d_c, ldc, m, d_m, n, ldw, (slope_on & 1) != 0, slope);
+        if (e == hipSuccess)
+            e = launch_linear_sb16(s, d_a, lda, planes, count, ldw, d_bias, d_c, ldc, m, d_m, n, ldw, (slope_on & 1) != 0, slope, (slope_on & 8) == 0);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         (void)hipFree(planes);
         HIPCHK(ctx, e);
@@ -1027,8 +1045,12 @@ int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
     if (!ctx) return MPE_ERR_INVALID;
     DeviceGuard dg(ctx);
-    if (gat_acc64 < 0 || gat_acc64 > 3 || mlp_acc64 < 0 || mlp_acc64 > 3)
-        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0|1|2|3, MLP 0|1|2|3");
+    if (gat_acc64 < 0 || gat_acc64 > 6 || mlp_acc64 < 0 || mlp_acc64 > 3)
+        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0..6, MLP 0|1|2|3");
+    // GAT modes 4 / 5: modes 0 / 1 with the GEMMs of layers >= 1 in the split-bf16 form (4 = the default); 6 = mode 3 likewise
+    // (the fc2 launches that store fp16 rows stay on the fp32 MFMA)
+    ctx->gat_split = gat_acc64 >= 4;
+    if (gat_acc64 >= 4) gat_acc64 = gat_acc64 == 4 ? 0 : gat_acc64 == 5 ? 1 : 3;
     ctx->gat_acc64 = gat_acc64 == 1;
     ctx->gat_reduced = gat_acc64 == 2;
     ctx->gat_attn_fp16 = gat_acc64 == 3;

@@ -72,17 +72,23 @@ __device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, bf16x8 
 __device__ __forceinline__ int a_swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }   // gemm.hip: dma_swz
 __device__ __forceinline__ int w_swz(int row) { return (row >> 2) & 3; }                                  // 64-byte rows
 
-constexpr int SB_NL = 2;                              // loader waves (6-wave workgroups: 168 registers at two workgroups per CU)
+// loader waves: 2 with f64 running sums (6-wave workgroups: 168 registers at two workgroups per CU), 4 without
 constexpr int SB_A_BYTES = GEMM_BM * GEMM_BK * 4;     // 16 KiB: the activation tile, fp32, the image of k_linear_dma
 
 __host__ __device__ constexpr int sb_stage_bytes(int ntt) { return SB_A_BYTES + 3 * ntt * 16 * GEMM_BK * 2; }
 
-template <bool LEAKY, int NTT>
-__global__ __launch_bounds__(256 + 64 * SB_NL, 3) void k_linear_sb(const float *__restrict__ A, int lda,
+// A12 (fc2 of a graph-attention layer with 40-wide attention heads, 80-wide tiles): the epilogue also emits a1 | a2 =
+// <ft2[row, head, :], attn_l / attn_r[head]> (gat2.py:57-58) from the values the lanes hold -- the code of k_linear_dma<.., A12>,
+// same lane layout, same canonical order (coef40() in gat.hip mirrors it for the paths that compute the coefficients elsewhere).
+template <bool LEAKY, int NTT, bool F64, int SB_NL, bool A12 = false>
+__global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear_sb(const float *__restrict__ A, int lda,
                                                                    const unsigned short *__restrict__ W3, size_t w_plane, int ldw,
                                                                    const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                                    int m_cap, const int32_t *__restrict__ d_m, int n, int k_pad,
-                                                                   float slope, int ntn, int n_major) {
+                                                                   float slope, int ntn, int n_major,
+                                                                   const float *__restrict__ attn_l = nullptr,
+                                                                   const float *__restrict__ attn_r = nullptr,
+                                                                   float *__restrict__ a12 = nullptr) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int STAGE = sb_stage_bytes(NTT);
     constexpr int WPL = NTT * 16 * GEMM_BK * 2;       // bytes of one weight plane of a stage
@@ -170,14 +176,16 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, 3) void k_linear_sb(const float *
     const int c0 = ((fq * 2 + 0) ^ fsw) << 4, c1 = ((fq * 2 + 1) ^ fsw) << 4;      // k = 8 fq .. 8 fq + 7 of the row
 
     f32x4 acc[NTT][2];
-    double run[NTT][2][4];
+    double run[F64 ? NTT : 1][2][4];
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (F64) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) run[nt][mt][i] = 0.0;
+                for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] = 0.0;
+            }
         }
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
@@ -197,29 +205,51 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, 3) void k_linear_sb(const float *
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) SB_STAGE(acc[nt][mt], ap[mt], wp);
         }
-        if ((kt & 1) || kt == nk - 1) {
+        if (F64 && ((kt & 1) || kt == nk - 1)) {
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) run[nt][mt][i] += (double)acc[nt][mt][i];
+                    for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
                     acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
         }
+    }
+    float pl[2][2], pr[2][2];            // A12: per (head of the tile, row tile) partial dot products
+    if (A12) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) pl[h][mt] = pr[h][mt] = 0.f;
     }
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) {
         const int nb = n0 + nt * 16 + fq * 4;
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+        f32x4 al = {0.f, 0.f, 0.f, 0.f}, ar = {0.f, 0.f, 0.f, 0.f};
+        if (A12 && nb + 3 < n) {
+            al = *reinterpret_cast<const f32x4 *>(attn_l + nb);
+            ar = *reinterpret_cast<const f32x4 *>(attn_r + nb);
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int m = m0 + wave * 32 + mt * 16 + fr;
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                v[i] = (float)(run[nt][mt][i] + (double)bv[i]);
+                v[i] = F64 ? (float)(run[F64 ? nt : 0][mt][i] + (double)bv[i]) : acc[nt][mt][i] + bv[i];
                 if (LEAKY) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+            }
+            if (A12) {
+                // a 4-feature group never straddles the 40-feature head boundary of the tile
+                const int hp = (nt * 16 + fq * 4) >= 40 ? 1 : 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float l1 = __builtin_fmaf(v[i], al[i], hp ? pl[1][mt] : pl[0][mt]);
+                    const float r1 = __builtin_fmaf(v[i], ar[i], hp ? pr[1][mt] : pr[0][mt]);
+                    if (hp) { pl[1][mt] = l1; pr[1][mt] = r1; } else { pl[0][mt] = l1; pr[0][mt] = r1; }
+                }
             }
             if (m >= M) continue;
             float *dst = C + (size_t)m * ldc + nb;
@@ -231,6 +261,24 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, 3) void k_linear_sb(const float *
                     if (nb + i < n) dst[i] = v[i];
             }
         }
+    }
+    if (A12) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float x = pl[h][mt], y = pr[h][mt];
+                x = x + __shfl_xor(x, 16);
+                y = y + __shfl_xor(y, 16);
+                x = x + __shfl_xor(x, 32);
+                y = y + __shfl_xor(y, 32);
+                const int m = m0 + wave * 32 + mt * 16 + fr;
+                const int head = (n0 / 40) + h;
+                if (fq == 0 && m < M && head * 40 < n) {
+                    a12[(size_t)m * 32 + head] = x;
+                    a12[(size_t)m * 32 + 16 + head] = y;
+                }
+            }
     }
 }
 
@@ -249,7 +297,7 @@ __device__ __forceinline__ void sb_load(SbFrag &f, const float *pa, const unsign
     for (int p = 0; p < 3; ++p) f.w[p] = *reinterpret_cast<const bf16x8 *>(pw + p * w_plane + ko);
 }
 
-template <bool LEAKY>
+template <bool LEAKY, bool F64>
 __global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
                                                            size_t w_plane, int ldw, const float *__restrict__ bias,
                                                            float *__restrict__ C, int ldc, int m_cap,
@@ -278,7 +326,7 @@ __global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restric
         bf16x8 ap[3];
         split8(f.a0, f.a1, ap[0], ap[1], ap[2]);
         SB_STAGE(acc, ap, f.w);
-        if ((kt & 1) || kt == nk - 1) {
+        if (F64 && ((kt & 1) || kt == nk - 1)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) run[i] += (double)acc[i];
             acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -304,7 +352,7 @@ __global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restric
     float *dst = C + (size_t)m * ldc + nb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float v = (float)(run[i] + (double)bv[i]);
+        float v = F64 ? (float)(run[i] + (double)bv[i]) : acc[i] + bv[i];
         if (LEAKY) v = v > 0.f ? v : v * slope;
         if (nb + i < n) dst[i] = v;
     }
@@ -392,14 +440,15 @@ hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsi
 // small batches and for outputs of at most four 16-wide tiles at any batch size, the tile kernel otherwise.
 hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
-                              float slope) {
+                              float slope, bool f64, const AttnCoef *coef, bool *coef_done) {
+    if (coef_done) *coef_done = false;
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     static const int skinny_waves = getenv("MPE_SKINNY_WAVES") ? atoi(getenv("MPE_SKINNY_WAVES")) : 1024;
     static const int narrow_on = getenv("MPE_GEMM_NARROW") ? atoi(getenv("MPE_GEMM_NARROW")) : 1;
     const int nt16 = (n + 15) / 16, nk = k_pad / GEMM_BK;
     const long waves16 = (long)((m_cap + 15) / 16) * nt16;
-    const bool narrow = narrow_on && nt16 <= 4;
-    if ((waves16 <= skinny_waves || narrow) && nk <= 256 && nk >= 8) {
+    const bool narrow = narrow_on && nt16 <= (f64 ? 4 : 1);
+    if (f64 && (waves16 <= skinny_waves || narrow) && nk <= 256 && nk >= 8) {
         const size_t shm = (size_t)((nk + 1) / 2) * 1024;
         static PerDeviceFlag attr_done;
         if (!attr_done.test()) {
@@ -421,34 +470,49 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     }
     if (waves16 <= skinny_waves || narrow) {
         const dim3 grid((unsigned)((waves16 + 3) / 4)), block(256);
-        if (leaky)
-            hipLaunchKernelGGL((k_linear_sb_skinny<true>), grid, block, 0, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad,
-                               slope, nt16);
-        else
-            hipLaunchKernelGGL((k_linear_sb_skinny<false>), grid, block, 0, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad,
-                               slope, nt16);
+#define MPE_SBS(L_, F_)                                                                                                   \
+    hipLaunchKernelGGL((k_linear_sb_skinny<L_, F_>), grid, block, 0, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
+                       slope, nt16)
+        if (leaky && f64) MPE_SBS(true, true);
+        else if (leaky) MPE_SBS(true, false);
+        else if (f64) MPE_SBS(false, true);
+        else MPE_SBS(false, false);
+#undef MPE_SBS
         return hipGetLastError();
     }
     static PerDeviceFlag lds_attr;
     if (!lds_attr.test()) {
         hipError_t e = hipSuccess;
-        const void *fns[2] = {reinterpret_cast<const void *>(k_linear_sb<true, 4>), reinterpret_cast<const void *>(k_linear_sb<false, 4>)};
+        const void *fns[5] = {reinterpret_cast<const void *>(k_linear_sb<true, 4, true, 2>), reinterpret_cast<const void *>(k_linear_sb<false, 4, true, 2>),
+                              reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4>),
+                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true>)};
         for (const void *fn : fns)
-            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sb_stage_bytes(4));
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sb_stage_bytes(5));
         if (e != hipSuccess) return e;
         lds_attr.set();
     }
     const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
-    // 64-wide feature tiles only: with 80 the f64 running sums of the wider wave tile do not fit the 168 registers that two
-    // six-wave workgroups per CU leave (the compiler spills); the MLP's layers balance with 64 anyway
-    const int ntn = (n + 63) / 64;
-    const dim3 grid((unsigned)(ntm * ntn)), block(256 + 64 * SB_NL);
-#define MPE_SB(L_, N_)                                                                                                     \
-    hipLaunchKernelGGL((k_linear_sb<L_, N_>), grid, block, 2 * sb_stage_bytes(N_), s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, \
-                       d_m, n, k_pad, slope, ntn, n_major)
-    if (leaky) MPE_SB(true, 4);
-    else MPE_SB(false, 4);
+#define MPE_SB(L_, N_, F_, NL_)                                                                                                     \
+    hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, NL_>), dim3((unsigned)(ntm * ntn)), dim3(256 + 64 * NL_), 2 * sb_stage_bytes(N_), s, A, lda, W3, \
+                       w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major)
+    if (f64) {
+        // 64-wide feature tiles: with 80 the f64 running sums of the wider wave tile do not fit the 168 registers that two six-wave
+        // workgroups per CU leave (the compiler spills); the MLP's layers balance with 64 anyway
+        const int ntn = (n + 63) / 64;
+        if (leaky) MPE_SB(true, 4, true, 2);
+        else MPE_SB(false, 4, true, 2);
+    } else if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky) {
+        // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile), as launch_linear
+        const int ntn = (n + 79) / 80;
+        hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true>), dim3((unsigned)(ntm * ntn)), dim3(512), 2 * sb_stage_bytes(5), s, A, lda, W3,
+                           w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12);
+        if (coef_done) *coef_done = true;
+    } else {
+        const int ntn = (n + 79) / 80;
+        if (leaky) MPE_SB(true, 5, false, 4);
+        else MPE_SB(false, 5, false, 4);
+    }
 #undef MPE_SB
     return hipGetLastError();
 }

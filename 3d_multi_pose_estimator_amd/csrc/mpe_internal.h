@@ -94,6 +94,8 @@ struct mpe_ctx {
     bool gat_acc64 = false;
     bool gat_reduced = false;      // reduced precision: bf16 MFMA GEMMs + fp16 feature rows in the attention stage
     bool gat_attn_fp16 = false;    // configs[4] as BASELINE words it: fp16 feature rows (ft2) in the attention stage, GEMMs stay fp32
+    bool gat_split = true;         // DEFAULT (GAT mode 4): fc1 / fc2 of layers >= 1 in the split-bf16 form (gemm_sb16.hip); layer 0 (head rows only,
+                                   // gathered / grouped launches) stays on the fp32 MFMA
     mpe::Linear mlp[MPE_MAX_MLP_LAYERS];
     bool mlp_ready[MPE_MAX_MLP_LAYERS] = {};
     // workspace (sized at create / grown when weights define the widths)
@@ -152,6 +154,9 @@ struct AttnCoef {              // fc2 of a graph-attention layer: also emit a1|a
     float *a12;                     // [rows][32]: a1[0..15] | a2[0..15]
     int heads, out_dim;
 };
+hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
+                              const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
+                              float slope, bool f64 = true, const AttnCoef *coef = nullptr, bool *coef_done = nullptr);
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64, const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr,
@@ -172,10 +177,6 @@ hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsi
 
 // gemm_sb16.hip: fp32-accurate nn.Linear on the bf16 MFMA (three bf16 planes per operand, f64 flush every second stage)
 hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsigned short *planes);
-hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
-                              const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
-                              float slope);
-
 // gat.hip
 hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *node_off, int32_t *head_frame,
                            int32_t *en_frame, int32_t *en_pair, int max_heads_per_frame, int32_t *status,

@@ -819,23 +819,30 @@ class Engine:
         self._chk(self.lib.mpe_dlt_pairs(self.ctx, self._stream(), _ptr(pts), _ptr(cams), n, _ptr(out)))
         return out
 
-    def set_precision(self, gat_acc64=False, mlp_acc64=True, mlp_bf16=False, gat_reduced=False, attn_fp16=False, mlp_split=None):
+    def set_precision(self, gat_acc64=False, mlp_acc64=True, mlp_bf16=False, gat_reduced=False, attn_fp16=False, mlp_split=None,
+                      gat_split=None):
         """GAT: plain fp32 MFMA chain / f64 running sums / `attn_fp16` (BASELINE configs[4] as worded: the transformed
         features ft2 travel to the attention stage as fp16 rows, the GEMMs stay fp32) / `gat_reduced` (additionally
         bf16 MFMA for fc1/fc2); MLP: fp32 / f64 running sums (default, parity) / bf16 MFMA.  The reduced modes are
         never used on the parity path."""
+        # gat_split (default True): fc1 / fc2 of the layers >= 1 in the split-bf16 form (fp32-accurate, bf16 matrix pipe);
+        # gat_split=False = the fp32 MFMA of rounds 1-3.  Layer 0 always runs on the fp32 MFMA (head rows only).
+        if gat_split is None:
+            gat_split = not gat_reduced
         gat = 2 if gat_reduced else 3 if attn_fp16 else int(gat_acc64)
+        if gat_split and gat != 2:
+            gat = {0: 4, 1: 5, 3: 6}[gat]
         # The parity MLP (mlp_acc64=True, not bf16) has two forms of the same accuracy class: the library default
         # (mlp_split=None / True: fp32 operands as three bf16 planes, six products on the bf16 matrix pipe, f64 sums every
         # second K stage; csrc/gemm_sb16.hip) and the fp32 MFMA with f64 sums per stage of rounds 1-3 (mlp_split=False).
         if mlp_split is None:
             mlp_split = bool(mlp_acc64) and not mlp_bf16
         self._chk(self.lib.mpe_set_precision(self.ctx, gat, 2 if mlp_bf16 else 3 if mlp_split else int(mlp_acc64)))
-        self._state['precision'] = (gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16, mlp_split)
+        self._state['precision'] = (gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16, mlp_split, gat_split)
         for e in self._siblings:
-            e.set_precision(gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16, mlp_split)
+            e.set_precision(gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16, mlp_split, gat_split)
 
-    def linear(self, x, w, b, slope=None, acc64=False, split=False):
+    def linear(self, x, w, b, slope=None, acc64=False, split=False, split_f64=True):
         """act(x @ w.T + b) through the MFMA GEMM (parity tests). x device [m,k]; w,b host.  split: the split-bf16
         arithmetic of csrc/gemm_sb16.hip."""
         w = _np32(w)
@@ -851,7 +858,7 @@ class Engine:
             ldc = (n + 3) // 4 * 4
             y = torch.empty((m, ldc), dtype=torch.float32, device=self.device)
             self._chk(self.lib.mpe_linear(self.ctx, self._stream(), _ptr(xp), ldw.value, dw, ldw.value, dbias,
-                                          _ptr(y), ldc, m, None, n, k, (0 if slope is None else 1) | (2 if acc64 else 0) | (4 if split else 0),
+                                          _ptr(y), ldc, m, None, n, k, (0 if slope is None else 1) | (2 if acc64 else 0) | (4 if split else 0) | (0 if split_f64 else 8),
                                           0.0 if slope is None else float(slope)))
             torch.cuda.synchronize(self.device)
             return y[:, :n].contiguous()

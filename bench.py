@@ -79,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument('--fast-mlp', action='store_true', help='plain fp32 accumulation in the MLP GEMMs')
     ap.add_argument('--gat-acc', choices=['default', 'f32', 'f64'], default='default',
                     help='accumulation of the GAT GEMMs: one fp32 MFMA chain, or f64 running sums per 32-deep K stage')
+    ap.add_argument('--gat-fp32-mfma', action='store_true',
+                    help='GAT GEMMs of layers >= 1 on the fp32 MFMA (the default of rounds 1-3) instead of the split-bf16 form')
     ap.add_argument('--mlp-fp32-mfma', action='store_true',
                     help='MLP GEMMs on the fp32 MFMA with f64 running sums per K stage (the default of rounds 1-3) instead of the '
                          'split-bf16 form (same accuracy class, csrc/gemm_sb16.hip)')
@@ -285,8 +287,9 @@ def run_rank(args):
         eng.set_precision(args.gat_acc == 'f64', True)
     if args.fast_mlp:
         eng.set_precision(args.gat_acc == 'f64', False)
-    if args.mlp_fp32_mfma:
-        eng.set_precision(args.gat_acc == 'f64', True, mlp_split=False)
+    if args.mlp_fp32_mfma or args.gat_fp32_mfma:
+        eng.set_precision(args.gat_acc == 'f64', not args.fast_mlp, mlp_split=False if args.mlp_fp32_mfma else None,
+                          gat_split=False if args.gat_fp32_mfma else None)
     if args.bf16_mlp:
         eng.set_precision(False, False, mlp_bf16=True)
     if args.reduced:

@@ -130,7 +130,7 @@ int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_d
  * 4) = the same accuracy class on the bf16 matrix pipe: every fp32 operand is taken as the exact sum of three bf16 numbers, the
  * six significant partial products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulators flushed into f64 sums every second
  * stage (csrc/gemm_sb16.hip; measured error against exactly evaluated dot products: that of mode 1 or below, 1.35x faster
- * launches).  Defaults: GAT 0, MLP 3 (the MLP's K is up to 3072 and its 3D output is compared with the reference at the
+ * launches).  Defaults: GAT 4 (below), MLP 3 (the MLP's K is up to 3072 and its 3D output is compared with the reference at the
  * micrometre level: DESIGN.md section 5; mode 1 stays selectable).  MLP mode 2 is the
  * reduced-precision variant of BASELINE.json configs[4]: weights and staged activations in
  * bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~3 significant digits; not parity).
@@ -139,7 +139,10 @@ int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_d
  * stay fp32; the layer-0 edge-node constants stay fp32).  GAT mode 3 is configs[4] as BASELINE.json words it
  * ("fp16 GATv2 attention + bf16 MLP" with MLP mode 2): only the ft2 rows are fp16 -- fc2 stores them from its fp32
  * results, the attention coefficients a1/a2 still come from the fp32 values in the GEMM epilogue -- and fc1/fc2 stay
- * on the fp32 MFMA. */
+ * on the fp32 MFMA.  GAT modes 4 (the GAT DEFAULT since round 4), 5 and 6 are modes 0, 1 and 3 with fc1 / fc2 of the layers
+ * >= 1 in the split-bf16 form of MLP mode 3 (fp32-accurate: rms error of a launch at or below the fp32 MFMA chain's, 1.5x
+ * faster launches; without f64 sums where mode 0 has none); layer 0 (head rows only, gathered launches) and the launches
+ * that store fp16 rows stay on the fp32 MFMA. */
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64);
 
 /* ---- batch entry points ---------------------------------------------------------------
