@@ -168,7 +168,10 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
                const int32_t *c_rows = nullptr, double flop_override = -1.0, const AttnCoef *coef = nullptr,
                bool *coef_done = nullptr) {
     if (coef_done) *coef_done = false;
-    if (ctx->gat_split && !ctx->gat_reduced && !out_half && !a_rows && !c_rows && &L != &ctx->gat[0].fc1 && &L != &ctx->gat[0].fc2 &&
+    // (fp16 result rows exist in the split kernel's coefficient epilogue only: the fc2 launches of 40-wide heads; the others of
+    // the fp16-attention mode stay on the fp32 MFMA)
+    const bool sb_half_ok = !out_half || (coef && coef->out_dim == 40 && L.out_dim == coef->heads * 40 && !leaky && L.in_dim <= 512 && !ctx->gat_acc64);
+    if (ctx->gat_split && !ctx->gat_reduced && sb_half_ok && !a_rows && !c_rows && &L != &ctx->gat[0].fc1 && &L != &ctx->gat[0].fc2 &&
         L.w != ctx->l0_w) {
         // split-bf16 form (gemm_sb16.hip): fp32-accurate products on the bf16 matrix pipe; f64 sums where the fp32 path has them
         static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
@@ -181,7 +184,7 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
         GemmProf gp(ctx, s, flop_override >= 0.0 ? flop_override : (d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim),
                     host_m ? 0 : L.out_dim, host_m ? 0 : L.in_dim, 1);
         HIPCHK(ctx, launch_linear_sb16(s, A, lda, L.w3, (size_t)weight_rows(L.out_dim) * L.ldw, L.ldw, L.b, C, ldc, m, d_m, L.out_dim, L.ldw,
-                                       leaky, slope, f64, f64 ? nullptr : coef, coef_done));
+                                       leaky, slope, f64, f64 ? nullptr : coef, coef_done, out_half));
         return MPE_OK;
     }
     if (!ctx->gat_reduced) {

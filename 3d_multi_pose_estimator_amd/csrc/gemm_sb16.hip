@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
                                                                    float slope, int ntn, int n_major,
                                                                    const float *__restrict__ attn_l = nullptr,
                                                                    const float *__restrict__ attn_r = nullptr,
-                                                                   float *__restrict__ a12 = nullptr) {
+                                                                   float *__restrict__ a12 = nullptr, int out_half = 0) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int STAGE = sb_stage_bytes(NTT);
     constexpr int WPL = NTT * 16 * GEMM_BK * 2;       // bytes of one weight plane of a stage
@@ -252,6 +252,18 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
                 }
             }
             if (m >= M) continue;
+            if (out_half) {                    // fp16 rows for the attention stage (configs[4]); ldc counts halves
+                _Float16 *dh = reinterpret_cast<_Float16 *>(C) + (size_t)m * ldc + nb;
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                if (nb + 3 < n) {
+                    *reinterpret_cast<h4 *>(dh) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < n) dh[i] = (_Float16)v[i];
+                }
+                continue;
+            }
             float *dst = C + (size_t)m * ldc + nb;
             if (nb + 3 < n) {
                 *reinterpret_cast<f32x4 *>(dst) = v;
@@ -440,7 +452,7 @@ hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsi
 // small batches and for outputs of at most four 16-wide tiles at any batch size, the tile kernel otherwise.
 hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
-                              float slope, bool f64, const AttnCoef *coef, bool *coef_done) {
+                              float slope, bool f64, const AttnCoef *coef, bool *coef_done, bool out_half) {
     if (coef_done) *coef_done = false;
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     static const int skinny_waves = getenv("MPE_SKINNY_WAVES") ? atoi(getenv("MPE_SKINNY_WAVES")) : 1024;
@@ -506,7 +518,8 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile), as launch_linear
         const int ntn = (n + 79) / 80;
         hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true>), dim3((unsigned)(ntm * ntn)), dim3(512), 2 * sb_stage_bytes(5), s, A, lda, W3,
-                           w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12);
+                           w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12,
+                           out_half ? 1 : 0);
         if (coef_done) *coef_done = true;
     } else {
         const int ntn = (n + 79) / 80;

@@ -486,6 +486,9 @@ def run_rank(args):
                                         else 'one context, one stream'),
                    'mlp_accumulate': 'bf16 mfma (reduced precision)' if reduced else ('f32' if args.fast_mlp else 'f32 mfma + f64 running sums per K stage' if args.mlp_fp32_mfma
                                       else 'fp32 operands as three bf16 planes, six products on the bf16 mfma, f32 accumulators + f64 running sums every second K stage (fp32-accurate)'),
+                   'gemm_arithmetic': ('reduced precision' if reduced else
+                                       'fp32 in / fp32 out everywhere; GAT layers 1-4: %s; GAT layer 0 (head rows): fp32 MFMA; MLP: see mlp_accumulate'
+                                       % ('fp32 MFMA chain' if args.gat_fp32_mfma else 'fp32 operands as three bf16 planes, six products on the bf16 MFMA, fp32 accumulators (fp32-accurate)')),
                    'weights': 'deterministic hash init (no checkpoint offline)'},
         'io_inclusive': io,
         'json_inclusive': jsn,
@@ -634,33 +637,38 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
     # time the two matrix pipes would need at their peaks for one step's launches: fp32 launches at the fp32 MFMA peak, the
     # split-bf16 launches (six bf16 products per fp32-equivalent product) at the dense bf16 peak
     t_min = (prof['gemm_flop'] / sampled) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + 6.0 * (split_flop / sampled) / (PEAK_BF16_MFMA_TFLOPS * 1e12)
-    split = None
+    measured = ('HIP events around every GEMM launch of %d sampled steps of a single-stream pass (%d steps) after the timed region; '
+                'rocprofv3 --kernel-trace --stats agrees with it on the one-context one-stream command (`bench.py --contexts 1 --streams 1`, '
+                'profiles/r04_bench_streams1_kernel_stats.csv); with two contexts in flight the kernels of two steps overlap and a launch\'s '
+                'duration as rocprofv3 sees it is longer, which is why the kernel-level figure comes from this pass' % (sampled, args.profile_steps))
+    fp32 = {'kernel': 'mpe::k_linear_dma / k_linear_skinny* (fp32 MFMA 16x16x4; K stages by LDS-DMA from loader waves, fused bias + LeakyReLU): '
+                      + ('layer 0 of the GAT (head rows only: grouped fc1 by camera, fc2 with f64 sums)' if split_n else 'every mpe_linear launch of a step'),
+            'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+            'launches': prof['gemm_launches'], 'avg_launch_ms': prof['gemm_ms'] / max(1, prof['gemm_launches']),
+            'flop_per_step': prof['gemm_flop'] / sampled}
     if split_n:
         eq = split_flop / (split_ms * 1e-3) / 1e12
-        split = {'kernel': 'mpe::k_linear_sb (MLP launches: fp32 operands as three bf16 planes, six products per fp32 product on '
-                           'v_mfma_f32_16x16x32_bf16, fp32 accumulators + f64 running sums every second K stage)',
-                 'achieved_fp32_equivalent': eq, 'executed_bf16': 6.0 * eq, 'peak_bf16': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                 'frac': 6.0 * eq / PEAK_BF16_MFMA_TFLOPS, 'launches': split_n, 'avg_launch_ms': split_ms / split_n,
-                 'flop_per_step_fp32_equivalent': split_flop / sampled,
-                 'note': 'fp32-equivalent = algorithmic 2*M*N*K; the same launches on the fp32 MFMA (--mlp-fp32-mfma) reach 105-112 TFLOP/s'}
-    return {
-        'kernel': 'mpe::k_linear_dma (fp32 MFMA 16x16x4 GEMM; K stages by LDS-DMA from loader waves, fused bias + LeakyReLU); the '
-                  'launches counted are the launches of a step ON THE fp32 MFMA: the GAT\'s (9 of k_linear_dma, one of them grouped, + the '
-                  'narrow last fc2 on k_linear_skinny)' + ('' if split_n else ' and the MLP\'s (8 + the narrow last layer)') +
-                  '; compare with rocprofv3 over k_linear_dma / k_linear_skinny*' + ('; the MLP launches run on the bf16 MFMA: roofline.mlp_split' if split_n else ''),
-        'bound': 'mfma',
-        'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': src,
-        'launches': prof['gemm_launches'], 'avg_launch_ms': prof['gemm_ms'] / max(1, prof['gemm_launches']),
-        'measured': 'HIP events around every GEMM launch of %d sampled steps of a single-stream pass (%d steps) after the '
-                    'timed region; rocprofv3 --kernel-trace --stats agrees with it on the one-context one-stream command '
-                    '(`bench.py --contexts 1 --streams 1`, profiles/r03_bench_streams1_kernel_stats.csv); with two contexts in '
-                    'flight the kernels of two steps overlap and a launch\'s duration as rocprofv3 sees it is ~1.9x longer, which '
-                    'is why the kernel-level figure comes from this pass' % (sampled, args.profile_steps),
+        main = {'kernel': 'mpe::k_linear_sb* (csrc/gemm_sb16.hip: nn.Linear with fp32 operands taken as three bf16 planes each, the six '
+                          'significant partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulators (+ f64 running sums every second K '
+                          'stage in the MLP), activation tile and weight planes staged by LDS-DMA from loader waves, fused bias + LeakyReLU '
+                          '+ attention coefficients): the GAT launches of layers 1-4 and all MLP launches = %.0f %% of the GEMM time of a step'
+                          % (100.0 * split_ms / max(1e-9, split_ms + prof['gemm_ms'])),
+                'bound': 'mfma',
+                'achieved': 6.0 * eq, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': 6.0 * eq / PEAK_BF16_MFMA_TFLOPS,
+                'achieved_definition': 'EXECUTED bf16 matrix FLOP/s = 6 x the algorithmic 2*M*N*K of the launches / their time, against the dense '
+                                       'bf16 MFMA peak (the pipe the kernel runs on)',
+                'achieved_fp32_equivalent': eq, 'fp32_equivalent_vs_fp32_mfma_peak': eq / PEAK_FP32_MFMA_TFLOPS,
+                'fp32_equivalent_note': 'algorithmic 2*M*N*K per second; the fp32 MFMA these launches ran on until round 3 peaks at %.1f '
+                                        'TFLOP/s (they reached 105-116 there)' % PEAK_FP32_MFMA_TFLOPS,
+                'launches': split_n, 'avg_launch_ms': split_ms / split_n, 'flop_per_step_fp32_equivalent': split_flop / sampled,
+                'fp32_mfma_launches': fp32}
+    else:
+        main = dict(fp32, bound='mfma')
+    main.update({
+        'traffic': traffic, 'traffic_source': src, 'measured': measured,
         'sampled_steps': sampled, 'flop_per_step': flop_per_step,
-        'gemm_share_of_single_stream_step': (gemm_s / sampled) / (prof['single_stream_ms_per_step'] * 1e-3),
+        'gemm_share_of_single_stream_step': ((gemm_s + split_ms * 1e-3) / sampled) / (prof['single_stream_ms_per_step'] * 1e-3),
         'single_stream_ms_per_step': prof['single_stream_ms_per_step'],
-        'mlp_split': split,
         'step': {'achieved': step_tf, 'frac': t_min / step_s, 'unit': 'TFLOP/s',
                  'frac_against_fp32_peak': step_tf / PEAK_FP32_MFMA_TFLOPS,
                  'definition': 'achieved: algorithmic GEMM FLOPs (2*M*N*K, fp32-equivalent) of one step / wall time of one step of the '
@@ -671,11 +679,12 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
                                % (PEAK_FP32_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS)},
         'flop_definition': 'algorithmic 2*M*N*K of the launches (layer-0 edge-node rows de-duplicated)'
                            + ('; NOTE: reduced-precision run, bf16 launches are priced against the fp32 peak here' if reduced else ''),
-        'hbm': {'achieved': hbm_tbs, 'peak': PEAK_HBM_TBS, 'unit': 'TB/s', 'frac': hbm_tbs / PEAK_HBM_TBS,
-                'bytes_per_frame': bytes_per_frame,
-                'definition': 'compulsory bytes of the whole path per frame (packed input + poses + weights once per '
-                              'batch) x frames/s per GPU; tiny by construction: the path is MFMA-bound'},
-    }
+    })
+    main['hbm'] = {'achieved': hbm_tbs, 'peak': PEAK_HBM_TBS, 'unit': 'TB/s', 'frac': hbm_tbs / PEAK_HBM_TBS,
+                   'bytes_per_frame': bytes_per_frame,
+                   'definition': 'compulsory bytes of the whole path per frame (packed input + poses + weights once per '
+                                 'batch) x frames/s per GPU; tiny by construction: the path is MFMA-bound'}
+    return main
 
 
 def json_inclusive(args, torch, eng, wire, B, uniq, contexts=1):
