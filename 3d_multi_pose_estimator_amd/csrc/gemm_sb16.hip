@@ -25,7 +25,9 @@
 
 namespace mpe {
 
-namespace {
+// (kernels in namespace mpe, not an anonymous one: profilers print "(anonymous namespace)::" in front of such names and the
+// tools that cut a kernel name at its first parenthesis then see nothing)
+namespace sb {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -439,7 +441,8 @@ __global__ void k_split_planes(const float *__restrict__ w, size_t count, unsign
     }
 }
 
-}  // namespace
+}  // namespace sb
+using namespace sb;
 
 hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsigned short *planes) {
     if (count == 0) return hipSuccess;

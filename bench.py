@@ -62,7 +62,7 @@ PKG = '3d_multi_pose_estimator_amd'
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_TBS = 8.0
-TRAFFIC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+TRAFFIC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
 def parse_args(argv=None):
@@ -753,7 +753,9 @@ def pmc_traffic():
     for name in TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as fh:
-                return json.load(fh)['k_linear_bytes_per_launch'], 'offline: profiles/' + name
+                d = json.load(fh)
+                # the dominant kernel's launches: k_linear_sb (round 4 on), else all k_linear* launches
+                return d.get('k_linear_sb_bytes_per_launch', d['k_linear_bytes_per_launch']), 'offline: profiles/' + name
         except (OSError, KeyError, ValueError):
             continue
     return None, None

@@ -15,7 +15,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
-        name = re.sub(r'\(.*', '', r['Kernel_Name']).strip()
+        name = re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', '')).strip()
         tot[name] += float(r['Counter_Value'])
         cnt[name] += 1
     return tot, cnt
@@ -36,6 +36,10 @@ for k in fetch:
     if 'k_linear' in k:
         lin_bytes += b * n
         lin_n += n
+# the dominant kernel since round 4: the split-bf16 tile kernel (csrc/gemm_sb16.hip)
+sb = [(k, v) for k, v in out['kernels'].items() if 'k_linear_sb<' in k]
+if sb:
+    out['k_linear_sb_bytes_per_launch'] = sum(v['bytes_corrected_per_launch'] * v['launches'] for _, v in sb) / sum(v['launches'] for _, v in sb)
 out['k_linear_bytes_per_launch'] = lin_bytes / max(1, lin_n)
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print('k_linear launches %d, corrected bytes per launch %.1f MB' % (lin_n, out['k_linear_bytes_per_launch'] / 1e6))

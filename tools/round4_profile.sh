@@ -49,8 +49,8 @@ if [ "$1" = A ]; then
 import csv, json
 d = json.load(open('$O/bench_streams1_under_rocprof.json')); r = d['roofline']
 rows = list(csv.DictReader(open('$O/stats1/run_kernel_stats.csv')))
-g = [x for x in rows if 'k_linear' in x['Name']]
-print('under rocprof: value', round(d['value'], 1), '| live HIP events: GEMM avg launch', round(r['avg_launch_ms'], 5), 'ms | rocprof k_linear_* avg',
+g = [x for x in rows if 'k_linear_sb' in x['Name']]
+print('under rocprof: value', round(d['value'], 1), '| live HIP events: split-bf16 GEMM avg launch', round(r['avg_launch_ms'], 5), 'ms | rocprof k_linear_sb* avg',
       round(sum(float(x['TotalDurationNs']) for x in g) / sum(int(x['Calls']) for x in g) / 1e6, 5), 'ms over', sum(int(x['Calls']) for x in g), 'launches')
 PY
 fi
