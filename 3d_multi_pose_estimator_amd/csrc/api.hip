@@ -171,8 +171,8 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
     // (fp16 result rows exist in the split kernel's coefficient epilogue only: the fc2 launches of 40-wide heads; the others of
     // the fp16-attention mode stay on the fp32 MFMA)
     const bool sb_half_ok = !out_half || (coef && coef->out_dim == 40 && L.out_dim == coef->heads * 40 && !leaky && L.in_dim <= 512 && !ctx->gat_acc64);
-    if (ctx->gat_split && !ctx->gat_reduced && sb_half_ok && !a_rows && !c_rows && &L != &ctx->gat[0].fc1 && &L != &ctx->gat[0].fc2 &&
-        L.w != ctx->l0_w) {
+    // (launches with gathered rows -- layer-0 fc1 per camera -- stay on the fp32 MFMA; the grouped layer-0 launch does not come here)
+    if (ctx->gat_split && !ctx->gat_reduced && sb_half_ok && !a_rows && !c_rows && L.w != ctx->l0_w) {
         // split-bf16 form (gemm_sb16.hip): fp32-accurate products on the bf16 matrix pipe; f64 sums where the fp32 path has them
         static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
         const bool f64 = ctx->gat_acc64 || (mink > 0 && L.in_dim > mink);
@@ -457,6 +457,12 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
             return rc;
         a->ft2 = ctx->act[2];
         *n_rows_ft2 = n_nodes;
+    }
+    if (!done && cp && g.out_dim == 40 && !half_rows && ctx->gat_split && !red) {
+        // the split-bf16 form with f64 sums (layer-0 fc2: K = 902) has no coefficient epilogue: a1 | a2 by the coefficient kernel
+        // (canonical order = the epilogue's, gat.hip:coef40), so that the attention stage still finds them ready
+        HIPCHK(ctx, launch_attn_coef(s, a->ft2, ld_ft, *n_rows_ft2, g.heads, g.out_dim, g.attn_l, g.attn_r, ctx->a12, 0));
+        done = true;
     }
     a->a12_ready = done ? 1 : 0;
     return MPE_OK;

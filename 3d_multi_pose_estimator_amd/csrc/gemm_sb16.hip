@@ -13,8 +13,9 @@
 // into three bf16 planes [3][rows][ldw].
 //
 // Three kernels, one arithmetic -- per 16 x 16 output tile and K stage the six MFMAs in the order (a1,w3) (a2,w2) (a1,w2)
-// (a3,w1) (a2,w1) (a1,w1), stages ascending, flush after every odd stage and after the last one -- so a row has the same
-// bits in a batch of one and of a thousand:
+// (a3,w1) (a2,w1) (a1,w1), stages ascending; with f64 sums (MLP) one fp32 chain flushed after every odd stage and after the
+// last one, without (GAT) the even and the odd stages in two fp32 chains added at the end -- so a row has the same bits in a
+// batch of one and of a thousand:
 //   k_linear_sb         128 x 64|80 x 32 tiles, 4 MFMA waves + 2 loader waves (LDS-DMA of the fp32 activation tile and the
 //                       three weight planes), double-buffered LDS, one barrier per stage
 //   k_linear_sb_skinny  one wave per 16 x 16 tile, operands streamed from global memory (small batches, narrow outputs)
@@ -177,19 +178,25 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
     const int fsw = a_swz(fr);
     const int c0 = ((fq * 2 + 0) ^ fsw) << 4, c1 = ((fq * 2 + 1) ^ fsw) << 4;      // k = 8 fq .. 8 fq + 7 of the row
 
+    // Without f64 sums (GAT launches) the even and the odd K stages accumulate into separate fp32 chains that are added at the
+    // end: half the chain length of a single accumulator (rms error 0.5-0.6 ulp of the output scale at K = 416 against 0.75 for one
+    // chain and 0.91 for the fp32 MFMA chain it replaces), for 40 more registers (126 of the 128 that 2 x 8 waves per CU leave).
     f32x4 acc[NTT][2];
+    f32x4 acc_odd[NTT][2];               // (unused with F64: the compiler drops it)
     double run[F64 ? NTT : 1][2][4];
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc_odd[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (F64) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] = 0.0;
             }
         }
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K stage into the accumulator set ACC (the barrier is the landing wait and the buffer hand-over)
+    auto do_stage = [&](int kt, f32x4 (&ACC)[NTT][2]) {
         __syncthreads();
         const unsigned char *cur = lds + (kt & 1) * STAGE;
         bf16x8 ap[2][3];
@@ -205,17 +212,30 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
 #pragma unroll
             for (int p = 0; p < 3; ++p) wp[p] = *reinterpret_cast<const bf16x8 *>(cur + p * WPL + w_rd[nt]);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) SB_STAGE(acc[nt][mt], ap[mt], wp);
+            for (int mt = 0; mt < 2; ++mt) SB_STAGE(ACC[nt][mt], ap[mt], wp);
         }
-        if (F64 && ((kt & 1) || kt == nk - 1)) {
+    };
+    if (F64) {
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            do_stage(kt, acc);
+            if ((kt & 1) || kt == nk - 1) {
 #pragma unroll
-            for (int nt = 0; nt < NTT; ++nt)
+                for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                    for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
-                    acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+                        for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
+                        acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+        }
+    } else {
+        // even stages into `acc`, odd stages into `acc_odd`: the loop walks two stages per trip, each with its own code
+#pragma unroll 1
+        for (int kt = 0; kt < nk; kt += 2) {
+            do_stage(kt, acc);
+            if (kt + 1 < nk) do_stage(kt + 1, acc_odd);
         }
     }
     float pl[2][2], pr[2][2];            // A12: per (head of the tile, row tile) partial dot products
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                v[i] = F64 ? (float)(run[F64 ? nt : 0][mt][i] + (double)bv[i]) : acc[nt][mt][i] + bv[i];
+                v[i] = F64 ? (float)(run[F64 ? nt : 0][mt][i] + (double)bv[i]) : (acc[nt][mt][i] + acc_odd[nt][mt][i]) + bv[i];
                 if (LEAKY) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
             }
             if (A12) {
@@ -334,12 +354,13 @@ __global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restric
     SbFrag fr_[SBS_DEPTH];
 #pragma unroll
     for (int d = 0; d < SBS_DEPTH; ++d) sb_load(fr_[d], pa, pw, w_plane, (d < nk ? d : nk - 1) * GEMM_BK);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_odd = {0.f, 0.f, 0.f, 0.f};
     double run[4] = {0.0, 0.0, 0.0, 0.0};
     auto stage = [&](const SbFrag &f, int kt) {
         bf16x8 ap[3];
         split8(f.a0, f.a1, ap[0], ap[1], ap[2]);
-        SB_STAGE(acc, ap, f.w);
+        if (F64 || !(kt & 1)) SB_STAGE(acc, ap, f.w);
+        else SB_STAGE(acc_odd, ap, f.w);             // without f64 sums: even / odd stages in separate chains, as k_linear_sb
         if (F64 && ((kt & 1) || kt == nk - 1)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) run[i] += (double)acc[i];
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restric
     float *dst = C + (size_t)m * ldc + nb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float v = F64 ? (float)(run[i] + (double)bv[i]) : acc[i] + bv[i];
+        float v = F64 ? (float)(run[i] + (double)bv[i]) : (acc[i] + acc_odd[i]) + bv[i];
         if (LEAKY) v = v > 0.f ? v : v * slope;
         if (nb + i < n) dst[i] = v;
     }
