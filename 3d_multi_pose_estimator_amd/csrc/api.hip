@@ -172,7 +172,12 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
     // the fp16-attention mode stay on the fp32 MFMA)
     const bool sb_half_ok = !out_half || (coef && coef->out_dim == 40 && L.out_dim == coef->heads * 40 && !leaky && L.in_dim <= 512 && !ctx->gat_acc64);
     // (launches with gathered rows -- layer-0 fc1 per camera -- stay on the fp32 MFMA; the grouped layer-0 launch does not come here)
-    if (ctx->gat_split && !ctx->gat_reduced && sb_half_ok && !a_rows && !c_rows && L.w != ctx->l0_w) {
+    // In the explicit f64-sum mode (mpe_set_precision GAT 1 on top of the split form) layer 0's fc2 keeps the fp32 MFMA with a
+    // flush per 32-deep stage: the split form flushes every second stage, and on the K = 902 sum of the steep layer-0 features
+    // that cadence left one 5x4 fixture frame 1.46x the reference's own distance from the f64 network where the mode promises
+    // <= 1 (tests/test_gpu_stages.py::test_score_noise_against_the_f64_network; 0.79 with the flush per stage).
+    const bool l0_fc2_f64_mode = ctx->gat_acc64 && &L == &ctx->gat[0].fc2;
+    if (ctx->gat_split && !ctx->gat_reduced && sb_half_ok && !a_rows && !c_rows && L.w != ctx->l0_w && !l0_fc2_f64_mode) {
         // split-bf16 form (gemm_sb16.hip): fp32-accurate products on the bf16 matrix pipe; f64 sums where the fp32 path has them
         static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
         const bool f64 = ctx->gat_acc64 || (mink > 0 && L.in_dim > mink);
