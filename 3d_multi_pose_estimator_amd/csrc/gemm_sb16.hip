@@ -21,8 +21,13 @@
 //   k_linear_sb_skinny  one wave per 16 x 16 tile, operands streamed from global memory (small batches, narrow outputs)
 //   k_linear_sb_ks      the same with the stage pairs of a tile dealt to eight waves and an ordered f64 reduction through LDS
 #include <cstdlib>
+#include <type_traits>
 
 #include "mpe_internal.h"
+
+#ifndef MPE_SBEXP
+#define MPE_SBEXP 0            // timing ablations of a diagnostic build (csrc/Makefile `exp`; wrong results, never shipped); 0 in the product
+#endif
 
 namespace mpe {
 
@@ -42,6 +47,19 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// x - y as ONE v_sub_f32: left to itself the compiler pairs the residual subtractions of split8 into v_pk_add_f32, and a packed
+// fp32 instruction in the shadow of MFMAs costs 13-22 cycles more than the two plain ones it replaces (MI355X_MICROARCH.md, cycle
+// constants: "an anti-lever beside MFMAs").  Not volatile: the scheduler still places it.
+__device__ __forceinline__ float sub1(float x, float y) {
+#ifdef SB_NO_SUB1
+    return x - y;
+#else
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#endif
+}
+
 // eight fp32 values -> their three bf16 planes (exact: x = p0 + p1 + p2)
 __device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
     u32x4 q0, q1, q2;
@@ -49,9 +67,9 @@ __device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, bf16x8 
     for (int j = 0; j < 4; ++j) {
         const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
         const unsigned u0 = pack2_bf16(a, b);
-        const float ra = a - __uint_as_float(u0 << 16), rb = b - __uint_as_float(u0 & 0xFFFF0000u);
+        const float ra = sub1(a, __uint_as_float(u0 << 16)), rb = sub1(b, __uint_as_float(u0 & 0xFFFF0000u));
         const unsigned u1 = pack2_bf16(ra, rb);
-        const float sa = ra - __uint_as_float(u1 << 16), sb = rb - __uint_as_float(u1 & 0xFFFF0000u);
+        const float sa = sub1(ra, __uint_as_float(u1 << 16)), sb = sub1(rb, __uint_as_float(u1 & 0xFFFF0000u));
         q0[j] = u0;
         q1[j] = u1;
         q2[j] = pack2_bf16(sa, sb);
@@ -72,19 +90,60 @@ __device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, bf16x8 
         ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[0], ACC, 0, 0, 0);   \
     } while (0)
 
+// the same with the chain started from zero (C operand = the inline constant 0: no accumulator to clear after a flush)
+#define SB_STAGE0(ACC, A, W)                                                                                       \
+    do {                                                                                                           \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[2], (A)[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);     \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[1], (A)[1], ACC, 0, 0, 0);                              \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[1], (A)[0], ACC, 0, 0, 0);                              \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[2], ACC, 0, 0, 0);                              \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[1], ACC, 0, 0, 0);                              \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[0], ACC, 0, 0, 0);                              \
+    } while (0)
+
 __device__ __forceinline__ int a_swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }   // gemm.hip: dma_swz
-__device__ __forceinline__ int w_swz(int row) { return (row >> 2) & 3; }                                  // 64-byte rows
+// 64-byte rows (weight planes): chunk c of row r sits at position c ^ w_swz(r).  ds_read_b128 serves its 64 lanes in four
+// NON-contiguous groups of 16 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, and the same + 32: MI355X_MICROARCH.md, LDS table);
+// in the fragment read (lane = 16 fq + fr reads chunk fq of row fr) a group therefore holds all sixteen rows, rows 0-3 and
+// 12-15 with one chunk index and rows 4-11 with the other of a pair (0 | 1 or 2 | 3).  The four rows that share (row & 3) --
+// the same 64-byte quarter of the 256-byte bank line -- must land on four different positions: the table {0, 2, 3, 1} over
+// (row >> 2) & 3 does that for all four groups (with the plain (row >> 2) & 3 of the first version rows r and r + 4 of a
+// group collided: SQ_LDS_BANK_CONFLICT was 43 % of the LDS-active cycles, 7.0 instead of 4 cycles per ds_read_b128).
+__device__ __forceinline__ int w_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 // loader waves: 2 with f64 running sums (6-wave workgroups: 168 registers at two workgroups per CU), 4 without
-constexpr int SB_A_BYTES = GEMM_BM * GEMM_BK * 4;     // 16 KiB: the activation tile, fp32, the image of k_linear_dma
+// One LDS-DMA piece (1 KiB per wave-instruction) in the `saddr + voffset` form: wave-uniform 64-bit base in an SGPR pair, per-lane
+// 32-bit byte offset, LDS destination (wave-uniform byte address) through M0, written in the statement that reads it.  hipcc does
+// not count asm loads: the caller waits with an explicit `s_waitcnt vmcnt(0)` before the stage barrier.
+__device__ __forceinline__ void glds16(unsigned voff, const void *sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
 
-__host__ __device__ constexpr int sb_stage_bytes(int ntt) { return SB_A_BYTES + 3 * ntt * 16 * GEMM_BK * 2; }
+// the activation tile, fp32, the image of k_linear_dma: 32 rows per MFMA wave (16 KiB with four MFMA waves, 32 KiB with eight)
+__host__ __device__ constexpr int sb_a_bytes(int mw) { return mw * 32 * GEMM_BK * 4; }
+
+__host__ __device__ constexpr int sb_stage_bytes(int ntt, int mw = 4) { return sb_a_bytes(mw) + 3 * ntt * 16 * GEMM_BK * 2; }
 
 // A12 (fc2 of a graph-attention layer with 40-wide attention heads, 80-wide tiles): the epilogue also emits a1 | a2 =
 // <ft2[row, head, :], attn_l / attn_r[head]> (gat2.py:57-58) from the values the lanes hold -- the code of k_linear_dma<.., A12>,
 // same lane layout, same canonical order (coef40() in gat.hip mirrors it for the paths that compute the coefficients elsewhere).
-template <bool LEAKY, int NTT, bool F64, int SB_NL, bool A12 = false>
-__global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear_sb(const float *__restrict__ A, int lda,
+// MW = MFMA waves per workgroup (32 rows each).  The launches with f64 running sums run as ONE twelve-wave workgroup per CU (MW = 8:
+// 256 x 64 tiles, eight MFMA + four loader waves, 147 registers at three waves per SIMD).  Their first form -- two six-wave
+// workgroups (MW = 4, two loaders) -- never ran two per CU: the dispatcher deals a workgroup's waves to the SIMDs 2-2-1-1 from the
+// same SIMD each time, the second workgroup's pair does not fit behind the first at 152 registers, and every SIMD ran ONE MFMA
+// wave with nothing to cover its fragment reads, split arithmetic and barrier (found with SQ_WAVE_CYCLES = half the slot time and
+// confirmed by padding the LDS request to one workgroup per CU: same duration).
+#ifndef SB_F64_NTT
+#define SB_F64_NTT 4
+#define SB_F64_NL 4
+#define SB_F64_MW 8
+#endif
+template <bool LEAKY, int NTT, bool F64, int SB_NL, bool A12 = false, int MW = 4>
+__global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4) void k_linear_sb(const float *__restrict__ A, int lda,
                                                                    const unsigned short *__restrict__ W3, size_t w_plane, int ldw,
                                                                    const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                                    int m_cap, const int32_t *__restrict__ d_m, int n, int k_pad,
@@ -93,14 +152,15 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
                                                                    const float *__restrict__ attn_r = nullptr,
                                                                    float *__restrict__ a12 = nullptr, int out_half = 0) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    constexpr int STAGE = sb_stage_bytes(NTT);
+    constexpr int STAGE = sb_stage_bytes(NTT, MW);
+    constexpr int SB_A_BYTES = sb_a_bytes(MW), BM = 32 * MW;
     constexpr int WPL = NTT * 16 * GEMM_BK * 2;       // bytes of one weight plane of a stage
     int M = m_cap;
     if (d_m) {
         const int dm = *d_m;
         M = dm < m_cap ? dm : m_cap;
     }
-    const int ntm = (M + GEMM_BM - 1) / GEMM_BM;
+    const int ntm = (M + BM - 1) / BM;
     const int bid = blockIdx.x, nwg = ntm * ntn;
     if (bid >= nwg) return;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -116,26 +176,31 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
         tm = swz / ntn;
         tn = swz - tm * ntn;
     }
-    const int m0 = tm * GEMM_BM, n0 = tn * NTT * 16;
+    const int m0 = tm * BM, n0 = tn * NTT * 16;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nk = k_pad / GEMM_BK;
 
-    if (wave >= 4) {
+    if (wave >= MW) {
         // ---- loader waves: 16 activation groups (8 rows x 128 B each) + 3 NTT weight groups (16 rows x 64 B) per stage ----
-        const int li = wave - 4;
+        const int li = wave - MW;
         const int dr = lane >> 3, dp = lane & 7, wr = lane >> 2, wc = lane & 3;
         __builtin_amdgcn_s_setprio(3);
-        constexpr int NA = 16 / SB_NL;
+        constexpr int NA = (BM / 8) / SB_NL;
         constexpr int NW = 3 * NTT, NWL = (NW + SB_NL - 1) / SB_NL;
-        const float *la[NA];
-        const unsigned short *lw[NWL];
+        // Addresses as a UNIFORM base (SGPR pair, advanced by scalar adds per stage) + a loop-invariant 32-bit byte offset per lane:
+        // the loads then take the `saddr + voffset` form and a stage's pieces cost the loader wave no vector instruction at all.
+        // (With per-lane 64-bit pointers every piece carried a v_lshl_add_u64 that had to find a slot on a SIMD whose vector issue
+        // the two MFMA waves keep busy -- the loader waves, not the memory path, paced the stage.)
+        const unsigned char *abase = reinterpret_cast<const unsigned char *>(A + (size_t)m0 * lda);
+        const unsigned char *wbase = reinterpret_cast<const unsigned char *>(W3 + (size_t)n0 * ldw);
+        unsigned la[NA], lw[NWL];
         int lw_dst[NWL];
 #pragma unroll
         for (int g = 0; g < NA; ++g) {
             const int row = (li * NA + g) * 8 + dr;
             int grow = m0 + row;
-            grow = grow < M ? grow : M - 1;
-            la[g] = A + (size_t)grow * lda + ((dp ^ a_swz(row)) << 2);
+            grow = grow < M ? grow : M - 1;                 // (M - 1 >= m0: the tile exists)
+            la[g] = (unsigned)(((grow - m0) * lda + ((dp ^ a_swz(row)) << 2)) * 4);
         }
 #pragma unroll
         for (int g = 0; g < NWL; ++g) {
@@ -143,23 +208,24 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
             idx = idx < NW ? idx : NW - 1;
             const int p = idx / NTT, grp = idx - p * NTT;
             const int row = grp * 16 + wr;
-            lw[g] = W3 + p * w_plane + (size_t)(n0 + row) * ldw + ((wc ^ w_swz(row)) << 3);
+            lw[g] = (unsigned)((p * w_plane + (size_t)row * ldw + ((wc ^ w_swz(row)) << 3)) * 2);
             lw_dst[g] = SB_A_BYTES + p * WPL + grp * 1024;
         }
         auto fill = [&](int kt, int buf) {
-            unsigned char *base = lds + buf * STAGE;
-            const int koff = kt * GEMM_BK;
+            const unsigned base = (unsigned)(size_t)(lds_void *)lds + (unsigned)(buf * STAGE);
+            const unsigned char *ab = abase + (size_t)kt * (GEMM_BK * 4), *wb = wbase + (size_t)kt * (GEMM_BK * 2);
 #pragma unroll
-            for (int g = 0; g < NA; ++g)
-                __builtin_amdgcn_global_load_lds((glb_void *)(la[g] + koff), (lds_void *)(base + (li * NA + g) * 8 * 128), 16, 0, 0);
+            for (int g = 0; g < NA; ++g) glds16(la[g], ab, base + (unsigned)((li * NA + g) * 8 * 128));
 #pragma unroll
             for (int g = 0; g < NWL; ++g)
-                if ((g + 1) * SB_NL <= NW || li + SB_NL * g < NW)
-                    __builtin_amdgcn_global_load_lds((glb_void *)(lw[g] + koff), (lds_void *)(base + lw_dst[g]), 16, 0, 0);
+                if ((g + 1) * SB_NL <= NW || li + SB_NL * g < NW) glds16(lw[g], wb, base + (unsigned)lw_dst[g]);
         };
         fill(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();                       // vmcnt(0): stage kt has landed; the MFMA waves are done with the other buffer
+            if (!(F64 && LEAKY && MPE_SBEXP == 35) && !(!F64 && MPE_SBEXP == 45))               // (ablation 35 / 45: no landing wait)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage kt has landed ...
+            __syncthreads();                                        // ... and the MFMA waves are done with the other buffer
+            if ((F64 && LEAKY && MPE_SBEXP == 34) || (!F64 && MPE_SBEXP == 44)) continue;          // (ablation 34 / 44: no staging at all)
             if (kt + 1 < nk) fill(kt + 1, (kt + 1) & 1);
         }
         return;
@@ -196,7 +262,7 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
             }
         }
     // one K stage into the accumulator set ACC (the barrier is the landing wait and the buffer hand-over)
-    auto do_stage = [&](int kt, f32x4 (&ACC)[NTT][2]) {
+    auto do_stage = [&](int kt, f32x4 (&ACC)[NTT][2], auto from_zero) {
         __syncthreads();
         const unsigned char *cur = lds + (kt & 1) * STAGE;
         bf16x8 ap[2][3];
@@ -204,6 +270,11 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
         for (int mt = 0; mt < 2; ++mt) {
             const f32x4 x0 = *reinterpret_cast<const f32x4 *>(cur + a_rd[mt] + c0);
             const f32x4 x1 = *reinterpret_cast<const f32x4 *>(cur + a_rd[mt] + c1);
+            if ((F64 && LEAKY && (MPE_SBEXP == 31 || MPE_SBEXP == 33)) || (!F64 && MPE_SBEXP == 41)) {          // ablation (MLP launches only: nothing consumes their values): no split arithmetic (what do the 88 VALU instructions cost?)
+                ap[mt][0] = __builtin_bit_cast(bf16x8, x0);
+                ap[mt][1] = __builtin_bit_cast(bf16x8, x1);
+                ap[mt][2] = __builtin_bit_cast(bf16x8, x0);
+            } else
             split8(x0, x1, ap[mt][0], ap[mt][1], ap[mt][2]);
         }
 #pragma unroll
@@ -212,30 +283,38 @@ __global__ __launch_bounds__(256 + 64 * SB_NL, SB_NL == 2 ? 3 : 4) void k_linear
 #pragma unroll
             for (int p = 0; p < 3; ++p) wp[p] = *reinterpret_cast<const bf16x8 *>(cur + p * WPL + w_rd[nt]);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) SB_STAGE(ACC[nt][mt], ap[mt], wp);
+            for (int mt = 0; mt < 2; ++mt) {
+                if (decltype(from_zero)::value) SB_STAGE0(ACC[nt][mt], ap[mt], wp);
+                else SB_STAGE(ACC[nt][mt], ap[mt], wp);
+            }
         }
     };
+    using std::false_type;
+    using std::true_type;
     if (F64) {
+        // pairs of stages: the first starts its fp32 chains from zero (0 + x = x exactly: the bits of a cleared accumulator
+        // without clearing it), the pair's sums go into the f64 running sums
+        auto flush = [&]() {
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
+        };
 #pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            do_stage(kt, acc);
-            if ((kt & 1) || kt == nk - 1) {
-#pragma unroll
-                for (int nt = 0; nt < NTT; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
-                        acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-            }
+        for (int kt = 0; kt < nk; kt += 2) {
+            do_stage(kt, acc, true_type());
+            if (kt + 1 < nk) do_stage(kt + 1, acc, false_type());
+            if (LEAKY && (MPE_SBEXP == 32 || MPE_SBEXP == 33) && kt + 2 < nk) continue;      // (ablation 32 / 33: one flush at the end)
+            flush();
         }
     } else {
         // even stages into `acc`, odd stages into `acc_odd`: the loop walks two stages per trip, each with its own code
 #pragma unroll 1
         for (int kt = 0; kt < nk; kt += 2) {
-            do_stage(kt, acc);
-            if (kt + 1 < nk) do_stage(kt + 1, acc_odd);
+            do_stage(kt, acc, false_type());
+            if (kt + 1 < nk) do_stage(kt + 1, acc_odd, false_type());
         }
     }
     float pl[2][2], pr[2][2];            // A12: per (head of the tile, row tile) partial dot products
@@ -519,25 +598,29 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     static PerDeviceFlag lds_attr;
     if (!lds_attr.test()) {
         hipError_t e = hipSuccess;
-        const void *fns[5] = {reinterpret_cast<const void *>(k_linear_sb<true, 4, true, 2>), reinterpret_cast<const void *>(k_linear_sb<false, 4, true, 2>),
+        const void *fns[5] = {reinterpret_cast<const void *>(k_linear_sb<true, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW>),
+                              reinterpret_cast<const void *>(k_linear_sb<false, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW>),
                               reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4>),
                               reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true>)};
         for (const void *fn : fns)
-            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sb_stage_bytes(5));
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sb_stage_bytes(5, 8) + 56 * 1024);
         if (e != hipSuccess) return e;
         lds_attr.set();
     }
-    const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
-#define MPE_SB(L_, N_, F_, NL_)                                                                                                     \
-    hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, NL_>), dim3((unsigned)(ntm * ntn)), dim3(256 + 64 * NL_), 2 * sb_stage_bytes(N_), s, A, lda, W3, \
-                       w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major)
+    // diagnostic: extra dynamic LDS per workgroup (occupancy experiments: how many workgroups does a CU really hold?)
+    static const int lds_pad = getenv("MPE_SB_LDS_PAD") ? atoi(getenv("MPE_SB_LDS_PAD")) * 1024 : 0;
+#define MPE_SB(L_, N_, F_, NL_, MW_)                                                                                                \
+    hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, NL_, false, MW_>), dim3((unsigned)(((m_cap + 32 * MW_ - 1) / (32 * MW_)) * ntn)),         \
+                       dim3(64 * (MW_ + NL_)), 2 * sb_stage_bytes(N_, MW_) + lds_pad, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, \
+                       k_pad, slope, ntn, n_major)
+    const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;           // (the four-MFMA-wave launches below)
     if (f64) {
-        // 64-wide feature tiles: with 80 the f64 running sums of the wider wave tile do not fit the 168 registers that two six-wave
-        // workgroups per CU leave (the compiler spills); the MLP's layers balance with 64 anyway
-        const int ntn = (n + 63) / 64;
-        if (leaky) MPE_SB(true, 4, true, 2);
-        else MPE_SB(false, 4, true, 2);
+        // 64-wide feature tiles: with 80 the f64 running sums of the wider wave tile do not fit the 168 registers that three waves per
+        // SIMD leave (the compiler spills); the MLP's layers balance with 64 anyway
+        const int ntn = (n + SB_F64_NTT * 16 - 1) / (SB_F64_NTT * 16);
+        if (leaky) MPE_SB(true, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW);
+        else MPE_SB(false, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW);
     } else if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky) {
         // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile), as launch_linear
         const int ntn = (n + 79) / 80;
@@ -547,8 +630,8 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         if (coef_done) *coef_done = true;
     } else {
         const int ntn = (n + 79) / 80;
-        if (leaky) MPE_SB(true, 5, false, 4);
-        else MPE_SB(false, 5, false, 4);
+        if (leaky) MPE_SB(true, 5, false, 4, 4);
+        else MPE_SB(false, 5, false, 4, 4);
     }
 #undef MPE_SB
     return hipGetLastError();

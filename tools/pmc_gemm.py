@@ -22,7 +22,7 @@ import sys
 
 
 def short(name):
-    m = re.match(r'(?:void )?(?:mpe::)?([A-Za-z0-9_]+(?:<[^>]*>)?)', name)
+    m = re.match(r'(?:void )?(?:[A-Za-z0-9_]+::)*([A-Za-z0-9_]+(?:<[^>]*>)?)', name)   # any namespaces (mpe::, mpe::sb::)
     return m.group(1) if m else name[:60]
 
 

@@ -28,7 +28,7 @@ if [ "$1" = C ]; then
     tail -2 $O/p$i.err | cut -c1-300
   done
   python3 $R/tools/pmc_gemm.py $O/pmc_lds.json $O/p4/d_counter_collection.csv $O/p5/d_counter_collection.csv $O/p6/d_counter_collection.csv $O/p7/d_counter_collection.csv $O/p8/d_counter_collection.csv > $O/pmc_lds.txt 2>&1; head -14 $O/pmc_lds.txt
-  rm -f $O/*/*_kernel_trace.csv
+  rm -f $O/*/*_kernel_trace.csv $O/p?/d_counter_collection.csv       # (the merged json / txt are the record; gpurun_out/ is capped at 64 MiB)
 fi
 show() { python3 -c "
 import json,sys

@@ -14,6 +14,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
+#ifndef SB_SWZ_OLD
+#define SB_SWZ_OLD 0
+#endif
+#ifndef SB_ORDER
+#define SB_ORDER 0
+#endif
+#ifndef SB_RANDOM
+#define SB_RANDOM 0
+#endif
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -25,7 +35,11 @@ constexpr int ROW_B = BK * 2;                         // bytes per tile row
 constexpr int PLANE_A = BM * ROW_B, PLANE_W = BN * ROW_B;
 constexpr int STAGE_B = 3 * PLANE_A + 3 * PLANE_W;    // 39936 bytes
 
-__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+#if SB_SWZ_OLD
+__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }      // the first version: 2-way conflicts in the real ds_read_b128 lane groups
+#else
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }      // gemm_sb16.hip: w_swz
+#endif
 
 // NPROD: 6 = fp32-accurate split, 3 = a1b1 + a1b2 + a2b1 (~16 significant bits), 1 = plain bf16 (planes 0 only)
 // STAGING: 1 = LDS-DMA from loader waves, 0 = no staging at all (the MFMA + fragment-read ceiling)
@@ -95,6 +109,27 @@ __global__ __launch_bounds__(512, 2) void k_sb16(float *out, int nk, const unsig
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) af[p][mt] = *reinterpret_cast<const bf16x8 *>(cur + p * PLANE_A + a_rd[mt]);
+#if SB_ORDER == 1
+        // production order (gemm_sb16.hip SB_STAGE): the six products of one accumulator back to back, weight fragments per column tile
+        if (NPROD == 6) {
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                bf16x8 wp[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wp[p] = *reinterpret_cast<const bf16x8 *>(cur + p * PLANE_W + w_rd[nt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[2], af[0][mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[1], af[1][mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[1], af[0][mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[0], af[2][mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[0], af[1][mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[0], af[0][mt], acc[nt][mt], 0, 0, 0);
+                }
+            }
+            continue;
+        }
+#endif
 #pragma unroll
         for (int pw = 0; pw < NP; ++pw) {
             bf16x8 wf[5];
@@ -130,6 +165,15 @@ static void run(const char *what, int M, int N, int K) {
     hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
     hipMemset(A, 0x3c, 3 * plane_a * 2);               // 0x3c3c = 0.0115 as bf16: finite, non-trivial operand bits
     hipMemset(W, 0x3c, 3 * plane_w * 2);
+#if SB_RANDOM
+    {   // operands with random mantissas and signs (the matrix pipe's power, hence the clock, depends on the operand bits)
+        std::vector<unsigned short> h(1 << 22);
+        unsigned x = 12345u;
+        for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(((x >> 16) & 0x80FFu) | 0x3C00u | ((x >> 9) & 0x0300u)); }
+        for (size_t o = 0; o < 3 * plane_a * 2; o += h.size() * 2) hipMemcpy((char *)A + o, h.data(), std::min(h.size() * 2, 3 * plane_a * 2 - o), hipMemcpyHostToDevice);
+        for (size_t o = 0; o < 3 * plane_w * 2; o += h.size() * 2) hipMemcpy((char *)W + o, h.data(), std::min(h.size() * 2, 3 * plane_w * 2 - o), hipMemcpyHostToDevice);
+    }
+#endif
     const void *fn = reinterpret_cast<const void *>(k_sb16<NPROD, STAGING>);
     hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
     hipEvent_t e0, e1;
@@ -159,6 +203,7 @@ static void run(const char *what, int M, int N, int K) {
 int main() {
     // the two shapes that carry the step: GAT fc1 / fc2 (180 k rows, K = 416 padded, N = 400) and the MLP's big layers (4 k rows)
     const int shapes[3][3] = {{180224, 400, 416}, {180224, 400, 3328}, {4096, 3040, 3072}};
+    printf("SB_ORDER %d SB_RANDOM %d\n", SB_ORDER, SB_RANDOM);
     for (auto &s : shapes) {
         run<6, 1>("split-bf16, 6 products, LDS-DMA staging", s[0], s[1], s[2]);
         run<6, 0>("split-bf16, 6 products, no staging (ceiling)", s[0], s[1], s[2]);
