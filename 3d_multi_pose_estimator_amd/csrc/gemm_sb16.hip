@@ -126,6 +126,9 @@ __device__ __forceinline__ void glds16(unsigned voff, const void *sbase, unsigne
 // the activation tile, fp32, the image of k_linear_dma: 32 rows per MFMA wave (16 KiB with four MFMA waves, 32 KiB with eight)
 __host__ __device__ constexpr int sb_a_bytes(int mw) { return mw * 32 * GEMM_BK * 4; }
 
+// K stages resident in LDS: two (one being read, one landing) in the four-MFMA-wave form; three in the eight-wave form, where the
+// second MFMA wave of every SIMD runs half a stage behind the first and still reads stage kt - 1 while stage kt + 1 lands
+__host__ __device__ constexpr int sb_ring(int mw) { return mw == 8 ? 3 : 2; }
 __host__ __device__ constexpr int sb_stage_bytes(int ntt, int mw = 4) { return sb_a_bytes(mw) + 3 * ntt * 16 * GEMM_BK * 2; }
 
 // A12 (fc2 of a graph-attention layer with 40-wide attention heads, 80-wide tiles): the epilogue also emits a1 | a2 =
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int STAGE = sb_stage_bytes(NTT, MW);
     constexpr int SB_A_BYTES = sb_a_bytes(MW), BM = 32 * MW;
+    constexpr int RING = sb_ring(MW);               // K stages resident in LDS
     constexpr int WPL = NTT * 16 * GEMM_BK * 2;       // bytes of one weight plane of a stage
     int M = m_cap;
     if (d_m) {
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
             lw_dst[g] = SB_A_BYTES + p * WPL + grp * 1024;
         }
         auto fill = [&](int kt, int buf) {
-            const unsigned base = (unsigned)(size_t)(lds_void *)lds + (unsigned)(buf * STAGE);
+            const unsigned base = (unsigned)(size_t)(lds_void *)lds + (unsigned)(buf * STAGE);      // buf = kt mod RING
             const unsigned char *ab = abase + (size_t)kt * (GEMM_BK * 4), *wb = wbase + (size_t)kt * (GEMM_BK * 2);
 #pragma unroll
             for (int g = 0; g < NA; ++g) glds16(la[g], ab, base + (unsigned)((li * NA + g) * 8 * 128));
@@ -220,13 +224,18 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
             for (int g = 0; g < NWL; ++g)
                 if ((g + 1) * SB_NL <= NW || li + SB_NL * g < NW) glds16(lw[g], wb, base + (unsigned)lw_dst[g]);
         };
+        // One stage ahead in both forms: stage kt + 1 is issued after barrier kt and has landed before barrier kt + 1.  With the
+        // ring of three (eight MFMA waves) the buffer it goes to is the one of stage kt - 2: stage kt - 1 is still being read by the
+        // second wave of every SIMD between barriers kt and kt + 1 (main loop below).
         fill(0, 0);
+        int nb = 1;
         for (int kt = 0; kt < nk; ++kt) {
             if (!(F64 && LEAKY && MPE_SBEXP == 35) && !(!F64 && MPE_SBEXP == 45))               // (ablation 35 / 45: no landing wait)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage kt has landed ...
-            __syncthreads();                                        // ... and the MFMA waves are done with the other buffer
+            __syncthreads();                                        // ... and nobody reads the buffer stage kt + 1 goes to
             if ((F64 && LEAKY && MPE_SBEXP == 34) || (!F64 && MPE_SBEXP == 44)) continue;          // (ablation 34 / 44: no staging at all)
-            if (kt + 1 < nk) fill(kt + 1, (kt + 1) & 1);
+            if (kt + 1 < nk) fill(kt + 1, nb);
+            nb = nb + 1 == RING ? 0 : nb + 1;
         }
         return;
     }
@@ -291,6 +300,114 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
     };
     using std::false_type;
     using std::true_type;
+    if constexpr (RING == 3) {
+        // Eight MFMA waves, ring of three stages, the two MFMA waves of a SIMD HALF A STAGE APART.  A stage of a wave is: split the
+        // activation fragments (88 vector instructions, nothing to multiply yet), then the six-product chains of the first and of the
+        // second half of the column tiles.  Waves 0-3 run a stage between two barriers.  Waves 4-7 (the second wave of every SIMD)
+        // run the loop rotated by half a stage: after barrier kt they finish stage kt - 1 (second half of its column tiles: MFMAs
+        // only) and then start stage kt (split + first half) -- so one wave's split arithmetic falls into the other's MFMA-only half,
+        // where two waves in step would both sit in front of their first MFMA.  Stage kt - 1 is still read after barrier kt: that is
+        // what the third buffer is for (the loaders refill it after barrier kt + 1).  Every 16 x 16 tile still sees its six products
+        // per stage in the canonical order, stages ascending: the bits of the other forms.
+        bf16x8 ap[2][3];
+        auto split_stage = [&](const unsigned char *buf) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(buf + a_rd[mt] + c0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(buf + a_rd[mt] + c1);
+                if ((F64 && LEAKY && (MPE_SBEXP == 31 || MPE_SBEXP == 33)) || (!F64 && MPE_SBEXP == 41)) {      // (ablation: no split arithmetic)
+                    ap[mt][0] = __builtin_bit_cast(bf16x8, x0);
+                    ap[mt][1] = __builtin_bit_cast(bf16x8, x1);
+                    ap[mt][2] = __builtin_bit_cast(bf16x8, x0);
+                } else
+                split8(x0, x1, ap[mt][0], ap[mt][1], ap[mt][2]);
+            }
+        };
+        constexpr int NH = (NTT + 1) / 2;              // column tiles of the first half
+        auto half = [&](const unsigned char *buf, const int h, f32x4 (&ACC)[NTT][2], auto from_zero) {
+#pragma unroll
+            for (int nt = h ? NH : 0; nt < (h ? NTT : NH); ++nt) {
+                bf16x8 wp[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wp[p] = *reinterpret_cast<const bf16x8 *>(buf + p * WPL + w_rd[nt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    if (decltype(from_zero)::value) SB_STAGE0(ACC[nt][mt], ap[mt], wp);
+                    else SB_STAGE(ACC[nt][mt], ap[mt], wp);
+                }
+            }
+        };
+        // half h of an even / odd stage (fp32 chains: from zero on the even stages with f64 sums; even / odd accumulators without)
+        auto even_half = [&](const unsigned char *buf, const int h) {
+            if (F64) half(buf, h, acc, std::true_type());
+            else half(buf, h, acc, std::false_type());
+        };
+        auto odd_half = [&](const unsigned char *buf, const int h) {
+            if (F64) half(buf, h, acc, std::false_type());
+            else half(buf, h, acc_odd, std::false_type());
+        };
+        auto flush = [&](bool last) {                  // the pair's sums into the f64 running sums
+            if (!F64) return;
+            if (LEAKY && (MPE_SBEXP == 32 || MPE_SBEXP == 33) && !last) return;      // (ablation 32 / 33: one flush at the end)
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
+        };
+        int b = 0;                                     // buffer of the stage in hand (stage j lives in buffer j mod 3)
+        auto buf_at = [&](int i) { return lds + i * STAGE; };
+        auto next_b = [&](int i) { return i + 1 == RING ? 0 : i + 1; };
+        if (wave < MW / 2) {
+#pragma unroll 1
+            for (int kt = 0; kt < nk; kt += 2) {
+                __syncthreads();                       // barrier kt: stage kt has landed
+                split_stage(buf_at(b));
+                even_half(buf_at(b), 0);
+                even_half(buf_at(b), 1);
+                b = next_b(b);
+                if (kt + 1 < nk) {
+                    __syncthreads();
+                    split_stage(buf_at(b));
+                    odd_half(buf_at(b), 0);
+                    odd_half(buf_at(b), 1);
+                    b = next_b(b);
+                }
+                flush(kt + 2 >= nk);
+            }
+        } else {
+            __syncthreads();                           // barrier 0
+            split_stage(buf_at(0));
+            even_half(buf_at(0), 0);
+            int kt = 1;
+#pragma unroll 1
+            for (; kt + 1 < nk; kt += 2) {             // kt odd
+                __syncthreads();                       // barrier kt
+                even_half(buf_at(b), 1);               // second half of stage kt - 1
+                b = next_b(b);
+                split_stage(buf_at(b));
+                odd_half(buf_at(b), 0);
+                __syncthreads();                       // barrier kt + 1
+                odd_half(buf_at(b), 1);
+                flush(false);
+                b = next_b(b);
+                split_stage(buf_at(b));
+                even_half(buf_at(b), 0);
+            }
+            if (kt < nk) {                             // nk even: one odd stage left
+                __syncthreads();
+                even_half(buf_at(b), 1);
+                b = next_b(b);
+                split_stage(buf_at(b));
+                odd_half(buf_at(b), 0);
+                odd_half(buf_at(b), 1);
+            } else {                                   // nk odd: the last (even) stage has its first half done
+                even_half(buf_at(b), 1);
+            }
+            flush(true);
+        }
+    } else
     if (F64) {
         // pairs of stages: the first starts its fp32 chains from zero (0 + x = x exactly: the bits of a cleared accumulator
         // without clearing it), the pair's sums go into the f64 running sums
@@ -598,12 +715,14 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     static PerDeviceFlag lds_attr;
     if (!lds_attr.test()) {
         hipError_t e = hipSuccess;
-        const void *fns[5] = {reinterpret_cast<const void *>(k_linear_sb<true, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW>),
+        const void *fns[8] = {reinterpret_cast<const void *>(k_linear_sb<true, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW>),
                               reinterpret_cast<const void *>(k_linear_sb<false, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW>),
                               reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4>),
-                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true>)};
+                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true>),
+                              reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4, false, 8>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, false, 8>),
+                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true, 8>)};
         for (const void *fn : fns)
-            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sb_stage_bytes(5, 8) + 56 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         lds_attr.set();
     }
@@ -612,26 +731,42 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     static const int lds_pad = getenv("MPE_SB_LDS_PAD") ? atoi(getenv("MPE_SB_LDS_PAD")) * 1024 : 0;
 #define MPE_SB(L_, N_, F_, NL_, MW_)                                                                                                \
     hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, NL_, false, MW_>), dim3((unsigned)(((m_cap + 32 * MW_ - 1) / (32 * MW_)) * ntn)),         \
-                       dim3(64 * (MW_ + NL_)), 2 * sb_stage_bytes(N_, MW_) + lds_pad, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, \
+                       dim3(64 * (MW_ + NL_)), sb_ring(MW_) * sb_stage_bytes(N_, MW_) + lds_pad, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, \
                        k_pad, slope, ntn, n_major)
-    const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;           // (the four-MFMA-wave launches below)
+    // launches without f64 sums: eight MFMA waves (256 x 80 tiles, one workgroup per CU) or four (128 x 80, two per CU).  Measured
+    // (one board, 180 000 rows): plain launches 257.7 against 267.5 us with eight; with the coefficient epilogue 336.1 against 333.9:
+    // eight for the first, four for the second.  MPE_SB_GAT_MW = 4 | 8 forces one form for both (diagnostic).
+    static const int gat_mw = getenv("MPE_SB_GAT_MW") ? atoi(getenv("MPE_SB_GAT_MW")) : 0;
+    const bool with_coef = coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky;
+    const int mw = gat_mw == 4 ? 4 : gat_mw == 8 ? 8 : with_coef ? 4 : 8;
+    const int ntm = (m_cap + 32 * mw - 1) / (32 * mw);
     if (f64) {
         // 64-wide feature tiles: with 80 the f64 running sums of the wider wave tile do not fit the 168 registers that three waves per
         // SIMD leave (the compiler spills); the MLP's layers balance with 64 anyway
         const int ntn = (n + SB_F64_NTT * 16 - 1) / (SB_F64_NTT * 16);
         if (leaky) MPE_SB(true, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW);
         else MPE_SB(false, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW);
-    } else if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky) {
+    } else if (with_coef) {
         // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile), as launch_linear
         const int ntn = (n + 79) / 80;
-        hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true>), dim3((unsigned)(ntm * ntn)), dim3(512), 2 * sb_stage_bytes(5), s, A, lda, W3,
-                           w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12,
-                           out_half ? 1 : 0);
+        if (mw == 8)
+            hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true, 8>), dim3((unsigned)(ntm * ntn)), dim3(768), 3 * sb_stage_bytes(5, 8), s, A, lda,
+                               W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12,
+                               out_half ? 1 : 0);
+        else
+            hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true>), dim3((unsigned)(ntm * ntn)), dim3(512), 2 * sb_stage_bytes(5), s, A, lda, W3,
+                               w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12,
+                               out_half ? 1 : 0);
         if (coef_done) *coef_done = true;
     } else {
         const int ntn = (n + 79) / 80;
-        if (leaky) MPE_SB(true, 5, false, 4, 4);
-        else MPE_SB(false, 5, false, 4, 4);
+        if (mw == 8) {
+            if (leaky) MPE_SB(true, 5, false, 4, 8);
+            else MPE_SB(false, 5, false, 4, 8);
+        } else {
+            if (leaky) MPE_SB(true, 5, false, 4, 4);
+            else MPE_SB(false, 5, false, 4, 4);
+        }
     }
 #undef MPE_SB
     return hipGetLastError();

@@ -728,6 +728,13 @@ def test_split_bf16_linear_is_fp32_accurate_and_batch_invariant(engine, k, n, sl
     for m in (1, 16, 37):
         small = engine.linear(x[:m].cuda(), w, b, slope, split=True).cpu()
         assert torch.equal(small, big[:m]), (m, (small - big[:m]).abs().max().item())
+    # the same for rows that other waves of the tile kernel own: rows 128-255 of a 256-row tile belong to the second MFMA wave of
+    # every SIMD, which runs half a K stage behind the first and reads a stage one barrier longer (round 4: a loader that
+    # refilled that buffer too early went unnoticed by the checks above, which only ever looked at rows 0-36), and the last,
+    # partial tile
+    for m0, m in ((131, 37), (250, 12), (2950, 37), (2984, 16)):
+        small = engine.linear(x[m0:m0 + m].cuda(), w, b, slope, split=True).cpu()
+        assert torch.equal(small, big[m0:m0 + m]), (m0, m, (small - big[m0:m0 + m]).abs().max().item())
     # non-finite operands travel like in any fp32 GEMM (garbage in, garbage out -- but no fault, no hang)
     xb = x[:40].clone()
     xb[3, 5] = float('inf')
