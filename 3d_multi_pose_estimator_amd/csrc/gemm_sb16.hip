@@ -7,19 +7,25 @@
 // result's scale at K = 416 ... 3072 -- the same as the fp32 MFMA chain with a flush per stage that the MLP launches ran on
 // (0.26), with half as many flushes and 6 x 16-cycle instead of 8 x 32-cycle matrix instructions per 16 x 16 x 32 block.
 //
-// Replaces the same reference code as gemm.hip (nn.Linear + LeakyReLU of utils/mlp.py:8-28) for the MLP launches when the
-// context's MLP mode is 3.  Activations stay fp32 in memory and are split in registers by the MFMA waves (88 VALU
-// instructions per stage and wave, hidden behind the other workgroup's MFMAs); the weights are split once (k_split_planes)
-// into three bf16 planes [3][rows][ldw].
+// Replaces the same reference code as gemm.hip (nn.Linear + LeakyReLU of utils/mlp.py:8-28, gat2.py:53-55) for the MLP launches
+// (MLP mode 3) and the GAT launches of layers >= 1 (GAT mode 4).  Activations stay fp32 in memory and are split in registers by
+// the MFMA waves (88 vector instructions per stage and wave); the weights are split once (k_split_planes) into three bf16 planes
+// [3][rows][ldw].
 //
 // Three kernels, one arithmetic -- per 16 x 16 output tile and K stage the six MFMAs in the order (a1,w3) (a2,w2) (a1,w2)
-// (a3,w1) (a2,w1) (a1,w1), stages ascending; with f64 sums (MLP) one fp32 chain flushed after every odd stage and after the
-// last one, without (GAT) the even and the odd stages in two fp32 chains added at the end -- so a row has the same bits in a
-// batch of one and of a thousand:
-//   k_linear_sb         128 x 64|80 x 32 tiles, 4 MFMA waves + 2 loader waves (LDS-DMA of the fp32 activation tile and the
-//                       three weight planes), double-buffered LDS, one barrier per stage
+// (a3,w1) (a2,w1) (a1,w1), stages ascending; with f64 sums (MLP) one fp32 chain per stage PAIR (started from a zero C operand,
+// added to the f64 running sum after the odd stage and after the last one), without (GAT) the even and the odd stages in two
+// fp32 chains added at the end -- so a row has the same bits in a batch of one and of a thousand:
+//   k_linear_sb         tile kernel, LDS-DMA staging from four loader waves (fp32 activation tile + three weight planes per
+//                       stage, `saddr + voffset` loads: no vector instruction per piece), one barrier per stage, two forms:
+//                       MW = 8  256 x 64|80 tiles, eight MFMA waves, ONE twelve-wave workgroup per CU, ring of three stages,
+//                               the second MFMA wave of every SIMD half a stage behind the first (f64-sum launches, plain GAT launches)
+//                       MW = 4  128 x 80 tiles, four MFMA waves, two eight-wave workgroups per CU, two stages (coefficient epilogue)
 //   k_linear_sb_skinny  one wave per 16 x 16 tile, operands streamed from global memory (small batches, narrow outputs)
 //   k_linear_sb_ks      the same with the stage pairs of a tile dealt to eight waves and an ordered f64 reduction through LDS
+// What the tile kernel waits for, by ablation builds of it (make exp EXPFLAGS=-DMPE_SBEXP=n, tools/run_variants.sh):
+// MLP form -- no f64 flush -26 %, no split arithmetic -18 %, no staging -5 %; GAT four-wave form -- no staging -25 %, no split
+// arithmetic -10..-14 %, no landing wait -1..-4 %.
 #include <cstdlib>
 #include <type_traits>
 
@@ -111,13 +117,15 @@ __device__ __forceinline__ int a_swz(int row) { return ((row >> 1) & 1) | (((row
 // group collided: SQ_LDS_BANK_CONFLICT was 43 % of the LDS-active cycles, 7.0 instead of 4 cycles per ds_read_b128).
 __device__ __forceinline__ int w_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
-// loader waves: 2 with f64 running sums (6-wave workgroups: 168 registers at two workgroups per CU), 4 without
 // One LDS-DMA piece (1 KiB per wave-instruction) in the `saddr + voffset` form: wave-uniform 64-bit base in an SGPR pair, per-lane
 // 32-bit byte offset, LDS destination (wave-uniform byte address) through M0, written in the statement that reads it.  hipcc does
 // not count asm loads: the caller waits with an explicit `s_waitcnt vmcnt(0)` before the stage barrier.
 __device__ __forceinline__ void glds16(unsigned voff, const void *sbase, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+#ifndef SB_GLDS_MOD
+#define SB_GLDS_MOD ""            // cache-policy bits of the staging loads (experiments: " sc0", " sc1", " nt")
+#endif
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" SB_GLDS_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                     if (hp) { pl[1][mt] = l1; pr[1][mt] = r1; } else { pl[0][mt] = l1; pr[0][mt] = r1; }
                 }
             }
-            if (m >= M) continue;
+            if (m >= M || (A12 && MPE_SBEXP == 47)) continue;          // (ablation 47: no result stores of the coefficient launches)
             if (out_half) {                    // fp16 rows for the attention stage (configs[4]); ldc counts halves
                 _Float16 *dh = reinterpret_cast<_Float16 *>(C) + (size_t)m * ldc + nb;
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 y = y + __shfl_xor(y, 32);
                 const int m = m0 + wave * 32 + mt * 16 + fr;
                 const int head = (n0 / 40) + h;
-                if (fq == 0 && m < M && head * 40 < n) {
+                if (fq == 0 && m < M && head * 40 < n && MPE_SBEXP != 46) {          // (ablation 46: no coefficient stores)
                     a12[(size_t)m * 32 + head] = x;
                     a12[(size_t)m * 32 + 16 + head] = y;
                 }

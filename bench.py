@@ -487,8 +487,10 @@ def run_rank(args):
                    'mlp_accumulate': 'bf16 mfma (reduced precision)' if reduced else ('f32' if args.fast_mlp else 'f32 mfma + f64 running sums per K stage' if args.mlp_fp32_mfma
                                       else 'fp32 operands as three bf16 planes, six products on the bf16 mfma, f32 accumulators + f64 running sums every second K stage (fp32-accurate)'),
                    'gemm_arithmetic': ('reduced precision' if reduced else
-                                       'fp32 in / fp32 out everywhere; GAT layers 1-4: %s; GAT layer 0 (head rows): fp32 MFMA; MLP: see mlp_accumulate'
-                                       % ('fp32 MFMA chain' if args.gat_fp32_mfma else 'fp32 operands as three bf16 planes, six products on the bf16 MFMA, fp32 accumulators (fp32-accurate)')),
+                                       'fp32 in / fp32 out everywhere; GAT layers 1-4: %s; GAT layer 0 (head rows): fc1 per camera block (K = 180) on the fp32 MFMA, fc2 (K = 902) %s; MLP: see mlp_accumulate'
+                                       % (('fp32 MFMA chain', 'on the fp32 MFMA with f64 running sums per K stage') if args.gat_fp32_mfma else
+                                          ('fp32 operands as three bf16 planes, six products on the bf16 MFMA, fp32 accumulators (fp32-accurate)',
+                                           'in the same split form with f64 running sums every second K stage'))),
                    'weights': 'deterministic hash init (no checkpoint offline)'},
         'io_inclusive': io,
         'json_inclusive': jsn,
@@ -642,7 +644,7 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
                 'profiles/r04_bench_streams1_kernel_stats.csv); with two contexts in flight the kernels of two steps overlap and a launch\'s '
                 'duration as rocprofv3 sees it is longer, which is why the kernel-level figure comes from this pass' % (sampled, args.profile_steps))
     fp32 = {'kernel': 'mpe::k_linear_dma / k_linear_skinny* (fp32 MFMA 16x16x4; K stages by LDS-DMA from loader waves, fused bias + LeakyReLU): '
-                      + ('layer 0 of the GAT (head rows only: grouped fc1 by camera, fc2 with f64 sums)' if split_n else 'every mpe_linear launch of a step'),
+                      + ('fc1 of GAT layer 0 (head rows only, grouped by camera: K = 180 blocks)' if split_n else 'every mpe_linear launch of a step'),
             'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
             'launches': prof['gemm_launches'], 'avg_launch_ms': prof['gemm_ms'] / max(1, prof['gemm_launches']),
             'flop_per_step': prof['gemm_flop'] / sampled}
@@ -650,7 +652,8 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
         eq = split_flop / (split_ms * 1e-3) / 1e12
         main = {'kernel': 'mpe::k_linear_sb* (csrc/gemm_sb16.hip: nn.Linear with fp32 operands taken as three bf16 planes each, the six '
                           'significant partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulators (+ f64 running sums every second K '
-                          'stage in the MLP), activation tile and weight planes staged by LDS-DMA from loader waves, fused bias + LeakyReLU '
+                          'stage in the MLP), activation tile and weight planes staged by LDS-DMA from loader waves (MLP and plain GAT launches: one twelve-wave '
+                          'workgroup per CU, 256-row tiles, ring of three K stages; coefficient launches: two eight-wave workgroups), fused bias + LeakyReLU '
                           '+ attention coefficients): the GAT launches of layers 1-4 and all MLP launches = %.0f %% of the GEMM time of a step'
                           % (100.0 * split_ms / max(1e-9, split_ms + prof['gemm_ms'])),
                 'bound': 'mfma',
