@@ -433,7 +433,7 @@ int gat_layer_linear(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, int l, Gat
             HIPCHK(ctx, launch_linear_grouped(s, ctx->xc, ctx->l0_ld, ctx->l0_w, ctx->l0_ld,
                                               (long)weight_rows(g.in_dim) * ctx->l0_ld, ctx->l0_b, ctx->h0, ctx->feat_ld,
                                               b->n_heads, ctx->cam_count, V, ctx->cam_list, ctx->cfg.max_heads, g.in_dim,
-                                              ctx->l0_ld, true, ctx->gat_alpha));
+                                              ctx->l0_ld, true, ctx->gat_alpha, ctx->gat_acc64));
         } else if (ctx->l0_grouped) {
             // small batches / reduced precision: one launch per camera over that camera's heads
             const double flop_each = 2.0 * b->n_heads * (double)g.in_dim * (J * 10) / V;

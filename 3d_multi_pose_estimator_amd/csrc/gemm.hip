@@ -1089,15 +1089,18 @@ static void launch_dma_acc64(hipStream_t s, int grid, const DmaLaunch &a, bool l
 
 hipError_t launch_linear_grouped(hipStream_t s, const float *A, int lda, const float *W, int ldw, long w_grp_stride,
                                  const float *bias, float *C, int ldc, int m_cap, const int32_t *grp_count, int n_grp,
-                                 const int32_t *row_lists, int grp_stride, int n, int k_pad, bool leaky, float slope) {
+                                 const int32_t *row_lists, int grp_stride, int n, int k_pad, bool leaky, float slope, bool acc64) {
     if (m_cap <= 0 || n <= 0 || n_grp <= 0) return hipSuccess;
     const int ntm_cap = (m_cap + GEMM_BM - 1) / GEMM_BM + n_grp;       // sum of per-group ceilings
-    DmaLaunch a{A, lda, W, ldw, bias, C, ldc, m_cap, nullptr, n, k_pad, slope, (n + 79) / 80, 0, row_lists, row_lists};
+    // (f64 running sums -- the GAT's explicit f64-sum mode -- on 64-wide tiles, as launch_linear: the per-camera launches of a small
+    // batch take that form too, so a row keeps its bits whatever the batch)
+    DmaLaunch a{A, lda, W, ldw, bias, C, ldc, m_cap, nullptr, n, k_pad, slope, acc64 ? (n + 63) / 64 : (n + 79) / 80, 0, row_lists, row_lists};
     a.grp_count = grp_count;
     a.n_grp = n_grp;
     a.grp_stride = grp_stride;
     a.w_grp_stride = w_grp_stride;
-    launch_dma_plain<5>(s, ntm_cap * a.ntn, a, leaky);
+    if (acc64) launch_dma_acc64<4>(s, ntm_cap * a.ntn, a, leaky);
+    else launch_dma_plain<5>(s, ntm_cap * a.ntn, a, leaky);
     return hipGetLastError();
 }
 

@@ -698,6 +698,27 @@ def test_random_frame_shapes_vs_oracle(preset, n):
     assert rep['native_packer_same_bits']
 
 
+def test_tile_kernels_and_wave_per_tile_kernels_give_the_same_scores(tmp_path):
+    """Every GEMM of the path has a tile kernel (big batches) and wave-per-16x16-tile kernels (small batches, narrow outputs)
+    that are meant to give a row the same bits.  tests/checkers/skinny_vs_tile.py writes the scores of every fixture frame
+    and the activations of every layer (mpe_gat_layer), in the default arithmetic and in the f64-sum mode, once in a plain
+    process (small frames: wave-per-tile kernels) and once with MPE_SKINNY_WAVES=0 (tile kernels at every batch size: the
+    split-bf16 tile forms with four and eight MFMA waves, the fp32 tile kernel, the grouped layer-0 launch); every array must
+    be identical.  (Round 4: in the f64-sum mode the grouped layer-0 launch had no f64 sums while the per-camera launches of
+    a small batch had them -- 16 of 180 arrays differed by up to 9e-6.)"""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, 'tests', 'checkers', 'skinny_vs_tile.py')
+    a, b = str(tmp_path / 'plain.npz'), str(tmp_path / 'tile.npz')
+    for path, extra in ((a, {}), (b, {'MPE_SKINNY_WAVES': '0'})):
+        r = subprocess.run([sys.executable, tool, 'dump', path], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, tool, 'cmp', a, b], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith('0 of ') and int(last.split()[2]) >= 150, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize('k,n,slope', [(1260, 3072, 0.1), (3072, 2048, 0.1), (1024, 54, None), (416, 400, 0.15), (96, 16, None), (33, 70, 0.1)])
 def test_split_bf16_linear_is_fp32_accurate_and_batch_invariant(engine, k, n, slope):
     """csrc/gemm_sb16.hip, the arithmetic of the MLP launches (MLP mode 3, the default): every fp32 operand as the exact sum
