@@ -132,12 +132,12 @@ __device__ __forceinline__ void glds16(unsigned voff, const void *sbase, unsigne
 }
 
 // the activation tile, fp32, the image of k_linear_dma: 32 rows per MFMA wave (16 KiB with four MFMA waves, 32 KiB with eight)
-__host__ __device__ constexpr int sb_a_bytes(int mw) { return mw * 32 * GEMM_BK * 4; }
+__host__ __device__ constexpr int sb_a_bytes(int mw, int mt = 2) { return mw * 16 * mt * GEMM_BK * 4; }
 
 // K stages resident in LDS: two (one being read, one landing) in the four-MFMA-wave form; three in the eight-wave form, where the
 // second MFMA wave of every SIMD runs half a stage behind the first and still reads stage kt - 1 while stage kt + 1 lands
 __host__ __device__ constexpr int sb_ring(int mw) { return mw == 8 ? 3 : 2; }
-__host__ __device__ constexpr int sb_stage_bytes(int ntt, int mw = 4) { return sb_a_bytes(mw) + 3 * ntt * 16 * GEMM_BK * 2; }
+__host__ __device__ constexpr int sb_stage_bytes(int ntt, int mw = 4, int mt = 2) { return sb_a_bytes(mw, mt) + 3 * ntt * 16 * GEMM_BK * 2; }
 
 // A12 (fc2 of a graph-attention layer with 40-wide attention heads, 80-wide tiles): the epilogue also emits a1 | a2 =
 // <ft2[row, head, :], attn_l / attn_r[head]> (gat2.py:57-58) from the values the lanes hold -- the code of k_linear_dma<.., A12>,
@@ -149,11 +149,15 @@ __host__ __device__ constexpr int sb_stage_bytes(int ntt, int mw = 4) { return s
 // wave with nothing to cover its fragment reads, split arithmetic and barrier (found with SQ_WAVE_CYCLES = half the slot time and
 // confirmed by padding the LDS request to one workgroup per CU: same duration).
 #ifndef SB_F64_NTT
-#define SB_F64_NTT 4
-#define SB_F64_NL 4
+#define SB_F64_NTT 4           // (8 with SB_F64_MT 1 = 16 x 128 outputs per wave: half the split arithmetic, twice the weight-fragment
+#define SB_F64_NL 4            //  reads -- measured the same 157.7 against 157.5 us, profiles/r04_sb_tile_ablations.txt)
 #define SB_F64_MW 8
+#define SB_F64_MT 2
 #endif
-template <bool LEAKY, int NTT, bool F64, int SB_NL, bool A12 = false, int MW = 4>
+// MT = 16-row tiles per MFMA wave: 2 (32 rows x NTT column tiles per wave) or 1 (16 rows: the f64-sum launches, whose wave then
+// covers 16 x 128 outputs -- the same 32 accumulator registers as 32 x 64, half the activation fragments to split per MFMA, the
+// weight fragments read by twice as many waves)
+template <bool LEAKY, int NTT, bool F64, int SB_NL, bool A12 = false, int MW = 4, int MT = 2>
 __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4) void k_linear_sb(const float *__restrict__ A, int lda,
                                                                    const unsigned short *__restrict__ W3, size_t w_plane, int ldw,
                                                                    const float *__restrict__ bias, float *__restrict__ C, int ldc,
@@ -163,8 +167,9 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                                                                    const float *__restrict__ attn_r = nullptr,
                                                                    float *__restrict__ a12 = nullptr, int out_half = 0) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    constexpr int STAGE = sb_stage_bytes(NTT, MW);
-    constexpr int SB_A_BYTES = sb_a_bytes(MW), BM = 32 * MW;
+    static_assert(MT == 2 || !A12, "the coefficient epilogue assumes two row tiles per wave");
+    constexpr int STAGE = sb_stage_bytes(NTT, MW, MT);
+    constexpr int SB_A_BYTES = sb_a_bytes(MW, MT), BM = 16 * MT * MW;
     constexpr int RING = sb_ring(MW);               // K stages resident in LDS
     constexpr int WPL = NTT * 16 * GEMM_BK * 2;       // bytes of one weight plane of a stage
     int M = m_cap;
@@ -250,9 +255,9 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
 
     // ---- MFMA waves: 32 rows x 16 NTT features each ----
     const int fq = lane >> 4, fr = lane & 15;
-    int a_rd[2], w_rd[NTT];
+    int a_rd[MT], w_rd[NTT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) a_rd[mt] = (wave * 32 + mt * 16 + fr) * 128;
+    for (int mt = 0; mt < MT; ++mt) a_rd[mt] = (wave * 16 * MT + mt * 16 + fr) * 128;
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) {
         const int row = nt * 16 + fr;
@@ -264,13 +269,13 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
     // Without f64 sums (GAT launches) the even and the odd K stages accumulate into separate fp32 chains that are added at the
     // end: half the chain length of a single accumulator (rms error 0.5-0.6 ulp of the output scale at K = 416 against 0.75 for one
     // chain and 0.91 for the fp32 MFMA chain it replaces), for 40 more registers (126 of the 128 that 2 x 8 waves per CU leave).
-    f32x4 acc[NTT][2];
-    f32x4 acc_odd[NTT][2];               // (unused with F64: the compiler drops it)
-    double run[F64 ? NTT : 1][2][4];
+    f32x4 acc[NTT][MT];
+    f32x4 acc_odd[NTT][MT];               // (unused with F64: the compiler drops it)
+    double run[F64 ? NTT : 1][MT][4];
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc_odd[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (F64) {
@@ -279,12 +284,12 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
             }
         }
     // one K stage into the accumulator set ACC (the barrier is the landing wait and the buffer hand-over)
-    auto do_stage = [&](int kt, f32x4 (&ACC)[NTT][2], auto from_zero) {
+    auto do_stage = [&](int kt, f32x4 (&ACC)[NTT][MT], auto from_zero) {
         __syncthreads();
         const unsigned char *cur = lds + (kt & 1) * STAGE;
-        bf16x8 ap[2][3];
+        bf16x8 ap[MT][3];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const f32x4 x0 = *reinterpret_cast<const f32x4 *>(cur + a_rd[mt] + c0);
             const f32x4 x1 = *reinterpret_cast<const f32x4 *>(cur + a_rd[mt] + c1);
             if ((F64 && LEAKY && (MPE_SBEXP == 31 || MPE_SBEXP == 33)) || (!F64 && MPE_SBEXP == 41)) {          // ablation (MLP launches only: nothing consumes their values): no split arithmetic (what do the 88 VALU instructions cost?)
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
 #pragma unroll
             for (int p = 0; p < 3; ++p) wp[p] = *reinterpret_cast<const bf16x8 *>(cur + p * WPL + w_rd[nt]);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 if (decltype(from_zero)::value) SB_STAGE0(ACC[nt][mt], ap[mt], wp);
                 else SB_STAGE(ACC[nt][mt], ap[mt], wp);
             }
@@ -317,10 +322,10 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         // where two waves in step would both sit in front of their first MFMA.  Stage kt - 1 is still read after barrier kt: that is
         // what the third buffer is for (the loaders refill it after barrier kt + 1).  Every 16 x 16 tile still sees its six products
         // per stage in the canonical order, stages ascending: the bits of the other forms.
-        bf16x8 ap[2][3];
+        bf16x8 ap[MT][3];
         auto split_stage = [&](const unsigned char *buf) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4 *>(buf + a_rd[mt] + c0);
                 const f32x4 x1 = *reinterpret_cast<const f32x4 *>(buf + a_rd[mt] + c1);
                 if ((F64 && LEAKY && (MPE_SBEXP == 31 || MPE_SBEXP == 33)) || (!F64 && MPE_SBEXP == 41)) {      // (ablation: no split arithmetic)
@@ -332,14 +337,14 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
             }
         };
         constexpr int NH = (NTT + 1) / 2;              // column tiles of the first half
-        auto half = [&](const unsigned char *buf, const int h, f32x4 (&ACC)[NTT][2], auto from_zero) {
+        auto half = [&](const unsigned char *buf, const int h, f32x4 (&ACC)[NTT][MT], auto from_zero) {
 #pragma unroll
             for (int nt = h ? NH : 0; nt < (h ? NTT : NH); ++nt) {
                 bf16x8 wp[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wp[p] = *reinterpret_cast<const bf16x8 *>(buf + p * WPL + w_rd[nt]);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     if (decltype(from_zero)::value) SB_STAGE0(ACC[nt][mt], ap[mt], wp);
                     else SB_STAGE(ACC[nt][mt], ap[mt], wp);
                 }
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
         };
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
         };
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) pl[h][mt] = pr[h][mt] = 0.f;
+            for (int mt = 0; mt < MT; ++mt) pl[h][mt] = pr[h][mt] = 0.f;
     }
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) {
@@ -459,8 +464,8 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
             ar = *reinterpret_cast<const f32x4 *>(attn_r + nb);
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int m = m0 + wave * 32 + mt * 16 + fr;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wave * 16 * MT + mt * 16 + fr;
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -504,13 +509,13 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 float x = pl[h][mt], y = pr[h][mt];
                 x = x + __shfl_xor(x, 16);
                 y = y + __shfl_xor(y, 16);
                 x = x + __shfl_xor(x, 32);
                 y = y + __shfl_xor(y, 32);
-                const int m = m0 + wave * 32 + mt * 16 + fr;
+                const int m = m0 + wave * 16 * MT + mt * 16 + fr;
                 const int head = (n0 / 40) + h;
                 if (fq == 0 && m < M && head * 40 < n && MPE_SBEXP != 46) {          // (ablation 46: no coefficient stores)
                     a12[(size_t)m * 32 + head] = x;
@@ -723,8 +728,8 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     static PerDeviceFlag lds_attr;
     if (!lds_attr.test()) {
         hipError_t e = hipSuccess;
-        const void *fns[8] = {reinterpret_cast<const void *>(k_linear_sb<true, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW>),
-                              reinterpret_cast<const void *>(k_linear_sb<false, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW>),
+        const void *fns[8] = {reinterpret_cast<const void *>(k_linear_sb<true, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW, SB_F64_MT>),
+                              reinterpret_cast<const void *>(k_linear_sb<false, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW, SB_F64_MT>),
                               reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4>),
                               reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true>),
                               reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4, false, 8>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, false, 8>),
@@ -737,9 +742,9 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
     // diagnostic: extra dynamic LDS per workgroup (occupancy experiments: how many workgroups does a CU really hold?)
     static const int lds_pad = getenv("MPE_SB_LDS_PAD") ? atoi(getenv("MPE_SB_LDS_PAD")) * 1024 : 0;
-#define MPE_SB(L_, N_, F_, NL_, MW_)                                                                                                \
-    hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, NL_, false, MW_>), dim3((unsigned)(((m_cap + 32 * MW_ - 1) / (32 * MW_)) * ntn)),         \
-                       dim3(64 * (MW_ + NL_)), sb_ring(MW_) * sb_stage_bytes(N_, MW_) + lds_pad, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, \
+#define MPE_SB(L_, N_, F_, NL_, MW_, MT_)                                                                                           \
+    hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, NL_, false, MW_, MT_>), dim3((unsigned)(((m_cap + 16 * MT_ * MW_ - 1) / (16 * MT_ * MW_)) * ntn)), \
+                       dim3(64 * (MW_ + NL_)), sb_ring(MW_) * sb_stage_bytes(N_, MW_, MT_) + lds_pad, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, \
                        k_pad, slope, ntn, n_major)
     // launches without f64 sums: eight MFMA waves (256 x 80 tiles, one workgroup per CU) or four (128 x 80, two per CU).  Measured
     // (one board, 180 000 rows): plain launches 257.7 against 267.5 us with eight; with the coefficient epilogue 336.1 against 333.9:
@@ -752,8 +757,8 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         // 64-wide feature tiles: with 80 the f64 running sums of the wider wave tile do not fit the 168 registers that three waves per
         // SIMD leave (the compiler spills); the MLP's layers balance with 64 anyway
         const int ntn = (n + SB_F64_NTT * 16 - 1) / (SB_F64_NTT * 16);
-        if (leaky) MPE_SB(true, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW);
-        else MPE_SB(false, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW);
+        if (leaky) MPE_SB(true, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW, SB_F64_MT);
+        else MPE_SB(false, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW, SB_F64_MT);
     } else if (with_coef) {
         // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile), as launch_linear
         const int ntn = (n + 79) / 80;
@@ -769,11 +774,11 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     } else {
         const int ntn = (n + 79) / 80;
         if (mw == 8) {
-            if (leaky) MPE_SB(true, 5, false, 4, 8);
-            else MPE_SB(false, 5, false, 4, 8);
+            if (leaky) MPE_SB(true, 5, false, 4, 8, 2);
+            else MPE_SB(false, 5, false, 4, 8, 2);
         } else {
-            if (leaky) MPE_SB(true, 5, false, 4, 4);
-            else MPE_SB(false, 5, false, 4, 4);
+            if (leaky) MPE_SB(true, 5, false, 4, 4, 2);
+            else MPE_SB(false, 5, false, 4, 4, 2);
         }
     }
 #undef MPE_SB
