@@ -167,6 +167,9 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                                                                    const float *__restrict__ attn_r = nullptr,
                                                                    float *__restrict__ a12 = nullptr, int out_half = 0) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    auto stage_barrier = [&]() {
+        if (!(F64 && LEAKY && MPE_SBEXP == 48)) __syncthreads();          // (ablation 48: no stage barrier -- timing only)
+    };
     static_assert(MT == 2 || !A12, "the coefficient epilogue assumes two row tiles per wave");
     constexpr int STAGE = sb_stage_bytes(NTT, MW, MT);
     constexpr int SB_A_BYTES = sb_a_bytes(MW, MT), BM = 16 * MT * MW;
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         for (int kt = 0; kt < nk; ++kt) {
             if (!(F64 && LEAKY && MPE_SBEXP == 35) && !(!F64 && MPE_SBEXP == 45))               // (ablation 35 / 45: no landing wait)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage kt has landed ...
-            __syncthreads();                                        // ... and nobody reads the buffer stage kt + 1 goes to
+            stage_barrier();                                        // ... and nobody reads the buffer stage kt + 1 goes to
             if ((F64 && LEAKY && MPE_SBEXP == 34) || (!F64 && MPE_SBEXP == 44)) continue;          // (ablation 34 / 44: no staging at all)
             if (kt + 1 < nk) fill(kt + 1, nb);
             nb = nb + 1 == RING ? 0 : nb + 1;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         }
     // one K stage into the accumulator set ACC (the barrier is the landing wait and the buffer hand-over)
     auto do_stage = [&](int kt, f32x4 (&ACC)[NTT][MT], auto from_zero) {
-        __syncthreads();
+        stage_barrier();
         const unsigned char *cur = lds + (kt & 1) * STAGE;
         bf16x8 ap[MT][3];
 #pragma unroll
@@ -375,13 +378,13 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         if (wave < MW / 2) {
 #pragma unroll 1
             for (int kt = 0; kt < nk; kt += 2) {
-                __syncthreads();                       // barrier kt: stage kt has landed
+                stage_barrier();                       // barrier kt: stage kt has landed
                 split_stage(buf_at(b));
                 even_half(buf_at(b), 0);
                 even_half(buf_at(b), 1);
                 b = next_b(b);
                 if (kt + 1 < nk) {
-                    __syncthreads();
+                    stage_barrier();
                     split_stage(buf_at(b));
                     odd_half(buf_at(b), 0);
                     odd_half(buf_at(b), 1);
@@ -390,18 +393,18 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 flush(kt + 2 >= nk);
             }
         } else {
-            __syncthreads();                           // barrier 0
+            stage_barrier();                           // barrier 0
             split_stage(buf_at(0));
             even_half(buf_at(0), 0);
             int kt = 1;
 #pragma unroll 1
             for (; kt + 1 < nk; kt += 2) {             // kt odd
-                __syncthreads();                       // barrier kt
+                stage_barrier();                       // barrier kt
                 even_half(buf_at(b), 1);               // second half of stage kt - 1
                 b = next_b(b);
                 split_stage(buf_at(b));
                 odd_half(buf_at(b), 0);
-                __syncthreads();                       // barrier kt + 1
+                stage_barrier();                       // barrier kt + 1
                 odd_half(buf_at(b), 1);
                 flush(false);
                 b = next_b(b);
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 even_half(buf_at(b), 0);
             }
             if (kt < nk) {                             // nk even: one odd stage left
-                __syncthreads();
+                stage_barrier();
                 even_half(buf_at(b), 1);
                 b = next_b(b);
                 split_stage(buf_at(b));
