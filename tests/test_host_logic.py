@@ -562,6 +562,49 @@ def test_fused_attention_window_isa(tmp_path):
         assert not re.search(r'scratch_|buffer_(load|store)', body), (k, 'scratch access in the kernel')
 
 
+def test_split_bf16_tile_kernel_occupancy_pins(tmp_path):
+    """Static pins of what the split-bf16 tile kernel's design rests on (csrc/gemm_sb16.hip), read from the gfx950
+    assembly of every k_linear_sb instantiation (no GPU):
+      * no register spills and no scratch;
+      * the eight-MFMA-wave form is ONE twelve-wave workgroup per CU: 768 threads and at most 168 registers (three waves per SIMD);
+        the four-MFMA-wave form is two eight-wave workgroups per CU: 512 threads and at most 128 registers (four waves per SIMD).
+        (Round 4: a six-wave form with 147 registers was meant to run two workgroups per CU and never did.)
+      * the loader waves' LDS-DMA pieces take the `saddr + voffset` form -- `global_load_lds_dwordx4 vN, s[a:b]` -- so that a
+        piece costs them no vector instruction (the compiler's own form carried a v_lshl_add_u64 per piece).
+    Replaces nn.Linear of gat2.py:53-55 / utils/mlp.py:8-28 on the production path."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, '3d_multi_pose_estimator_amd', 'csrc', 'gemm_sb16.hip')
+    out = str(tmp_path / 'gemm_sb16.s')
+    subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-S', '--cuda-device-only', '-o', out, src],
+                   check=True, capture_output=True, timeout=900)
+    text = open(out).read()
+    meta = {}
+    for m in re.finditer(r'\.max_flat_workgroup_size: (\d+)\n\s+\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count: (\d+)', text):
+        meta[m.group(2)] = (int(m.group(1)), int(m.group(3)), int(m.group(4)))
+    tile = {k: v for k, v in meta.items() if k.startswith('_ZN3mpe2sb11k_linear_sbIL')}
+    assert len(tile) >= 7, sorted(meta)
+    seen = set()
+    for name, (threads, vgpr, spills) in tile.items():
+        assert spills == 0, (name, spills)
+        mw = int(re.search(r'k_linear_sbILb[01]ELi\d+ELb[01]ELi\d+ELb[01]ELi(\d+)E', name).group(1))
+        seen.add(mw)
+        if mw == 8:
+            assert threads == 768 and vgpr <= 168, (name, threads, vgpr)
+        else:
+            assert mw == 4 and threads == 512 and vgpr <= 128, (name, threads, vgpr)
+        body = text[text.index(name + ':'):]
+        body = body[:body.index('s_endpgm')]
+        assert not re.search(r'scratch_', body), name
+        pieces = re.findall(r'global_load_lds_dwordx4 (\S+), (\S+)', body)
+        assert pieces and all(re.fullmatch(r'v\d+,?', a.rstrip(',') + ',') or re.fullmatch(r'v\d+', a.rstrip(',')) for a, _ in pieces), (name, pieces[:3])
+        assert all(re.fullmatch(r's\[\d+:\d+\]', b) for _, b in pieces), (name, pieces[:3])
+    assert seen == {4, 8}, seen
+
+
 def test_eisel_lemire_against_strtod(tmp_path):
     """csrc/el_double.h (the exact decimal -> binary64 conversion the device-side JSON parser uses) built for the host
     and run against glibc strtod on two million tokens: pixel-coordinate doubles in 17- and 15-digit form, random
