@@ -719,7 +719,8 @@ def test_tile_kernels_and_wave_per_tile_kernels_give_the_same_scores(tmp_path):
     assert last.startswith('0 of ') and int(last.split()[2]) >= 150, r.stdout[-3000:]
 
 
-@pytest.mark.parametrize('k,n,slope', [(1260, 3072, 0.1), (3072, 2048, 0.1), (1024, 54, None), (416, 400, 0.15), (96, 16, None), (33, 70, 0.1)])
+@pytest.mark.parametrize('k,n,slope', [(1260, 3072, 0.1), (3072, 2048, 0.1), (1024, 54, None), (416, 400, 0.15), (96, 16, None), (33, 70, 0.1),
+                                       (20, 96, 0.1), (72, 208, 0.1)])      # (one K stage / three: the shortest loops of the tile kernel's two wave groups)
 def test_split_bf16_linear_is_fp32_accurate_and_batch_invariant(engine, k, n, slope):
     """csrc/gemm_sb16.hip, the arithmetic of the MLP launches (MLP mode 3, the default): every fp32 operand as the exact sum
     of three bf16 numbers, six products on the bf16 MFMA, f64 sums every second K stage.  (i) Against the exactly evaluated
