@@ -31,6 +31,12 @@
 
 #include "mpe_internal.h"
 
+#ifndef SB_PRIO_MFMA
+#define SB_PRIO_MFMA 2
+#endif
+#ifndef SB_PRIO_SPLIT
+#define SB_PRIO_SPLIT 0        // priority of an MFMA wave while it splits its fragments (its MFMA phases: 2, its flush: 0, loaders: 3)
+#endif
 #ifndef MPE_SBEXP
 #define MPE_SBEXP 0            // timing ablations of a diagnostic build (csrc/Makefile `exp`; wrong results, never shipped); 0 in the product
 #endif
@@ -327,6 +333,9 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         // per stage in the canonical order, stages ascending: the bits of the other forms.
         bf16x8 ap[MT][3];
         auto split_stage = [&](const unsigned char *buf) {
+            // f64-sum launches: a wave in its vector-heavy phases (split arithmetic, flush) yields the issue port to the other wave
+            // of its SIMD while that one multiplies (MLP launches 159.3 -> 153.8 us; the plain GAT launches lost 0.8 % with it)
+            if (F64) __builtin_amdgcn_s_setprio(SB_PRIO_SPLIT);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4 *>(buf + a_rd[mt] + c0);
@@ -341,6 +350,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         };
         constexpr int NH = (NTT + 1) / 2;              // column tiles of the first half
         auto half = [&](const unsigned char *buf, const int h, f32x4 (&ACC)[NTT][MT], auto from_zero) {
+            if (F64) __builtin_amdgcn_s_setprio(SB_PRIO_MFMA);
 #pragma unroll
             for (int nt = h ? NH : 0; nt < (h ? NTT : NH); ++nt) {
                 bf16x8 wp[3];
@@ -364,6 +374,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         };
         auto flush = [&](bool last) {                  // the pair's sums into the f64 running sums
             if (!F64) return;
+            __builtin_amdgcn_s_setprio(0);
             if (LEAKY && (MPE_SBEXP == 32 || MPE_SBEXP == 33) && !last) return;      // (ablation 32 / 33: one flush at the end)
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt)
