@@ -163,7 +163,12 @@ __host__ __device__ constexpr int sb_stage_bytes(int ntt, int mw = 4, int mt = 2
 // MT = 16-row tiles per MFMA wave: 2 (32 rows x NTT column tiles per wave) or 1 (16 rows: the f64-sum launches, whose wave then
 // covers 16 x 128 outputs -- the same 32 accumulator registers as 32 x 64, half the activation fragments to split per MFMA, the
 // weight fragments read by twice as many waves)
-template <bool LEAKY, int NTT, bool F64, int SB_NL, bool A12 = false, int MW = 4, int MT = 2>
+// PERS (ring of three only): a PERSISTENT workgroup per CU that walks the tiles bid, bid + gridDim.x, ... (gridDim.x a multiple of
+// eight: a workgroup's tiles keep its XCD and the tile order of the plain launch).  The loader waves run on across tile borders --
+// stage 0 of the next tile is issued behind the barrier of the last stage of this one -- and the result stores of a tile drain
+// while the next one is multiplied.  With one workgroup per CU nothing else covers a tile's first-stage latency, its stores and the
+// dispatch of its successor: at K = 416 they were a quarter of a launch (tools/sb_ksweep.py: 84 of 347 us do not scale with K).
+template <bool LEAKY, int NTT, bool F64, int SB_NL, bool A12 = false, int MW = 4, int MT = 2, bool PERS = false>
 __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4) void k_linear_sb(const float *__restrict__ A, int lda,
                                                                    const unsigned short *__restrict__ W3, size_t w_plane, int ldw,
                                                                    const float *__restrict__ bias, float *__restrict__ C, int ldc,
@@ -173,8 +178,11 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                                                                    const float *__restrict__ attn_r = nullptr,
                                                                    float *__restrict__ a12 = nullptr, int out_half = 0) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    // Stage barrier: this wave's LDS operations done + s_barrier, and NOT __syncthreads(): its fence also waits for the wave's global
+    // stores, i.e. for the result rows of the previous tile in the persistent form (what must have landed in LDS is waited for by the
+    // loader waves themselves: their explicit vmcnt(0) in front of this barrier).
     auto stage_barrier = [&]() {
-        if (!(F64 && LEAKY && MPE_SBEXP == 48)) __syncthreads();          // (ablation 48: no stage barrier -- timing only)
+        if (!(F64 && LEAKY && MPE_SBEXP == 48)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (ablation 48: none -- timing only)
     };
     static_assert(MT == 2 || !A12, "the coefficient epilogue assumes two row tiles per wave");
     constexpr int STAGE = sb_stage_bytes(NTT, MW, MT);
@@ -186,23 +194,31 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         const int dm = *d_m;
         M = dm < m_cap ? dm : m_cap;
     }
+    static_assert(!PERS || RING == 3, "persistent form: ring of three");
     const int ntm = (M + BM - 1) / BM;
     const int bid = blockIdx.x, nwg = ntm * ntn;
     if (bid >= nwg) return;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    int tm, tn;
-    if (n_major) {
-        constexpr int RB = 8;
-        const int band = swz / (RB * ntn), rem = swz - band * (RB * ntn);
-        const int rows = ntm - band * RB < RB ? ntm - band * RB : RB;
-        tn = rem / rows;
-        tm = band * RB + (rem - tn * rows);
-    } else {
-        tm = swz / ntn;
-        tn = swz - tm * ntn;
-    }
-    const int m0 = tm * BM, n0 = tn * NTT * 16;
+    const int vstep = PERS ? (int)gridDim.x : nwg;      // tiles of this workgroup: bid, bid + vstep, ... (the plain form: one)
+    // tile of (virtual) workgroup v: XCD-aware order (v & 7 = the XCD the hardware dispatcher gives workgroup v, and v + 8 k stays there)
+    auto tile_of = [&](int v, int &m0o, int &n0o) {
+        const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        int tm, tn;
+        if (n_major) {
+            constexpr int RB = 8;
+            const int band = swz / (RB * ntn), rem = swz - band * (RB * ntn);
+            const int rows = ntm - band * RB < RB ? ntm - band * RB : RB;
+            tn = rem / rows;
+            tm = band * RB + (rem - tn * rows);
+        } else {
+            tm = swz / ntn;
+            tn = swz - tm * ntn;
+        }
+        m0o = tm * BM;
+        n0o = tn * NTT * 16;
+    };
+    int m0, n0;
+    tile_of(bid, m0, n0);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nk = k_pad / GEMM_BK;
 
@@ -217,17 +233,21 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         // the loads then take the `saddr + voffset` form and a stage's pieces cost the loader wave no vector instruction at all.
         // (With per-lane 64-bit pointers every piece carried a v_lshl_add_u64 that had to find a slot on a SIMD whose vector issue
         // the two MFMA waves keep busy -- the loader waves, not the memory path, paced the stage.)
-        const unsigned char *abase = reinterpret_cast<const unsigned char *>(A + (size_t)m0 * lda);
-        const unsigned char *wbase = reinterpret_cast<const unsigned char *>(W3 + (size_t)n0 * ldw);
+        const unsigned char *abase, *wbase;
         unsigned la[NA], lw[NWL];
         int lw_dst[NWL];
+        auto setup = [&]() {                                // the tile at (m0, n0)
+            abase = reinterpret_cast<const unsigned char *>(A + (size_t)m0 * lda);
+            wbase = reinterpret_cast<const unsigned char *>(W3 + (size_t)n0 * ldw);
 #pragma unroll
-        for (int g = 0; g < NA; ++g) {
-            const int row = (li * NA + g) * 8 + dr;
-            int grow = m0 + row;
-            grow = grow < M ? grow : M - 1;                 // (M - 1 >= m0: the tile exists)
-            la[g] = (unsigned)(((grow - m0) * lda + ((dp ^ a_swz(row)) << 2)) * 4);
-        }
+            for (int g = 0; g < NA; ++g) {
+                const int row = (li * NA + g) * 8 + dr;
+                int grow = m0 + row;
+                grow = grow < M ? grow : M - 1;             // (M - 1 >= m0: the tile exists)
+                la[g] = (unsigned)(((grow - m0) * lda + ((dp ^ a_swz(row)) << 2)) * 4);
+            }
+        };
+        setup();
 #pragma unroll
         for (int g = 0; g < NWL; ++g) {
             int idx = li + SB_NL * g;
@@ -251,13 +271,22 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         // second wave of every SIMD between barriers kt and kt + 1 (main loop below).
         fill(0, 0);
         int nb = 1;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (!(F64 && LEAKY && MPE_SBEXP == 35) && !(!F64 && MPE_SBEXP == 45))               // (ablation 35 / 45: no landing wait)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage kt has landed ...
-            stage_barrier();                                        // ... and nobody reads the buffer stage kt + 1 goes to
-            if ((F64 && LEAKY && MPE_SBEXP == 34) || (!F64 && MPE_SBEXP == 44)) continue;          // (ablation 34 / 44: no staging at all)
-            if (kt + 1 < nk) fill(kt + 1, nb);
-            nb = nb + 1 == RING ? 0 : nb + 1;
+        for (int v = bid; v < nwg; v += vstep) {
+            const bool more = PERS && v + vstep < nwg;
+            for (int kt = 0; kt < nk; ++kt) {
+                if (!(F64 && LEAKY && MPE_SBEXP == 35) && !(!F64 && MPE_SBEXP == 45))               // (ablation 35 / 45: no landing wait)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage kt has landed ...
+                stage_barrier();                                        // ... and nobody reads the buffer stage kt + 1 goes to
+                if ((F64 && LEAKY && MPE_SBEXP == 34) || (!F64 && MPE_SBEXP == 44)) continue;          // (ablation 34 / 44: no staging at all)
+                if (kt + 1 < nk) {
+                    fill(kt + 1, nb);
+                } else if (more) {                                      // behind the last stage: stage 0 of this workgroup's next tile
+                    tile_of(v + vstep, m0, n0);
+                    setup();
+                    fill(0, nb);
+                }
+                nb = nb + 1 == RING ? 0 : nb + 1;
+            }
         }
         return;
     }
@@ -278,6 +307,9 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
     // Without f64 sums (GAT launches) the even and the odd K stages accumulate into separate fp32 chains that are added at the
     // end: half the chain length of a single accumulator (rms error 0.5-0.6 ulp of the output scale at K = 416 against 0.75 for one
     // chain and 0.91 for the fp32 MFMA chain it replaces), for 40 more registers (126 of the 128 that 2 x 8 waves per CU leave).
+    int b = 0;                                         // ring buffer of the stage in hand (runs on across the tiles of a persistent workgroup)
+    for (int v = bid; v < nwg; v += vstep) {
+    if (v != bid) tile_of(v, m0, n0);
     f32x4 acc[NTT][MT];
     f32x4 acc_odd[NTT][MT];               // (unused with F64: the compiler drops it)
     double run[F64 ? NTT : 1][MT][4];
@@ -383,7 +415,6 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
         };
-        int b = 0;                                     // buffer of the stage in hand (stage j lives in buffer j mod 3)
         auto buf_at = [&](int i) { return lds + i * STAGE; };
         auto next_b = [&](int i) { return i + 1 == RING ? 0 : i + 1; };
         if (wave < MW / 2) {
@@ -404,9 +435,9 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 flush(kt + 2 >= nk);
             }
         } else {
-            stage_barrier();                           // barrier 0
-            split_stage(buf_at(0));
-            even_half(buf_at(0), 0);
+            stage_barrier();                           // barrier 0 (of this tile)
+            split_stage(buf_at(b));
+            even_half(buf_at(b), 0);
             int kt = 1;
 #pragma unroll 1
             for (; kt + 1 < nk; kt += 2) {             // kt odd
@@ -433,6 +464,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 even_half(buf_at(b), 1);
             }
             flush(true);
+            b = next_b(b);                             // the first stage of the next tile
         }
     } else
     if (F64) {
@@ -537,6 +569,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 }
             }
     }
+    }      // tiles of this workgroup
 }
 
 // ---- one wave per 16 x 16 tile (small batches, narrow outputs): operands streamed from global memory --------------------------
@@ -742,12 +775,17 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     static PerDeviceFlag lds_attr;
     if (!lds_attr.test()) {
         hipError_t e = hipSuccess;
-        const void *fns[8] = {reinterpret_cast<const void *>(k_linear_sb<true, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW, SB_F64_MT>),
+        const void *fns[13] = {reinterpret_cast<const void *>(k_linear_sb<true, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW, SB_F64_MT>),
                               reinterpret_cast<const void *>(k_linear_sb<false, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW, SB_F64_MT>),
                               reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4>),
                               reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true>),
                               reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4, false, 8>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, false, 8>),
-                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true, 8>)};
+                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true, 8>),
+                              reinterpret_cast<const void *>(k_linear_sb<true, 4, true, 4, false, 8, 2, true>),
+                              reinterpret_cast<const void *>(k_linear_sb<false, 4, true, 4, false, 8, 2, true>),
+                              reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4, false, 8, 2, true>),
+                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, false, 8, 2, true>),
+                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true, 8, 2, true>)};
         for (const void *fn : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -760,6 +798,20 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, NL_, false, MW_, MT_>), dim3((unsigned)(((m_cap + 16 * MT_ * MW_ - 1) / (16 * MT_ * MW_)) * ntn)), \
                        dim3(64 * (MW_ + NL_)), sb_ring(MW_) * sb_stage_bytes(N_, MW_, MT_) + lds_pad, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, \
                        k_pad, slope, ntn, n_major)
+    // persistent form of the eight-wave launches: one workgroup per CU walking its tiles (grid = the CU count, a multiple of eight)
+    static const int pers_on = getenv("MPE_SB_PERS") ? atoi(getenv("MPE_SB_PERS")) : 7;       // bits: 1 f64-sum launches, 2 plain, 4 coefficient launches (0 = the plain grid of tiles: diagnostic)
+    static const int n_cu = [] {
+        int dev = 0, cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        return cu >= 8 ? cu / 8 * 8 : 8;
+    }();
+#define MPE_SBPERS(L_, N_, F_)                                                                                                      \
+    do {                                                                                                                            \
+        const int tiles = ((m_cap + 255) / 256) * ntn;                                                                              \
+        hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, 4, false, 8, 2, true>), dim3((unsigned)(tiles < n_cu ? tiles : n_cu)), dim3(768), \
+                           3 * sb_stage_bytes(N_, 8, 2) + lds_pad, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, \
+                           n_major);                                                                                                \
+    } while (0)
     // launches without f64 sums: eight MFMA waves (256 x 80 tiles, one workgroup per CU) or four (128 x 80, two per CU).  Measured
     // (one board, 180 000 rows): plain launches 257.7 against 267.5 us with eight; with the coefficient epilogue 336.1 against 333.9:
     // eight for the first, four for the second.  MPE_SB_GAT_MW = 4 | 8 forces one form for both (diagnostic).
@@ -771,12 +823,21 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         // 64-wide feature tiles: with 80 the f64 running sums of the wider wave tile do not fit the 168 registers that three waves per
         // SIMD leave (the compiler spills); the MLP's layers balance with 64 anyway
         const int ntn = (n + SB_F64_NTT * 16 - 1) / (SB_F64_NTT * 16);
+        if (pers_on & 1) {
+            if (leaky) MPE_SBPERS(true, 4, true);
+            else MPE_SBPERS(false, 4, true);
+        } else
         if (leaky) MPE_SB(true, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW, SB_F64_MT);
         else MPE_SB(false, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW, SB_F64_MT);
     } else if (with_coef) {
         // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile), as launch_linear
         const int ntn = (n + 79) / 80;
-        if (mw == 8)
+        if (pers_on & 4) {
+            const int tiles = ((m_cap + 255) / 256) * ntn;
+            hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true, 8, 2, true>), dim3((unsigned)(tiles < n_cu ? tiles : n_cu)), dim3(768),
+                               3 * sb_stage_bytes(5, 8), s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major,
+                               coef->attn_l, coef->attn_r, coef->a12, out_half ? 1 : 0);
+        } else if (mw == 8)
             hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true, 8>), dim3((unsigned)(ntm * ntn)), dim3(768), 3 * sb_stage_bytes(5, 8), s, A, lda,
                                W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12,
                                out_half ? 1 : 0);
@@ -787,7 +848,10 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         if (coef_done) *coef_done = true;
     } else {
         const int ntn = (n + 79) / 80;
-        if (mw == 8) {
+        if (mw == 8 && (pers_on & 2)) {
+            if (leaky) MPE_SBPERS(true, 5, false);
+            else MPE_SBPERS(false, 5, false);
+        } else if (mw == 8) {
             if (leaky) MPE_SB(true, 5, false, 4, 8, 2);
             else MPE_SB(false, 5, false, 4, 8, 2);
         } else {
@@ -796,6 +860,7 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         }
     }
 #undef MPE_SB
+#undef MPE_SBPERS
     return hipGetLastError();
 }
 
