@@ -19,8 +19,9 @@
 //   k_linear_sb         tile kernel, LDS-DMA staging from four loader waves (fp32 activation tile + three weight planes per
 //                       stage, `saddr + voffset` loads: no vector instruction per piece), one barrier per stage, two forms:
 //                       MW = 8  256 x 64|80 tiles, eight MFMA waves, ONE twelve-wave workgroup per CU, ring of three stages,
-//                               the second MFMA wave of every SIMD half a stage behind the first (f64-sum launches, plain GAT launches)
-//                       MW = 4  128 x 80 tiles, four MFMA waves, two eight-wave workgroups per CU, two stages (coefficient epilogue)
+//                               the second MFMA wave of every SIMD half a stage behind the first; PERSISTENT: the workgroup walks
+//                               its tiles, loaders running on across tile borders (every launch of the production path)
+//                       MW = 4  128 x 80 tiles, four MFMA waves, two eight-wave workgroups per CU, two stages (MPE_SB_GAT_MW=4)
 //   k_linear_sb_skinny  one wave per 16 x 16 tile, operands streamed from global memory (small batches, narrow outputs)
 //   k_linear_sb_ks      the same with the stage pairs of a tile dealt to eight waves and an ordered f64 reduction through LDS
 // What the tile kernel waits for, by ablation builds of it (make exp EXPFLAGS=-DMPE_SBEXP=n, tools/run_variants.sh):
