@@ -553,22 +553,29 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         }
     }
     if (A12) {
+        // (s0 + s1) + (s2 + s3) over the four lane groups: after the two exchanges all four lanes of a row hold the same bits, so
+        // lane group 0 stores the tile's a1 pair and lane group 1 its a2 pair, eight bytes each (heads 2 tn and 2 tn + 1 are
+        // neighbours in a row of a1 | a2) -- one store instruction per row tile where four scattered 4-byte ones stood
+        const int head0 = n0 / 40;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int mt = 0; mt < MT; ++mt) {
+            float x[2], y[2];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float x = pl[h][mt], y = pr[h][mt];
-                x = x + __shfl_xor(x, 16);
-                y = y + __shfl_xor(y, 16);
-                x = x + __shfl_xor(x, 32);
-                y = y + __shfl_xor(y, 32);
-                const int m = m0 + wave * 16 * MT + mt * 16 + fr;
-                const int head = (n0 / 40) + h;
-                if (fq == 0 && m < M && head * 40 < n && MPE_SBEXP != 46) {          // (ablation 46: no coefficient stores)
-                    a12[(size_t)m * 32 + head] = x;
-                    a12[(size_t)m * 32 + 16 + head] = y;
-                }
+            for (int h = 0; h < 2; ++h) {
+                x[h] = pl[h][mt];
+                y[h] = pr[h][mt];
+                x[h] = x[h] + __shfl_xor(x[h], 16);
+                y[h] = y[h] + __shfl_xor(y[h], 16);
+                x[h] = x[h] + __shfl_xor(x[h], 32);
+                y[h] = y[h] + __shfl_xor(y[h], 32);
             }
+            const int m = m0 + wave * 16 * MT + mt * 16 + fr;
+            if (m >= M || head0 * 40 >= n || MPE_SBEXP == 46 || fq > 1) continue;          // (ablation 46: no coefficient stores)
+            float *dst = a12 + (size_t)m * 32 + (fq ? 16 : 0) + head0;
+            const float v0 = fq ? y[0] : x[0], v1 = fq ? y[1] : x[1];
+            if ((head0 + 1) * 40 < n) *reinterpret_cast<float2 *>(dst) = make_float2(v0, v1);
+            else dst[0] = v0;
+        }
     }
     }      // tiles of this workgroup
 }
