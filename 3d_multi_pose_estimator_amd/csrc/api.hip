@@ -168,9 +168,13 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
                const int32_t *c_rows = nullptr, double flop_override = -1.0, const AttnCoef *coef = nullptr,
                bool *coef_done = nullptr) {
     if (coef_done) *coef_done = false;
-    // (fp16 result rows exist in the split kernel's coefficient epilogue only: the fc2 launches of 40-wide heads; the others of
-    // the fp16-attention mode stay on the fp32 MFMA)
-    const bool sb_half_ok = !out_half || (coef && coef->out_dim == 40 && L.out_dim == coef->heads * 40 && !leaky && L.in_dim <= 512 && !ctx->gat_acc64);
+    static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
+    const bool sb_f64 = ctx->gat_acc64 || (mink > 0 && L.in_dim > mink);
+    // (fp16 result rows exist in the split TILE kernel's coefficient epilogue only: the fc2 launches of 40-wide heads at batch
+    // sizes the tile kernel takes, without f64 sums; every other launch of the fp16-attention mode stays on the fp32 MFMA, whose
+    // tile and wave-per-tile kernels all store fp16 rows)
+    const bool sb_half_ok = !out_half || (coef && coef->out_dim == 40 && L.out_dim == coef->heads * 40 && !leaky && !sb_f64 &&
+                                          linear_sb16_uses_tile_kernel(m, L.out_dim, false));
     // (launches with gathered rows -- layer-0 fc1 per camera -- stay on the fp32 MFMA; the grouped layer-0 launch does not come here)
     // In the explicit f64-sum mode (mpe_set_precision GAT 1 on top of the split form) layer 0's fc2 keeps the fp32 MFMA with a
     // flush per 32-deep stage: the split form flushes every second stage, and on the K = 902 sum of the steep layer-0 features
@@ -179,8 +183,7 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
     const bool l0_fc2_f64_mode = ctx->gat_acc64 && &L == &ctx->gat[0].fc2;
     if (ctx->gat_split && !ctx->gat_reduced && sb_half_ok && !a_rows && !c_rows && L.w != ctx->l0_w && !l0_fc2_f64_mode) {
         // split-bf16 form (gemm_sb16.hip): fp32-accurate products on the bf16 matrix pipe; f64 sums where the fp32 path has them
-        static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
-        const bool f64 = ctx->gat_acc64 || (mink > 0 && L.in_dim > mink);
+        const bool f64 = sb_f64;
         if (m <= 0) return MPE_OK;
         int rc = ensure_split_weights(ctx, s, &L);
         if (rc) return rc;
@@ -198,8 +201,7 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
         // score noise (ARPLAB frames of random shape: 3.2e-5 from the reference with it, 2.3e-5 without, where
         // the reference's own fp32 scores sit 1.8e-5 from the float64 network).  MPE_GAT_ACC64_MINK overrides
         // the threshold (0 = never), mpe_set_precision(ctx, 1, .) extends it to every GAT GEMM.
-        static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
-        const bool acc64 = ctx->gat_acc64 || (mink > 0 && L.in_dim > mink);
+        const bool acc64 = sb_f64;
         // out_half here = the fp16-attention mode (fp32 MFMA GEMM, result rows stored as fp16)
         return linear(ctx, s, A, lda, L, C, ldc, m, d_m, leaky, slope, acc64, a_rows, c_rows, flop_override, coef, coef_done, out_half);
     }
@@ -766,7 +768,11 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
         // split-bf16 arithmetic (gemm_sb16.hip) on caller-provided weights: the planes are made for this call (a stage-level
         // entry point for tests; the batch entry points keep theirs with the context)
         hipStream_t s = static_cast<hipStream_t>(stream);
+        // (d_w must hold weight_rows(n) = round_up(n, 16) + 208 rows of ldw floats, zero padded, as mpe_upload_linear prepares
+        // them: the planes are made of all of them, and the loader's 32-bit per-lane offset covers 3 planes of that size)
         const size_t count = (size_t)weight_rows(n) * ldw;
+        if (3 * count * sizeof(unsigned short) >= ((size_t)1 << 32))
+            return fail(ctx, MPE_ERR_INVALID, "mpe_linear (split form): n x ldw too large for the 32-bit plane offsets");
         unsigned short *planes = nullptr;
         HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&planes), 3 * count * sizeof(unsigned short)));
         hipError_t e = launch_split_planes(s, d_w, count, planes);
@@ -1062,7 +1068,7 @@ int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
     if (gat_acc64 < 0 || gat_acc64 > 6 || mlp_acc64 < 0 || mlp_acc64 > 3)
         return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0..6, MLP 0|1|2|3");
     // GAT modes 4 / 5: modes 0 / 1 with the GEMMs of layers >= 1 in the split-bf16 form (4 = the default); 6 = mode 3 likewise
-    // (the fc2 launches that store fp16 rows stay on the fp32 MFMA)
+    // (fp16 rows: from the split tile kernel's coefficient epilogue where gat_linear finds it applicable, the fp32 MFMA otherwise)
     ctx->gat_split = gat_acc64 >= 4;
     if (gat_acc64 >= 4) gat_acc64 = gat_acc64 == 4 ? 0 : gat_acc64 == 5 ? 1 : 3;
     ctx->gat_acc64 = gat_acc64 == 1;

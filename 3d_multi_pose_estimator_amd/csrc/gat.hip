@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_topology_explicit(int n_frames, const i
     int flag = 0;
     uint16_t *tab = head_src + (size_t)f * hmax * deg_cap;
     // one thread per head row of the table; deg = entries written so far
-    int deg_a[4];                                   // rows t, t + 256, ... (hmax < 1024 in explicit mode: checked by the caller)
+    int deg_a[4];                                   // rows t, t + 256, ... (hmax <= 1024 = 4 x 256 rows in explicit mode: checked by the caller)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int h = t + r * 256;

@@ -738,16 +738,38 @@ hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsi
 
 // Same dispatch rules as launch_linear's f64-sum branch (gemm.hip): K split over eight waves / one wave per 16 x 16 tile for
 // small batches and for outputs of at most four 16-wide tiles at any batch size, the tile kernel otherwise.
+static int sb_skinny_waves() {
+    static const int v = getenv("MPE_SKINNY_WAVES") ? atoi(getenv("MPE_SKINNY_WAVES")) : 1024;
+    return v;
+}
+static int sb_narrow_on() {
+    static const int v = getenv("MPE_GEMM_NARROW") ? atoi(getenv("MPE_GEMM_NARROW")) : 1;
+    return v;
+}
+
+// Does launch_linear_sb16 take the tile kernel for this shape?  (Only the tile kernel's coefficient epilogue stores fp16 rows:
+// callers that want `out_half` ask here first and keep the launch on the fp32 MFMA otherwise.)
+bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64) {
+    const int nt16 = (n + 15) / 16;
+    const long waves16 = (long)((m_cap + 15) / 16) * nt16;
+    const bool narrow = sb_narrow_on() && nt16 <= (f64 ? 4 : 1);
+    return !(waves16 <= sb_skinny_waves() || narrow);
+}
+
 hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                               float slope, bool f64, const AttnCoef *coef, bool *coef_done, bool out_half) {
     if (coef_done) *coef_done = false;
     if (m_cap <= 0 || n <= 0) return hipSuccess;
-    static const int skinny_waves = getenv("MPE_SKINNY_WAVES") ? atoi(getenv("MPE_SKINNY_WAVES")) : 1024;
-    static const int narrow_on = getenv("MPE_GEMM_NARROW") ? atoi(getenv("MPE_GEMM_NARROW")) : 1;
+    const int skinny_waves = sb_skinny_waves();
+    const int narrow_on = sb_narrow_on();
     const int nt16 = (n + 15) / 16, nk = k_pad / GEMM_BK;
     const long waves16 = (long)((m_cap + 15) / 16) * nt16;
     const bool narrow = narrow_on && nt16 <= (f64 ? 4 : 1);
+    // fp16 result rows exist in the tile kernel's coefficient epilogue only: refuse the launch rather than store fp32 rows into a
+    // buffer the caller strides in halves
+    if (out_half && (f64 || leaky || waves16 <= skinny_waves || narrow || !(coef && coef->out_dim == 40 && n == coef->heads * 40)))
+        return hipErrorInvalidValue;
     if (f64 && (waves16 <= skinny_waves || narrow) && nk <= 256 && nk >= 8) {
         const size_t shm = (size_t)((nk + 1) / 2) * 1024;
         static PerDeviceFlag attr_done;

@@ -157,7 +157,8 @@ struct AttnCoef {              // fc2 of a graph-attention layer: also emit a1|a
 hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                               float slope, bool f64 = true, const AttnCoef *coef = nullptr, bool *coef_done = nullptr,
-                              bool out_half = false);     // out_half: only with the coefficient epilogue (fp16 ft2 rows, configs[4])
+                              bool out_half = false);     // out_half: only with the tile kernel's coefficient epilogue (fp16 ft2 rows, configs[4]); hipErrorInvalidValue otherwise
+bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64);
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64, const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr,

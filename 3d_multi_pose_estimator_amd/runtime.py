@@ -69,7 +69,9 @@ def calibration_from_dicts(params, camera_matrices, distortion_coefficients, pro
 # frame and has the frame's arrays on the device, so it computes every person's row with one mpe_mlp_input_rows launch and
 # leaves them here, keyed by exactly the strings the caller is about to hand to PoseEstimatorDataset
 # (json.dumps([jsons_for_head[head]]) per camera, :250-252).  A row is a pure function of those strings and the
-# calibration, so an entry can never be stale; PoseEstimatorDataset falls back to its own launch on a miss.
+# calibration, and the key holds both BY CONTENT (the calibration as the hash of its arrays, not the object's id, which
+# CPython may hand to another calibration later), so an entry cannot be stale; PoseEstimatorDataset falls back to its
+# own launch on a miss.
 # MPE_DROPIN_PREFETCH=0 switches the prefetch off.
 _row_cache = {}
 _ROW_CACHE_CAP = 512
@@ -103,4 +105,7 @@ def cached_mlp_row(eng, key):
 
 
 def _engine_key(eng):
-    return id(eng.calib)
+    k = getattr(eng, '_calib_content_key', None)
+    if k is None:
+        k = eng._calib_content_key = _calib_key(eng.calib)
+    return k

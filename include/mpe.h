@@ -102,7 +102,10 @@ typedef struct {
      * camera slot and one edge-node per ORDERED head pair -- or any other pair list.  The heads may then come in any
      * order; d_slot_cam / d_slot_n are not read and may be NULL.  Per-frame limits, checked on the device and reported by
      * mpe_sync_status: heads <= max_heads_per_frame, edge-nodes <= the power of two >= max(512, max_heads_per_frame^2 / 2 + 1),
-     * every pair inside its frame with h1 != h2 (else MPE_ERR_INVALID).  Available on contexts with
+     * every pair inside its frame with h1 != h2 (else MPE_ERR_INVALID).  A process_training-style graph holds one edge-node per ORDERED
+     * cross-camera head pair, up to H^2 (V - 1) / V of them: with V = 5 a frame of H heads fits while 0.8 H^2 <= that power of two
+     * (H <= 35 at max_heads_per_frame = 40, whose capacity is 1024) -- a larger frame is reported (MPE_ERR_CAPACITY), never
+     * truncated; raise max_heads_per_frame to make room.  Available on contexts with
      * max_heads_per_frame <= 1024 whose per-frame node ids fit 16 bits (MPE_ERR_UNSUPPORTED otherwise). */
     const int32_t *d_en_pair;
 } mpe_batch;
@@ -141,8 +144,10 @@ int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_d
  * results, the attention coefficients a1/a2 still come from the fp32 values in the GEMM epilogue -- and fc1/fc2 stay
  * on the fp32 MFMA.  GAT modes 4 (the GAT DEFAULT since round 4), 5 and 6 are modes 0, 1 and 3 with fc1 / fc2 of the layers
  * >= 1 in the split-bf16 form of MLP mode 3 (fp32-accurate: rms error of a launch at or below the fp32 MFMA chain's, 1.5x
- * faster launches; without f64 sums where mode 0 has none); layer 0 (head rows only, gathered launches) and the launches
- * that store fp16 rows stay on the fp32 MFMA. */
+ * faster launches; without f64 sums where mode 0 has none); layer 0's gathered launches stay on the fp32 MFMA.  In mode 6 the
+ * fc2 launches of 40-wide attention heads store their fp16 rows from the split tile kernel's coefficient epilogue when the
+ * batch is large enough for the tile kernel (more than MPE_SKINNY_WAVES = 1024 16 x 16 tiles); every other fp16-row launch
+ * (small batches, 30-wide and 1-wide heads, f64-sum launches) stays on the fp32 MFMA, whose kernels all store fp16 rows. */
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64);
 
 /* ---- batch entry points ---------------------------------------------------------------

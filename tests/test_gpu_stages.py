@@ -262,6 +262,37 @@ def test_reduced_mode_cluster_agreement_with_oracle(tmp_path, mode):
         eng.close()
 
 
+@pytest.mark.parametrize('n_frames', [1, 3, 9])
+def test_attn_fp16_small_batches_split_form_equals_fp32_mfma_form(n_frames):
+    """`attn_fp16` at batch sizes BELOW the split tile kernel's switch-over (a few 5x4 frames: the wave-per-tile kernels, which
+    store fp32 rows only).  Round 4 routed the fp16-row fc2 launches of GAT mode 6 there: fp32 rows written into a buffer strided
+    in halves.  Mode 6 (split GEMMs) must give what mode 3 (fp32 MFMA, whose wave-per-tile kernels store fp16
+    rows) gives up to the fp16 rounding of the rows, and both must sit within the mode's bound of the fp32 scores."""
+    onp = oracle()
+    syn = pkg('synthetic')
+    e = env('panoptic')
+    sd, prm = e.gat
+    eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=n_frames, max_persons_per_camera=4)
+    try:
+        eng.load_gat(sd, prm)
+        frames = [onp.processed_input(syn.make_frame(e.calib, 4100 + i, syn.FrameSpec(persons=4, noise_px=1.0))[0])
+                  for i in range(n_frames)]
+        db = eng.to_device(eng.pack(frames))
+        eng.set_precision(False, False)
+        s32 = eng.gat_scores(db).cpu().numpy()
+        eng.set_precision(False, False, attn_fp16=True, gat_split=False)
+        s_mfma = eng.gat_scores(db).cpu().numpy()
+        eng.set_precision(False, False, attn_fp16=True)                 # gat_split defaults to True: mode 6
+        s_split = eng.gat_scores(db).cpu().numpy()
+        eng.sync_status()
+        assert np.isfinite(s_split).all()
+        assert np.abs(s_mfma - s32).max() < ATTN_FP16_SCORE_BOUND
+        assert np.abs(s_split - s32).max() < ATTN_FP16_SCORE_BOUND, np.abs(s_split - s32).max()
+        assert np.abs(s_split - s_mfma).max() < ATTN_FP16_SCORE_BOUND
+    finally:
+        eng.close()
+
+
 def test_cfg4_as_worded_full_shape_vs_oracle():
     """BASELINE configs[4] as it is worded -- "23-view x 10-person stress; fp16 GATv2 attention + bf16 MLP MFMA GEMM" -- at
     its FULL shape: fp16 ft2 rows in the attention stage only (the GAT GEMMs stay on the fp32 MFMA, the attention
