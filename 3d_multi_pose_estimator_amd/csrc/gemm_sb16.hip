@@ -580,6 +580,311 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
     }      // tiles of this workgroup
 }
 
+// ---- the 32 x 32 x 16 form of the tile kernel ----------------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16: the same matrix-pipe time per product as the 16 x 16 x 32 instruction (32 against 16 cycles for twice
+// the products) but HALF the vector-issue slots per product -- an MFMA of either shape holds the SIMD's vector issue for 8 cycles
+// (MI355X_MICROARCH.md, cycle constants), and the f64-sum launches are bound by vector issue: per stage pair and SIMD 192 MFMAs x 8
+// + the split arithmetic + the half-rate f64 flush = ~4100 issue cycles against 3072 cycles of matrix-pipe time.
+// A wave still owns 32 rows x NC * 32 features; per 32-deep stage it reads the same 4 + 6 NC fragments from LDS and splits the
+// same 16 activation values per lane, and issues 12 NC MFMAs of 32 cycles instead of 24 NC of 16.
+// Lane layout (l = lane, g = l >> 5): both operands hold row (l & 31), k = 8 g .. 8 g + 7 of a 16-deep half-stage h (k = 16 h + 8 g +
+// 0..7 of the stage); the result holds, for activation row (l & 31), the features 8 b + 4 g + 0..3 of the tile for b = 0..3 in
+// registers 4 b .. 4 b + 3.  In-stage order: half-stage 0 then half-stage 1, each the canonical six products.
+__device__ __forceinline__ int a_swz32(int row) { return (row >> 1) & 7; }      // 128-byte rows read by 32-row lane groups: conflict-free
+                                                                                // in the four ds_read_b128 groups (rows {0-3, 12-15, 20-27} | {4-11, 16-19, 28-31})
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define SB32_CHAIN(ACC, A, W, ZERO)                                                                                   \
+    do {                                                                                                              \
+        if (ZERO) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[2], (A)[0], (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+        else ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[2], (A)[0], ACC, 0, 0, 0);                             \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[1], (A)[1], ACC, 0, 0, 0);                                  \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[1], (A)[0], ACC, 0, 0, 0);                                  \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[0], (A)[2], ACC, 0, 0, 0);                                  \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[0], (A)[1], ACC, 0, 0, 0);                                  \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[0], (A)[0], ACC, 0, 0, 0);                                  \
+    } while (0)
+
+__host__ __device__ constexpr int sb32_stage_bytes(int nc) { return 256 * GEMM_BK * 4 + 3 * nc * 32 * GEMM_BK * 2; }
+
+// NC = 32-wide column tiles per wave; FL = stages per f64 flush (F64 only: 2 = the default cadence, 1 = a flush per stage)
+template <bool LEAKY, int NC, bool F64, int FL = 2>
+__global__ __launch_bounds__(768, 3) void k_linear_sb32(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
+                                                        size_t w_plane, int ldw, const float *__restrict__ bias, float *__restrict__ C,
+                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n, int k_pad, float slope,
+                                                        int ntn, int n_major) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    auto stage_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    constexpr int MW = 8, SB_NL = 4, BM = 256, RING = 3;
+    constexpr int STAGE = sb32_stage_bytes(NC);
+    constexpr int SB_A_BYTES = BM * GEMM_BK * 4;
+    constexpr int WPL = NC * 32 * GEMM_BK * 2;         // bytes of one weight plane of a stage
+    static_assert(FL == 1 || FL == 2, "flush per stage or per stage pair");
+    int M = m_cap;
+    if (d_m) {
+        const int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    const int ntm = (M + BM - 1) / BM;
+    const int bid = blockIdx.x, nwg = ntm * ntn;
+    if (bid >= nwg) return;
+    const int vstep = (int)gridDim.x;
+    auto tile_of = [&](int v, int &m0o, int &n0o) {
+        const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        int tm, tn;
+        if (n_major) {
+            constexpr int RB = 8;
+            const int band = swz / (RB * ntn), rem = swz - band * (RB * ntn);
+            const int rows = ntm - band * RB < RB ? ntm - band * RB : RB;
+            tn = rem / rows;
+            tm = band * RB + (rem - tn * rows);
+        } else {
+            tm = swz / ntn;
+            tn = swz - tm * ntn;
+        }
+        m0o = tm * BM;
+        n0o = tn * NC * 32;
+    };
+    int m0, n0;
+    tile_of(bid, m0, n0);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nk = k_pad / GEMM_BK;
+
+    if (wave >= MW) {
+        // ---- loader waves (as k_linear_sb): 32 activation groups (8 rows x 128 B) + 3 x 2 NC weight groups (16 rows x 64 B) per stage
+        const int li = wave - MW;
+        const int dr = lane >> 3, dp = lane & 7, wr = lane >> 2, wc = lane & 3;
+        __builtin_amdgcn_s_setprio(3);
+        constexpr int NA = (BM / 8) / SB_NL;
+        constexpr int NG = 2 * NC, NW = 3 * NG, NWL = (NW + SB_NL - 1) / SB_NL;
+        const unsigned char *abase, *wbase;
+        unsigned la[NA], lw[NWL];
+        int lw_dst[NWL];
+        auto setup = [&]() {
+            abase = reinterpret_cast<const unsigned char *>(A + (size_t)m0 * lda);
+            wbase = reinterpret_cast<const unsigned char *>(W3 + (size_t)n0 * ldw);
+#pragma unroll
+            for (int g = 0; g < NA; ++g) {
+                const int row = (li * NA + g) * 8 + dr;
+                int grow = m0 + row;
+                grow = grow < M ? grow : M - 1;
+                la[g] = (unsigned)(((grow - m0) * lda + ((dp ^ a_swz32(row)) << 2)) * 4);
+            }
+        };
+        setup();
+#pragma unroll
+        for (int g = 0; g < NWL; ++g) {
+            int idx = li + SB_NL * g;
+            idx = idx < NW ? idx : NW - 1;
+            const int p = idx / NG, grp = idx - p * NG;
+            const int row = grp * 16 + wr;
+            lw[g] = (unsigned)((p * w_plane + (size_t)row * ldw + ((wc ^ w_swz(row)) << 3)) * 2);
+            lw_dst[g] = SB_A_BYTES + p * WPL + grp * 1024;
+        }
+        auto fill = [&](int kt, int buf) {
+            const unsigned base = (unsigned)(size_t)(lds_void *)lds + (unsigned)(buf * STAGE);
+            const unsigned char *ab = abase + (size_t)kt * (GEMM_BK * 4), *wb = wbase + (size_t)kt * (GEMM_BK * 2);
+#pragma unroll
+            for (int g = 0; g < NA; ++g) glds16(la[g], ab, base + (unsigned)((li * NA + g) * 8 * 128));
+#pragma unroll
+            for (int g = 0; g < NWL; ++g)
+                if ((g + 1) * SB_NL <= NW || li + SB_NL * g < NW) glds16(lw[g], wb, base + (unsigned)lw_dst[g]);
+        };
+        fill(0, 0);
+        int nb = 1;
+        for (int v = bid; v < nwg; v += vstep) {
+            const bool more = v + vstep < nwg;
+            for (int kt = 0; kt < nk; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage kt has landed ...
+                stage_barrier();                                        // ... and nobody reads the buffer stage kt + 1 goes to
+                if (kt + 1 < nk) {
+                    fill(kt + 1, nb);
+                } else if (more) {
+                    tile_of(v + vstep, m0, n0);
+                    setup();
+                    fill(0, nb);
+                }
+                nb = nb + 1 == RING ? 0 : nb + 1;
+            }
+        }
+        return;
+    }
+
+    // ---- MFMA waves: 32 rows x NC * 32 features each ----
+    const int g = lane >> 5, r32 = lane & 31;
+    const int a_row = (wave * 32 + r32) * 128;
+    int a_c[2][2], w_rd[2];
+    {
+        const int asw = a_swz32(r32);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            a_c[h][0] = a_row + (((4 * h + 2 * g) ^ asw) << 4);
+            a_c[h][1] = a_row + (((4 * h + 2 * g + 1) ^ asw) << 4);
+            w_rd[h] = SB_A_BYTES + r32 * 64 + (((2 * h + g) ^ w_swz(r32)) << 4);      // (+ c * 2048 per column tile: w_swz repeats every 16 rows)
+        }
+    }
+    int b = 0;
+    for (int v = bid; v < nwg; v += vstep) {
+        if (v != bid) tile_of(v, m0, n0);
+        f32x16 acc[NC], acc_odd[F64 ? 1 : NC];
+        double run[F64 ? NC : 1][16];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[c][i] = 0.f;
+                if (!F64) acc_odd[c][i] = 0.f;
+                if (F64) run[F64 ? c : 0][i] = 0.0;
+            }
+        }
+        // A stage of a wave = 2 NC chains of six MFMAs, chain q = (column tile q >> 1, half-stage q & 1).  The weight fragments of
+        // chain q + 1 are requested before chain q is issued (its 192 cycles of MFMAs cover their LDS latency), those of chain 0
+        // together with the activation fragments, in front of the split arithmetic: left to itself the compiler requests a chain's
+        // fragments right in front of it (at 161 registers it has no room to do otherwise) and every chain starts with an LDS round trip.
+        bf16x8 ap[2][3], wnext[3];
+        auto prefetch = [&](const unsigned char *buf, const int q) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wnext[p] = *reinterpret_cast<const bf16x8 *>(buf + p * WPL + (q >> 1) * 2048 + w_rd[q & 1]);
+        };
+        auto chain = [&](const unsigned char *buf, const int q, f32x16 (&ACC)[NC], const bool zero) {
+            const bf16x8 wc[3] = {wnext[0], wnext[1], wnext[2]};
+            if (q + 1 < 2 * NC) prefetch(buf, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            SB32_CHAIN(ACC[q >> 1], ap[q & 1], wc, zero && (q & 1) == 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int NH = (NC + 1) / 2;               // column tiles of the first half of a stage
+        // first piece of a stage: fragments, split arithmetic, the chains of the first NH column tiles; second piece: the others
+        auto piece_a = [&](const unsigned char *buf, f32x16 (&ACC)[NC], const bool zero) {
+            if (F64) __builtin_amdgcn_s_setprio(SB_PRIO_SPLIT);
+            f32x4 x[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                x[h][0] = *reinterpret_cast<const f32x4 *>(buf + a_c[h][0]);
+                x[h][1] = *reinterpret_cast<const f32x4 *>(buf + a_c[h][1]);
+            }
+            prefetch(buf, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) split8(x[h][0], x[h][1], ap[h][0], ap[h][1], ap[h][2]);
+            if (F64) __builtin_amdgcn_s_setprio(SB_PRIO_MFMA);
+#pragma unroll
+            for (int q = 0; q < 2 * NH; ++q) chain(buf, q, ACC, zero);
+        };
+        auto piece_b = [&](const unsigned char *buf, f32x16 (&ACC)[NC], const bool zero) {
+            if (F64) __builtin_amdgcn_s_setprio(SB_PRIO_MFMA);
+#pragma unroll
+            for (int q = 2 * NH; q < 2 * NC; ++q) chain(buf, q, ACC, zero);
+        };
+        auto even_a = [&](const unsigned char *buf) { piece_a(buf, acc, F64); };
+        auto even_b = [&](const unsigned char *buf) { piece_b(buf, acc, F64); };
+        auto odd_a = [&](const unsigned char *buf) {
+            if constexpr (F64) piece_a(buf, acc, FL == 1);
+            else piece_a(buf, acc_odd, false);
+        };
+        auto odd_b = [&](const unsigned char *buf) {
+            if constexpr (F64) piece_b(buf, acc, FL == 1);
+            else piece_b(buf, acc_odd, false);
+        };
+        // f64 flush of the column tiles [c0, c1)
+        auto flush_cols = [&](const int c0, const int c1) {
+            if constexpr (F64) {
+                __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (c >= c0 && c < c1) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) run[c][i] += (double)acc[c][i];
+                    }
+            }
+        };
+        auto flush = [&]() { flush_cols(0, NC); };
+        auto buf_at = [&](int i) { return lds + i * STAGE; };
+        auto next_b = [&](int i) { return i + 1 == RING ? 0 : i + 1; };
+        if (wave < MW / 2) {
+#pragma unroll 1
+            for (int kt = 0; kt < nk; kt += 2) {
+                stage_barrier();                       // barrier kt: stage kt has landed
+                even_a(buf_at(b));
+                even_b(buf_at(b));
+                b = next_b(b);
+                if (FL == 1) flush();
+                if (kt + 1 < nk) {
+                    stage_barrier();
+                    odd_a(buf_at(b));
+                    odd_b(buf_at(b));
+                    b = next_b(b);
+                    flush();
+                } else if (FL == 2) flush();
+            }
+        } else {
+            // the second MFMA wave of every SIMD: the loop rotated by half a stage (k_linear_sb has the protocol)
+            stage_barrier();                           // barrier 0 (of this tile)
+            even_a(buf_at(b));
+            if (FL == 1) flush_cols(0, NH);
+            int kt = 1;
+#pragma unroll 1
+            for (; kt + 1 < nk; kt += 2) {             // kt odd
+                stage_barrier();                       // barrier kt
+                even_b(buf_at(b));                     // second piece of stage kt - 1
+                if (FL == 1) flush_cols(NH, NC);
+                b = next_b(b);
+                odd_a(buf_at(b));
+                if (FL == 1) flush_cols(0, NH);
+                stage_barrier();                       // barrier kt + 1
+                odd_b(buf_at(b));
+                if (FL == 1) flush_cols(NH, NC);
+                else flush();
+                b = next_b(b);
+                even_a(buf_at(b));
+                if (FL == 1) flush_cols(0, NH);
+            }
+            if (kt < nk) {                             // nk even: one odd stage left
+                stage_barrier();
+                even_b(buf_at(b));
+                if (FL == 1) flush_cols(NH, NC);
+                b = next_b(b);
+                odd_a(buf_at(b));
+                odd_b(buf_at(b));
+                flush();
+            } else {                                   // nk odd: the last (even) stage has its first piece done
+                even_b(buf_at(b));
+                if (FL == 1) flush_cols(NH, NC);
+                else flush();
+            }
+            b = next_b(b);                             // the first stage of the next tile
+        }
+        const int m = m0 + wave * 32 + r32;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nb = n0 + c * 32 + q * 8 + g * 4;
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x;
+                    if constexpr (F64) x = (float)(run[c][4 * q + i] + (double)bv[i]);
+                    else x = (acc[c][4 * q + i] + acc_odd[c][4 * q + i]) + bv[i];
+                    if (LEAKY) x = x > 0.f ? x : x * slope;
+                    o[i] = x;
+                }
+                if (m >= M) continue;
+                float *dst = C + (size_t)m * ldc + nb;
+                if (nb + 3 < n) {
+                    *reinterpret_cast<f32x4 *>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < n) dst[i] = o[i];
+                }
+            }
+        }
+    }      // tiles of this workgroup
+}
+
 // ---- one wave per 16 x 16 tile (small batches, narrow outputs): operands streamed from global memory --------------------------
 constexpr int SBS_DEPTH = 4;
 
@@ -822,6 +1127,38 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         lds_attr.set();
     }
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
+    static const int m32_on = getenv("MPE_SB_M32") ? atoi(getenv("MPE_SB_M32")) : 0;      // 32 x 32 x 16 form: bits 1 f64-sum launches, 2 plain launches
+    if ((f64 && (m32_on & 1)) || (!f64 && (m32_on & 2) && !(coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky))) {
+        static PerDeviceFlag attr32;
+        if (!attr32.test()) {
+            hipError_t e = hipSuccess;
+            const void *fns[] = {reinterpret_cast<const void *>(k_linear_sb32<true, 2, true>), reinterpret_cast<const void *>(k_linear_sb32<false, 2, true>),
+                                 reinterpret_cast<const void *>(k_linear_sb32<true, 2, true, 1>), reinterpret_cast<const void *>(k_linear_sb32<false, 2, true, 1>),
+                                 reinterpret_cast<const void *>(k_linear_sb32<true, 3, false>), reinterpret_cast<const void *>(k_linear_sb32<false, 3, false>),
+                                 reinterpret_cast<const void *>(k_linear_sb32<true, 2, false>), reinterpret_cast<const void *>(k_linear_sb32<false, 2, false>)};
+            for (const void *fn : fns)
+                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr32.set();
+        }
+        int dev = 0, cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        cu = cu >= 8 ? cu / 8 * 8 : 8;
+        static const int nc_plain = getenv("MPE_SB_M32_NC") ? atoi(getenv("MPE_SB_M32_NC")) : 3;
+        const int nc = f64 ? 2 : nc_plain == 2 ? 2 : 3;
+        const int ntn = (n + nc * 32 - 1) / (nc * 32);
+        const int tiles = ((m_cap + 255) / 256) * ntn;
+        const dim3 grid((unsigned)(tiles < cu ? tiles : cu)), block(768);
+        const size_t shm = 3 * (size_t)sb32_stage_bytes(nc);
+        static const int fl1 = getenv("MPE_SB_FL1") ? atoi(getenv("MPE_SB_FL1")) : 0;
+#define MPE_SB32(L_, N_, F_, FL_) hipLaunchKernelGGL((k_linear_sb32<L_, N_, F_, FL_>), grid, block, shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major)
+        if (f64 && fl1) { if (leaky) MPE_SB32(true, 2, true, 1); else MPE_SB32(false, 2, true, 1); }
+        else if (f64) { if (leaky) MPE_SB32(true, 2, true, 2); else MPE_SB32(false, 2, true, 2); }
+        else if (nc == 2) { if (leaky) MPE_SB32(true, 2, false, 2); else MPE_SB32(false, 2, false, 2); }
+        else { if (leaky) MPE_SB32(true, 3, false, 2); else MPE_SB32(false, 3, false, 2); }
+#undef MPE_SB32
+        return hipGetLastError();
+    }
     // diagnostic: extra dynamic LDS per workgroup (occupancy experiments: how many workgroups does a CU really hold?)
     static const int lds_pad = getenv("MPE_SB_LDS_PAD") ? atoi(getenv("MPE_SB_LDS_PAD")) * 1024 : 0;
 #define MPE_SB(L_, N_, F_, NL_, MW_, MT_)                                                                                           \
