@@ -54,6 +54,24 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// In-kernel clock of a launch (MI355X_MICROARCH.md, DVFS give-back item 6), DIAGNOSTIC builds only (make exp EXPFLAGS=-DMPE_SB_CLOCK,
+// tools/sb_clock_probe.py): the first MFMA wave of every workgroup stamps the shader clock (s_memtime) and the constant 100 MHz
+// clock (s_memrealtime) around its tile loop into a buffer nothing else reads.  The product build has no stamp.
+#ifdef MPE_SB_CLOCK
+__device__ unsigned long long g_sb_stamp[1024][4];
+#define SB_STAMP(SLOT)                                                                              \
+    do {                                                                                            \
+        if (threadIdx.x == 0) {                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            g_sb_stamp[blockIdx.x & 1023][SLOT] = __builtin_amdgcn_s_memtime();                     \
+            g_sb_stamp[blockIdx.x & 1023][(SLOT) + 1] = __builtin_amdgcn_s_memrealtime();           \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+        }                                                                                           \
+    } while (0)
+#else
+#define SB_STAMP(SLOT) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
     bf2 v = {(__bf16)lo, (__bf16)hi};                    // v_cvt_pk_bf16_f32: round to nearest even
@@ -309,6 +327,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
     // end: half the chain length of a single accumulator (rms error 0.5-0.6 ulp of the output scale at K = 416 against 0.75 for one
     // chain and 0.91 for the fp32 MFMA chain it replaces), for 40 more registers (126 of the 128 that 2 x 8 waves per CU leave).
     int b = 0;                                         // ring buffer of the stage in hand (runs on across the tiles of a persistent workgroup)
+    SB_STAMP(0);
     for (int v = bid; v < nwg; v += vstep) {
     if (v != bid) tile_of(v, m0, n0);
     f32x4 acc[NTT][MT];
@@ -578,6 +597,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         }
     }
     }      // tiles of this workgroup
+    SB_STAMP(2);
 }
 
 // ---- the 32 x 32 x 16 form of the tile kernel ----------------------------------------------------------------------------------
@@ -725,6 +745,7 @@ __global__ __launch_bounds__(768, 3) void k_linear_sb32(const float *__restrict_
         }
     }
     int b = 0;
+    SB_STAMP(0);
     for (int v = bid; v < nwg; v += vstep) {
         if (v != bid) tile_of(v, m0, n0);
         f32x16 acc[NC], acc_odd[F64 ? 1 : NC];
@@ -883,6 +904,268 @@ __global__ __launch_bounds__(768, 3) void k_linear_sb32(const float *__restrict_
             }
         }
     }      // tiles of this workgroup
+    SB_STAMP(2);
+}
+
+// ---- the 32 x 32 x 16 form, software-pipelined: every MFMA wave hides its OWN vector work under its OWN MFMAs -----------------
+// What the twelve-wave kernels above wait for is that the two MFMA waves of a SIMD do not overlap: per stage and SIMD they take
+// about the SUM of their instruction streams (MFMAs 1536 cycles of matrix-pipe time + fragment waits + split arithmetic + flush),
+// not the maximum -- measured 3340 cycles per stage and SIMD for the f64-sum launches, where either form's issue-slot count would
+// allow ~2000.  With the 16 x 16 x 32 instruction a wave cannot help itself: an MFMA holds the vector issue
+// for 8 of its 16 cycles and two other vector instructions fill the rest.  The 32 x 32 x 16 instruction leaves 24 of 32 cycles:
+// six vector instructions per MFMA, and a stage has 24 MFMAs for 88 instructions of split arithmetic and 32 (64 at half rate) of
+// f64 flush.  So here a wave's stream is ONE pipeline over the K stages of all its tiles:
+//   phase 1  chain (c0, h0) | under it: f64 flush of column tile c1 (the sums of the previous flush interval)
+//   phase 2  chain (c1, h0) | split of the activation fragments of half-stage 1 (read in phase 1)
+//   phase 3  chain (c0, h1) | split of the fragments of half-stage 0 of the NEXT stage (read in phase 2)
+//   phase 4  chain (c1, h1) | f64 flush of column tile c0
+// (chain = the canonical six MFMAs of one 32 x 32 tile and one 16-deep half-stage; the weight fragments of a chain are requested
+// during the chain before it.)  The next stage's fragments are read while this stage is multiplied, so the loader waves run TWO
+// stages ahead of the multiplication: barrier s = "stage s + 1 has landed, nobody reads stage s - 1 any more"; the ring of three
+// stages is the same as before.  All eight MFMA waves run in step (no half-stage offset: a wave no longer needs its neighbour).
+// The pipeline runs on across tile borders: the last phases of a tile already split the first fragments of the next one.
+// nk (K stages) must be even and >= 2.
+template <bool LEAKY, int FL>
+__global__ __launch_bounds__(768, 3) void k_linear_sb32p(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
+                                                         size_t w_plane, int ldw, const float *__restrict__ bias, float *__restrict__ C,
+                                                         int ldc, int m_cap, const int32_t *__restrict__ d_m, int n, int k_pad, float slope,
+                                                         int ntn, int n_major) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    auto stage_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    constexpr int NC = 2, MW = 8, SB_NL = 4, BM = 256, RING = 3;
+    constexpr int STAGE = sb32_stage_bytes(NC);
+    constexpr int SB_A_BYTES = BM * GEMM_BK * 4;
+    constexpr int WPL = NC * 32 * GEMM_BK * 2;
+    static_assert(FL == 1 || FL == 2, "flush per stage or per stage pair");
+    int M = m_cap;
+    if (d_m) {
+        const int dm = *d_m;
+        M = dm < m_cap ? dm : m_cap;
+    }
+    const int ntm = (M + BM - 1) / BM;
+    const int bid = blockIdx.x, nwg = ntm * ntn;
+    if (bid >= nwg) return;
+    const int vstep = (int)gridDim.x;
+    auto tile_of = [&](int v, int &m0o, int &n0o) {
+        const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        int tm, tn;
+        if (n_major) {
+            constexpr int RB = 8;
+            const int band = swz / (RB * ntn), rem = swz - band * (RB * ntn);
+            const int rows = ntm - band * RB < RB ? ntm - band * RB : RB;
+            tn = rem / rows;
+            tm = band * RB + (rem - tn * rows);
+        } else {
+            tm = swz / ntn;
+            tn = swz - tm * ntn;
+        }
+        m0o = tm * BM;
+        n0o = tn * NC * 32;
+    };
+    int m0, n0;
+    tile_of(bid, m0, n0);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nk = k_pad / GEMM_BK;
+
+    if (wave >= MW) {
+        // ---- loader waves, two stages ahead ----
+        const int li = wave - MW;
+        const int dr = lane >> 3, dp = lane & 7, wr = lane >> 2, wc = lane & 3;
+        __builtin_amdgcn_s_setprio(3);
+        constexpr int NA = (BM / 8) / SB_NL;
+        constexpr int NG = 2 * NC, NW = 3 * NG, NWL = (NW + SB_NL - 1) / SB_NL;
+        const unsigned char *abase, *wbase;
+        unsigned la[NA], lw[NWL];
+        int lw_dst[NWL];
+        auto setup = [&]() {
+            abase = reinterpret_cast<const unsigned char *>(A + (size_t)m0 * lda);
+            wbase = reinterpret_cast<const unsigned char *>(W3 + (size_t)n0 * ldw);
+#pragma unroll
+            for (int g = 0; g < NA; ++g) {
+                const int row = (li * NA + g) * 8 + dr;
+                int grow = m0 + row;
+                grow = grow < M ? grow : M - 1;
+                la[g] = (unsigned)(((grow - m0) * lda + ((dp ^ a_swz32(row)) << 2)) * 4);
+            }
+        };
+        setup();
+#pragma unroll
+        for (int g = 0; g < NWL; ++g) {
+            int idx = li + SB_NL * g;
+            idx = idx < NW ? idx : NW - 1;
+            const int p = idx / NG, grp = idx - p * NG;
+            const int row = grp * 16 + wr;
+            lw[g] = (unsigned)((p * w_plane + (size_t)row * ldw + ((wc ^ w_swz(row)) << 3)) * 2);
+            lw_dst[g] = SB_A_BYTES + p * WPL + grp * 1024;
+        }
+        auto fill = [&](int kt, int buf) {
+            const unsigned base = (unsigned)(size_t)(lds_void *)lds + (unsigned)(buf * STAGE);
+            const unsigned char *ab = abase + (size_t)kt * (GEMM_BK * 4), *wb = wbase + (size_t)kt * (GEMM_BK * 2);
+#pragma unroll
+            for (int g = 0; g < NA; ++g) glds16(la[g], ab, base + (unsigned)((li * NA + g) * 8 * 128));
+#pragma unroll
+            for (int g = 0; g < NWL; ++g)
+                if ((g + 1) * SB_NL <= NW || li + SB_NL * g < NW) glds16(lw[g], wb, base + (unsigned)lw_dst[g]);
+        };
+        fill(0, 0);
+        fill(1, 1);
+        int nb = 2;
+        for (int v = bid; v < nwg; v += vstep) {
+            const bool more = v + vstep < nwg;
+            for (int kt = 0; kt < nk; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stages kt and kt + 1 have landed ...
+                stage_barrier();                                        // ... and nobody reads the buffer of stage kt - 1: stage kt + 2 goes there
+                if (kt + 2 < nk) {
+                    fill(kt + 2, nb);
+                } else if (more) {                                      // stages 0 and 1 of this workgroup's next tile
+                    if (kt + 2 == nk) {
+                        tile_of(v + vstep, m0, n0);
+                        setup();
+                    }
+                    fill(kt + 2 - nk, nb);
+                }
+                nb = nb + 1 == RING ? 0 : nb + 1;
+            }
+        }
+        stage_barrier();                                                // the barrier behind the last stage of the last tile
+        return;
+    }
+
+    // ---- MFMA waves ----
+    const int g = lane >> 5, r32 = lane & 31;
+    int a_c[2][2], w_rd[2];
+    {
+        const int a_row = (wave * 32 + r32) * 128;
+        const int asw = a_swz32(r32);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            a_c[h][0] = a_row + (((4 * h + 2 * g) ^ asw) << 4);
+            a_c[h][1] = a_row + (((4 * h + 2 * g + 1) ^ asw) << 4);
+            w_rd[h] = SB_A_BYTES + r32 * 64 + (((2 * h + g) ^ w_swz(r32)) << 4);
+        }
+    }
+    auto buf_at = [&](int i) { return lds + i * STAGE; };
+    auto next_b = [&](int i) { return i + 1 == RING ? 0 : i + 1; };
+    f32x16 acc[NC];
+    double run[NC][16];
+    bf16x8 ap[2][3], wa[3], wb[3];
+    f32x4 xa[2], xb[2];
+    auto read_w = [&](bf16x8 (&w)[3], const unsigned char *buf, const int c, const int h) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[p] = *reinterpret_cast<const bf16x8 *>(buf + p * WPL + c * 2048 + w_rd[h]);
+    };
+    auto read_x = [&](f32x4 (&x)[2], const unsigned char *buf, const int h) {
+        x[0] = *reinterpret_cast<const f32x4 *>(buf + a_c[h][0]);
+        x[1] = *reinterpret_cast<const f32x4 *>(buf + a_c[h][1]);
+    };
+    auto flush_col = [&](const int c) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) run[c][i] += (double)acc[c][i];
+    };
+    // the interleave of a phase: one MFMA per group, behind the first one the phase's D0 LDS reads, behind each V vector instructions
+#define SB32_IL1(V, D0)                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+    if constexpr ((D0) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (D0) > 0 ? (D0) : 1, 0); \
+    if constexpr ((V) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (V) > 0 ? (V) : 1, 0)
+#define SB32_IL(V, D0)                                            \
+    do {                                                         \
+        SB32_IL1(V, D0);                                         \
+        SB32_IL1(V, 0);                                          \
+        SB32_IL1(V, 0);                                          \
+        SB32_IL1(V, 0);                                          \
+        SB32_IL1(V, 0);                                          \
+        SB32_IL1(V, 0);                                          \
+    } while (0)
+    int b = 0;
+    SB_STAMP(0);
+    stage_barrier();                                   // barrier 0: stages 0 and 1 of the first tile have landed
+    read_x(xa, buf_at(b), 0);
+    read_w(wa, buf_at(b), 0, 0);
+    split8(xa[0], xa[1], ap[0][0], ap[0][1], ap[0][2]);
+    read_x(xb, buf_at(b), 1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[c][i] = 0.f;
+            run[c][i] = 0.0;
+        }
+    for (int v = bid; v < nwg; v += vstep) {
+        if (v != bid) tile_of(v, m0, n0);
+        // one stage: ZERO = its chains start the fp32 sums afresh (and the pending sums of column tile c1 are flushed in phase 1);
+        // FLUSH = column tile c0 is flushed in phase 4 (and c1 in phase 1 of the next stage)
+        auto stage = [&](const unsigned char *cur, const unsigned char *nxt, auto zero_c, auto flush_c) {
+            constexpr bool ZERO = decltype(zero_c)::value, FLUSH = decltype(flush_c)::value;
+            // phase 1: chain (c0, h0) with wa; reads: wb = W(c1, h0); vector work: flush of c1 (ZERO stages)
+            __builtin_amdgcn_sched_barrier(0);
+            read_w(wb, cur, 1, 0);
+            if (ZERO) flush_col(1);
+            SB32_CHAIN(acc[0], ap[0], wa, ZERO);
+            SB32_IL(ZERO ? 6 : 0, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 2: chain (c1, h0) with wb; reads: wa = W(c0, h1), xa = fragments of half-stage 0 of the next stage;
+            // vector work: split of xb (half-stage 1 of this stage) -> ap[1]
+            read_w(wa, cur, 0, 1);
+            read_x(xa, nxt, 0);
+            split8(xb[0], xb[1], ap[1][0], ap[1][1], ap[1][2]);
+            SB32_CHAIN(acc[1], ap[0], wb, ZERO);
+            SB32_IL(8, 5);
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 3: chain (c0, h1) with wa; reads: wb = W(c1, h1); vector work: split of xa -> ap[0] (the next stage's)
+            read_w(wb, cur, 1, 1);
+            SB32_CHAIN(acc[0], ap[1], wa, false);
+            split8(xa[0], xa[1], ap[0][0], ap[0][1], ap[0][2]);
+            SB32_IL(8, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 4: chain (c1, h1) with wb; reads: wa = W(c0, h0) and xb = half-stage 1 of the next stage; vector work: flush of c0
+            read_w(wa, nxt, 0, 0);
+            read_x(xb, nxt, 1);
+            SB32_CHAIN(acc[1], ap[1], wb, false);
+            if (FLUSH) flush_col(0);
+            SB32_IL(FLUSH ? 6 : 0, 5);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll 1
+        for (int kt = 0; kt < nk; kt += 2) {
+            const int b1 = next_b(b), b2 = next_b(b1);
+            stage(buf_at(b), buf_at(b1), std::true_type(), std::bool_constant<FL == 1>());
+            stage_barrier();
+            stage(buf_at(b1), buf_at(b2), std::bool_constant<FL == 1>(), std::true_type());
+            stage_barrier();
+            b = b2;
+        }
+        flush_col(1);
+        const int m = m0 + wave * 32 + r32;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nb = n0 + c * 32 + q * 8 + g * 4;
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = (float)(run[c][4 * q + i] + (double)bv[i]);
+                    if (LEAKY) x = x > 0.f ? x : x * slope;
+                    o[i] = x;
+                    run[c][4 * q + i] = 0.0;
+                }
+                if (m >= M) continue;
+                float *dst = C + (size_t)m * ldc + nb;
+                if (nb + 3 < n) {
+                    *reinterpret_cast<f32x4 *>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < n) dst[i] = o[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[1][i] = 0.f;       // (phase 1 of the next tile's first stage flushes c1: zeros)
+    }      // tiles of this workgroup
+    SB_STAMP(2);
 }
 
 // ---- one wave per 16 x 16 tile (small batches, narrow outputs): operands streamed from global memory --------------------------
@@ -1034,6 +1317,16 @@ __global__ void k_split_planes(const float *__restrict__ w, size_t count, unsign
 }  // namespace sb
 using namespace sb;
 
+#ifdef MPE_SB_CLOCK
+}  // namespace mpe
+extern "C" int mpe_debug_sb_stamps(unsigned long long *out, int n_wg) {      // diagnostic builds only; not part of include/mpe.h
+    if (n_wg > 1024) n_wg = 1024;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mpe::sb::g_sb_stamp), (size_t)n_wg * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+namespace mpe {
+using namespace sb;
+#endif
+
 hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsigned short *planes) {
     if (count == 0) return hipSuccess;
     const size_t pairs = (count + 1) / 2;
@@ -1128,7 +1421,7 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     }
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
     static const int m32_on = getenv("MPE_SB_M32") ? atoi(getenv("MPE_SB_M32")) : 0;      // 32 x 32 x 16 form: bits 1 f64-sum launches, 2 plain launches
-    if ((f64 && (m32_on & 1)) || (!f64 && (m32_on & 2) && !(coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky))) {
+    if ((f64 && (m32_on & 5)) || (!f64 && (m32_on & 2) && !(coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky))) {
         static PerDeviceFlag attr32;
         if (!attr32.test()) {
             hipError_t e = hipSuccess;
@@ -1151,6 +1444,23 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         const dim3 grid((unsigned)(tiles < cu ? tiles : cu)), block(768);
         const size_t shm = 3 * (size_t)sb32_stage_bytes(nc);
         static const int fl1 = getenv("MPE_SB_FL1") ? atoi(getenv("MPE_SB_FL1")) : 0;
+        if (f64 && (m32_on & 4) && (k_pad / GEMM_BK) % 2 == 0 && k_pad >= 2 * GEMM_BK) {       // the software-pipelined form
+            static PerDeviceFlag attr32p;
+            if (!attr32p.test()) {
+                hipError_t e = hipSuccess;
+                const void *fns[] = {reinterpret_cast<const void *>(k_linear_sb32p<true, 1>), reinterpret_cast<const void *>(k_linear_sb32p<false, 1>),
+                                     reinterpret_cast<const void *>(k_linear_sb32p<true, 2>), reinterpret_cast<const void *>(k_linear_sb32p<false, 2>)};
+                for (const void *fn : fns)
+                    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr32p.set();
+            }
+#define MPE_SB32P(L_, FL_) hipLaunchKernelGGL((k_linear_sb32p<L_, FL_>), grid, block, shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major)
+            if (fl1) { if (leaky) MPE_SB32P(true, 1); else MPE_SB32P(false, 1); }
+            else { if (leaky) MPE_SB32P(true, 2); else MPE_SB32P(false, 2); }
+#undef MPE_SB32P
+            return hipGetLastError();
+        }
 #define MPE_SB32(L_, N_, F_, FL_) hipLaunchKernelGGL((k_linear_sb32<L_, N_, F_, FL_>), grid, block, shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major)
         if (f64 && fl1) { if (leaky) MPE_SB32(true, 2, true, 1); else MPE_SB32(false, 2, true, 1); }
         else if (f64) { if (leaky) MPE_SB32(true, 2, true, 2); else MPE_SB32(false, 2, true, 2); }
