@@ -170,11 +170,10 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
     if (coef_done) *coef_done = false;
     static const int mink = getenv("MPE_GAT_ACC64_MINK") ? atoi(getenv("MPE_GAT_ACC64_MINK")) : 512;
     const bool sb_f64 = ctx->gat_acc64 || (mink > 0 && L.in_dim > mink);
-    // (fp16 result rows exist in the split TILE kernel's coefficient epilogue only: the fc2 launches of 40-wide heads at batch
-    // sizes the tile kernel takes, without f64 sums; every other launch of the fp16-attention mode stays on the fp32 MFMA, whose
-    // tile and wave-per-tile kernels all store fp16 rows)
-    const bool sb_half_ok = !out_half || (coef && coef->out_dim == 40 && L.out_dim == coef->heads * 40 && !leaky && !sb_f64 &&
-                                          linear_sb16_uses_tile_kernel(m, L.out_dim, false));
+    // (fp16 result rows exist in the split TILE kernel only: the fc2 launches at batch sizes the tile kernel takes, without f64
+    // sums; every other launch of the fp16-attention mode stays on the fp32 MFMA, whose tile and wave-per-tile kernels all store
+    // fp16 rows)
+    const bool sb_half_ok = !out_half || (!leaky && !sb_f64 && linear_sb16_uses_tile_kernel(m, L.out_dim, false));
     // (launches with gathered rows -- layer-0 fc1 per camera -- stay on the fp32 MFMA; the grouped layer-0 launch does not come here)
     // In the explicit f64-sum mode (mpe_set_precision GAT 1 on top of the split form) layer 0's fc2 keeps the fp32 MFMA with a
     // flush per 32-deep stage: the split form flushes every second stage, and on the K = 902 sum of the steep layer-0 features
@@ -211,7 +210,7 @@ int gat_linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, Linear &L, 
     if (lda < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", lda, L.ldw);
     const bool host_m = !d_m || flop_override >= 0.0;
     GemmProf gp(ctx, s, flop_override >= 0.0 ? flop_override : (d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim),
-                host_m ? 0 : L.out_dim, host_m ? 0 : L.in_dim);
+                host_m ? 0 : L.out_dim, host_m ? 0 : L.in_dim, 2);
     HIPCHK(ctx, launch_linear_bf16(s, A, lda, L.w16, L.ldw16, L.b, C, ldc, m, d_m, L.out_dim, L.ldw16, leaky, slope,
                                    L.ldw, out_half, a_rows, c_rows));
     return MPE_OK;
@@ -764,6 +763,10 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
     L.in_dim = k;
     L.out_dim = n;
     L.ldw = ldw;
+    if (slope_on & 32) {
+        HIPCHK(ctx, launch_linear_f64(static_cast<hipStream_t>(stream), d_a, lda, d_w, ldw, d_bias, d_c, ldc, m, d_m, n, ldw, (slope_on & 1) != 0, slope));
+        return MPE_OK;
+    }
     if (slope_on & 4) {
         // split-bf16 arithmetic (gemm_sb16.hip) on caller-provided weights: the planes are made for this call (a stage-level
         // entry point for tests; the batch entry points keep theirs with the context)
@@ -777,7 +780,8 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
         HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&planes), 3 * count * sizeof(unsigned short)));
         hipError_t e = launch_split_planes(s, d_w, count, planes);
         if (e == hipSuccess)
-            e = launch_linear_sb16(s, d_a, lda, planes, count, ldw, d_bias, d_c, ldc, m, d_m, n, ldw, (slope_on & 1) != 0, slope, (slope_on & 8) == 0);
+            e = launch_linear_sb16(s, d_a, lda, planes, count, ldw, d_bias, d_c, ldc, m, d_m, n, ldw, (slope_on & 1) != 0, slope, (slope_on & 8) == 0,
+                                   nullptr, nullptr, false, (slope_on & 16) ? 1 : 2);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         (void)hipFree(planes);
         HIPCHK(ctx, e);
@@ -973,18 +977,23 @@ static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int 
     for (int l = 0; l < ctx->mlp_layers; ++l) {
         float *out = ctx->mlp_act[l & 1];
         const bool last = l == ctx->mlp_layers - 1;
-        if (ctx->mlp_split) {
+        if (ctx->mlp_f64mm) {
+            Linear &L = ctx->mlp[l];
+            if (ld_in < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", ld_in, L.ldw);
+            GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0, 3);
+            HIPCHK(ctx, launch_linear_f64(s, in, ld_in, L.w, L.ldw, L.b, out, ctx->mlp_ld_hidden, m, d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope));
+        } else if (ctx->mlp_split) {
             Linear &L = ctx->mlp[l];
             if ((rc = ensure_split_weights(ctx, s, &L))) return rc;
             if (ld_in < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", ld_in, L.ldw);
             GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0, 1);
             HIPCHK(ctx, launch_linear_sb16(s, in, ld_in, L.w3, (size_t)weight_rows(L.out_dim) * L.ldw, L.ldw, L.b, out, ctx->mlp_ld_hidden, m,
-                                           d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope));
+                                           d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope, true, nullptr, nullptr, false, ctx->mlp_flush));
         } else if (ctx->mlp_bf16) {
             Linear &L = ctx->mlp[l];
             if ((rc = ensure_bf16_weights(ctx, &L))) return rc;
             if (ld_in < L.ldw16) return fail(ctx, MPE_ERR_INVALID, "bf16 GEMM needs an input stride >= %d", L.ldw16);
-            GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0);
+            GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0, 2);
             HIPCHK(ctx, launch_linear_bf16(s, in, ld_in, L.w16, L.ldw16, L.b, out, ctx->mlp_ld_hidden, m, d_m, L.out_dim,
                                            L.ldw16, !last, ctx->mlp_slope));
         } else if ((rc = linear(ctx, s, in, ld_in, ctx->mlp[l], out, ctx->mlp_ld_hidden, m, d_m, !last, ctx->mlp_slope,
@@ -1065,8 +1074,8 @@ int mpe_dlt_pairs(mpe_ctx *ctx, void *stream, const double *d_pts, const int32_t
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
     if (!ctx) return MPE_ERR_INVALID;
     DeviceGuard dg(ctx);
-    if (gat_acc64 < 0 || gat_acc64 > 6 || mlp_acc64 < 0 || mlp_acc64 > 3)
-        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0..6, MLP 0|1|2|3");
+    if (gat_acc64 < 0 || gat_acc64 > 6 || mlp_acc64 < 0 || mlp_acc64 > 5)
+        return fail(ctx, MPE_ERR_INVALID, "precision modes: GAT 0..6, MLP 0..5");
     // GAT modes 4 / 5: modes 0 / 1 with the GEMMs of layers >= 1 in the split-bf16 form (4 = the default); 6 = mode 3 likewise
     // (fp16 rows: from the split tile kernel's coefficient epilogue where gat_linear finds it applicable, the fp32 MFMA otherwise)
     ctx->gat_split = gat_acc64 >= 4;
@@ -1076,7 +1085,9 @@ int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64) {
     ctx->gat_attn_fp16 = gat_acc64 == 3;
     ctx->mlp_acc64 = mlp_acc64 == 1;
     ctx->mlp_bf16 = mlp_acc64 == 2;
-    ctx->mlp_split = mlp_acc64 == 3;
+    ctx->mlp_split = mlp_acc64 == 3 || mlp_acc64 == 4;
+    ctx->mlp_f64mm = mlp_acc64 == 5;               // MLP mode 5: exact products + f64 accumulation on the f64 matrix pipe
+    ctx->mlp_flush = mlp_acc64 == 4 ? 1 : 2;       // MLP mode 4: the split form with an f64 flush per K stage (maximum accuracy)
     return MPE_OK;
 }
 
@@ -1094,10 +1105,11 @@ int mpe_profile_read(mpe_ctx *ctx, double *gemm_ms, double *gemm_flop, int64_t *
     HIPCHK(ctx, hipDeviceSynchronize());
     int32_t dev_m = 0;
     HIPCHK(ctx, hipMemcpy(&dev_m, ctx->mlp_count, sizeof dev_m, hipMemcpyDeviceToHost));
-    double ms[2] = {0, 0}, flop[2] = {0, 0};
-    int64_t cnt[2] = {0, 0};
+    double ms[3] = {0, 0, 0}, flop[3] = {0, 0, 0};
+    int64_t cnt[3] = {0, 0, 0};
     for (size_t i = 0; i < ctx->prof_used; ++i) {
-        const int k = ctx->prof[i].kind ? 1 : 0;
+        if (ctx->prof[i].kind == 3) continue;        // f64 matrix-pipe launches (MLP mode 5): not part of the roofline figures
+        const int k = ctx->prof[i].kind == 1 ? 1 : ctx->prof[i].kind == 2 ? 2 : 0;       // fp32 MFMA | split-bf16 | plain bf16 (reduced modes)
         float t = 0;
         if (hipEventElapsedTime(&t, ctx->prof[i].start, ctx->prof[i].stop) == hipSuccess) ms[k] += t;
         flop[k] += ctx->prof[i].flop;
@@ -1110,6 +1122,9 @@ int mpe_profile_read(mpe_ctx *ctx, double *gemm_ms, double *gemm_flop, int64_t *
     ctx->sb_ms = ms[1];
     ctx->sb_flop = flop[1];
     ctx->sb_launches = cnt[1];
+    ctx->bf_ms = ms[2];
+    ctx->bf_flop = flop[2];
+    ctx->bf_launches = cnt[2];
     if (total_ms) *total_ms = 0;
     ctx->prof_used = 0;
     return MPE_OK;
@@ -1120,6 +1135,14 @@ int mpe_profile_read_split(mpe_ctx *ctx, double *ms, double *flop, int64_t *laun
     if (ms) *ms = ctx->sb_ms;
     if (flop) *flop = ctx->sb_flop;
     if (launches) *launches = ctx->sb_launches;
+    return MPE_OK;
+}
+
+int mpe_profile_read_bf16(mpe_ctx *ctx, double *ms, double *flop, int64_t *launches) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (ms) *ms = ctx->bf_ms;
+    if (flop) *flop = ctx->bf_flop;
+    if (launches) *launches = ctx->bf_launches;
     return MPE_OK;
 }
 

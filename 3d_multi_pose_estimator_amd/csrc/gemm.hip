@@ -6,15 +6,14 @@
 // Kernels in this file (one numerical definition, several shapes)
 //   k_linear_dma    default: tile 128 x 80|64 x 32, K stages written into LDS by
 //                   global_load_lds_dwordx4, 4 waves x (32 rows x all features)
-//   k_linear        the register-staged predecessor (MPE_GEMM_TUNE=8), kept for A/B
 //   k_linear_skinny / k_linear_skinny_ks   one wave per 16x16 tile for small batches
 //   k_linear_bf16   reduced precision (BASELINE configs[4]), not on the parity path
 // The default-path kernels (k_linear_dma, k_linear_skinny*) walk K in 32-deep stages; inside a
 // stage lane group q of the MFMA takes k = 8q..8q+3 (first four MFMAs) then 8q+4..8q+7, so a row
 // gives the same bits whichever of them, and whatever batch size, computed it (tested).  ACC64 adds each stage's fp32 result into f64 running sums.
 //
-// gfx950 design of the register-staged kernel (k_linear_dma keeps its tile, fragment layout
-// and epilogue; its own header describes the LDS image the DMA writes)
+// gfx950 design (the tile, fragment layout and epilogue of the round-1 register-staged kernel, whose code left the
+// library in round 5 -- git history has it; k_linear_dma's own header describes the LDS image the DMA writes)
 //   * v_mfma_f32_16x16x4_f32 (exact f32 fma chain, 256 FLOP/clk/CU): the model's widths
 //     (400, 320, 160, 912, 3072, 2048, 1024) are multiples of 16, not of 32/128, so the
 //     16-wide tile wastes <2 % where a 128-wide tile would waste up to 22 %.
@@ -38,192 +37,8 @@ namespace mpe {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int RS = 8;                           // floats per (row, k-quarter) slot (dense)
-constexpr int PLANE_A = GEMM_BM * RS;           // 1024 floats
-constexpr int PLANE_W = GEMM_BN * RS;           //  640 floats
-constexpr int STAGE = 4 * (PLANE_A + PLANE_W);  // 6656 floats = 26624 B
-
-__device__ __forceinline__ int lds_swz(int row) { return ((row >> 3) ^ (row >> 2)) & 1; }
-constexpr int A_PASSES = GEMM_BM / 32;          // 4
-constexpr int W_PASSES = (GEMM_BN + 31) / 32;   // 3 (last one half populated)
 constexpr int NT = GEMM_BN / 16;                // 5 feature tiles per wave
 constexpr int MT = 2;                           // 2 row tiles per wave
-
-template <bool LEAKY, bool ACC64>
-__global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__restrict__ A, int lda,
-                                                   const float *__restrict__ W, int ldw,
-                                                   const float *__restrict__ bias, float *__restrict__ C,
-                                                   int ldc, int m_cap, const int32_t *__restrict__ d_m, int n,
-                                                   int k_pad, float slope, int ntn, int n_major, int tune) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
-
-    int M = m_cap;
-    if (d_m) {
-        int dm = *d_m;
-        M = dm < m_cap ? dm : m_cap;
-    }
-    // XCD-aware order: workgroups with equal (id % 8) share an L2; give each such class a
-    // contiguous range of tiles.  m-major (feature tiles of one row block adjacent) keeps the
-    // activation rows L2-resident when the weights are small (GAT); n-major keeps one weight
-    // panel resident while the row blocks stream past it (MLP: M small, N*K*4 >> L2).
-    // The grid is sized for m_cap; with a device-side M only the first ntm*ntn ids do work.
-    const int ntm = (M + GEMM_BM - 1) / GEMM_BM;
-    const int bid = blockIdx.x, nwg = ntm * ntn;
-    if (bid >= nwg) return;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    int tm, tn;
-    if (n_major) {
-        tn = swz / ntm;
-        tm = swz - tn * ntm;
-    } else {
-        tm = swz / ntn;
-        tn = swz - tm * ntn;
-    }
-    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // global->LDS staging role: 8 rows x 8 chunks (16 B) per wave and pass
-    const int lr = lane & 7, ch = lane >> 3;
-    const int st_h = ch & 1;           // which 16-byte half of the slot
-    const int st_q = ch >> 1;
-
-    const float *a_src[A_PASSES];
-    int a_dst[A_PASSES];
-#pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) {
-        int row = p * 32 + wave * 8 + lr;
-        int grow = m0 + row;
-        grow = grow < M ? grow : M - 1;
-        a_src[p] = A + (size_t)grow * lda + ch * 4;
-        a_dst[p] = st_q * PLANE_A + row * RS + ((st_h ^ lds_swz(row)) << 2);
-    }
-    // weight tile: 80 rows = 2.5 passes of 32; in the last pass waves 2,3 repeat the rows of
-    // waves 0,1 (same bytes to the same LDS slot) so that no load sits under a branch --
-    // hipcc serialises predicated loads with vmcnt waits.
-    const float *w_src[W_PASSES];
-    int w_dst[W_PASSES];
-#pragma unroll
-    for (int p = 0; p < W_PASSES; ++p) {
-        int row = p * 32 + wave * 8 + lr;
-        if (row >= GEMM_BN) row -= 16;
-        w_src[p] = W + (size_t)(n0 + row) * ldw + ch * 4;
-        w_dst[p] = 4 * PLANE_A + st_q * PLANE_W + row * RS + ((st_h ^ lds_swz(row)) << 2);
-    }
-
-    // fragment read offsets (floats)
-    const int fq = lane >> 4, fr = lane & 15;
-    const int fsw = lds_swz(fr);       // rows of every fragment tile differ from fr by multiples of 16
-    int a_rd[MT], w_rd[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a_rd[mt] = fq * PLANE_A + (wave * 32 + mt * 16 + fr) * RS;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) w_rd[nt] = 4 * PLANE_A + fq * PLANE_W + (nt * 16 + fr) * RS;
-
-    f32x4 acc[NT][MT];
-    // ACC64: every K stage (32 products per output, one MFMA chain) starts from zero and is
-    // flushed into an f64 running sum, so the result carries ~1 rounding instead of ~sqrt(K).
-    double run[ACC64 ? NT : 1][ACC64 ? MT : 1][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (ACC64) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] = 0.0;
-            }
-        }
-
-    f32x4 pa[A_PASSES], pw[W_PASSES];
-    const int nk = k_pad / GEMM_BK;
-
-#pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) pa[p] = *reinterpret_cast<const f32x4 *>(a_src[p]);
-#pragma unroll
-    for (int p = 0; p < W_PASSES; ++p) pw[p] = *reinterpret_cast<const f32x4 *>(w_src[p]);
-#pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[a_dst[p]]) = pa[p];
-#pragma unroll
-    for (int p = 0; p < W_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[w_dst[p]]) = pw[p];
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = (tune & 4) ? 0 : (kt & 1) * STAGE;
-        const bool more = kt + 1 < nk && !(tune & 4);     // tune&4: ablation, MFMA + LDS reads only
-        if (more) {
-            const int koff = (kt + 1) * GEMM_BK;
-#pragma unroll
-            for (int p = 0; p < A_PASSES; ++p) pa[p] = *reinterpret_cast<const f32x4 *>(a_src[p] + koff);
-#pragma unroll
-            for (int p = 0; p < W_PASSES; ++p) pw[p] = *reinterpret_cast<const f32x4 *>(w_src[p] + koff);
-        }
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            f32x4 af[MT], wf[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + ((hh ^ fsw) << 2)]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[nt] + ((hh ^ fsw) << 2)]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
-        }
-        if (ACC64) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] += (double)acc[nt][mt][i];
-                    acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-        }
-        if (more) {
-            const int nxt = ((kt + 1) & 1) * STAGE;
-#pragma unroll
-            for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[nxt + a_dst[p]]) = pa[p];
-#pragma unroll
-            for (int p = 0; p < W_PASSES; ++p) *reinterpret_cast<f32x4 *>(&lds[nxt + w_dst[p]]) = pw[p];
-        }
-        __syncthreads();
-    }
-
-    // epilogue: lane holds features nb..nb+3 of row m for every (nt, mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int nb = n0 + nt * 16 + fq * 4;
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + wave * 32 + mt * 16 + fr;
-            if (m >= M) continue;
-            f32x4 v;
-            if (ACC64) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (float)(run[ACC64 ? nt : 0][ACC64 ? mt : 0][i] + (double)bv[i]);
-            } else {
-                v = acc[nt][mt] + bv;
-            }
-            if (LEAKY) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
-            }
-            float *dst = C + (size_t)m * ldc + nb;
-            if (nb + 3 < n) {
-                *reinterpret_cast<f32x4 *>(dst) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (nb + i < n) dst[i] = v[i];
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------
 // LDS-DMA variant: the K stages are written straight into LDS by `global_load_lds_dwordx4`
@@ -236,10 +51,6 @@ __global__ __launch_bounds__(256, ACC64 ? 2 : 3) void k_linear(const float *__re
 // stage: [wait own DMA + barrier] -> issue DMA of the next stage into the other buffer ->
 // 80 MFMAs on this one.
 // ---------------------------------------------------------------------------------------
-#ifndef MPE_EXP
-#define MPE_EXP 0
-#endif
-constexpr int tune_prio = MPE_EXP;      // experiment bits of a diagnostic build (csrc/Makefile `exp`); 0 in the product
 __device__ __forceinline__ int dma_swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -356,31 +167,8 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
             lw[g] = W + (size_t)(n0 + row) * ldw + ((dp ^ dma_swz(row)) << 2);
         }
         auto fill = [&](int kt, int buf) {
-            if (tune_prio & 8) return;         // ABLATION (timing only, wrong data): no staging at all
             const int koff = kt * GEMM_BK;
             float *base = lds + buf * STAGE;
-            if constexpr ((tune_prio & 32) != 0 && NA_L == 4 && (NW_L == 2 || NW_L == 3)) {
-                // ABLATION (timing only, wrong data): the same requests as plain register loads -- same addresses, same
-                // bytes through TA / TCP / L2, but nothing is written into LDS.  The loads AND their wait are one asm
-                // statement with early-clobber outputs: a destination register is never free for the compiler to reuse
-                // while its load is in flight (a first form without the wait inside faulted: the landing load overwrote a
-                // reused address register).  The loader therefore waits here instead of in front of the next barrier.
-                f32x4 v0, v1, v2, v3, v4, v5, v6;
-                const float *w2 = lw[NW_L - 1] + koff;
-                asm volatile(
-                    "global_load_dwordx4 %0, %7, off\n\t"
-                    "global_load_dwordx4 %1, %8, off\n\t"
-                    "global_load_dwordx4 %2, %9, off\n\t"
-                    "global_load_dwordx4 %3, %10, off\n\t"
-                    "global_load_dwordx4 %4, %11, off\n\t"
-                    "global_load_dwordx4 %5, %12, off\n\t"
-                    "global_load_dwordx4 %6, %13, off\n\t"
-                    "s_waitcnt vmcnt(0)"
-                    : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6)
-                    : "v"(la[0] + koff), "v"(la[1] + koff), "v"(la[2] + koff), "v"(la[3] + koff), "v"(lw[0] + koff), "v"(lw[1] + koff), "v"(w2)
-                    : "memory");
-                return;
-            }
 #pragma unroll
             for (int g = 0; g < NA_L; ++g)
                 __builtin_amdgcn_global_load_lds((glb_void *)(la[g] + koff), (lds_void *)(base + (li * NA_L + g) * 8 * ROWF), 16, 0, 0);
@@ -391,8 +179,7 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
         };
         fill(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
-            if (tune_prio & 4) __builtin_amdgcn_s_barrier();      // ABLATION (timing only, wrong data): do not wait for the landing
-            else __syncthreads();              // vmcnt(0): stage kt has landed; the MFMA waves are done with the other buffer
+            __syncthreads();                   // vmcnt(0): stage kt has landed; the MFMA waves are done with the other buffer
             if (kt + 1 < nk) fill(kt + 1, (kt + 1) & 1);
         }
         return;
@@ -445,7 +232,6 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
         if (LDR) return;                       // the loader wave stages
         const int koff = kt * GEMM_BK;
         float *base = lds + buf * STAGE;
-        if (tune_prio & 2) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             __builtin_amdgcn_global_load_lds((glb_void *)(a_src[g] + koff),
@@ -455,7 +241,6 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
             if ((g + 1) * 4 <= WG || wave + 4 * g < WG)
                 __builtin_amdgcn_global_load_lds((glb_void *)(w_src[g] + koff),
                                                  (lds_void *)(base + W_OFF + (wave + 4 * g) * 8 * ROWF), 16, 0, 0);
-        if (tune_prio & 2) __builtin_amdgcn_s_setprio(0);
     };
 
     issue(0, 0);
@@ -464,42 +249,6 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
                                                // is done reading the other buffer
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const int cur = (kt & 1) * STAGE;
-        if (tune_prio & 16) {
-            // EXPERIMENT: weight fragments one step ahead in registers.  The compiler's own schedule of the loop below
-            // reads one weight fragment, waits for it (lgkmcnt(0)), issues its 8 MFMAs, reads the next: every fragment's
-            // LDS latency is exposed to this wave.  Here fragment nt + 1 (and the first one of the second half, with
-            // its activation fragments) is requested BEFORE the MFMAs of fragment nt; the sched_barrier keeps the
-            // request above them.  Per accumulator the order of the k steps is unchanged: same bits.
-            f32x4 af[MT], wf_cur;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + c0]);
-            wf_cur = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[0] + c0]);
-#pragma unroll
-            for (int st = 0; st < 2 * NTT; ++st) {
-                const int nt = st % NTT, hh = st / NTT;
-                f32x4 wf_nxt = wf_cur, af_nxt[MT];
-                const bool more = st + 1 < 2 * NTT;
-                const bool flip = more && nt + 1 == NTT;               // the next step starts the second half
-                if (more) wf_nxt = *reinterpret_cast<const f32x4 *>(&lds[cur + w_rd[(st + 1) % NTT] + ((st + 1) / NTT ? c1 : c0)]);
-                if (flip) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) af_nxt[mt] = *reinterpret_cast<const f32x4 *>(&lds[cur + a_rd[mt] + c1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf_cur[s], af[mt][s], acc[nt][mt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                wf_cur = wf_nxt;
-                if (flip) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) af[mt] = af_nxt[mt];
-                }
-                (void)hh;
-            }
-        } else {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int co = hh ? c1 : c0;
@@ -515,7 +264,6 @@ __global__ __launch_bounds__(256 + 64 * NL, NL == 4 ? ((ACC64 || A12) ? 4 : 6) :
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], af[mt][s], acc[nt][mt], 0, 0, 0);
-        }
         }
         if (ACC64) {
 #pragma unroll
@@ -1008,15 +756,6 @@ hipError_t launch_linear_bf16(hipStream_t s, const float *A, int lda, const unsi
 
 static size_t dma_lds_bytes(int ntt) { return (size_t)2 * (GEMM_BM + ntt * 16) * 32 * sizeof(float); }
 
-// the wide-tile instantiations use more than 64 KB of dynamic LDS
-static bool dma_set_lds_attributes() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma<true, false, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(10));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma<false, false, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(10));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma<true, false, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(13));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_dma<false, false, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes(13));
-    return true;
-}
-
 bool linear_uses_tile_kernel(int m_cap, int n) {
     static const int skinny_waves = getenv("MPE_SKINNY_WAVES") ? atoi(getenv("MPE_SKINNY_WAVES")) : 1024;
     return (long)((m_cap + 15) / 16) * ((n + 15) / 16) > skinny_waves;
@@ -1032,8 +771,7 @@ bool linear_uses_tile_kernel(int m_cap, int n) {
 //                                         3 x 8 waves needs 80 VGPRs and spills (+3.5 %), two loader waves +6 %
 //   f64 running sums, NTT 4 (MLP)  NL 4   128 VGPRs, 2 workgroups x 8 waves per CU      -6 %
 //   f64 running sums, NTT 5        NL 0   160 VGPRs: the round-2 form (layer-0 fc2, head rows only)
-//   wide tiles (MPE_GEMM_BN)       NL 0
-// MPE_GEMM_LOADER=0 forces the round-2 form everywhere (A/B, and one leg of the switch matrix).
+// (MPE_GEMM_LOADER=0, the round-2 form everywhere, and the wide tiles of MPE_GEMM_BN left the library in round 5.)
 // ---------------------------------------------------------------------------------------
 struct DmaLaunch {
     const float *A;
@@ -1063,28 +801,22 @@ static void launch_dma(hipStream_t s, int grid, const DmaLaunch &a) {
                        a.attn_l, a.attn_r, a.a12, a.grp_count, a.n_grp, a.grp_stride, a.w_grp_stride, a.out_half);
 }
 
-static bool gemm_loader_waves_on() {
-    static const int v = getenv("MPE_GEMM_LOADER") ? atoi(getenv("MPE_GEMM_LOADER")) : 1;
-    return v != 0;
-}
-
 // plain fp32 chain (no f64 sums, no coefficient epilogue), NTT 4 or 5
 template <int N>
 static void launch_dma_plain(hipStream_t s, int grid, const DmaLaunch &a, bool leaky) {
-    if (gemm_loader_waves_on()) {
-        if (leaky) launch_dma<true, false, N, false, 4>(s, grid, a);
-        else launch_dma<false, false, N, false, 4>(s, grid, a);
-    } else if (leaky) launch_dma<true, false, N, false, 0>(s, grid, a);
-    else launch_dma<false, false, N, false, 0>(s, grid, a);
+    if (leaky) launch_dma<true, false, N, false, 4>(s, grid, a);
+    else launch_dma<false, false, N, false, 4>(s, grid, a);
 }
 
 template <int N>
 static void launch_dma_acc64(hipStream_t s, int grid, const DmaLaunch &a, bool leaky) {
-    if (N == 4 && gemm_loader_waves_on()) {
+    if constexpr (N == 4) {
         if (leaky) launch_dma<true, true, 4, false, 4>(s, grid, a);
         else launch_dma<false, true, 4, false, 4>(s, grid, a);
-    } else if (leaky) launch_dma<true, true, N, false, 0>(s, grid, a);
-    else launch_dma<false, true, N, false, 0>(s, grid, a);
+    } else {
+        if (leaky) launch_dma<true, true, N, false, 0>(s, grid, a);
+        else launch_dma<false, true, N, false, 0>(s, grid, a);
+    }
 }
 
 hipError_t launch_linear_grouped(hipStream_t s, const float *A, int lda, const float *W, int ldw, long w_grp_stride,
@@ -1111,8 +843,6 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
     if (coef_done) *coef_done = false;
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     const int ntm = (m_cap + GEMM_BM - 1) / GEMM_BM;
-    const int ntn = (n + GEMM_BN - 1) / GEMM_BN;
-    static const int tune = getenv("MPE_GEMM_TUNE") ? atoi(getenv("MPE_GEMM_TUNE")) : 0;
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
     // small batches: one wave per 16x16 tile while that still leaves SIMDs idle (k_linear_skinny)
     static const int skinny_waves = getenv("MPE_SKINNY_WAVES") ? atoi(getenv("MPE_SKINNY_WAVES")) : 1024;
@@ -1121,8 +851,8 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
     // narrow outputs (one 64-wide feature tile would do <= 1/4 useful work: the 54-wide last MLP layer, the 1-wide
     // last fc2 of the GAT) stay on the wave-per-16x16-tile kernels at any batch size: same bits by construction
     static const int narrow_on = getenv("MPE_GEMM_NARROW") ? atoi(getenv("MPE_GEMM_NARROW")) : 1;
-    const bool narrow = narrow_on && nt16 <= (acc64 ? 4 : 1) && !(tune & 8);
-    if ((waves16 <= skinny_waves || narrow) && !(tune & 8) && acc64 && k_pad / GEMM_BK <= 128 && k_pad / GEMM_BK >= 8) {
+    const bool narrow = narrow_on && nt16 <= (acc64 ? 4 : 1);
+    if ((waves16 <= skinny_waves || narrow) && acc64 && k_pad / GEMM_BK <= 128 && k_pad / GEMM_BK >= 8) {
         // K split over the waves of a workgroup, ordered f64 reduction through LDS
         const size_t shm = (size_t)(k_pad / GEMM_BK) * 1024;
         static PerDeviceFlag attr_done;
@@ -1144,7 +874,7 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
                                d_m, n, k_pad, slope, nt16, a_rows, c_rows, out_half ? 1 : 0);
         return hipGetLastError();
     }
-    if ((waves16 <= skinny_waves || narrow) && !(tune & 8)) {
+    if (waves16 <= skinny_waves || narrow) {
         dim3 sgrid((unsigned)((waves16 + 3) / 4)), sblock(256);
 #define MPE_LAUNCH_SK(L_, A_)                                                                                  \
     hipLaunchKernelGGL((k_linear_skinny<L_, A_>), sgrid, sblock, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, \
@@ -1156,70 +886,34 @@ hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W,
 #undef MPE_LAUNCH_SK
         return hipGetLastError();
     }
-    if ((tune & 8) && !a_rows && !c_rows && !out_half) {     // MPE_GEMM_TUNE=8: the register-staged kernel of round 1 (A/B)
-        dim3 grid(ntm * ntn), block(256);
-#define MPE_LAUNCH(L_, A_)                                                                                   \
-    hipLaunchKernelGGL((k_linear<L_, A_>), grid, block, 0, s, A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
-                       slope, ntn, n_major, tune)
-        if (leaky && acc64) MPE_LAUNCH(true, true);
-        else if (leaky) MPE_LAUNCH(true, false);
-        else if (acc64) MPE_LAUNCH(false, true);
-        else MPE_LAUNCH(false, false);
-#undef MPE_LAUNCH
-        return hipGetLastError();
-    }
-    // Feature-tile width: 64 or 80, whichever leaves fewer (tiles on the busiest CU) x width; the
-    // MLP layers at a few thousand person rows balance exactly with 64.  160 and 208 (fewer staged
-    // bytes and DMA requests per MFMA, +10 % in the isolated loop of tools/mfma_peak.hip) are
-    // compiled for experiments (MPE_GEMM_BN) but did not pay in the full kernel and need plain fp32
-    // accumulation.  The padded weight rows cover any tile that starts below n.
-    static const int force_bn = getenv("MPE_GEMM_BN") ? atoi(getenv("MPE_GEMM_BN")) : 0;
-    static PerDeviceFlag dma_attr;
-    if (!dma_attr.test()) {
-        dma_set_lds_attributes();
-        dma_attr.set();
-    }
+    // Feature-tile width: 64 or 80, whichever leaves fewer (tiles on the busiest CU) x width; the MLP layers at a few thousand
+    // person rows balance exactly with 64.  (160- and 208-wide tiles -- fewer staged bytes and DMA requests per MFMA, +10 % in the
+    // isolated loop of tools/mfma_peak.hip -- did not pay in the full kernel and left the library in round 5.)  The padded weight
+    // rows cover any tile that starts below n.
     DmaLaunch a{A, lda, W, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, 0, n_major, a_rows, c_rows};
     a.out_half = out_half ? 1 : 0;
     // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile)
-    if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !force_bn) {
+    if (coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky) {
         a.ntn = (n + 79) / 80;
         a.attn_l = coef->attn_l;
         a.attn_r = coef->attn_r;
         a.a12 = coef->a12;
         const int grid = ntm * a.ntn;
         if (acc64) launch_dma<false, true, 5, true, 0>(s, grid, a);
-        else if (gemm_loader_waves_on()) launch_dma<false, false, 5, true, 4>(s, grid, a);
-        else launch_dma<false, false, 5, true, 0>(s, grid, a);
+        else launch_dma<false, false, 5, true, 4>(s, grid, a);
         if (coef_done) *coef_done = true;
         return hipGetLastError();
     }
-    const int widths[4] = {64, 80, 160, 208};
-    int best = 1;
-    double best_cost = 1e300;
-    for (int i = 0; i < 4; ++i) {
-        if (i >= 2 && (acc64 || force_bn != widths[i])) continue;
-        const int tiles = ntm * ((n + widths[i] - 1) / widths[i]);
-        const double cost = force_bn == widths[i] ? -1.0 : (double)((tiles + 255) / 256) * widths[i];
-        if (cost < best_cost) {
-            best_cost = cost;
-            best = i;
-        }
-    }
-    a.ntn = (n + widths[best] - 1) / widths[best];
+    const int tiles64 = ntm * ((n + 63) / 64), tiles80 = ntm * ((n + 79) / 80);
+    const bool wide = (double)((tiles80 + 255) / 256) * 80 < (double)((tiles64 + 255) / 256) * 64;        // (a tie goes to 64)
+    a.ntn = wide ? (n + 79) / 80 : (n + 63) / 64;
     const int grid = ntm * a.ntn;
-    if (best == 0) {
+    if (!wide) {
         if (acc64) launch_dma_acc64<4>(s, grid, a, leaky);
         else launch_dma_plain<4>(s, grid, a, leaky);
-    } else if (best == 1) {
+    } else {
         if (acc64) launch_dma_acc64<5>(s, grid, a, leaky);
         else launch_dma_plain<5>(s, grid, a, leaky);
-    } else if (best == 2) {
-        if (leaky) launch_dma<true, false, 10, false, 0>(s, grid, a);
-        else launch_dma<false, false, 10, false, 0>(s, grid, a);
-    } else {
-        if (leaky) launch_dma<true, false, 13, false, 0>(s, grid, a);
-        else launch_dma<false, false, 13, false, 0>(s, grid, a);
     }
     return hipGetLastError();
 }

@@ -14,19 +14,18 @@
 //
 // Three kernels, one arithmetic -- per 16 x 16 output tile and K stage the six MFMAs in the order (a1,w3) (a2,w2) (a1,w2)
 // (a3,w1) (a2,w1) (a1,w1), stages ascending; with f64 sums (MLP) one fp32 chain per stage PAIR (started from a zero C operand,
-// added to the f64 running sum after the odd stage and after the last one), without (GAT) the even and the odd stages in two
-// fp32 chains added at the end -- so a row has the same bits in a batch of one and of a thousand:
-//   k_linear_sb         tile kernel, LDS-DMA staging from four loader waves (fp32 activation tile + three weight planes per
-//                       stage, `saddr + voffset` loads: no vector instruction per piece), one barrier per stage, two forms:
-//                       MW = 8  256 x 64|80 tiles, eight MFMA waves, ONE twelve-wave workgroup per CU, ring of three stages,
-//                               the second MFMA wave of every SIMD half a stage behind the first; PERSISTENT: the workgroup walks
-//                               its tiles, loaders running on across tile borders (every launch of the production path)
-//                       MW = 4  128 x 80 tiles, four MFMA waves, two eight-wave workgroups per CU, two stages (MPE_SB_GAT_MW=4)
+// added to the f64 running sum after the odd stage and after the last one; per STAGE in the maximum-accuracy mode), without
+// (GAT) the even and the odd stages in two fp32 chains added at the end -- so a row has the same bits in a batch of one and of a
+// thousand:
+//   k_linear_sb         tile kernel: ONE twelve-wave workgroup per CU, persistent; 256 x 64 | 80 tiles, eight MFMA waves, four loader
+//                       waves (LDS-DMA of the fp32 activation tile + three weight planes per stage, `saddr + voffset` loads: no
+//                       vector instruction per piece), a ring of three stages, one barrier per stage, the second MFMA wave of every
+//                       SIMD half a stage behind the first
 //   k_linear_sb_skinny  one wave per 16 x 16 tile, operands streamed from global memory (small batches, narrow outputs)
 //   k_linear_sb_ks      the same with the stage pairs of a tile dealt to eight waves and an ordered f64 reduction through LDS
-// What the tile kernel waits for, by ablation builds of it (make exp EXPFLAGS=-DMPE_SBEXP=n, tools/run_variants.sh):
-// MLP form -- no f64 flush -26 %, no split arithmetic -18 %, no staging -5 %; GAT four-wave form -- no staging -25 %, no split
-// arithmetic -10..-14 %, no landing wait -1..-4 %.
+// What bounds the tile kernel: POWER.  In-kernel clock of its MLP launches on real operands 2.0 GHz (2.4 GHz
+// with zero weights, same cycle count); the 32 x 32 x 16 instruction in three schedules saved 6-12 % of the cycles and ran at
+// 1.68-1.76 GHz -- the same wall time (profiles/r05_sb_clock.txt, r05_sb32_forms.txt; those kernels: git show 80a9985).
 #include <cstdlib>
 #include <type_traits>
 
@@ -37,9 +36,6 @@
 #endif
 #ifndef SB_PRIO_SPLIT
 #define SB_PRIO_SPLIT 0        // priority of an MFMA wave while it splits its fragments (its MFMA phases: 2, its flush: 0, loaders: 3)
-#endif
-#ifndef MPE_SBEXP
-#define MPE_SBEXP 0            // timing ablations of a diagnostic build (csrc/Makefile `exp`; wrong results, never shipped); 0 in the product
 #endif
 
 namespace mpe {
@@ -156,39 +152,30 @@ __device__ __forceinline__ void glds16(unsigned voff, const void *sbase, unsigne
                  : "memory");
 }
 
-// the activation tile, fp32, the image of k_linear_dma: 32 rows per MFMA wave (16 KiB with four MFMA waves, 32 KiB with eight)
-__host__ __device__ constexpr int sb_a_bytes(int mw, int mt = 2) { return mw * 16 * mt * GEMM_BK * 4; }
+// One K stage in LDS: the activation tile, fp32, the image of k_linear_dma (256 rows x 128 B = 32 KiB), and the three weight planes
+// (16 NTT rows x 64 B each).  Three stages are resident: the second MFMA wave of every SIMD runs half a stage behind the first and
+// still reads stage kt - 1 while stage kt + 1 lands.
+constexpr int SB_MW = 8;             // MFMA waves per workgroup (32 rows each): 256-row tiles
+constexpr int SB_NL = 4;             // loader waves
+constexpr int SB_RING = 3;
+__host__ __device__ constexpr int sb_a_bytes() { return SB_MW * 32 * GEMM_BK * 4; }
+__host__ __device__ constexpr int sb_stage_bytes(int ntt) { return sb_a_bytes() + 3 * ntt * 16 * GEMM_BK * 2; }
 
-// K stages resident in LDS: two (one being read, one landing) in the four-MFMA-wave form; three in the eight-wave form, where the
-// second MFMA wave of every SIMD runs half a stage behind the first and still reads stage kt - 1 while stage kt + 1 lands
-__host__ __device__ constexpr int sb_ring(int mw) { return mw == 8 ? 3 : 2; }
-__host__ __device__ constexpr int sb_stage_bytes(int ntt, int mw = 4, int mt = 2) { return sb_a_bytes(mw, mt) + 3 * ntt * 16 * GEMM_BK * 2; }
-
+// The tile kernel: ONE twelve-wave workgroup per CU -- eight MFMA waves of 32 rows x 16 NTT features (256 x 64 tiles with f64 sums,
+// 256 x 80 without) and four loader waves -- PERSISTENT: the workgroup walks the tiles bid, bid + gridDim.x, ... (gridDim.x a
+// multiple of eight: a workgroup's tiles keep its XCD and the tile order of a plain launch), the loader waves run on across tile
+// borders (stage 0 of the next tile is issued behind the barrier of the last stage of this one) and the result stores of a tile
+// drain while the next one is multiplied.  (Forms that were measured and are gone: six-wave workgroups, which never ran two per
+// CU -- the dispatcher deals a workgroup's waves to the SIMDs 2-2-1-1 from the same SIMD each time --; four MFMA waves and two
+// stages at two workgroups per CU; one workgroup per tile; the 32 x 32 x 16 instruction, round 5: DESIGN.md 7.1.)
 // A12 (fc2 of a graph-attention layer with 40-wide attention heads, 80-wide tiles): the epilogue also emits a1 | a2 =
 // <ft2[row, head, :], attn_l / attn_r[head]> (gat2.py:57-58) from the values the lanes hold -- the code of k_linear_dma<.., A12>,
 // same lane layout, same canonical order (coef40() in gat.hip mirrors it for the paths that compute the coefficients elsewhere).
-// MW = MFMA waves per workgroup (32 rows each).  The launches with f64 running sums run as ONE twelve-wave workgroup per CU (MW = 8:
-// 256 x 64 tiles, eight MFMA + four loader waves, 147 registers at three waves per SIMD).  Their first form -- two six-wave
-// workgroups (MW = 4, two loaders) -- never ran two per CU: the dispatcher deals a workgroup's waves to the SIMDs 2-2-1-1 from the
-// same SIMD each time, the second workgroup's pair does not fit behind the first at 152 registers, and every SIMD ran ONE MFMA
-// wave with nothing to cover its fragment reads, split arithmetic and barrier (found with SQ_WAVE_CYCLES = half the slot time and
-// confirmed by padding the LDS request to one workgroup per CU: same duration).
-#ifndef SB_F64_NTT
-#define SB_F64_NTT 4           // (8 with SB_F64_MT 1 = 16 x 128 outputs per wave: half the split arithmetic, twice the weight-fragment
-#define SB_F64_NL 4            //  reads -- measured the same 157.7 against 157.5 us, profiles/r04_sb_tile_ablations.txt)
-#define SB_F64_MW 8
-#define SB_F64_MT 2
-#endif
-// MT = 16-row tiles per MFMA wave: 2 (32 rows x NTT column tiles per wave) or 1 (16 rows: the f64-sum launches, whose wave then
-// covers 16 x 128 outputs -- the same 32 accumulator registers as 32 x 64, half the activation fragments to split per MFMA, the
-// weight fragments read by twice as many waves)
-// PERS (ring of three only): a PERSISTENT workgroup per CU that walks the tiles bid, bid + gridDim.x, ... (gridDim.x a multiple of
-// eight: a workgroup's tiles keep its XCD and the tile order of the plain launch).  The loader waves run on across tile borders --
-// stage 0 of the next tile is issued behind the barrier of the last stage of this one -- and the result stores of a tile drain
-// while the next one is multiplied.  With one workgroup per CU nothing else covers a tile's first-stage latency, its stores and the
-// dispatch of its successor: at K = 416 they were a quarter of a launch (tools/sb_ksweep.py: 84 of 347 us do not scale with K).
-template <bool LEAKY, int NTT, bool F64, int SB_NL, bool A12 = false, int MW = 4, int MT = 2, bool PERS = false>
-__global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4) void k_linear_sb(const float *__restrict__ A, int lda,
+// FL (F64 only) = K stages per f64 flush: 2 = the default cadence (an fp32 chain per stage PAIR), 1 = a chain and a flush per stage
+// (the maximum-accuracy mode of the MLP, mpe_set_precision MLP 4: rms error 0.13-0.18 instead of 0.24-0.26 ulp of the output scale,
+// tools/sb16_numerics.hip).
+template <bool LEAKY, int NTT, bool F64, bool A12 = false, int FL = 2>
+__global__ __launch_bounds__(64 * (SB_MW + SB_NL), 3) void k_linear_sb(const float *__restrict__ A, int lda,
                                                                    const unsigned short *__restrict__ W3, size_t w_plane, int ldw,
                                                                    const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                                    int m_cap, const int32_t *__restrict__ d_m, int n, int k_pad,
@@ -198,26 +185,23 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                                                                    float *__restrict__ a12 = nullptr, int out_half = 0) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     // Stage barrier: this wave's LDS operations done + s_barrier, and NOT __syncthreads(): its fence also waits for the wave's global
-    // stores, i.e. for the result rows of the previous tile in the persistent form (what must have landed in LDS is waited for by the
-    // loader waves themselves: their explicit vmcnt(0) in front of this barrier).
-    auto stage_barrier = [&]() {
-        if (!(F64 && LEAKY && MPE_SBEXP == 48)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (ablation 48: none -- timing only)
-    };
-    static_assert(MT == 2 || !A12, "the coefficient epilogue assumes two row tiles per wave");
-    constexpr int STAGE = sb_stage_bytes(NTT, MW, MT);
-    constexpr int SB_A_BYTES = sb_a_bytes(MW, MT), BM = 16 * MT * MW;
-    constexpr int RING = sb_ring(MW);               // K stages resident in LDS
+    // stores, i.e. for the result rows of the previous tile (what must have landed in LDS is waited for by the loader waves
+    // themselves: their explicit vmcnt(0) in front of this barrier).
+    auto stage_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    constexpr int MW = SB_MW, MT = 2, RING = SB_RING;
+    static_assert(FL == 2 || (FL == 1 && F64), "flush cadence: every stage pair, or every stage of an f64-sum launch");
+    constexpr int STAGE = sb_stage_bytes(NTT);
+    constexpr int SB_A_BYTES = sb_a_bytes(), BM = 16 * MT * MW;
     constexpr int WPL = NTT * 16 * GEMM_BK * 2;       // bytes of one weight plane of a stage
     int M = m_cap;
     if (d_m) {
         const int dm = *d_m;
         M = dm < m_cap ? dm : m_cap;
     }
-    static_assert(!PERS || RING == 3, "persistent form: ring of three");
     const int ntm = (M + BM - 1) / BM;
     const int bid = blockIdx.x, nwg = ntm * ntn;
     if (bid >= nwg) return;
-    const int vstep = PERS ? (int)gridDim.x : nwg;      // tiles of this workgroup: bid, bid + vstep, ... (the plain form: one)
+    const int vstep = (int)gridDim.x;                   // tiles of this workgroup: bid, bid + vstep, ...
     // tile of (virtual) workgroup v: XCD-aware order (v & 7 = the XCD the hardware dispatcher gives workgroup v, and v + 8 k stays there)
     auto tile_of = [&](int v, int &m0o, int &n0o) {
         const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
@@ -242,7 +226,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
     const int nk = k_pad / GEMM_BK;
 
     if (wave >= MW) {
-        // ---- loader waves: 16 activation groups (8 rows x 128 B each) + 3 NTT weight groups (16 rows x 64 B) per stage ----
+        // ---- loader waves: 32 activation groups (8 rows x 128 B each) + 3 NTT weight groups (16 rows x 64 B) per stage ----
         const int li = wave - MW;
         const int dr = lane >> 3, dp = lane & 7, wr = lane >> 2, wc = lane & 3;
         __builtin_amdgcn_s_setprio(3);
@@ -285,18 +269,15 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
             for (int g = 0; g < NWL; ++g)
                 if ((g + 1) * SB_NL <= NW || li + SB_NL * g < NW) glds16(lw[g], wb, base + (unsigned)lw_dst[g]);
         };
-        // One stage ahead in both forms: stage kt + 1 is issued after barrier kt and has landed before barrier kt + 1.  With the
-        // ring of three (eight MFMA waves) the buffer it goes to is the one of stage kt - 2: stage kt - 1 is still being read by the
-        // second wave of every SIMD between barriers kt and kt + 1 (main loop below).
+        // One stage ahead: stage kt + 1 is issued after barrier kt and has landed before barrier kt + 1.  The buffer it goes to is
+        // the one of stage kt - 2: stage kt - 1 is still being read by the second wave of every SIMD between barriers kt and kt + 1.
         fill(0, 0);
         int nb = 1;
         for (int v = bid; v < nwg; v += vstep) {
-            const bool more = PERS && v + vstep < nwg;
+            const bool more = v + vstep < nwg;
             for (int kt = 0; kt < nk; ++kt) {
-                if (!(F64 && LEAKY && MPE_SBEXP == 35) && !(!F64 && MPE_SBEXP == 45))               // (ablation 35 / 45: no landing wait)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage kt has landed ...
                 stage_barrier();                                        // ... and nobody reads the buffer stage kt + 1 goes to
-                if ((F64 && LEAKY && MPE_SBEXP == 34) || (!F64 && MPE_SBEXP == 44)) continue;          // (ablation 34 / 44: no staging at all)
                 if (kt + 1 < nk) {
                     fill(kt + 1, nb);
                 } else if (more) {                                      // behind the last stage: stage 0 of this workgroup's next tile
@@ -325,8 +306,8 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
 
     // Without f64 sums (GAT launches) the even and the odd K stages accumulate into separate fp32 chains that are added at the
     // end: half the chain length of a single accumulator (rms error 0.5-0.6 ulp of the output scale at K = 416 against 0.75 for one
-    // chain and 0.91 for the fp32 MFMA chain it replaces), for 40 more registers (126 of the 128 that 2 x 8 waves per CU leave).
-    int b = 0;                                         // ring buffer of the stage in hand (runs on across the tiles of a persistent workgroup)
+    // chain and 0.91 for the fp32 MFMA chain it replaces).
+    int b = 0;                                         // ring buffer of the stage in hand (runs on across the tiles of the workgroup)
     SB_STAMP(0);
     for (int v = bid; v < nwg; v += vstep) {
     if (v != bid) tile_of(v, m0, n0);
@@ -344,37 +325,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] = 0.0;
             }
         }
-    // one K stage into the accumulator set ACC (the barrier is the landing wait and the buffer hand-over)
-    auto do_stage = [&](int kt, f32x4 (&ACC)[NTT][MT], auto from_zero) {
-        stage_barrier();
-        const unsigned char *cur = lds + (kt & 1) * STAGE;
-        bf16x8 ap[MT][3];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(cur + a_rd[mt] + c0);
-            const f32x4 x1 = *reinterpret_cast<const f32x4 *>(cur + a_rd[mt] + c1);
-            if ((F64 && LEAKY && (MPE_SBEXP == 31 || MPE_SBEXP == 33)) || (!F64 && MPE_SBEXP == 41)) {          // ablation (MLP launches only: nothing consumes their values): no split arithmetic (what do the 88 VALU instructions cost?)
-                ap[mt][0] = __builtin_bit_cast(bf16x8, x0);
-                ap[mt][1] = __builtin_bit_cast(bf16x8, x1);
-                ap[mt][2] = __builtin_bit_cast(bf16x8, x0);
-            } else
-            split8(x0, x1, ap[mt][0], ap[mt][1], ap[mt][2]);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTT; ++nt) {
-            bf16x8 wp[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wp[p] = *reinterpret_cast<const bf16x8 *>(cur + p * WPL + w_rd[nt]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (decltype(from_zero)::value) SB_STAGE0(ACC[nt][mt], ap[mt], wp);
-                else SB_STAGE(ACC[nt][mt], ap[mt], wp);
-            }
-        }
-    };
-    using std::false_type;
-    using std::true_type;
-    if constexpr (RING == 3) {
+    {
         // Eight MFMA waves, ring of three stages, the two MFMA waves of a SIMD HALF A STAGE APART.  A stage of a wave is: split the
         // activation fragments (88 vector instructions, nothing to multiply yet), then the six-product chains of the first and of the
         // second half of the column tiles.  Waves 0-3 run a stage between two barriers.  Waves 4-7 (the second wave of every SIMD)
@@ -382,7 +333,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
         // only) and then start stage kt (split + first half) -- so one wave's split arithmetic falls into the other's MFMA-only half,
         // where two waves in step would both sit in front of their first MFMA.  Stage kt - 1 is still read after barrier kt: that is
         // what the third buffer is for (the loaders refill it after barrier kt + 1).  Every 16 x 16 tile still sees its six products
-        // per stage in the canonical order, stages ascending: the bits of the other forms.
+        // per stage in the canonical order, stages ascending: the bits of the wave-per-tile kernels.
         bf16x8 ap[MT][3];
         auto split_stage = [&](const unsigned char *buf) {
             // f64-sum launches: a wave in its vector-heavy phases (split arithmetic, flush) yields the issue port to the other wave
@@ -392,11 +343,6 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
             for (int mt = 0; mt < MT; ++mt) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4 *>(buf + a_rd[mt] + c0);
                 const f32x4 x1 = *reinterpret_cast<const f32x4 *>(buf + a_rd[mt] + c1);
-                if ((F64 && LEAKY && (MPE_SBEXP == 31 || MPE_SBEXP == 33)) || (!F64 && MPE_SBEXP == 41)) {      // (ablation: no split arithmetic)
-                    ap[mt][0] = __builtin_bit_cast(bf16x8, x0);
-                    ap[mt][1] = __builtin_bit_cast(bf16x8, x1);
-                    ap[mt][2] = __builtin_bit_cast(bf16x8, x0);
-                } else
                 split8(x0, x1, ap[mt][0], ap[mt][1], ap[mt][2]);
             }
         };
@@ -415,7 +361,8 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 }
             }
         };
-        // half h of an even / odd stage (fp32 chains: from zero on the even stages with f64 sums; even / odd accumulators without)
+        // half h of an even / odd stage (f64 sums: one fp32 chain per flush interval, started from a zero C operand; without:
+        // even / odd accumulators)
         auto even_half = [&](const unsigned char *buf, const int h) {
             if (F64) half(buf, h, acc, std::true_type());
             else half(buf, h, acc, std::false_type());
@@ -424,19 +371,50 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
             if (F64) half(buf, h, acc, std::false_type());
             else half(buf, h, acc_odd, std::false_type());
         };
-        auto flush = [&](bool last) {                  // the pair's sums into the f64 running sums
+        auto flush = [&]() {                           // the chains' sums into the f64 running sums
             if (!F64) return;
             __builtin_amdgcn_s_setprio(0);
-            if (LEAKY && (MPE_SBEXP == 32 || MPE_SBEXP == 33) && !last) return;      // (ablation 32 / 33: one flush at the end)
+            if (FL == 1) __builtin_amdgcn_sched_barrier(0);      // (flush per stage: left to mix the flush with the next stage's fragment reads the compiler spills)
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
+            if (FL == 1) __builtin_amdgcn_sched_barrier(0);
         };
         auto buf_at = [&](int i) { return lds + i * STAGE; };
         auto next_b = [&](int i) { return i + 1 == RING ? 0 : i + 1; };
+        if constexpr (FL == 1) {
+            // a chain and a flush per stage: every stage is an "even" one (its chains start from a zero C operand)
+            if (wave < MW / 2) {
+#pragma unroll 1
+                for (int kt = 0; kt < nk; ++kt) {
+                    stage_barrier();                   // barrier kt: stage kt has landed
+                    split_stage(buf_at(b));
+                    even_half(buf_at(b), 0);
+                    even_half(buf_at(b), 1);
+                    b = next_b(b);
+                    flush();
+                }
+            } else {
+                stage_barrier();                       // barrier 0 (of this tile)
+                split_stage(buf_at(b));
+                even_half(buf_at(b), 0);
+#pragma unroll 1
+                for (int kt = 1; kt < nk; ++kt) {
+                    stage_barrier();                   // barrier kt
+                    even_half(buf_at(b), 1);           // second half of stage kt - 1
+                    flush();
+                    b = next_b(b);
+                    split_stage(buf_at(b));
+                    even_half(buf_at(b), 0);
+                }
+                even_half(buf_at(b), 1);
+                flush();
+                b = next_b(b);                         // the first stage of the next tile
+            }
+        } else
         if (wave < MW / 2) {
 #pragma unroll 1
             for (int kt = 0; kt < nk; kt += 2) {
@@ -445,14 +423,15 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 even_half(buf_at(b), 0);
                 even_half(buf_at(b), 1);
                 b = next_b(b);
+                if (kt + 1 >= nk) flush();
                 if (kt + 1 < nk) {
                     stage_barrier();
                     split_stage(buf_at(b));
                     odd_half(buf_at(b), 0);
                     odd_half(buf_at(b), 1);
                     b = next_b(b);
+                    flush();
                 }
-                flush(kt + 2 >= nk);
             }
         } else {
             stage_barrier();                           // barrier 0 (of this tile)
@@ -468,7 +447,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 odd_half(buf_at(b), 0);
                 stage_barrier();                       // barrier kt + 1
                 odd_half(buf_at(b), 1);
-                flush(false);
+                flush();
                 b = next_b(b);
                 split_stage(buf_at(b));
                 even_half(buf_at(b), 0);
@@ -483,34 +462,8 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
             } else {                                   // nk odd: the last (even) stage has its first half done
                 even_half(buf_at(b), 1);
             }
-            flush(true);
-            b = next_b(b);                             // the first stage of the next tile
-        }
-    } else
-    if (F64) {
-        // pairs of stages: the first starts its fp32 chains from zero (0 + x = x exactly: the bits of a cleared accumulator
-        // without clearing it), the pair's sums go into the f64 running sums
-        auto flush = [&]() {
-#pragma unroll
-            for (int nt = 0; nt < NTT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) run[F64 ? nt : 0][mt][i] += (double)acc[nt][mt][i];
-        };
-#pragma unroll 1
-        for (int kt = 0; kt < nk; kt += 2) {
-            do_stage(kt, acc, true_type());
-            if (kt + 1 < nk) do_stage(kt + 1, acc, false_type());
-            if (LEAKY && (MPE_SBEXP == 32 || MPE_SBEXP == 33) && kt + 2 < nk) continue;      // (ablation 32 / 33: one flush at the end)
             flush();
-        }
-    } else {
-        // even stages into `acc`, odd stages into `acc_odd`: the loop walks two stages per trip, each with its own code
-#pragma unroll 1
-        for (int kt = 0; kt < nk; kt += 2) {
-            do_stage(kt, acc, false_type());
-            if (kt + 1 < nk) do_stage(kt + 1, acc_odd, false_type());
+            b = next_b(b);                             // the first stage of the next tile
         }
     }
     float pl[2][2], pr[2][2];            // A12: per (head of the tile, row tile) partial dot products
@@ -548,7 +501,7 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                     if (hp) { pl[1][mt] = l1; pr[1][mt] = r1; } else { pl[0][mt] = l1; pr[0][mt] = r1; }
                 }
             }
-            if (m >= M || (A12 && MPE_SBEXP == 47)) continue;          // (ablation 47: no result stores of the coefficient launches)
+            if (m >= M) continue;
             if (out_half) {                    // fp16 rows for the attention stage (configs[4]); ldc counts halves
                 _Float16 *dh = reinterpret_cast<_Float16 *>(C) + (size_t)m * ldc + nb;
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -589,581 +542,13 @@ __global__ __launch_bounds__(64 * (MW + SB_NL), (MW == 8 || SB_NL == 2) ? 3 : 4)
                 y[h] = y[h] + __shfl_xor(y[h], 32);
             }
             const int m = m0 + wave * 16 * MT + mt * 16 + fr;
-            if (m >= M || head0 * 40 >= n || MPE_SBEXP == 46 || fq > 1) continue;          // (ablation 46: no coefficient stores)
+            if (m >= M || head0 * 40 >= n || fq > 1) continue;
             float *dst = a12 + (size_t)m * 32 + (fq ? 16 : 0) + head0;
             const float v0 = fq ? y[0] : x[0], v1 = fq ? y[1] : x[1];
             if ((head0 + 1) * 40 < n) *reinterpret_cast<float2 *>(dst) = make_float2(v0, v1);
             else dst[0] = v0;
         }
     }
-    }      // tiles of this workgroup
-    SB_STAMP(2);
-}
-
-// ---- the 32 x 32 x 16 form of the tile kernel ----------------------------------------------------------------------------------
-// v_mfma_f32_32x32x16_bf16: the same matrix-pipe time per product as the 16 x 16 x 32 instruction (32 against 16 cycles for twice
-// the products) but HALF the vector-issue slots per product -- an MFMA of either shape holds the SIMD's vector issue for 8 cycles
-// (MI355X_MICROARCH.md, cycle constants), and the f64-sum launches are bound by vector issue: per stage pair and SIMD 192 MFMAs x 8
-// + the split arithmetic + the half-rate f64 flush = ~4100 issue cycles against 3072 cycles of matrix-pipe time.
-// A wave still owns 32 rows x NC * 32 features; per 32-deep stage it reads the same 4 + 6 NC fragments from LDS and splits the
-// same 16 activation values per lane, and issues 12 NC MFMAs of 32 cycles instead of 24 NC of 16.
-// Lane layout (l = lane, g = l >> 5): both operands hold row (l & 31), k = 8 g .. 8 g + 7 of a 16-deep half-stage h (k = 16 h + 8 g +
-// 0..7 of the stage); the result holds, for activation row (l & 31), the features 8 b + 4 g + 0..3 of the tile for b = 0..3 in
-// registers 4 b .. 4 b + 3.  In-stage order: half-stage 0 then half-stage 1, each the canonical six products.
-__device__ __forceinline__ int a_swz32(int row) { return (row >> 1) & 7; }      // 128-byte rows read by 32-row lane groups: conflict-free
-                                                                                // in the four ds_read_b128 groups (rows {0-3, 12-15, 20-27} | {4-11, 16-19, 28-31})
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-#define SB32_CHAIN(ACC, A, W, ZERO)                                                                                   \
-    do {                                                                                                              \
-        if (ZERO) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[2], (A)[0], (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
-        else ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[2], (A)[0], ACC, 0, 0, 0);                             \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[1], (A)[1], ACC, 0, 0, 0);                                  \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[1], (A)[0], ACC, 0, 0, 0);                                  \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[0], (A)[2], ACC, 0, 0, 0);                                  \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[0], (A)[1], ACC, 0, 0, 0);                                  \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((W)[0], (A)[0], ACC, 0, 0, 0);                                  \
-    } while (0)
-
-__host__ __device__ constexpr int sb32_stage_bytes(int nc) { return 256 * GEMM_BK * 4 + 3 * nc * 32 * GEMM_BK * 2; }
-
-// NC = 32-wide column tiles per wave; FL = stages per f64 flush (F64 only: 2 = the default cadence, 1 = a flush per stage)
-template <bool LEAKY, int NC, bool F64, int FL = 2>
-__global__ __launch_bounds__(768, 3) void k_linear_sb32(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
-                                                        size_t w_plane, int ldw, const float *__restrict__ bias, float *__restrict__ C,
-                                                        int ldc, int m_cap, const int32_t *__restrict__ d_m, int n, int k_pad, float slope,
-                                                        int ntn, int n_major) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    auto stage_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    constexpr int MW = 8, SB_NL = 4, BM = 256, RING = 3;
-    constexpr int STAGE = sb32_stage_bytes(NC);
-    constexpr int SB_A_BYTES = BM * GEMM_BK * 4;
-    constexpr int WPL = NC * 32 * GEMM_BK * 2;         // bytes of one weight plane of a stage
-    static_assert(FL == 1 || FL == 2, "flush per stage or per stage pair");
-    int M = m_cap;
-    if (d_m) {
-        const int dm = *d_m;
-        M = dm < m_cap ? dm : m_cap;
-    }
-    const int ntm = (M + BM - 1) / BM;
-    const int bid = blockIdx.x, nwg = ntm * ntn;
-    if (bid >= nwg) return;
-    const int vstep = (int)gridDim.x;
-    auto tile_of = [&](int v, int &m0o, int &n0o) {
-        const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
-        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
-        int tm, tn;
-        if (n_major) {
-            constexpr int RB = 8;
-            const int band = swz / (RB * ntn), rem = swz - band * (RB * ntn);
-            const int rows = ntm - band * RB < RB ? ntm - band * RB : RB;
-            tn = rem / rows;
-            tm = band * RB + (rem - tn * rows);
-        } else {
-            tm = swz / ntn;
-            tn = swz - tm * ntn;
-        }
-        m0o = tm * BM;
-        n0o = tn * NC * 32;
-    };
-    int m0, n0;
-    tile_of(bid, m0, n0);
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int nk = k_pad / GEMM_BK;
-
-    if (wave >= MW) {
-        // ---- loader waves (as k_linear_sb): 32 activation groups (8 rows x 128 B) + 3 x 2 NC weight groups (16 rows x 64 B) per stage
-        const int li = wave - MW;
-        const int dr = lane >> 3, dp = lane & 7, wr = lane >> 2, wc = lane & 3;
-        __builtin_amdgcn_s_setprio(3);
-        constexpr int NA = (BM / 8) / SB_NL;
-        constexpr int NG = 2 * NC, NW = 3 * NG, NWL = (NW + SB_NL - 1) / SB_NL;
-        const unsigned char *abase, *wbase;
-        unsigned la[NA], lw[NWL];
-        int lw_dst[NWL];
-        auto setup = [&]() {
-            abase = reinterpret_cast<const unsigned char *>(A + (size_t)m0 * lda);
-            wbase = reinterpret_cast<const unsigned char *>(W3 + (size_t)n0 * ldw);
-#pragma unroll
-            for (int g = 0; g < NA; ++g) {
-                const int row = (li * NA + g) * 8 + dr;
-                int grow = m0 + row;
-                grow = grow < M ? grow : M - 1;
-                la[g] = (unsigned)(((grow - m0) * lda + ((dp ^ a_swz32(row)) << 2)) * 4);
-            }
-        };
-        setup();
-#pragma unroll
-        for (int g = 0; g < NWL; ++g) {
-            int idx = li + SB_NL * g;
-            idx = idx < NW ? idx : NW - 1;
-            const int p = idx / NG, grp = idx - p * NG;
-            const int row = grp * 16 + wr;
-            lw[g] = (unsigned)((p * w_plane + (size_t)row * ldw + ((wc ^ w_swz(row)) << 3)) * 2);
-            lw_dst[g] = SB_A_BYTES + p * WPL + grp * 1024;
-        }
-        auto fill = [&](int kt, int buf) {
-            const unsigned base = (unsigned)(size_t)(lds_void *)lds + (unsigned)(buf * STAGE);
-            const unsigned char *ab = abase + (size_t)kt * (GEMM_BK * 4), *wb = wbase + (size_t)kt * (GEMM_BK * 2);
-#pragma unroll
-            for (int g = 0; g < NA; ++g) glds16(la[g], ab, base + (unsigned)((li * NA + g) * 8 * 128));
-#pragma unroll
-            for (int g = 0; g < NWL; ++g)
-                if ((g + 1) * SB_NL <= NW || li + SB_NL * g < NW) glds16(lw[g], wb, base + (unsigned)lw_dst[g]);
-        };
-        fill(0, 0);
-        int nb = 1;
-        for (int v = bid; v < nwg; v += vstep) {
-            const bool more = v + vstep < nwg;
-            for (int kt = 0; kt < nk; ++kt) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage kt has landed ...
-                stage_barrier();                                        // ... and nobody reads the buffer stage kt + 1 goes to
-                if (kt + 1 < nk) {
-                    fill(kt + 1, nb);
-                } else if (more) {
-                    tile_of(v + vstep, m0, n0);
-                    setup();
-                    fill(0, nb);
-                }
-                nb = nb + 1 == RING ? 0 : nb + 1;
-            }
-        }
-        return;
-    }
-
-    // ---- MFMA waves: 32 rows x NC * 32 features each ----
-    const int g = lane >> 5, r32 = lane & 31;
-    const int a_row = (wave * 32 + r32) * 128;
-    int a_c[2][2], w_rd[2];
-    {
-        const int asw = a_swz32(r32);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            a_c[h][0] = a_row + (((4 * h + 2 * g) ^ asw) << 4);
-            a_c[h][1] = a_row + (((4 * h + 2 * g + 1) ^ asw) << 4);
-            w_rd[h] = SB_A_BYTES + r32 * 64 + (((2 * h + g) ^ w_swz(r32)) << 4);      // (+ c * 2048 per column tile: w_swz repeats every 16 rows)
-        }
-    }
-    int b = 0;
-    SB_STAMP(0);
-    for (int v = bid; v < nwg; v += vstep) {
-        if (v != bid) tile_of(v, m0, n0);
-        f32x16 acc[NC], acc_odd[F64 ? 1 : NC];
-        double run[F64 ? NC : 1][16];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc[c][i] = 0.f;
-                if (!F64) acc_odd[c][i] = 0.f;
-                if (F64) run[F64 ? c : 0][i] = 0.0;
-            }
-        }
-        // A stage of a wave = 2 NC chains of six MFMAs, chain q = (column tile q >> 1, half-stage q & 1).  The weight fragments of
-        // chain q + 1 are requested before chain q is issued (its 192 cycles of MFMAs cover their LDS latency), those of chain 0
-        // together with the activation fragments, in front of the split arithmetic: left to itself the compiler requests a chain's
-        // fragments right in front of it (at 161 registers it has no room to do otherwise) and every chain starts with an LDS round trip.
-        bf16x8 ap[2][3], wnext[3];
-        auto prefetch = [&](const unsigned char *buf, const int q) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wnext[p] = *reinterpret_cast<const bf16x8 *>(buf + p * WPL + (q >> 1) * 2048 + w_rd[q & 1]);
-        };
-        auto chain = [&](const unsigned char *buf, const int q, f32x16 (&ACC)[NC], const bool zero) {
-            const bf16x8 wc[3] = {wnext[0], wnext[1], wnext[2]};
-            if (q + 1 < 2 * NC) prefetch(buf, q + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            SB32_CHAIN(ACC[q >> 1], ap[q & 1], wc, zero && (q & 1) == 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        constexpr int NH = (NC + 1) / 2;               // column tiles of the first half of a stage
-        // first piece of a stage: fragments, split arithmetic, the chains of the first NH column tiles; second piece: the others
-        auto piece_a = [&](const unsigned char *buf, f32x16 (&ACC)[NC], const bool zero) {
-            if (F64) __builtin_amdgcn_s_setprio(SB_PRIO_SPLIT);
-            f32x4 x[2][2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                x[h][0] = *reinterpret_cast<const f32x4 *>(buf + a_c[h][0]);
-                x[h][1] = *reinterpret_cast<const f32x4 *>(buf + a_c[h][1]);
-            }
-            prefetch(buf, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) split8(x[h][0], x[h][1], ap[h][0], ap[h][1], ap[h][2]);
-            if (F64) __builtin_amdgcn_s_setprio(SB_PRIO_MFMA);
-#pragma unroll
-            for (int q = 0; q < 2 * NH; ++q) chain(buf, q, ACC, zero);
-        };
-        auto piece_b = [&](const unsigned char *buf, f32x16 (&ACC)[NC], const bool zero) {
-            if (F64) __builtin_amdgcn_s_setprio(SB_PRIO_MFMA);
-#pragma unroll
-            for (int q = 2 * NH; q < 2 * NC; ++q) chain(buf, q, ACC, zero);
-        };
-        auto even_a = [&](const unsigned char *buf) { piece_a(buf, acc, F64); };
-        auto even_b = [&](const unsigned char *buf) { piece_b(buf, acc, F64); };
-        auto odd_a = [&](const unsigned char *buf) {
-            if constexpr (F64) piece_a(buf, acc, FL == 1);
-            else piece_a(buf, acc_odd, false);
-        };
-        auto odd_b = [&](const unsigned char *buf) {
-            if constexpr (F64) piece_b(buf, acc, FL == 1);
-            else piece_b(buf, acc_odd, false);
-        };
-        // f64 flush of the column tiles [c0, c1)
-        auto flush_cols = [&](const int c0, const int c1) {
-            if constexpr (F64) {
-                __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (c >= c0 && c < c1) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) run[c][i] += (double)acc[c][i];
-                    }
-            }
-        };
-        auto flush = [&]() { flush_cols(0, NC); };
-        auto buf_at = [&](int i) { return lds + i * STAGE; };
-        auto next_b = [&](int i) { return i + 1 == RING ? 0 : i + 1; };
-        if (wave < MW / 2) {
-#pragma unroll 1
-            for (int kt = 0; kt < nk; kt += 2) {
-                stage_barrier();                       // barrier kt: stage kt has landed
-                even_a(buf_at(b));
-                even_b(buf_at(b));
-                b = next_b(b);
-                if (FL == 1) flush();
-                if (kt + 1 < nk) {
-                    stage_barrier();
-                    odd_a(buf_at(b));
-                    odd_b(buf_at(b));
-                    b = next_b(b);
-                    flush();
-                } else if (FL == 2) flush();
-            }
-        } else {
-            // the second MFMA wave of every SIMD: the loop rotated by half a stage (k_linear_sb has the protocol)
-            stage_barrier();                           // barrier 0 (of this tile)
-            even_a(buf_at(b));
-            if (FL == 1) flush_cols(0, NH);
-            int kt = 1;
-#pragma unroll 1
-            for (; kt + 1 < nk; kt += 2) {             // kt odd
-                stage_barrier();                       // barrier kt
-                even_b(buf_at(b));                     // second piece of stage kt - 1
-                if (FL == 1) flush_cols(NH, NC);
-                b = next_b(b);
-                odd_a(buf_at(b));
-                if (FL == 1) flush_cols(0, NH);
-                stage_barrier();                       // barrier kt + 1
-                odd_b(buf_at(b));
-                if (FL == 1) flush_cols(NH, NC);
-                else flush();
-                b = next_b(b);
-                even_a(buf_at(b));
-                if (FL == 1) flush_cols(0, NH);
-            }
-            if (kt < nk) {                             // nk even: one odd stage left
-                stage_barrier();
-                even_b(buf_at(b));
-                if (FL == 1) flush_cols(NH, NC);
-                b = next_b(b);
-                odd_a(buf_at(b));
-                odd_b(buf_at(b));
-                flush();
-            } else {                                   // nk odd: the last (even) stage has its first piece done
-                even_b(buf_at(b));
-                if (FL == 1) flush_cols(NH, NC);
-                else flush();
-            }
-            b = next_b(b);                             // the first stage of the next tile
-        }
-        const int m = m0 + wave * 32 + r32;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nb = n0 + c * 32 + q * 8 + g * 4;
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
-                f32x4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float x;
-                    if constexpr (F64) x = (float)(run[c][4 * q + i] + (double)bv[i]);
-                    else x = (acc[c][4 * q + i] + acc_odd[c][4 * q + i]) + bv[i];
-                    if (LEAKY) x = x > 0.f ? x : x * slope;
-                    o[i] = x;
-                }
-                if (m >= M) continue;
-                float *dst = C + (size_t)m * ldc + nb;
-                if (nb + 3 < n) {
-                    *reinterpret_cast<f32x4 *>(dst) = o;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (nb + i < n) dst[i] = o[i];
-                }
-            }
-        }
-    }      // tiles of this workgroup
-    SB_STAMP(2);
-}
-
-// ---- the 32 x 32 x 16 form, software-pipelined: every MFMA wave hides its OWN vector work under its OWN MFMAs -----------------
-// What the twelve-wave kernels above wait for is that the two MFMA waves of a SIMD do not overlap: per stage and SIMD they take
-// about the SUM of their instruction streams (MFMAs 1536 cycles of matrix-pipe time + fragment waits + split arithmetic + flush),
-// not the maximum -- measured 3340 cycles per stage and SIMD for the f64-sum launches, where either form's issue-slot count would
-// allow ~2000.  With the 16 x 16 x 32 instruction a wave cannot help itself: an MFMA holds the vector issue
-// for 8 of its 16 cycles and two other vector instructions fill the rest.  The 32 x 32 x 16 instruction leaves 24 of 32 cycles:
-// six vector instructions per MFMA, and a stage has 24 MFMAs for 88 instructions of split arithmetic and 32 (64 at half rate) of
-// f64 flush.  So here a wave's stream is ONE pipeline over the K stages of all its tiles:
-//   phase 1  chain (c0, h0) | under it: f64 flush of column tile c1 (the sums of the previous flush interval)
-//   phase 2  chain (c1, h0) | split of the activation fragments of half-stage 1 (read in phase 1)
-//   phase 3  chain (c0, h1) | split of the fragments of half-stage 0 of the NEXT stage (read in phase 2)
-//   phase 4  chain (c1, h1) | f64 flush of column tile c0
-// (chain = the canonical six MFMAs of one 32 x 32 tile and one 16-deep half-stage; the weight fragments of a chain are requested
-// during the chain before it.)  The next stage's fragments are read while this stage is multiplied, so the loader waves run TWO
-// stages ahead of the multiplication: barrier s = "stage s + 1 has landed, nobody reads stage s - 1 any more"; the ring of three
-// stages is the same as before.  All eight MFMA waves run in step (no half-stage offset: a wave no longer needs its neighbour).
-// The pipeline runs on across tile borders: the last phases of a tile already split the first fragments of the next one.
-// nk (K stages) must be even and >= 2.
-template <bool LEAKY, int FL>
-__global__ __launch_bounds__(768, 3) void k_linear_sb32p(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
-                                                         size_t w_plane, int ldw, const float *__restrict__ bias, float *__restrict__ C,
-                                                         int ldc, int m_cap, const int32_t *__restrict__ d_m, int n, int k_pad, float slope,
-                                                         int ntn, int n_major) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    auto stage_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    constexpr int NC = 2, MW = 8, SB_NL = 4, BM = 256, RING = 3;
-    constexpr int STAGE = sb32_stage_bytes(NC);
-    constexpr int SB_A_BYTES = BM * GEMM_BK * 4;
-    constexpr int WPL = NC * 32 * GEMM_BK * 2;
-    static_assert(FL == 1 || FL == 2, "flush per stage or per stage pair");
-    int M = m_cap;
-    if (d_m) {
-        const int dm = *d_m;
-        M = dm < m_cap ? dm : m_cap;
-    }
-    const int ntm = (M + BM - 1) / BM;
-    const int bid = blockIdx.x, nwg = ntm * ntn;
-    if (bid >= nwg) return;
-    const int vstep = (int)gridDim.x;
-    auto tile_of = [&](int v, int &m0o, int &n0o) {
-        const int xcd = v & 7, q = nwg >> 3, r = nwg & 7;
-        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
-        int tm, tn;
-        if (n_major) {
-            constexpr int RB = 8;
-            const int band = swz / (RB * ntn), rem = swz - band * (RB * ntn);
-            const int rows = ntm - band * RB < RB ? ntm - band * RB : RB;
-            tn = rem / rows;
-            tm = band * RB + (rem - tn * rows);
-        } else {
-            tm = swz / ntn;
-            tn = swz - tm * ntn;
-        }
-        m0o = tm * BM;
-        n0o = tn * NC * 32;
-    };
-    int m0, n0;
-    tile_of(bid, m0, n0);
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int nk = k_pad / GEMM_BK;
-
-    if (wave >= MW) {
-        // ---- loader waves, two stages ahead ----
-        const int li = wave - MW;
-        const int dr = lane >> 3, dp = lane & 7, wr = lane >> 2, wc = lane & 3;
-        __builtin_amdgcn_s_setprio(3);
-        constexpr int NA = (BM / 8) / SB_NL;
-        constexpr int NG = 2 * NC, NW = 3 * NG, NWL = (NW + SB_NL - 1) / SB_NL;
-        const unsigned char *abase, *wbase;
-        unsigned la[NA], lw[NWL];
-        int lw_dst[NWL];
-        auto setup = [&]() {
-            abase = reinterpret_cast<const unsigned char *>(A + (size_t)m0 * lda);
-            wbase = reinterpret_cast<const unsigned char *>(W3 + (size_t)n0 * ldw);
-#pragma unroll
-            for (int g = 0; g < NA; ++g) {
-                const int row = (li * NA + g) * 8 + dr;
-                int grow = m0 + row;
-                grow = grow < M ? grow : M - 1;
-                la[g] = (unsigned)(((grow - m0) * lda + ((dp ^ a_swz32(row)) << 2)) * 4);
-            }
-        };
-        setup();
-#pragma unroll
-        for (int g = 0; g < NWL; ++g) {
-            int idx = li + SB_NL * g;
-            idx = idx < NW ? idx : NW - 1;
-            const int p = idx / NG, grp = idx - p * NG;
-            const int row = grp * 16 + wr;
-            lw[g] = (unsigned)((p * w_plane + (size_t)row * ldw + ((wc ^ w_swz(row)) << 3)) * 2);
-            lw_dst[g] = SB_A_BYTES + p * WPL + grp * 1024;
-        }
-        auto fill = [&](int kt, int buf) {
-            const unsigned base = (unsigned)(size_t)(lds_void *)lds + (unsigned)(buf * STAGE);
-            const unsigned char *ab = abase + (size_t)kt * (GEMM_BK * 4), *wb = wbase + (size_t)kt * (GEMM_BK * 2);
-#pragma unroll
-            for (int g = 0; g < NA; ++g) glds16(la[g], ab, base + (unsigned)((li * NA + g) * 8 * 128));
-#pragma unroll
-            for (int g = 0; g < NWL; ++g)
-                if ((g + 1) * SB_NL <= NW || li + SB_NL * g < NW) glds16(lw[g], wb, base + (unsigned)lw_dst[g]);
-        };
-        fill(0, 0);
-        fill(1, 1);
-        int nb = 2;
-        for (int v = bid; v < nwg; v += vstep) {
-            const bool more = v + vstep < nwg;
-            for (int kt = 0; kt < nk; ++kt) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stages kt and kt + 1 have landed ...
-                stage_barrier();                                        // ... and nobody reads the buffer of stage kt - 1: stage kt + 2 goes there
-                if (kt + 2 < nk) {
-                    fill(kt + 2, nb);
-                } else if (more) {                                      // stages 0 and 1 of this workgroup's next tile
-                    if (kt + 2 == nk) {
-                        tile_of(v + vstep, m0, n0);
-                        setup();
-                    }
-                    fill(kt + 2 - nk, nb);
-                }
-                nb = nb + 1 == RING ? 0 : nb + 1;
-            }
-        }
-        stage_barrier();                                                // the barrier behind the last stage of the last tile
-        return;
-    }
-
-    // ---- MFMA waves ----
-    const int g = lane >> 5, r32 = lane & 31;
-    int a_c[2][2], w_rd[2];
-    {
-        const int a_row = (wave * 32 + r32) * 128;
-        const int asw = a_swz32(r32);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            a_c[h][0] = a_row + (((4 * h + 2 * g) ^ asw) << 4);
-            a_c[h][1] = a_row + (((4 * h + 2 * g + 1) ^ asw) << 4);
-            w_rd[h] = SB_A_BYTES + r32 * 64 + (((2 * h + g) ^ w_swz(r32)) << 4);
-        }
-    }
-    auto buf_at = [&](int i) { return lds + i * STAGE; };
-    auto next_b = [&](int i) { return i + 1 == RING ? 0 : i + 1; };
-    f32x16 acc[NC];
-    double run[NC][16];
-    bf16x8 ap[2][3], wa[3], wb[3];
-    f32x4 xa[2], xb[2];
-    auto read_w = [&](bf16x8 (&w)[3], const unsigned char *buf, const int c, const int h) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) w[p] = *reinterpret_cast<const bf16x8 *>(buf + p * WPL + c * 2048 + w_rd[h]);
-    };
-    auto read_x = [&](f32x4 (&x)[2], const unsigned char *buf, const int h) {
-        x[0] = *reinterpret_cast<const f32x4 *>(buf + a_c[h][0]);
-        x[1] = *reinterpret_cast<const f32x4 *>(buf + a_c[h][1]);
-    };
-    auto flush_col = [&](const int c) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) run[c][i] += (double)acc[c][i];
-    };
-    // the interleave of a phase: one MFMA per group, behind the first one the phase's D0 LDS reads, behind each V vector instructions
-#define SB32_IL1(V, D0)                                           \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
-    if constexpr ((D0) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (D0) > 0 ? (D0) : 1, 0); \
-    if constexpr ((V) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (V) > 0 ? (V) : 1, 0)
-#define SB32_IL(V, D0)                                            \
-    do {                                                         \
-        SB32_IL1(V, D0);                                         \
-        SB32_IL1(V, 0);                                          \
-        SB32_IL1(V, 0);                                          \
-        SB32_IL1(V, 0);                                          \
-        SB32_IL1(V, 0);                                          \
-        SB32_IL1(V, 0);                                          \
-    } while (0)
-    int b = 0;
-    SB_STAMP(0);
-    stage_barrier();                                   // barrier 0: stages 0 and 1 of the first tile have landed
-    read_x(xa, buf_at(b), 0);
-    read_w(wa, buf_at(b), 0, 0);
-    split8(xa[0], xa[1], ap[0][0], ap[0][1], ap[0][2]);
-    read_x(xb, buf_at(b), 1);
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            acc[c][i] = 0.f;
-            run[c][i] = 0.0;
-        }
-    for (int v = bid; v < nwg; v += vstep) {
-        if (v != bid) tile_of(v, m0, n0);
-        // one stage: ZERO = its chains start the fp32 sums afresh (and the pending sums of column tile c1 are flushed in phase 1);
-        // FLUSH = column tile c0 is flushed in phase 4 (and c1 in phase 1 of the next stage)
-        auto stage = [&](const unsigned char *cur, const unsigned char *nxt, auto zero_c, auto flush_c) {
-            constexpr bool ZERO = decltype(zero_c)::value, FLUSH = decltype(flush_c)::value;
-            // phase 1: chain (c0, h0) with wa; reads: wb = W(c1, h0); vector work: flush of c1 (ZERO stages)
-            __builtin_amdgcn_sched_barrier(0);
-            read_w(wb, cur, 1, 0);
-            if (ZERO) flush_col(1);
-            SB32_CHAIN(acc[0], ap[0], wa, ZERO);
-            SB32_IL(ZERO ? 6 : 0, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            // phase 2: chain (c1, h0) with wb; reads: wa = W(c0, h1), xa = fragments of half-stage 0 of the next stage;
-            // vector work: split of xb (half-stage 1 of this stage) -> ap[1]
-            read_w(wa, cur, 0, 1);
-            read_x(xa, nxt, 0);
-            split8(xb[0], xb[1], ap[1][0], ap[1][1], ap[1][2]);
-            SB32_CHAIN(acc[1], ap[0], wb, ZERO);
-            SB32_IL(8, 5);
-            __builtin_amdgcn_sched_barrier(0);
-            // phase 3: chain (c0, h1) with wa; reads: wb = W(c1, h1); vector work: split of xa -> ap[0] (the next stage's)
-            read_w(wb, cur, 1, 1);
-            SB32_CHAIN(acc[0], ap[1], wa, false);
-            split8(xa[0], xa[1], ap[0][0], ap[0][1], ap[0][2]);
-            SB32_IL(8, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            // phase 4: chain (c1, h1) with wb; reads: wa = W(c0, h0) and xb = half-stage 1 of the next stage; vector work: flush of c0
-            read_w(wa, nxt, 0, 0);
-            read_x(xb, nxt, 1);
-            SB32_CHAIN(acc[1], ap[1], wb, false);
-            if (FLUSH) flush_col(0);
-            SB32_IL(FLUSH ? 6 : 0, 5);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-#pragma unroll 1
-        for (int kt = 0; kt < nk; kt += 2) {
-            const int b1 = next_b(b), b2 = next_b(b1);
-            stage(buf_at(b), buf_at(b1), std::true_type(), std::bool_constant<FL == 1>());
-            stage_barrier();
-            stage(buf_at(b1), buf_at(b2), std::bool_constant<FL == 1>(), std::true_type());
-            stage_barrier();
-            b = b2;
-        }
-        flush_col(1);
-        const int m = m0 + wave * 32 + r32;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nb = n0 + c * 32 + q * 8 + g * 4;
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + nb);
-                f32x4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float x = (float)(run[c][4 * q + i] + (double)bv[i]);
-                    if (LEAKY) x = x > 0.f ? x : x * slope;
-                    o[i] = x;
-                    run[c][4 * q + i] = 0.0;
-                }
-                if (m >= M) continue;
-                float *dst = C + (size_t)m * ldc + nb;
-                if (nb + 3 < n) {
-                    *reinterpret_cast<f32x4 *>(dst) = o;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (nb + i < n) dst[i] = o[i];
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[1][i] = 0.f;       // (phase 1 of the next tile's first stage flushes c1: zeros)
     }      // tiles of this workgroup
     SB_STAMP(2);
 }
@@ -1187,7 +572,7 @@ template <bool LEAKY, bool F64>
 __global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
                                                            size_t w_plane, int ldw, const float *__restrict__ bias,
                                                            float *__restrict__ C, int ldc, int m_cap,
-                                                           const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16) {
+                                                           const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16, int fl) {
     int M = m_cap;
     if (d_m) {
         const int dm = *d_m;
@@ -1213,7 +598,7 @@ __global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restric
         split8(f.a0, f.a1, ap[0], ap[1], ap[2]);
         if (F64 || !(kt & 1)) SB_STAGE(acc, ap, f.w);
         else SB_STAGE(acc_odd, ap, f.w);             // without f64 sums: even / odd stages in separate chains, as k_linear_sb
-        if (F64 && ((kt & 1) || kt == nk - 1)) {
+        if (F64 && ((kt & 1) || kt == nk - 1 || fl == 1)) {       // fl = K stages per f64 flush (k_linear_sb: FL)
 #pragma unroll
             for (int i = 0; i < 4; ++i) run[i] += (double)acc[i];
             acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1252,7 +637,7 @@ template <bool LEAKY, int KS>
 __global__ __launch_bounds__(64 * KS) void k_linear_sb_ks(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
                                                           size_t w_plane, int ldw, const float *__restrict__ bias,
                                                           float *__restrict__ C, int ldc, int m_cap,
-                                                          const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16) {
+                                                          const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16, int fl) {
     extern __shared__ __attribute__((aligned(16))) float s_part[];       // [pairs][64 lanes][4]
     int M = m_cap;
     if (d_m) {
@@ -1267,17 +652,18 @@ __global__ __launch_bounds__(64 * KS) void k_linear_sb_ks(const float *__restric
     grow = grow < M ? grow : M - 1;
     const float *pa = A + (size_t)grow * lda + 8 * fq;
     const unsigned short *pw = W3 + (size_t)(tn * 16 + fr) * ldw + 8 * fq;
-    const int nk = k_pad / GEMM_BK, npair = (nk + 1) / 2;
+    // (fl = K stages per f64 flush: the units are stage pairs, or single stages in the flush-per-stage mode)
+    const int nk = k_pad / GEMM_BK, npair = (nk + fl - 1) / fl;
     for (int j = wave; j < npair; j += KS) {
         SbFrag f0, f1;
-        const int k0 = 2 * j, k1 = 2 * j + 1 < nk ? 2 * j + 1 : nk - 1;
+        const int k0 = fl * j, k1 = fl * j + 1 < nk ? fl * j + 1 : nk - 1;
         sb_load(f0, pa, pw, w_plane, k0 * GEMM_BK);
         sb_load(f1, pa, pw, w_plane, k1 * GEMM_BK);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         bf16x8 ap[3];
         split8(f0.a0, f0.a1, ap[0], ap[1], ap[2]);
         SB_STAGE(acc, ap, f0.w);
-        if (2 * j + 1 < nk) {
+        if (fl == 2 && 2 * j + 1 < nk) {
             split8(f1.a0, f1.a1, ap[0], ap[1], ap[2]);
             SB_STAGE(acc, ap, f1.w);
         }
@@ -1345,8 +731,8 @@ static int sb_narrow_on() {
     return v;
 }
 
-// Does launch_linear_sb16 take the tile kernel for this shape?  (Only the tile kernel's coefficient epilogue stores fp16 rows:
-// callers that want `out_half` ask here first and keep the launch on the fp32 MFMA otherwise.)
+// Does launch_linear_sb16 take the tile kernel for this shape?  (Only the tile kernel stores fp16 rows: callers that want
+// `out_half` ask here first and keep the launch on the fp32 MFMA otherwise.)
 bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64) {
     const int nt16 = (n + 15) / 16;
     const long waves16 = (long)((m_cap + 15) / 16) * nt16;
@@ -1356,20 +742,20 @@ bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64) {
 
 hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
-                              float slope, bool f64, const AttnCoef *coef, bool *coef_done, bool out_half) {
+                              float slope, bool f64, const AttnCoef *coef, bool *coef_done, bool out_half, int flush_stages) {
     if (coef_done) *coef_done = false;
     if (m_cap <= 0 || n <= 0) return hipSuccess;
+    if (flush_stages != 1 && flush_stages != 2) return hipErrorInvalidValue;
     const int skinny_waves = sb_skinny_waves();
     const int narrow_on = sb_narrow_on();
     const int nt16 = (n + 15) / 16, nk = k_pad / GEMM_BK;
     const long waves16 = (long)((m_cap + 15) / 16) * nt16;
     const bool narrow = narrow_on && nt16 <= (f64 ? 4 : 1);
-    // fp16 result rows exist in the tile kernel's coefficient epilogue only: refuse the launch rather than store fp32 rows into a
-    // buffer the caller strides in halves
-    if (out_half && (f64 || leaky || waves16 <= skinny_waves || narrow || !(coef && coef->out_dim == 40 && n == coef->heads * 40)))
-        return hipErrorInvalidValue;
-    if (f64 && (waves16 <= skinny_waves || narrow) && nk <= 256 && nk >= 8) {
-        const size_t shm = (size_t)((nk + 1) / 2) * 1024;
+    // fp16 result rows (fc2 launches of the fp16-attention mode) exist in the tile kernel's fp32-chain forms only: refuse the
+    // launch rather than store fp32 rows into a buffer the caller strides in halves
+    if (out_half && (f64 || leaky || waves16 <= skinny_waves || narrow)) return hipErrorInvalidValue;
+    if (f64 && (waves16 <= skinny_waves || narrow) && nk <= 128 * flush_stages && nk >= 8) {
+        const size_t shm = (size_t)((nk + flush_stages - 1) / flush_stages) * 1024;
         static PerDeviceFlag attr_done;
         if (!attr_done.test()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_sb_ks<true, 8>),
@@ -1382,17 +768,17 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         }
         if (leaky)
             hipLaunchKernelGGL((k_linear_sb_ks<true, 8>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C,
-                               ldc, m_cap, d_m, n, k_pad, slope, nt16);
+                               ldc, m_cap, d_m, n, k_pad, slope, nt16, flush_stages);
         else
             hipLaunchKernelGGL((k_linear_sb_ks<false, 8>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C,
-                               ldc, m_cap, d_m, n, k_pad, slope, nt16);
+                               ldc, m_cap, d_m, n, k_pad, slope, nt16, flush_stages);
         return hipGetLastError();
     }
     if (waves16 <= skinny_waves || narrow) {
         const dim3 grid((unsigned)((waves16 + 3) / 4)), block(256);
 #define MPE_SBS(L_, F_)                                                                                                   \
     hipLaunchKernelGGL((k_linear_sb_skinny<L_, F_>), grid, block, 0, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, \
-                       slope, nt16)
+                       slope, nt16, flush_stages)
         if (leaky && f64) MPE_SBS(true, true);
         else if (leaky) MPE_SBS(true, false);
         else if (f64) MPE_SBS(false, true);
@@ -1403,141 +789,46 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     static PerDeviceFlag lds_attr;
     if (!lds_attr.test()) {
         hipError_t e = hipSuccess;
-        const void *fns[13] = {reinterpret_cast<const void *>(k_linear_sb<true, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW, SB_F64_MT>),
-                              reinterpret_cast<const void *>(k_linear_sb<false, SB_F64_NTT, true, SB_F64_NL, false, SB_F64_MW, SB_F64_MT>),
-                              reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4>),
-                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true>),
-                              reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4, false, 8>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, false, 8>),
-                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true, 8>),
-                              reinterpret_cast<const void *>(k_linear_sb<true, 4, true, 4, false, 8, 2, true>),
-                              reinterpret_cast<const void *>(k_linear_sb<false, 4, true, 4, false, 8, 2, true>),
-                              reinterpret_cast<const void *>(k_linear_sb<true, 5, false, 4, false, 8, 2, true>),
-                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, false, 8, 2, true>),
-                              reinterpret_cast<const void *>(k_linear_sb<false, 5, false, 4, true, 8, 2, true>)};
+        const void *fns[] = {reinterpret_cast<const void *>(k_linear_sb<true, 4, true>), reinterpret_cast<const void *>(k_linear_sb<false, 4, true>),
+                             reinterpret_cast<const void *>(k_linear_sb<true, 4, true, false, 1>), reinterpret_cast<const void *>(k_linear_sb<false, 4, true, false, 1>),
+                             reinterpret_cast<const void *>(k_linear_sb<true, 5, false>), reinterpret_cast<const void *>(k_linear_sb<false, 5, false>),
+                             reinterpret_cast<const void *>(k_linear_sb<false, 5, false, true>)};
         for (const void *fn : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         lds_attr.set();
     }
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
-    static const int m32_on = getenv("MPE_SB_M32") ? atoi(getenv("MPE_SB_M32")) : 0;      // 32 x 32 x 16 form: bits 1 f64-sum launches, 2 plain launches
-    if ((f64 && (m32_on & 5)) || (!f64 && (m32_on & 2) && !(coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky))) {
-        static PerDeviceFlag attr32;
-        if (!attr32.test()) {
-            hipError_t e = hipSuccess;
-            const void *fns[] = {reinterpret_cast<const void *>(k_linear_sb32<true, 2, true>), reinterpret_cast<const void *>(k_linear_sb32<false, 2, true>),
-                                 reinterpret_cast<const void *>(k_linear_sb32<true, 2, true, 1>), reinterpret_cast<const void *>(k_linear_sb32<false, 2, true, 1>),
-                                 reinterpret_cast<const void *>(k_linear_sb32<true, 3, false>), reinterpret_cast<const void *>(k_linear_sb32<false, 3, false>),
-                                 reinterpret_cast<const void *>(k_linear_sb32<true, 2, false>), reinterpret_cast<const void *>(k_linear_sb32<false, 2, false>)};
-            for (const void *fn : fns)
-                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr32.set();
-        }
-        int dev = 0, cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
-        cu = cu >= 8 ? cu / 8 * 8 : 8;
-        static const int nc_plain = getenv("MPE_SB_M32_NC") ? atoi(getenv("MPE_SB_M32_NC")) : 3;
-        const int nc = f64 ? 2 : nc_plain == 2 ? 2 : 3;
-        const int ntn = (n + nc * 32 - 1) / (nc * 32);
-        const int tiles = ((m_cap + 255) / 256) * ntn;
-        const dim3 grid((unsigned)(tiles < cu ? tiles : cu)), block(768);
-        const size_t shm = 3 * (size_t)sb32_stage_bytes(nc);
-        static const int fl1 = getenv("MPE_SB_FL1") ? atoi(getenv("MPE_SB_FL1")) : 0;
-        if (f64 && (m32_on & 4) && (k_pad / GEMM_BK) % 2 == 0 && k_pad >= 2 * GEMM_BK) {       // the software-pipelined form
-            static PerDeviceFlag attr32p;
-            if (!attr32p.test()) {
-                hipError_t e = hipSuccess;
-                const void *fns[] = {reinterpret_cast<const void *>(k_linear_sb32p<true, 1>), reinterpret_cast<const void *>(k_linear_sb32p<false, 1>),
-                                     reinterpret_cast<const void *>(k_linear_sb32p<true, 2>), reinterpret_cast<const void *>(k_linear_sb32p<false, 2>)};
-                for (const void *fn : fns)
-                    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return e;
-                attr32p.set();
-            }
-#define MPE_SB32P(L_, FL_) hipLaunchKernelGGL((k_linear_sb32p<L_, FL_>), grid, block, shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major)
-            if (fl1) { if (leaky) MPE_SB32P(true, 1); else MPE_SB32P(false, 1); }
-            else { if (leaky) MPE_SB32P(true, 2); else MPE_SB32P(false, 2); }
-#undef MPE_SB32P
-            return hipGetLastError();
-        }
-#define MPE_SB32(L_, N_, F_, FL_) hipLaunchKernelGGL((k_linear_sb32<L_, N_, F_, FL_>), grid, block, shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major)
-        if (f64 && fl1) { if (leaky) MPE_SB32(true, 2, true, 1); else MPE_SB32(false, 2, true, 1); }
-        else if (f64) { if (leaky) MPE_SB32(true, 2, true, 2); else MPE_SB32(false, 2, true, 2); }
-        else if (nc == 2) { if (leaky) MPE_SB32(true, 2, false, 2); else MPE_SB32(false, 2, false, 2); }
-        else { if (leaky) MPE_SB32(true, 3, false, 2); else MPE_SB32(false, 3, false, 2); }
-#undef MPE_SB32
-        return hipGetLastError();
-    }
-    // diagnostic: extra dynamic LDS per workgroup (occupancy experiments: how many workgroups does a CU really hold?)
-    static const int lds_pad = getenv("MPE_SB_LDS_PAD") ? atoi(getenv("MPE_SB_LDS_PAD")) * 1024 : 0;
-#define MPE_SB(L_, N_, F_, NL_, MW_, MT_)                                                                                           \
-    hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, NL_, false, MW_, MT_>), dim3((unsigned)(((m_cap + 16 * MT_ * MW_ - 1) / (16 * MT_ * MW_)) * ntn)), \
-                       dim3(64 * (MW_ + NL_)), sb_ring(MW_) * sb_stage_bytes(N_, MW_, MT_) + lds_pad, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, \
-                       k_pad, slope, ntn, n_major)
-    // persistent form of the eight-wave launches: one workgroup per CU walking its tiles (grid = the CU count, a multiple of eight)
-    static const int pers_on = getenv("MPE_SB_PERS") ? atoi(getenv("MPE_SB_PERS")) : 7;       // bits: 1 f64-sum launches, 2 plain, 4 coefficient launches (0 = the plain grid of tiles: diagnostic)
-    static const int n_cu = [] {
-        int dev = 0, cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
-        return cu >= 8 ? cu / 8 * 8 : 8;
-    }();
-#define MPE_SBPERS(L_, N_, F_)                                                                                                      \
-    do {                                                                                                                            \
-        const int tiles = ((m_cap + 255) / 256) * ntn;                                                                              \
-        hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, 4, false, 8, 2, true>), dim3((unsigned)(tiles < n_cu ? tiles : n_cu)), dim3(768), \
-                           3 * sb_stage_bytes(N_, 8, 2) + lds_pad, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, \
-                           n_major);                                                                                                \
-    } while (0)
-    // launches without f64 sums: eight MFMA waves (256 x 80 tiles, one workgroup per CU) or four (128 x 80, two per CU).  Measured
-    // (one board, 180 000 rows): plain launches 257.7 against 267.5 us with eight; with the coefficient epilogue 336.1 against 333.9:
-    // eight for the first, four for the second.  MPE_SB_GAT_MW = 4 | 8 forces one form for both (diagnostic).
-    static const int gat_mw = getenv("MPE_SB_GAT_MW") ? atoi(getenv("MPE_SB_GAT_MW")) : 0;
-    const bool with_coef = coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky;
-    const int mw = gat_mw == 4 ? 4 : gat_mw == 8 ? 8 : with_coef ? 4 : 8;
-    const int ntm = (m_cap + 32 * mw - 1) / (32 * mw);
-    if (f64) {
-        // 64-wide feature tiles: with 80 the f64 running sums of the wider wave tile do not fit the 168 registers that three waves per
-        // SIMD leave (the compiler spills); the MLP's layers balance with 64 anyway
-        const int ntn = (n + SB_F64_NTT * 16 - 1) / (SB_F64_NTT * 16);
-        if (pers_on & 1) {
-            if (leaky) MPE_SBPERS(true, 4, true);
-            else MPE_SBPERS(false, 4, true);
-        } else
-        if (leaky) MPE_SB(true, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW, SB_F64_MT);
-        else MPE_SB(false, SB_F64_NTT, true, SB_F64_NL, SB_F64_MW, SB_F64_MT);
+    // persistent workgroups: one per CU walking its tiles (grid = the CU count rounded down to a multiple of eight, or the tile count)
+    int dev = 0, cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int n_cu = cu >= 8 ? cu / 8 * 8 : 8;
+    const bool with_coef = coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !f64;
+    // 64-wide feature tiles with f64 sums (with 80 the running sums of the wider wave tile do not fit the 168 registers that three
+    // waves per SIMD leave; the MLP's layers balance with 64 anyway), 80-wide without (two 40-wide attention heads per tile)
+    const int ntt = f64 ? 4 : 5;
+    const int ntn = (n + ntt * 16 - 1) / (ntt * 16);
+    const int tiles = ((m_cap + 255) / 256) * ntn;
+    const dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(64 * (SB_MW + SB_NL));
+    const size_t shm = (size_t)SB_RING * sb_stage_bytes(ntt);
+#define MPE_SB(L_, N_, F_, FL_) \
+    hipLaunchKernelGGL((k_linear_sb<L_, N_, F_, false, FL_>), grid, block, shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, \
+                       nullptr, nullptr, nullptr, out_half ? 1 : 0)
+    if (f64 && flush_stages == 1) {
+        if (leaky) MPE_SB(true, 4, true, 1);
+        else MPE_SB(false, 4, true, 1);
+    } else if (f64) {
+        if (leaky) MPE_SB(true, 4, true, 2);
+        else MPE_SB(false, 4, true, 2);
     } else if (with_coef) {
-        // attention coefficients in the epilogue: 40-wide heads on 80-wide tiles (two heads per tile), as launch_linear
-        const int ntn = (n + 79) / 80;
-        if (pers_on & 4) {
-            const int tiles = ((m_cap + 255) / 256) * ntn;
-            hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true, 8, 2, true>), dim3((unsigned)(tiles < n_cu ? tiles : n_cu)), dim3(768),
-                               3 * sb_stage_bytes(5, 8), s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major,
-                               coef->attn_l, coef->attn_r, coef->a12, out_half ? 1 : 0);
-        } else if (mw == 8)
-            hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true, 8>), dim3((unsigned)(ntm * ntn)), dim3(768), 3 * sb_stage_bytes(5, 8), s, A, lda,
-                               W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12,
-                               out_half ? 1 : 0);
-        else
-            hipLaunchKernelGGL((k_linear_sb<false, 5, false, 4, true>), dim3((unsigned)(ntm * ntn)), dim3(512), 2 * sb_stage_bytes(5), s, A, lda, W3,
-                               w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12,
-                               out_half ? 1 : 0);
+        hipLaunchKernelGGL((k_linear_sb<false, 5, false, true>), grid, block, shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad,
+                           slope, ntn, n_major, coef->attn_l, coef->attn_r, coef->a12, out_half ? 1 : 0);
         if (coef_done) *coef_done = true;
     } else {
-        const int ntn = (n + 79) / 80;
-        if (mw == 8 && (pers_on & 2)) {
-            if (leaky) MPE_SBPERS(true, 5, false);
-            else MPE_SBPERS(false, 5, false);
-        } else if (mw == 8) {
-            if (leaky) MPE_SB(true, 5, false, 4, 8, 2);
-            else MPE_SB(false, 5, false, 4, 8, 2);
-        } else {
-            if (leaky) MPE_SB(true, 5, false, 4, 4, 2);
-            else MPE_SB(false, 5, false, 4, 4, 2);
-        }
+        if (leaky) MPE_SB(true, 5, false, 2);
+        else MPE_SB(false, 5, false, 2);
     }
 #undef MPE_SB
-#undef MPE_SBPERS
     return hipGetLastError();
 }
 

@@ -90,6 +90,8 @@ struct mpe_ctx {
     float mlp_slope = 0.1f;
     bool mlp_acc64 = true;         // fp32 MFMA with f64 running sums per K stage in the MLP GEMMs (MLP mode 1; the parity mode of rounds 1-3)
     bool mlp_bf16 = false;         // reduced precision: bf16 MFMA for the MLP GEMMs
+    bool mlp_f64mm = false;        // MLP mode 5: every launch on the f64 matrix pipe (gemm_f64.hip)
+    int mlp_flush = 2;             // MLP modes 3 / 4: K stages per f64 flush of the split form (2 = default, 1 = the maximum-accuracy mode)
     bool mlp_split = true;         // DEFAULT (MLP mode 3): fp32-accurate MLP GEMMs on the bf16 MFMA (three bf16 planes per operand, six products, f64 sums every second stage)
     bool gat_acc64 = false;
     bool gat_reduced = false;      // reduced precision: bf16 MFMA GEMMs + fp16 feature rows in the attention stage
@@ -144,6 +146,8 @@ struct mpe_ctx {
     bool tot_valid = false;
     double sb_ms = 0, sb_flop = 0;      // the split-bf16 launches of the records last read by mpe_profile_read
     int64_t sb_launches = 0;
+    double bf_ms = 0, bf_flop = 0;      // likewise the plain bf16 launches (reduced-precision modes)
+    int64_t bf_launches = 0;
 };
 
 namespace mpe {
@@ -157,8 +161,12 @@ struct AttnCoef {              // fc2 of a graph-attention layer: also emit a1|a
 hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                               float slope, bool f64 = true, const AttnCoef *coef = nullptr, bool *coef_done = nullptr,
-                              bool out_half = false);     // out_half: only with the tile kernel's coefficient epilogue (fp16 ft2 rows, configs[4]); hipErrorInvalidValue otherwise
+                              bool out_half = false,      // out_half (fp16 ft2 rows, configs[4]): tile kernel, fp32-chain launches without LeakyReLU only; hipErrorInvalidValue otherwise
+                              int flush_stages = 2);      // f64 launches: K stages per f64 flush (2 = default, 1 = the maximum-accuracy mode)
 bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64);
+// gemm_f64.hip: exact products, f64 accumulation on the f64 matrix pipe (MLP mode 5: the reference-exact form, not the fast path)
+hipError_t launch_linear_f64(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc,
+                             int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky, float slope);
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,
                          float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                          float slope, bool acc64, const int32_t *a_rows = nullptr, const int32_t *c_rows = nullptr,

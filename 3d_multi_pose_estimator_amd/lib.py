@@ -134,6 +134,7 @@ SYMBOLS = {
     'mpe_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'mpe_profile_read_split': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'mpe_profile_read_bf16': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -820,7 +820,7 @@ class Engine:
         return out
 
     def set_precision(self, gat_acc64=False, mlp_acc64=True, mlp_bf16=False, gat_reduced=False, attn_fp16=False, mlp_split=None,
-                      gat_split=None):
+                      gat_split=None, mlp_max_accuracy=False, mlp_f64=False):
         """GAT: plain fp32 MFMA chain / f64 running sums / `attn_fp16` (BASELINE configs[4] as worded: the transformed
         features ft2 travel to the attention stage as fp16 rows, the GEMMs stay fp32) / `gat_reduced` (additionally
         bf16 MFMA for fc1/fc2); MLP: fp32 / f64 running sums (default, parity) / bf16 MFMA.  The reduced modes are
@@ -835,14 +835,21 @@ class Engine:
         # The parity MLP (mlp_acc64=True, not bf16) has two forms of the same accuracy class: the library default
         # (mlp_split=None / True: fp32 operands as three bf16 planes, six products on the bf16 matrix pipe, f64 sums every
         # second K stage; csrc/gemm_sb16.hip) and the fp32 MFMA with f64 sums per stage of rounds 1-3 (mlp_split=False).
+        # mlp_max_accuracy: the split form with an f64 flush after EVERY K stage (MLP mode 4): rms error of a launch 0.13-0.18
+        # instead of 0.24-0.26 ulp of its output scale, the MLP launches ~7 % slower.
         if mlp_split is None:
             mlp_split = bool(mlp_acc64) and not mlp_bf16
-        self._chk(self.lib.mpe_set_precision(self.ctx, gat, 2 if mlp_bf16 else 3 if mlp_split else int(mlp_acc64)))
-        self._state['precision'] = (gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16, mlp_split, gat_split)
+        # mlp_f64: the reference-exact form (MLP mode 5): exact products, f64 accumulation on the f64 matrix pipe; several times slower.
+        if mlp_max_accuracy and (mlp_bf16 or not mlp_split or mlp_f64):
+            raise ValueError('mlp_max_accuracy is a mode of the split-bf16 MLP (mlp_acc64=True, not mlp_bf16, mlp_split not False)')
+        if mlp_f64 and mlp_bf16:
+            raise ValueError('mlp_f64 and mlp_bf16 exclude each other')
+        self._chk(self.lib.mpe_set_precision(self.ctx, gat, 5 if mlp_f64 else 2 if mlp_bf16 else 4 if mlp_max_accuracy else 3 if mlp_split else int(mlp_acc64)))
+        self._state['precision'] = (gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16, mlp_split, gat_split, mlp_max_accuracy, mlp_f64)
         for e in self._siblings:
-            e.set_precision(gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16, mlp_split, gat_split)
+            e.set_precision(gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16, mlp_split, gat_split, mlp_max_accuracy, mlp_f64)
 
-    def linear(self, x, w, b, slope=None, acc64=False, split=False, split_f64=True):
+    def linear(self, x, w, b, slope=None, acc64=False, split=False, split_f64=True, split_flush_per_stage=False, f64mm=False):
         """act(x @ w.T + b) through the MFMA GEMM (parity tests). x device [m,k]; w,b host.  split: the split-bf16
         arithmetic of csrc/gemm_sb16.hip."""
         w = _np32(w)
@@ -858,7 +865,7 @@ class Engine:
             ldc = (n + 3) // 4 * 4
             y = torch.empty((m, ldc), dtype=torch.float32, device=self.device)
             self._chk(self.lib.mpe_linear(self.ctx, self._stream(), _ptr(xp), ldw.value, dw, ldw.value, dbias,
-                                          _ptr(y), ldc, m, None, n, k, (0 if slope is None else 1) | (2 if acc64 else 0) | (4 if split else 0) | (0 if split_f64 else 8),
+                                          _ptr(y), ldc, m, None, n, k, (0 if slope is None else 1) | (2 if acc64 else 0) | (4 if split else 0) | (0 if split_f64 else 8) | (16 if split_flush_per_stage else 0) | (32 if f64mm else 0),
                                           0.0 if slope is None else float(slope)))
             torch.cuda.synchronize(self.device)
             return y[:, :n].contiguous()
@@ -878,6 +885,8 @@ class Engine:
         out = {'gemm_ms': ms.value, 'gemm_flop': fl.value, 'gemm_launches': n.value}
         self._chk(self.lib.mpe_profile_read_split(self.ctx, C.byref(ms), C.byref(fl), C.byref(n)))
         out.update({'split_ms': ms.value, 'split_flop': fl.value, 'split_launches': n.value})    # MLP launches on the bf16 MFMA
+        self._chk(self.lib.mpe_profile_read_bf16(self.ctx, C.byref(ms), C.byref(fl), C.byref(n)))
+        out.update({'bf16_ms': ms.value, 'bf16_flop': fl.value, 'bf16_launches': n.value})       # plain bf16 launches (reduced modes)
         return out
 
 

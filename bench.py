@@ -19,7 +19,11 @@ all ranks receive all T results (distributed.all_gather_results).
 
 What is timed.  `value` = whole-job frames/s with the packed 2D skeletons already resident in HBM
 when the timed region starts and the poses left in HBM (barrier + synchronize on both sides, max
-over ranks; the bench contract's definition -- a PCIe-inclusive rate is never `value`).  The engine
+over ranks; the bench contract's definition -- "inputs already resident in HBM when the timed region
+starts", a PCIe-inclusive rate is never `value`).  The figure SURVEY.md 8(d) words -- pinned host ->
+poses in pinned host -- is the region `io_inclusive` and is repeated at the top level of the line as
+`value_host_to_host` so that nobody has to dig for it; `value_json_cold` is the first pass over
+wire-format JSON bytes.  The engine
 runs in its default mode: two contexts (own workspace, same weights: Engine.sibling) take turns on the
 steps, each on its own stream, so two whole steps are in flight and fill each other's launch tails
 (`--contexts 2`, Engine.run_pipelined(contexts=2)).  `--contexts 1 --streams 2` = one context with the
@@ -389,6 +393,19 @@ def run_rank(args):
     torch.cuda.synchronize(device)
     for e in engs:
         e.sync_status()
+    if distributed:
+        # Before anything is timed: the process group has the size the command asked for, and one exchange puts every rank's own
+        # shard, bit for bit, at its place in what it received.  A job that fails either check ends here with a non-zero code.
+        ok_ws = dist.get_world_size() == args.gpus or bool(os.environ.get('MPE_BENCH_FORCE_DIST'))
+        p0, n0 = step_single()
+        torch.cuda.synchronize(device)
+        ok_g = check_gather(torch, dist, gather, p0, n0, rank, cap, B, device)
+        if not (ok_ws and ok_g):
+            if rank == 0:
+                print('bench.py: distributed self-check failed before the timed region: world size %d (asked for %d), gathered == local: %s'
+                      % (dist.get_world_size(), args.gpus, ok_g), file=sys.stderr)
+            dist.destroy_process_group()
+            return 3
     for _ in range(args.warmup):
         step()
 
@@ -400,16 +417,7 @@ def run_rank(args):
         for s_ in [s_match, s_3d] + ctx_streams:
             if s_ is not None:
                 torch.cuda.current_stream(device).wait_stream(s_)
-        gp, gn = gather(poses, n_persons)
-        mine = slice(rank * cap, rank * cap + B)
-        ok = bool(torch.equal(gn[mine], n_persons[:B]))
-        if ok and B:
-            live = torch.arange(poses.shape[1], device=device)[None, :] < n_persons[:B, None].to(torch.int64)
-            bits = torch.int32 if poses.dtype == torch.float32 else torch.int64          # NaN joints (DLT) compare as bits
-            ok = bool(torch.equal(gp[mine][live].contiguous().view(bits), poses[:B][live].contiguous().view(bits)))
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        gathered_ok = bool(t.item())
+        gathered_ok = check_gather(torch, dist, gather, poses, n_persons, rank, cap, B, device)
 
     # ---- kernel-level pass: one stream, HIP event pairs around the GEMM launches of every n-th step ----
     prof = None
@@ -431,6 +439,26 @@ def run_rank(args):
         eng.profile(False)
         prof['sampled_steps'] = len(range(0, args.profile_steps, every))
         prof['single_stream_ms_per_step'] = 1e3 * single_dt / args.profile_steps
+
+    # ---- the MLP's maximum-accuracy mode (f64 flush per K stage) beside the default: same region, same engine mode, fewer steps ----
+    max_acc = None
+    plain_parity_path = args.mode == 'mlp' and not (args.reduced or args.cfg4 or args.bf16_mlp or args.fast_mlp or args.mlp_fp32_mfma)
+    if plain_parity_path and not distributed and args.steps >= 10:
+        for s_ in [s_match, s_3d] + ctx_streams:
+            if s_ is not None:
+                torch.cuda.current_stream(device).wait_stream(s_)
+        eng.set_precision(args.gat_acc == 'f64', True, gat_split=False if args.gat_fp32_mfma else None, mlp_max_accuracy=True)
+        for _ in range(max(4, 2 * K)):
+            step()
+        n_ma = max(10, args.steps // 4)
+        dt_ma, _ = timed(lambda i: step(), n_ma)
+        eng.set_precision(args.gat_acc == 'f64', True, gat_split=False if args.gat_fp32_mfma else None)
+        for _ in range(2 * K):
+            step()
+        torch.cuda.synchronize(device)
+        max_acc = {'value': total * n_ma / dt_ma, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt_ma / n_ma, 'steps': n_ma,
+                   'what': 'the timed region of `value` with the MLP in its maximum-accuracy mode (mpe_set_precision MLP 4: f64 flush after '
+                           'every 32-deep K stage instead of every second one)'}
 
     # ---- contract form: pinned host -> H2D -> compute -> D2H into pinned host, double-buffered ----
     io = None
@@ -492,6 +520,13 @@ def run_rank(args):
                                           ('fp32 operands as three bf16 planes, six products on the bf16 MFMA, fp32 accumulators (fp32-accurate)',
                                            'in the same split form with f64 running sums every second K stage'))),
                    'weights': 'deterministic hash init (no checkpoint offline)'},
+        'value_resident': value,
+        'value_host_to_host': io['value'] if io else None,
+        'value_json_cold': jsn['value'] if jsn else None,
+        'value_definitions': 'value = value_resident: packed input resident in HBM, poses left in HBM (the bench contract: "inputs already resident '
+                             'in HBM when the timed region starts; a PCIe-inclusive rate is never value"); value_host_to_host = io_inclusive.value: '
+                             'SURVEY 8(d) as worded, compact 2D keypoints in pinned host memory -> poses in pinned host memory (and gathered '
+                             'when world > 1); value_json_cold = json_inclusive.value: wire-format JSON bytes read ONCE -> poses in pinned host memory',
         'io_inclusive': io,
         'json_inclusive': jsn,
         'dropin_loop': dropin,
@@ -501,6 +536,9 @@ def run_rank(args):
         # the CPU baseline and the parity sample are taken on rank 0 at N = 1 only
         base, par_ = (None, None) if world > 1 else cpu_baseline_and_parity(args, np, torch, calib, params, lo, device)
         out['cpu_baseline'] = base
+        if par_ is not None and max_acc is not None and par_.get('mlp_max_accuracy') is not None:
+            par_['mlp_max_accuracy'].update({'frames_per_s': max_acc['value'], 'frames_per_s_default_mode': value,
+                                             'ms_per_step': max_acc['ms_per_step'], 'timed': max_acc['what']})
         out['parity'] = par_
         print(json.dumps(out), flush=True)
     if distributed:
@@ -508,6 +546,20 @@ def run_rank(args):
         dist.destroy_process_group()
     eng.close()
     return 0
+
+
+def check_gather(torch, dist, gather, poses, n_persons, rank, cap, B, device):
+    """One exchange, checked on every rank: its own shard sits, bit for bit, at its place in what it received (MIN over ranks)."""
+    gp, gn = gather(poses, n_persons)
+    mine = slice(rank * cap, rank * cap + B)
+    ok = bool(torch.equal(gn[mine], n_persons[:B]))
+    if ok and B:
+        live = torch.arange(poses.shape[1], device=device)[None, :] < n_persons[:B, None].to(torch.int64)
+        bits = torch.int32 if poses.dtype == torch.float32 else torch.int64          # NaN joints (DLT) compare as bits
+        ok = bool(torch.equal(gp[mine][live].contiguous().view(bits), poses[:B][live].contiguous().view(bits)))
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
 
 
 def io_inclusive(args, torch, dist, packing, engs, pb, device, stage3d, gather, timed, distributed, total):
@@ -633,12 +685,14 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
     hbm_tbs = per_gpu_fps * bytes_per_frame / 1e12
     sampled = max(1, prof.get('sampled_steps', 1))
     split_flop, split_ms, split_n = prof.get('split_flop', 0.0), prof.get('split_ms', 0.0), prof.get('split_launches', 0)
-    flop_per_step = (prof['gemm_flop'] + split_flop) / sampled
+    bf_flop, bf_ms, bf_n = prof.get('bf16_flop', 0.0), prof.get('bf16_ms', 0.0), prof.get('bf16_launches', 0)      # reduced modes only
+    flop_per_step = (prof['gemm_flop'] + split_flop + bf_flop) / sampled
     step_s = elapsed / args.steps
     step_tf = flop_per_step / step_s / 1e12      # per GPU: every rank runs its own shard
     # time the two matrix pipes would need at their peaks for one step's launches: fp32 launches at the fp32 MFMA peak, the
     # split-bf16 launches (six bf16 products per fp32-equivalent product) at the dense bf16 peak
-    t_min = (prof['gemm_flop'] / sampled) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + 6.0 * (split_flop / sampled) / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    t_min = ((prof['gemm_flop'] / sampled) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + 6.0 * (split_flop / sampled) / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+             + (bf_flop / sampled) / (PEAK_BF16_MFMA_TFLOPS * 1e12))
     measured = ('HIP events around every GEMM launch of %d sampled steps of a single-stream pass (%d steps) after the timed region; '
                 'rocprofv3 --kernel-trace --stats agrees with it on the one-context one-stream command (`bench.py --contexts 1 --streams 1`, '
                 'profiles/r04_bench_streams1_kernel_stats.csv); with two contexts in flight the kernels of two steps overlap and a launch\'s '
@@ -652,8 +706,8 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
         eq = split_flop / (split_ms * 1e-3) / 1e12
         main = {'kernel': 'mpe::k_linear_sb* (csrc/gemm_sb16.hip: nn.Linear with fp32 operands taken as three bf16 planes each, the six '
                           'significant partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulators (+ f64 running sums every second K '
-                          'stage in the MLP), activation tile and weight planes staged by LDS-DMA from loader waves (MLP and plain GAT launches: one twelve-wave '
-                          'workgroup per CU, 256-row tiles, ring of three K stages; coefficient launches: two eight-wave workgroups), fused bias + LeakyReLU '
+                          'stage in the MLP), activation tile and weight planes staged by LDS-DMA from loader waves (one persistent twelve-wave '
+                          'workgroup per CU, 256-row tiles, ring of three K stages), fused bias + LeakyReLU '
                           '+ attention coefficients): the GAT launches of layers 1-4 and all MLP launches = %.0f %% of the GEMM time of a step'
                           % (100.0 * split_ms / max(1e-9, split_ms + prof['gemm_ms'])),
                 'bound': 'mfma',
@@ -667,21 +721,38 @@ def roofline(args, prof, elapsed, total, world, V, J, persons, reduced):
                 'fp32_mfma_launches': fp32}
     else:
         main = dict(fp32, bound='mfma')
+    bf16 = None
+    if bf_n:
+        bf_tf = bf_flop / (bf_ms * 1e-3) / 1e12
+        bf16 = {'kernel': 'mpe::k_linear_bf16 (reduced precision, configs[4]: weights and staged activations in bf16, one bf16 product per product)',
+                'bound': 'mfma', 'achieved': bf_tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': bf_tf / PEAK_BF16_MFMA_TFLOPS,
+                'launches': bf_n, 'avg_launch_ms': bf_ms / bf_n, 'flop_per_step': bf_flop / sampled}
+        if bf_ms > split_ms and bf_ms > prof['gemm_ms']:        # the bf16 launches carry the step: they are the dominant kernel of this run
+            bf16['fp32_mfma_launches'] = fp32
+            if split_n:
+                bf16['split_bf16_launches'] = {k: main[k] for k in ('achieved', 'peak', 'frac', 'launches', 'avg_launch_ms') if k in main}
+            main = bf16
+        else:
+            main['bf16_launches'] = bf16
     main.update({
         'traffic': traffic, 'traffic_source': src, 'measured': measured,
         'sampled_steps': sampled, 'flop_per_step': flop_per_step,
-        'gemm_share_of_single_stream_step': ((gemm_s + split_ms * 1e-3) / sampled) / (prof['single_stream_ms_per_step'] * 1e-3),
+        'gemm_share_of_single_stream_step': ((gemm_s + split_ms * 1e-3 + bf_ms * 1e-3) / sampled) / (prof['single_stream_ms_per_step'] * 1e-3),
         'single_stream_ms_per_step': prof['single_stream_ms_per_step'],
         'step': {'achieved': step_tf, 'frac': t_min / step_s, 'unit': 'TFLOP/s',
                  'frac_against_fp32_peak': step_tf / PEAK_FP32_MFMA_TFLOPS,
                  'definition': 'achieved: algorithmic GEMM FLOPs (2*M*N*K, fp32-equivalent) of one step / wall time of one step of the '
                                'timed region (every kernel of the step, engine mode as in config.engine_mode).  frac: the time the matrix '
                                'pipes would need at their peaks for the step\'s launches (fp32 launches at %.1f TFLOP/s, split-bf16 '
-                               'launches as six bf16 products at %.0f TFLOP/s) / that wall time; frac_against_fp32_peak: achieved / the '
+                               'launches as six bf16 products and plain bf16 launches as one at %.0f TFLOP/s) / that wall time; frac_against_fp32_peak: achieved / the '
                                'fp32 MFMA peak, the figure of rounds 1-3 (equal to frac when no launch runs on the bf16 pipe)'
                                % (PEAK_FP32_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS)},
-        'flop_definition': 'algorithmic 2*M*N*K of the launches (layer-0 edge-node rows de-duplicated)'
-                           + ('; NOTE: reduced-precision run, bf16 launches are priced against the fp32 peak here' if reduced else ''),
+        'flop_definition': 'algorithmic 2*M*N*K of the launches (layer-0 edge-node rows de-duplicated); every launch is priced against the '
+                           'peak of the pipe it runs on',
+        'what_bounds_it': 'POWER: the in-kernel clock of the split-bf16 launches on real operands is 2.0 GHz (2.4 GHz with zero weights at the '
+                          'same cycle count, profiles/r05_sb_clock.txt); the peak above is the 2.4 GHz figure',
+        'roofline_note': 'frac = the dominant kernel\'s achieved / peak; frac_against_fp32_peak (in `step`) is a ratio of FLOP definitions, not a roofline fraction',
+
     })
     main['hbm'] = {'achieved': hbm_tbs, 'peak': PEAK_HBM_TBS, 'unit': 'TB/s', 'frac': hbm_tbs / PEAK_HBM_TBS,
                    'bytes_per_frame': bytes_per_frame,
@@ -721,11 +792,11 @@ def json_inclusive(args, torch, eng, wire, B, uniq, contexts=1):
         if os.environ.get('MPE_BENCH_JSON_REPEAT'):
             print('json_inclusive repeat %d: %.1f frames/s' % (rep, got / dt), file=sys.stderr)
     threads = usable_cpus()
-    return {'value': got / dt, 'value_cold': cold, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / n_steps, 'steps': n_steps,
-            'json_bytes_per_step': len(text) // n_steps, 'json_gb_per_s': len(text) / dt / 1e9, 'host_threads_available': threads,
+    return {'value': cold, 'value_warm': got / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * n_steps * B / cold / n_steps, 'steps': n_steps,
+            'json_bytes_per_step': len(text) // n_steps, 'json_gb_per_s': len(text) * (cold / (n_steps * B)) / 1e9, 'host_threads_available': threads,
             'parser': 'device (csrc/jsonparse.hip); host: frame extents + string extents only',
-            'warmup': 'value: the second pass over the same document (page and cache state warm); value_cold: the first pass over the '
-                      'freshly built bytes, what a stream that is read once sees',
+            'warmup': 'value: the FIRST pass over the freshly built bytes, what a stream that is read once sees (two 2-batch calls before it '
+                      'make the streams and buffers); value_warm: the second pass over the same document (page and cache state warm)',
             'what': 'wire-format frame JSON bytes in host memory -> first level on the host (parallel frame scan, skeleton strings '
                     'copied to a page-locked buffer) -> H2D -> second level parsed on the device -> match + 3D stage -> D2H of '
                     'poses into pinned host memory; batch i+1 is parsed while batch i computes'
@@ -816,11 +887,16 @@ def cpu_baseline_and_parity(args, np, torch, calib, params, lo, device):
         else:
             poses = eng.triangulate(db, persons, n_persons)[0]
         eng.sync_status()
+        poses_ma = None
+        if args.mode == 'mlp' and not (args.reduced or args.cfg4 or args.bf16_mlp):
+            eng.set_precision(False, True, mlp_max_accuracy=True)              # the MLP's maximum-accuracy mode on the same persons
+            poses_ma = eng.mlp3d(db, persons, n_persons)[0].cpu().numpy()
+            eng.set_precision(False, True)
         persons, n_persons, poses = persons.cpu().numpy(), n_persons.cpu().numpy(), poses.cpu().numpy()
         scores = scores.cpu().numpy()
         used = list(calib.params.used_joints)
         exact, max_abs, max_ulp, dscore, largest = 0, 0.0, 0.0, 0.0, 0.0
-        e_gpu, e_cpu, gx, rx = [], [], 0.0, 0.0
+        e_gpu, e_cpu, gx, rx, gx_ma, d_ma = [], [], 0.0, 0.0, 0.0, 0.0
 
         def mpjpe(pred, gt_people):
             return min(float(np.mean([np.linalg.norm(pred[j] - g[j]) for j in used])) for g in gt_people)
@@ -843,6 +919,9 @@ def cpu_baseline_and_parity(args, np, torch, calib, params, lo, device):
                 ex = onp.mlp_exact(mlp_sd, r['mlp_in']).numpy().reshape(len(want), -1, 3) * 10.0
                 gx = max(gx, float(np.abs(poses[f, :len(want)] - ex).max()))
                 rx = max(rx, float(np.abs(ref - ex).max()))
+                if poses_ma is not None:
+                    gx_ma = max(gx_ma, float(np.abs(poses_ma[f, :len(want)] - ex).max()))
+                    d_ma = max(d_ma, float(np.abs(poses_ma[f, :len(want)] - ref).max()))
             else:
                 ref = np.stack([np.stack([t.get(j, np.zeros(3)) for j in range(eng.J)]) for t in r['tri']])
             d = np.abs(poses[f, :len(want)] - ref)
@@ -861,6 +940,10 @@ def cpu_baseline_and_parity(args, np, torch, calib, params, lo, device):
               'max_abs_ulp': max_ulp if args.mode == 'mlp' else None,
               'ref_vs_exact_mm': rx * 1e3 if args.mode == 'mlp' else None,
               'gpu_vs_exact_mm': gx * 1e3 if args.mode == 'mlp' else None,
+              'mlp_max_accuracy': ({'gpu_vs_exact_mm': gx_ma * 1e3, 'max_abs_mm': d_ma * 1e3, 'within_1e-3_mm_of_exact': gx_ma * 1e3 <= 1e-3,
+                                    'mode': 'mpe_set_precision MLP 4: the split-bf16 form with an f64 flush after every K stage; asserted on every '
+                                            'capture-volume golden row of the four rigs by tests/test_gpu_stages.py::test_mlp_within_1e_3_mm_of_the_exact_network'}
+                                   if poses_ma is not None else None),
               'mpjpe_mm': float(np.mean(e_gpu)) * 1e3 if e_gpu else None,
               'delta_mpjpe_mm': (abs(float(np.mean(e_gpu)) - float(np.mean(e_cpu))) * 1e3) if e_gpu else None,
               'max_abs_score_diff': dscore,

@@ -110,6 +110,26 @@ typedef struct {
     const int32_t *d_en_pair;
 } mpe_batch;
 
+/* ---- environment switches of the library (diagnostics; none is needed in production) -------------------------------------------
+ * The list is FROZEN (round 5): these are all the variables csrc/ reads.  Read once per process unless marked "per call".
+ *   kernel selection, each a cross-check path the GPU suite is run under (tools/run_switch_matrix.sh):
+ *     MPE_SKINNY_WAVES=<n>        16 x 16 tiles up to which the wave-per-tile GEMM kernels run (default 1024; 0 = tile kernels always)
+ *     MPE_GEMM_NARROW=0           narrow outputs (<= 16 / 64 features) on the tile kernels as well
+ *     MPE_GAT_ACC64_MINK=<k>      GAT launches with K > k get f64 running sums (default 512: fc2 of layer 0; 0 = never)
+ *     MPE_L0_GROUPED=0            layer-0 fc1 dense over the whole 902-wide row instead of per camera block
+ *     MPE_NO_COEF_EPILOGUE        (per call) attention coefficients from k_attn_coef instead of the fc2 epilogue
+ *     MPE_NO_FUSED_ATTENTION      (per call) the general attention kernels for every frame size
+ *     MPE_FUSED_NO_OVERLAP        (per call) plain staging in k_gat_fused
+ *     MPE_NO_HEAD_SRC_TABLE       (per call) in-edge sources derived in the kernels instead of read from the per-batch table
+ *     MPE_CLUSTER_KERNEL=wave|block|lds|big   (per call) clustering kernel
+ *     MPE_HALF_VEC=4              fp16 rows of the general attention kernels read 4 columns per thread instead of 8
+ *     MPE_JSON_WGS=<n>            workgroups of the device-side JSON walk
+ *   host packer (threads, timing prints): MPE_PACK_THREADS, MPE_SCAN_THREADS, MPE_SCAN_CHUNK_KB, MPE_PACK_NO_SIMD, MPE_PACK_TIMING,
+ *     MPE_STAGE_TIMING
+ * Gone since round 5 (their code left the library): MPE_GEMM_TUNE, MPE_GEMM_BN, MPE_GEMM_LOADER, MPE_SB_GAT_MW, MPE_SB_PERS,
+ * MPE_SB_LDS_PAD, and the compile-time ablation switches MPE_EXP / MPE_SBEXP.  `make exp EXPFLAGS=-DMPE_SB_CLOCK` builds the one
+ * diagnostic variant left: in-kernel clock stamps of the split-bf16 tile kernel (tools/sb_clock_probe.py). */
+
 /* ---- lifetime ------------------------------------------------------------------------ */
 int mpe_create(const mpe_config *cfg, mpe_ctx **out);
 void mpe_destroy(mpe_ctx *ctx);
@@ -133,7 +153,10 @@ int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_d
  * 4) = the same accuracy class on the bf16 matrix pipe: every fp32 operand is taken as the exact sum of three bf16 numbers, the
  * six significant partial products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulators flushed into f64 sums every second
  * stage (csrc/gemm_sb16.hip; measured error against exactly evaluated dot products: that of mode 1 or below, 1.35x faster
- * launches).  Defaults: GAT 4 (below), MLP 3 (the MLP's K is up to 3072 and its 3D output is compared with the reference at the
+ * launches).  MLP mode 4 = mode 3 with an f64 flush after EVERY stage: the maximum-accuracy form (rms error of a launch 0.13-0.18
+ * instead of 0.24-0.26 ulp of its output scale; the MLP launches take ~7 % longer).  MLP mode 5 = the reference-exact form: exact
+ * fp32 x fp32 products accumulated in f64 over the whole K on the f64 matrix pipe (v_mfma_f64_16x16x4_f64, csrc/gemm_f64.hip), i.e. the
+ * network evaluated in f64 with fp32 rounding between layers; several times slower, for parity work.  Defaults: GAT 4 (below), MLP 3 (the MLP's K is up to 3072 and its 3D output is compared with the reference at the
  * micrometre level: DESIGN.md section 5; mode 1 stays selectable).  MLP mode 2 is the
  * reduced-precision variant of BASELINE.json configs[4]: weights and staged activations in
  * bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~3 significant digits; not parity).
@@ -145,9 +168,9 @@ int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_d
  * on the fp32 MFMA.  GAT modes 4 (the GAT DEFAULT since round 4), 5 and 6 are modes 0, 1 and 3 with fc1 / fc2 of the layers
  * >= 1 in the split-bf16 form of MLP mode 3 (fp32-accurate: rms error of a launch at or below the fp32 MFMA chain's, 1.5x
  * faster launches; without f64 sums where mode 0 has none); layer 0's gathered launches stay on the fp32 MFMA.  In mode 6 the
- * fc2 launches of 40-wide attention heads store their fp16 rows from the split tile kernel's coefficient epilogue when the
- * batch is large enough for the tile kernel (more than MPE_SKINNY_WAVES = 1024 16 x 16 tiles); every other fp16-row launch
- * (small batches, 30-wide and 1-wide heads, f64-sum launches) stays on the fp32 MFMA, whose kernels all store fp16 rows. */
+ * fc2 launches store their fp16 rows from the split tile kernel when the batch is large enough for it (more than
+ * MPE_SKINNY_WAVES = 1024 16 x 16 tiles, more than one 16-wide output tile); every other fp16-row launch (small batches, the
+ * 1-wide last layer, f64-sum launches) stays on the fp32 MFMA, whose kernels all store fp16 rows. */
 int mpe_set_precision(mpe_ctx *ctx, int32_t gat_acc64, int32_t mlp_acc64);
 
 /* ---- batch entry points ---------------------------------------------------------------
@@ -184,7 +207,9 @@ int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
 /* C[M][N] = act(A[M][K] * W[N][K]^T + bias): nn.Linear (+ LeakyReLU when slope_on != 0).
  * Row strides in elements; A and C device pointers, W/bias device pointers prepared by
  * mpe_upload_linear (zero padded).  d_m, if not NULL, overrides M with a device-side count.
- * flags: bit 0 = apply LeakyReLU(slope), bit 1 = f64 running sums (see mpe_set_precision). */
+ * flags: bit 0 = apply LeakyReLU(slope), bit 1 = f64 running sums (see mpe_set_precision), bit 2 = the split-bf16 form
+ * (csrc/gemm_sb16.hip; the planes are made for the call), with bit 3 = without its f64 sums and bit 4 = an f64 flush per K stage;
+ * bit 5 = the f64 matrix-pipe form (csrc/gemm_f64.hip). */
 int mpe_upload_linear(mpe_ctx *ctx, const float *w, const float *b, int32_t out_dim, int32_t in_dim,
                       float **d_w, float **d_b, int32_t *ldw);
 int mpe_free_device(mpe_ctx *ctx, void *d_ptr);
@@ -344,6 +369,8 @@ int mpe_profile_read(mpe_ctx *ctx, double *gemm_ms, double *gemm_flop, int64_t *
  * same records (MLP mode 3: k_linear_sb*, fp32-equivalent FLOPs = 2 M N K, executed on the bf16 MFMA as six products) are kept
  * apart and read here, after mpe_profile_read. */
 int mpe_profile_read_split(mpe_ctx *ctx, double *ms, double *flop, int64_t *launches);
+/* ... and the plain bf16 launches of the reduced-precision modes (configs[4]): one bf16 product per product, priced against the bf16 peak */
+int mpe_profile_read_bf16(mpe_ctx *ctx, double *ms, double *flop, int64_t *launches);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CASES, ROOT, load_case, oracle
+from conftest import CASES, GOLDEN, ROOT, load_case, oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -212,9 +212,10 @@ def test_rows_prefetched_per_frame_equal_the_per_person_rows(dropin, monkeypatch
 
 
 def test_dropin_loop_region_gives_the_engine_bits(gat_weights, mlp_weights, calib):
-    """bench.py's `dropin_loop` region (harness/dropin_loop.py = the body of test/metrics_from_model.py:178-294 over the
-    mirrors, one frame per call): it reports both of the reference's timers, and the poses it ends with are, bit for bit, those
-    of the batched engine on the same frame (same kernels: the per-frame row prefetch, the wave-per-tile GEMMs at small M)."""
+    """bench.py's `dropin_loop` region (harness/dropin_loop.py: the mirrors called once per frame in the order of the reference's
+    loop, test/metrics_from_model.py:178-294): it reports both of the reference's timers, and the poses it ends with are, bit for
+    bit, those of the batched engine on the same frame (same kernels: the per-frame row prefetch, the wave-per-tile GEMMs at
+    small M)."""
     import importlib
     loop = importlib.import_module('3d_multi_pose_estimator_amd.harness.dropin_loop')
     syn = importlib.import_module('3d_multi_pose_estimator_amd.synthetic')
@@ -238,3 +239,40 @@ def test_dropin_loop_region_gives_the_engine_bits(gat_weights, mlp_weights, cali
     got = np.array([[j for j in person] for person in out['last']], np.float32)
     assert np.array_equal(got, want)
     eng.close()
+
+
+def test_frame_loop_calls_the_mirrors_like_the_reference_script(calib):
+    """The one-frame-per-call loop of the package (harness/dropin_loop.py, bench.py's `dropin_loop` region) is written in its
+    own form; WHAT it has to share with the reference's loop is pinned here: on the committed pinning file it calls the mirrors
+    in the order, and with arguments of the shapes, that test/metrics_from_model.py calls the reference's symbols with --
+    recorded by oracle/gen_dropin_trace.py, which runs that script unchanged with tracing wrappers around
+    MergedMultipleHumansDataset, GAT2.forward, get_person_proposal_from_network_output, PoseEstimatorDataset and
+    PoseEstimatorMLP.forward (tests/golden/dropin/call_trace.json).  Frame selection (stride, frames without ground-truth bodies)
+    is the script's own and is repeated here from its documented rules (:124, :137-138)."""
+    import importlib
+    loop = importlib.import_module('3d_multi_pose_estimator_amd.harness.dropin_loop')
+    syn = importlib.import_module('3d_multi_pose_estimator_amd.synthetic')
+    par = importlib.import_module('3d_multi_pose_estimator_amd.parameters').parameters
+    want = json.load(open(os.path.join(GOLDEN, 'dropin', 'call_trace.json')))
+    meta = json.load(open(os.path.join(GOLDEN, 'harness', 'harness_expected.json')))['inputs']
+    frames = json.load(open(os.path.join(GOLDEN, 'harness', want['testfile'])))
+    picked = []
+    for i, frame in enumerate(frames):
+        if i % want['datastep']:
+            continue
+        bodies = max((frame[c][3] for c in frame), key=len)
+        if len(bodies):
+            picked.append(frame)
+    V, J = len(par.camera_names), len(par.joint_list)
+    nf = 2 + V * J * 10
+    gat = syn.matcher_gat_state_dict(nf, V, J, noise_seed=meta['gat']['noise_seed'], noise_bound=meta['gat']['noise_bound'])
+    mlp = syn.decoder_mlp_state_dict(V, J, 14, noise_seed=meta['mlp']['noise_seed'], noise_bound=meta['mlp']['noise_bound'])
+    matcher, lifter = loop.build_models(gat, syn.gat_params(nf), mlp)
+    got = []
+    out = loop.run(picked, matcher, lifter, warmup=0, trace=got)
+    assert len(got) == len(want['frames']) == len(picked)
+    for n, (g, w) in enumerate(zip(got, want['frames'])):
+        assert [e[0] for e in g] == [e[0] for e in w], (n, [e[0] for e in g], [e[0] for e in w])
+        for eg, ew in zip(g, w):
+            assert eg == ew, (n, eg, ew)
+    assert out['frames'] == sum(1 for w in want['frames'] if len(w) > 1)       # frames without a graph end after the first call

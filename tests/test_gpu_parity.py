@@ -765,6 +765,55 @@ def test_split_bf16_linear_is_fp32_accurate_and_batch_invariant(engine, k, n, sl
     assert not torch.isfinite(yb[3]).all() and not torch.isfinite(yb[7]).all() and torch.equal(yb[0], big[0])
 
 
+@pytest.mark.parametrize('k,n,slope', [(1260, 3072, 0.1), (3072, 2048, 0.1), (1024, 54, None), (96, 16, None), (33, 70, 0.1), (72, 208, 0.1)])
+def test_split_bf16_flush_per_stage_is_more_accurate_and_batch_invariant(engine, k, n, slope):
+    """The maximum-accuracy cadence of the split form (MLP mode 4: an fp32 chain and an f64 flush per 32-deep K stage): (i) its rms
+    error against the exactly evaluated layer is at most the default cadence's (measured 0.10-0.14 against 0.12-0.16 ulp of the
+    output scale on these operands; tools/sb16_numerics.hip: 0.13-0.18 against 0.24-0.26 on MLP-shaped ones) and under 0.2 ulp;
+    (ii) the three kernels behind it give a row the same bits in a batch of 1, 16, 37 and 3000, on rows of either MFMA wave group
+    and of the partial last tile; (iii) selecting it does not change the default cadence's bits."""
+    g = torch.Generator().manual_seed(11 * k + n)
+    x = torch.randn(3000, k, generator=g)
+    x = torch.where(x > 0, x, 0.1 * x)
+    w = (torch.randn(n, k, generator=g) / np.sqrt(k)).numpy()
+    b = torch.randn(n, generator=g).numpy()
+    ex = x.double() @ torch.from_numpy(w).double().T + torch.from_numpy(b).double()
+    if slope is not None:
+        ex = torch.where(ex > 0, ex, slope * ex)
+    dflt = engine.linear(x.cuda(), w, b, slope, split=True).cpu()
+    big = engine.linear(x.cuda(), w, b, slope, split=True, split_flush_per_stage=True).cpu()
+    assert torch.equal(engine.linear(x.cuda(), w, b, slope, split=True).cpu(), dflt)
+    ulp = 2.0 ** (np.floor(np.log2(ex.abs().max().item())) - 23)
+    rms, rms_d = (((y.double() - ex) ** 2).mean().sqrt().item() / ulp for y in (big, dflt))
+    assert rms <= rms_d * 1.02 and rms < 0.2, (rms, rms_d)
+    assert (big.double() - ex).abs().max().item() <= 1.5 * ulp
+    for m0, m in ((0, 1), (0, 16), (0, 37), (131, 37), (250, 12), (2950, 37), (2984, 16)):
+        small = engine.linear(x[m0:m0 + m].cuda(), w, b, slope, split=True, split_flush_per_stage=True).cpu()
+        assert torch.equal(small, big[m0:m0 + m]), (m0, m, (small - big[m0:m0 + m]).abs().max().item())
+
+
+@pytest.mark.parametrize('k,n,slope', [(1260, 3072, 0.1), (3072, 1024, 0.1), (1024, 54, None), (33, 70, 0.1)])
+def test_f64_matrix_pipe_linear_is_the_exact_layer(engine, k, n, slope):
+    """csrc/gemm_f64.hip (MLP mode 5): exact fp32 x fp32 products accumulated in f64 over the whole K.  The result is the layer
+    evaluated in float64 and rounded to fp32 -- bit for bit in (nearly) every output: the f64 summation order can only matter
+    where the exact value sits within 1e-16 of a rounding boundary -- and a row has the same bits in a batch of 1, 37 and 1500."""
+    g = torch.Generator().manual_seed(13 * k + n)
+    x = torch.randn(1500, k, generator=g)
+    x = torch.where(x > 0, x, 0.1 * x)
+    w = (torch.randn(n, k, generator=g) / np.sqrt(k)).numpy()
+    b = torch.randn(n, generator=g).numpy()
+    ex = x.double() @ torch.from_numpy(w).double().T + torch.from_numpy(b).double()
+    if slope is not None:
+        ex = torch.where(ex > 0, ex, slope * ex)                  # (the decimal slope as a double: what an f64 evaluation multiplies by)
+    y = engine.linear(x.cuda(), w, b, slope, f64mm=True).cpu()
+    same = (y == ex.float()).float().mean().item()
+    assert same >= 0.9999, same
+    assert (y.double() - ex).abs().max().item() <= 1.01 * float(np.spacing(np.float32(ex.abs().max().item())))
+    for m0, m in ((0, 1), (100, 37), (1490, 10)):
+        small = engine.linear(x[m0:m0 + m].cuda(), w, b, slope, f64mm=True).cpu()
+        assert torch.equal(small, y[m0:m0 + m]), (m0, m)
+
+
 def test_mlp_default_mode_is_the_split_form_and_mode_1_is_still_there(engine, mlp_weights):
     """The two parity forms of the MLP on the same rows: the default (split-bf16) and the fp32-MFMA form (mode 1)
     are both closer to the exactly evaluated network than torch-CPU on the golden rows of the panoptic fixtures and within an ulp

@@ -524,6 +524,92 @@ def test_mlp_capture_volume_regime_every_golden_row():
     print(json.dumps(report))
 
 
+def test_mlp_within_1e_3_mm_of_the_exact_network():
+    """The reachable form of the north star's 3D tolerance.  "Within 1e-3 mm of the reference" cannot hold: the
+    reference's own torch-CPU MLP sits 1.6-6e-3 mm from its exactly evaluated network (f64 sums, fp32 rounding between layers,
+    test above).  What the path can claim, and what is asserted here on every capture-volume golden row of the four rigs, is
+    |gpu - exact| * 10 <= 1e-6 m in the MLP's REFERENCE-EXACT mode (mpe_set_precision MLP 5 = Engine.set_precision(mlp_f64=True):
+    exact fp32 x fp32 products accumulated in f64 over the whole K on the f64 matrix pipe, csrc/gemm_f64.hip) -- there the path
+    IS the exact network up to the f64 summation order.  Beside it the record holds the default mode and the MAXIMUM-ACCURACY
+    mode of the fast form (MLP 4: the split-bf16 form with an f64 flush after every K stage, rms error of a launch 0.13-0.18 ulp
+    against 0.24-0.26): it is asserted to be at least as close as the default on every rig and closer than the reference, and
+    reported against the 1e-3 mm line (measured: met on three rigs, 1.19e-3 mm on the fourth) with the layer whose own
+    deviation is largest.  gpurun_out/mlp_max_accuracy.json -> profiles/r05_mlp_max_accuracy.json."""
+    report = {}
+    for variant in ('panoptic', 'arplab', 'arprobot', 'ring23'):
+        e = env(variant)
+        eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=16, max_persons_per_camera=10)
+        try:
+            eng.load_mlp(e.mlp_room)
+            xs, refs = [], []
+            for v, name in ALL_CASES:
+                if v != variant:
+                    continue
+                arr, frames = load_case(name, variant)
+                for n in range(len(frames)):
+                    if 'f%d_mlp_in' % n in arr:
+                        xs.append(arr['f%d_mlp_in' % n])
+                        refs.append(arr['f%d_mlp_out_room' % n])
+            x = torch.from_numpy(np.concatenate(xs))
+            ref = np.concatenate(refs).astype(np.float64)
+            room = np.abs(ref).max(axis=1) <= 0.5                     # MLP units = metres / 10
+            exact = _exact_mlp(x, e.mlp_room).numpy()
+            y_def = eng.mlp_forward(x.cuda()).cpu().numpy().astype(np.float64)
+            eng.set_precision(False, True, mlp_max_accuracy=True)
+            y_max = eng.mlp_forward(x.cuda()).cpu().numpy().astype(np.float64)
+            y_one = eng.mlp_forward(x[:1].cuda()).cpu().numpy().astype(np.float64)
+            # per layer: the mode's own layer on the EXACT network's input of that layer (which layer's rounding is the largest?)
+            keys = sorted({int(k.split('.')[1]) for k in e.mlp_room})
+            h = x.double()
+            worst = (0.0, -1)
+            for li, k in enumerate(keys):
+                w = torch.as_tensor(np.asarray(e.mlp_room['layers.%d.weight' % k])).double()
+                b = torch.as_tensor(np.asarray(e.mlp_room['layers.%d.bias' % k])).double()
+                last = li == len(keys) - 1
+                y = h @ w.T + b
+                if not last:
+                    y = torch.where(y > 0, y, 0.1 * y)
+                got = eng.linear(h.float().cuda(), w.float().numpy(), b.float().numpy(), None if last else 0.1, split=True,
+                                 split_flush_per_stage=True).cpu().double()
+                y32 = y.float().double()
+                ulp = float(np.spacing(np.float32(y32.abs().max().item())))
+                dev = ((got - y32).abs().max().item()) / ulp
+                if dev > worst[0]:
+                    worst = (dev, li)
+                h = y32                                             # the exact network rounds to fp32 between layers
+            eng.set_precision(False, True, mlp_f64=True)
+            y_f64 = eng.mlp_forward(x.cuda()).cpu().numpy().astype(np.float64)
+            y_f64_one = eng.mlp_forward(x[:1].cuda()).cpu().numpy().astype(np.float64)
+            eng.set_precision(False, True)
+            assert np.array_equal(eng.mlp_forward(x.cuda()).cpu().numpy().astype(np.float64), y_def)      # the default's bits are back
+        finally:
+            eng.close()
+        assert np.array_equal(y_one[0], y_max[0]) and np.array_equal(y_f64_one[0], y_f64[0])       # same bits alone and in the batch
+        ref, exact, y_def, y_max, y_f64 = ref[room], exact[room], y_def[room], y_max[room], y_f64[room]
+        rec = {'rows_in_room': int(room.sum()), 'largest_pose_m': float(np.abs(ref).max() * 10),
+               'ref_vs_exact_mm': float(np.abs(ref - exact).max() * 1e4),
+               'default_vs_exact_mm': float(np.abs(y_def - exact).max() * 1e4),
+               'max_accuracy_vs_exact_mm': float(np.abs(y_max - exact).max() * 1e4),
+               'max_accuracy_vs_ref_mm': float(np.abs(y_max - ref).max() * 1e4),
+               'max_accuracy_within_1e-3_mm_of_exact': bool(np.abs(y_max - exact).max() * 1e4 <= 1e-3),
+               'largest_single_layer_deviation_ulp': worst[0], 'in_layer': worst[1],
+               'f64_mode_vs_exact_mm': float(np.abs(y_f64 - exact).max() * 1e4),
+               'f64_mode_outputs_equal_to_exact': float((y_f64 == exact).mean()),
+               'f64_mode_vs_ref_mm': float(np.abs(y_f64 - ref).max() * 1e4)}
+        report[variant] = rec
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'mlp_max_accuracy.json'), 'w') as fh:
+        json.dump(report, fh, indent=1)
+    print(json.dumps(report))
+    for variant, rec in report.items():
+        assert rec['f64_mode_vs_exact_mm'] <= 1e-3, (variant, rec)                       # the north star's number, against the exact network
+        # ... and in fact (nearly) every output bit for bit: only the f64 summation order can move one
+        assert rec['f64_mode_outputs_equal_to_exact'] >= 0.999, (variant, rec)
+        assert rec['max_accuracy_vs_exact_mm'] <= rec['default_vs_exact_mm'] <= rec['ref_vs_exact_mm'], (variant, rec)
+        assert rec['max_accuracy_vs_exact_mm'] <= 1.25e-3, (variant, rec)                # regression guard around the measured 0.8-1.2e-3 mm
+
+
 def test_attention_paths_give_identical_bits(monkeypatch):
     """The attention stage has two kernels (k_gat_fused for frames whose slice fits in LDS, the
     general k_aggregate_en / k_aggregate_heads pair otherwise) and two sources of the coefficients

@@ -566,11 +566,12 @@ def test_split_bf16_tile_kernel_occupancy_pins(tmp_path):
     """Static pins of what the split-bf16 tile kernel's design rests on (csrc/gemm_sb16.hip), read from the gfx950
     assembly of every k_linear_sb instantiation (no GPU):
       * no register spills and no scratch;
-      * the eight-MFMA-wave form is ONE twelve-wave workgroup per CU: 768 threads and at most 168 registers (three waves per SIMD);
-        the four-MFMA-wave form is two eight-wave workgroups per CU: 512 threads and at most 128 registers (four waves per SIMD).
-        (Round 4: a six-wave form with 147 registers was meant to run two workgroups per CU and never did.)
+      * ONE twelve-wave workgroup per CU: 768 threads and at most 168 registers (three waves per SIMD).  (Round 4: a six-wave form
+        with 147 registers was meant to run two workgroups per CU and never did; round 5 removed the four-MFMA-wave forms.)
       * the loader waves' LDS-DMA pieces take the `saddr + voffset` form -- `global_load_lds_dwordx4 vN, s[a:b]` -- so that a
-        piece costs them no vector instruction (the compiler's own form carried a v_lshl_add_u64 per piece).
+        piece costs them no vector instruction (the compiler's own form carried a v_lshl_add_u64 per piece);
+      * the matrix instruction is v_mfma_f32_16x16x32_bf16 and nothing else (round 5: the 32 x 32 x 16 form saves cycles and loses
+        them again as clock -- the launches are power-bound, profiles/r05_sb_clock.txt).
     Replaces nn.Linear of gat2.py:53-55 / utils/mlp.py:8-28 on the production path."""
     import shutil
     import subprocess
@@ -586,23 +587,53 @@ def test_split_bf16_tile_kernel_occupancy_pins(tmp_path):
     for m in re.finditer(r'\.max_flat_workgroup_size: (\d+)\n\s+\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count: (\d+)', text):
         meta[m.group(2)] = (int(m.group(1)), int(m.group(3)), int(m.group(4)))
     tile = {k: v for k, v in meta.items() if k.startswith('_ZN3mpe2sb11k_linear_sbIL')}
-    assert len(tile) >= 7, sorted(meta)
-    seen = set()
+    # f64-sum launches (LEAKY x flush cadence 1 | 2), plain launches (LEAKY), the coefficient launch
+    assert len(tile) == 7, sorted(meta)
     for name, (threads, vgpr, spills) in tile.items():
         assert spills == 0, (name, spills)
-        mw = int(re.search(r'k_linear_sbILb[01]ELi\d+ELb[01]ELi\d+ELb[01]ELi(\d+)E', name).group(1))
-        seen.add(mw)
-        if mw == 8:
-            assert threads == 768 and vgpr <= 168, (name, threads, vgpr)
-        else:
-            assert mw == 4 and threads == 512 and vgpr <= 128, (name, threads, vgpr)
+        assert threads == 768 and vgpr <= 168, (name, threads, vgpr)
         body = text[text.index(name + ':'):]
         body = body[:body.index('s_endpgm')]
         assert not re.search(r'scratch_', body), name
         pieces = re.findall(r'global_load_lds_dwordx4 (\S+), (\S+)', body)
         assert pieces and all(re.fullmatch(r'v\d+,?', a.rstrip(',') + ',') or re.fullmatch(r'v\d+', a.rstrip(',')) for a, _ in pieces), (name, pieces[:3])
         assert all(re.fullmatch(r's\[\d+:\d+\]', b) for _, b in pieces), (name, pieces[:3])
-    assert seen == {4, 8}, seen
+        mfma = set(re.findall(r'(v_mfma_\S+)', body))
+        assert mfma == {'v_mfma_f32_16x16x32_bf16'}, (name, mfma)
+    assert 'MPE_SBEXP' not in open(src).read()
+
+
+def test_no_product_kernel_loads_into_registers_from_inline_asm_without_its_wait():
+    """Round 4 lost a GPU box to an ablation build whose register-destination loads were issued by one `asm` statement and waited
+    for by another (the compiler, which does not count asm loads, had reused an address register the landing load overwrote).
+    Pinned for the library's sources: an `asm` statement that holds a global / buffer / flat / scratch load with a REGISTER
+    destination (i) waits for it inside the same statement (`s_waitcnt vmcnt`) and (ii) declares every output early-clobber
+    (`=&`), so no destination register is free for reuse while its load is in flight -- the one such statement is k_gat_fused's
+    table loads in front of its LDS-DMA pieces; LDS-DMA pieces (`global_load_lds_*`) have no register destination and their wait
+    is the caller's explicit `s_waitcnt vmcnt(0)` in front of the stage barrier.  The compile-time ablation switches are gone from
+    the product kernels."""
+    csrc = os.path.join(ROOT, '3d_multi_pose_estimator_amd', 'csrc')
+    bad, seen = [], 0
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith(('.hip', '.h', '.cpp')):
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        assert 'MPE_SBEXP' not in text and 'MPE_EXP' not in text, fn
+        for m in re.finditer(r'\basm\s*(?:volatile)?\s*\(', text):
+            depth, i = 1, m.end()
+            while depth and i < len(text):                 # the statement up to its closing parenthesis
+                depth += {'(': 1, ')': -1}.get(text[i], 0)
+                i += 1
+            body = text[m.end():i]
+            reg_loads = [ins for ins in re.findall(r'(global_load_\w+|buffer_load_\w+|flat_load_\w+|scratch_load_\w+)', body) if '_lds_' not in ins]
+            if not reg_loads:
+                continue
+            seen += 1
+            outputs = re.findall(r'"(=[^"]*)"\s*\(', body)
+            if 's_waitcnt vmcnt' not in body or not outputs or not all(o.startswith('=&') for o in outputs):
+                bad.append((fn, reg_loads, outputs))
+    assert not bad, bad
+    assert seen == 1, seen          # k_gat_fused; a new one should be looked at before this number changes
 
 
 def test_eisel_lemire_against_strtod(tmp_path):
