@@ -802,6 +802,20 @@ int mpe_head_features(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_f
     return MPE_OK;
 }
 
+int mpe_dense_rows(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_rows, int32_t ld) {
+    int rc = check_batch(ctx, b);
+    if (rc) return rc;
+    if (b->n_frames == 0) return MPE_OK;
+    DeviceGuard dg(ctx);
+    const int F = 2 + ctx->cfg.n_cameras * ctx->cfg.n_joints * 10;
+    if (!d_rows || ld < F) return fail(ctx, MPE_ERR_INVALID, "mpe_dense_rows: d_rows is NULL or ld < %d", F);
+    if (b->n_frames != 1) return fail(ctx, MPE_ERR_UNSUPPORTED, "mpe_dense_rows: one graph per call (node order = heads, then edge-nodes)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIPCHK(ctx, launch_head_features(s, ctx->d_cfg, *b, ctx->cfg.n_joints, d_rows, ld, 0, 0, true));
+    HIPCHK(ctx, launch_onehot_rows(s, d_rows + (size_t)b->n_heads * ld, b->n_edge_nodes, ld, 1));
+    return MPE_OK;
+}
+
 int mpe_gat_forward(mpe_ctx *ctx, void *stream, const mpe_batch *b, const float *d_feats, int32_t ld_feats,
                     float *d_scores_en, float *d_scores_heads) {
     int rc = check_batch(ctx, b);

@@ -260,6 +260,20 @@ hipError_t launch_head_features(hipStream_t s, const DevCfg *cfg, const mpe_batc
     return hipGetLastError();
 }
 
+// rows that are one-hot at `col` (the input rows of the edge-nodes, graph_generator.py:629-631: one-hot at column 1)
+__global__ void k_onehot_rows(float *__restrict__ rows, int n_rows, int ld, int col) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_rows * ld) return;
+    rows[i] = (int)(i % ld) == col ? 1.f : 0.f;
+}
+
+hipError_t launch_onehot_rows(hipStream_t s, float *rows, int n_rows, int ld, int col) {
+    if (n_rows <= 0) return hipSuccess;
+    const size_t n = (size_t)n_rows * ld;
+    hipLaunchKernelGGL(k_onehot_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, n_rows, ld, col);
+    return hipGetLastError();
+}
+
 // heads of every camera (order inside a camera is irrelevant: rows are independent).  A
 // workgroup counts its 1024 heads per camera in LDS and reserves one range per camera with a
 // single global atomic (20 000 heads on 5 cameras would otherwise serialise on 5 addresses).

@@ -177,6 +177,7 @@ hipError_t launch_linear_grouped(hipStream_t s, const float *A, int lda, const f
                                  const float *bias, float *C, int ldc, int m_cap, const int32_t *grp_count, int n_grp,
                                  const int32_t *row_lists, int grp_stride, int n, int k_pad, bool leaky, float slope, bool acc64 = false);
 bool linear_uses_tile_kernel(int m_cap, int n);
+hipError_t launch_onehot_rows(hipStream_t s, float *rows, int n_rows, int ld, int col);
 hipError_t launch_group_heads(hipStream_t s, int n_heads, int V, const int32_t *head_cam, int32_t *cam_count,
                               int32_t *cam_list, int list_stride, bool counts_zeroed = false);
 

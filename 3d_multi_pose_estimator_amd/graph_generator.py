@@ -149,6 +149,8 @@ class FrameGraph:
         kernel's output (mpe_head_features) -- a tensor on the engine's device, so the callers' `.to(device)` /
         `.float()` hand the same object back and GAT2.forward recognises the graph's own rows without comparing them."""
         eng = runtime.shared_engine(max_frames=self.batch_size)
+        if self.batch_size == 1 and self.H + self.M:
+            return eng.dense_rows(self.device_batch(eng))           # one graph: two launches of the library instead of a dozen indexing ops
         blk = eng.head_features(self.device_batch(eng))            # [H][J][10] on the device
         J = blk.shape[1]
         F = 2 + eng.V * J * 10

@@ -96,6 +96,7 @@ SYMBOLS = {
                              C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                              C.c_float]),
     'mpe_head_features': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p]),
+    'mpe_dense_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_int32]),
     'mpe_gat_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_void_p]),
     'mpe_set_gat_output': (C.c_int, [C.c_void_p, C.c_int32]),

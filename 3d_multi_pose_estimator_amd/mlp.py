@@ -23,7 +23,10 @@ class PoseEstimatorMLP(nn.Module):
         self._version = None
 
     def _ensure_engine(self):
-        ver = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        ps = self.__dict__.get('_param_list')
+        if ps is None:
+            ps = self.__dict__['_param_list'] = list(self.parameters())
+        ver = tuple((p.data_ptr(), p._version) for p in ps)
         if self._engine is not None and ver == self._version:
             return self._engine
         if self._engine is not None:

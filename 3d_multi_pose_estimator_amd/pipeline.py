@@ -766,6 +766,13 @@ class Engine:
                                              _ptr(persons), _ptr(n_persons)))
         return persons, n_persons
 
+    def dense_rows(self, db):
+        """graph.ndata['h'] of a one-frame batch: the dense [N, 2 + V*J*10] rows in node order (mpe_dense_rows)."""
+        F = 2 + self.V * self.J * 10
+        out = torch.empty((db.n_heads + db.n_edge_nodes, F), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.mpe_dense_rows(self.ctx, self._stream(), C.byref(db.struct), _ptr(out), F))
+        return out
+
     def head_features(self, db):
         out = torch.empty((max(db.n_heads, 1), self.J, 10), dtype=torch.float32, device=self.device)
         self._chk(self.lib.mpe_head_features(self.ctx, self._stream(), C.byref(db.struct), _ptr(out)))

@@ -81,11 +81,12 @@ def prefetch_enabled():
     return os.environ.get('MPE_DROPIN_PREFETCH', '1') != '0'
 
 
-def prefetch_mlp_rows(eng, db, persons, n_persons, rows, jsons_for_head, cams):
-    """rows: the frame's persons as lists of head ids per camera of `cams` (-1 = none)."""
+def prefetch_mlp_rows(eng, db, persons, n_persons, rows, jsons_for_head, cams, launched=None):
+    """rows: the frame's persons as lists of head ids per camera of `cams` (-1 = none).  launched: (rows, valid) device tensors
+    of an mpe_mlp_input_rows launch the caller has already queued behind the clustering (one synchronisation for both)."""
     import json
     used = [c for c in eng.params.used_cameras]
-    r, valid = eng.mlp_input_rows(db, persons, n_persons)
+    r, valid = launched if launched is not None else eng.mlp_input_rows(db, persons, n_persons)
     n = len(rows)
     r, valid = r[0, :n].cpu(), valid[0, :n].cpu()
     if len(_row_cache) > _ROW_CACHE_CAP:

@@ -27,12 +27,14 @@ def get_person_proposal_from_network_output(outputs, subgraph, indices, nodes_ca
         raise RuntimeError('engine / parameters mismatch')
     eng.set_threshold(CLASSIFICATION_THRESHOLD)
     persons, n_persons = eng.cluster(db, scores)
+    # the caller goes on to the 3D stage with these persons (metrics_from_model.py:243-277): their MLP input rows in ONE launch
+    # now instead of one launch per person later (runtime.prefetch_mlp_rows), queued behind the clustering so that the frame pays
+    # one synchronisation for both
+    ahead = eng.mlp_input_rows(db, persons, n_persons) if jsons_for_head is not None and runtime.prefetch_enabled() else None
     eng.sync_status()
     n = int(n_persons[0])
     rows = persons[0, :n].cpu().tolist()
     cams = list(parameters.used_cameras_skeleton_matching)
-    if jsons_for_head is not None and n and runtime.prefetch_enabled():
-        # the caller goes on to the 3D stage with these persons (metrics_from_model.py:243-277): their MLP input rows in ONE
-        # launch now instead of one launch per person later (runtime.prefetch_mlp_rows)
-        runtime.prefetch_mlp_rows(eng, db, persons, n_persons, rows, jsons_for_head, cams)
+    if ahead is not None and n:
+        runtime.prefetch_mlp_rows(eng, db, persons, n_persons, rows, jsons_for_head, cams, launched=ahead)
     return [{cam: (None if row[c] < 0 else row[c]) for c, cam in enumerate(cams)} for row in rows]

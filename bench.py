@@ -113,6 +113,9 @@ def parse_args(argv=None):
     ap.add_argument('--dropin-frames', type=int, default=200,
                     help="frames of the dropin_loop region (the reference's one-frame-per-call loop over the drop-in mirrors); 0 = skip")
     ap.add_argument('--no-io', action='store_true', help='skip the second (pinned host -> poses in pinned host) timed region')
+    ap.add_argument('--no-accuracy-modes', action='store_true',
+                    help="skip the short timed regions of the MLP's maximum-accuracy (mode 4) and reference-exact (mode 5) forms (kernel "
+                         'profiles of the default path)')
     ap.add_argument('--no-profile', action='store_true', help='no per-GEMM HIP events (roofline comes out null)')
     ap.add_argument('--profile-every', type=int, default=4,
                     help='HIP event pairs around the GEMM launches on every n-th step of the profile pass (the event packets '
@@ -443,7 +446,7 @@ def run_rank(args):
     # ---- the MLP's maximum-accuracy mode (f64 flush per K stage) beside the default: same region, same engine mode, fewer steps ----
     max_acc = None
     plain_parity_path = args.mode == 'mlp' and not (args.reduced or args.cfg4 or args.bf16_mlp or args.fast_mlp or args.mlp_fp32_mfma)
-    if plain_parity_path and not distributed and args.steps >= 10:
+    if plain_parity_path and not distributed and args.steps >= 10 and not args.no_accuracy_modes:
         for s_ in [s_match, s_3d] + ctx_streams:
             if s_ is not None:
                 torch.cuda.current_stream(device).wait_stream(s_)
@@ -459,6 +462,17 @@ def run_rank(args):
         max_acc = {'value': total * n_ma / dt_ma, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt_ma / n_ma, 'steps': n_ma,
                    'what': 'the timed region of `value` with the MLP in its maximum-accuracy mode (mpe_set_precision MLP 4: f64 flush after '
                            'every 32-deep K stage instead of every second one)'}
+        # ... and in its reference-exact mode (MLP 5: exact products, f64 accumulation on the f64 matrix pipe)
+        eng.set_precision(args.gat_acc == 'f64', True, gat_split=False if args.gat_fp32_mfma else None, mlp_f64=True)
+        for _ in range(max(4, 2 * K)):
+            step()
+        n_fx = max(6, args.steps // 16)
+        dt_fx, _ = timed(lambda i: step(), n_fx)
+        eng.set_precision(args.gat_acc == 'f64', True, gat_split=False if args.gat_fp32_mfma else None)
+        for _ in range(2 * K):
+            step()
+        torch.cuda.synchronize(device)
+        max_acc['f64'] = {'value': total * n_fx / dt_fx, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt_fx / n_fx, 'steps': n_fx}
 
     # ---- contract form: pinned host -> H2D -> compute -> D2H into pinned host, double-buffered ----
     io = None
@@ -539,6 +553,8 @@ def run_rank(args):
         if par_ is not None and max_acc is not None and par_.get('mlp_max_accuracy') is not None:
             par_['mlp_max_accuracy'].update({'frames_per_s': max_acc['value'], 'frames_per_s_default_mode': value,
                                              'ms_per_step': max_acc['ms_per_step'], 'timed': max_acc['what']})
+            par_['mlp_f64_exact'].update({'frames_per_s': max_acc['f64']['value'], 'frames_per_s_default_mode': value,
+                                          'ms_per_step': max_acc['f64']['ms_per_step']})
         out['parity'] = par_
         print(json.dumps(out), flush=True)
     if distributed:
@@ -887,16 +903,18 @@ def cpu_baseline_and_parity(args, np, torch, calib, params, lo, device):
         else:
             poses = eng.triangulate(db, persons, n_persons)[0]
         eng.sync_status()
-        poses_ma = None
+        poses_ma = poses_fx = None
         if args.mode == 'mlp' and not (args.reduced or args.cfg4 or args.bf16_mlp):
             eng.set_precision(False, True, mlp_max_accuracy=True)              # the MLP's maximum-accuracy mode on the same persons
             poses_ma = eng.mlp3d(db, persons, n_persons)[0].cpu().numpy()
+            eng.set_precision(False, True, mlp_f64=True)                       # ... and its reference-exact mode
+            poses_fx = eng.mlp3d(db, persons, n_persons)[0].cpu().numpy()
             eng.set_precision(False, True)
         persons, n_persons, poses = persons.cpu().numpy(), n_persons.cpu().numpy(), poses.cpu().numpy()
         scores = scores.cpu().numpy()
         used = list(calib.params.used_joints)
         exact, max_abs, max_ulp, dscore, largest = 0, 0.0, 0.0, 0.0, 0.0
-        e_gpu, e_cpu, gx, rx, gx_ma, d_ma = [], [], 0.0, 0.0, 0.0, 0.0
+        e_gpu, e_cpu, gx, rx, gx_ma, d_ma, gx_fx, d_fx = [], [], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0
 
         def mpjpe(pred, gt_people):
             return min(float(np.mean([np.linalg.norm(pred[j] - g[j]) for j in used])) for g in gt_people)
@@ -922,6 +940,8 @@ def cpu_baseline_and_parity(args, np, torch, calib, params, lo, device):
                 if poses_ma is not None:
                     gx_ma = max(gx_ma, float(np.abs(poses_ma[f, :len(want)] - ex).max()))
                     d_ma = max(d_ma, float(np.abs(poses_ma[f, :len(want)] - ref).max()))
+                    gx_fx = max(gx_fx, float(np.abs(poses_fx[f, :len(want)] - ex).max()))
+                    d_fx = max(d_fx, float(np.abs(poses_fx[f, :len(want)] - ref).max()))
             else:
                 ref = np.stack([np.stack([t.get(j, np.zeros(3)) for j in range(eng.J)]) for t in r['tri']])
             d = np.abs(poses[f, :len(want)] - ref)
@@ -944,6 +964,10 @@ def cpu_baseline_and_parity(args, np, torch, calib, params, lo, device):
                                     'mode': 'mpe_set_precision MLP 4: the split-bf16 form with an f64 flush after every K stage; asserted on every '
                                             'capture-volume golden row of the four rigs by tests/test_gpu_stages.py::test_mlp_within_1e_3_mm_of_the_exact_network'}
                                    if poses_ma is not None else None),
+              'mlp_f64_exact': ({'gpu_vs_exact_mm': gx_fx * 1e3, 'max_abs_mm': d_fx * 1e3, 'within_1e-3_mm_of_exact': gx_fx * 1e3 <= 1e-3,
+                                 'mode': 'mpe_set_precision MLP 5: exact fp32 x fp32 products accumulated in f64 on the f64 matrix pipe (csrc/gemm_f64.hip) -- '
+                                         'the network evaluated in f64 with fp32 rounding between layers; max_abs_mm is then the reference\'s own distance from it'}
+                                if poses_ma is not None else None),
               'mpjpe_mm': float(np.mean(e_gpu)) * 1e3 if e_gpu else None,
               'delta_mpjpe_mm': (abs(float(np.mean(e_gpu)) - float(np.mean(e_cpu))) * 1e3) if e_gpu else None,
               'max_abs_score_diff': dscore,

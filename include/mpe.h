@@ -220,6 +220,10 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
 /* HumanGraphFromView.initializeWithAlternative3 (graph_generator.py:444-508): the J*10
  * non-zero block of every head row: d_feat [n_heads][J][10]. */
 int mpe_head_features(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_feat);
+/* graph.ndata['h'] of ONE frame's graph as the reference builds it (graph_generator.py:444-508, 629-631): the dense
+ * [n_heads + n_edge_nodes][ld >= 2 + V*J*10] rows in node order -- head rows (column 0 = 1, the camera's J*10 block),
+ * then the edge-node rows (one-hot at column 1); pad columns are zeroed.  For callers that ask for the matrix itself. */
+int mpe_dense_rows(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_rows, int32_t ld);
 
 /* GAT2.forward over the batch (gat2.py:137-149).  d_feats == NULL: node rows are featurised
  * on the device from the packed skeletons (the production path; edge-node rows are constant

@@ -5,7 +5,7 @@ cd /tmp; export TMPDIR=/tmp
 i=0
 for e in "" "$@"; do i=$((i+1))
   ( [ -n "$e" ] && export $e
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r$i -o run -- python3 $R/bench.py --contexts 1 --streams 1 --steps 60 --warmup 10 --cpu-sample 0 --no-io --json-steps 0 --dropin-frames 0 --no-profile > $O/r$i.json 2> $O/r$i.err ) || { tail -5 $O/r$i.err; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r$i -o run -- python3 $R/bench.py --contexts 1 --streams 1 --steps 60 --warmup 10 --cpu-sample 0 --no-io --json-steps 0 --dropin-frames 0 --no-profile --no-accuracy-modes > $O/r$i.json 2> $O/r$i.err ) || { tail -5 $O/r$i.err; exit 1; }
   rm -f $O/r$i/run_kernel_trace.csv
   python3 - <<PY
 import csv, json

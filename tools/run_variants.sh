@@ -10,7 +10,7 @@ for v in $V; do
   export MPE_LIB_VARIANT=$v
   [ -z "$v" ] && unset MPE_LIB_VARIANT
   n=${v:-product}
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -o run -- python3 $R/bench.py --contexts 1 --streams 1 --steps 60 --warmup 10 --cpu-sample 0 --no-io --json-steps 0 --dropin-frames 0 --no-profile "$@" > $O/$n.json 2> $O/$n.err || { tail -5 $O/$n.err; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -o run -- python3 $R/bench.py --contexts 1 --streams 1 --steps 60 --warmup 10 --cpu-sample 0 --no-io --json-steps 0 --dropin-frames 0 --no-profile --no-accuracy-modes "$@" > $O/$n.json 2> $O/$n.err || { tail -5 $O/$n.err; exit 1; }
   python3 - <<PY
 import csv, collections
 # per (kernel, grid): the launches of one instantiation differ in their shapes (GRID=1 to see them)
