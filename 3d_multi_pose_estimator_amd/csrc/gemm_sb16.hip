@@ -54,13 +54,15 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // tools/sb_clock_probe.py): the first MFMA wave of every workgroup stamps the shader clock (s_memtime) and the constant 100 MHz
 // clock (s_memrealtime) around its tile loop into a buffer nothing else reads.  The product build has no stamp.
 #ifdef MPE_SB_CLOCK
-__device__ unsigned long long g_sb_stamp[1024][4];
+// (one bucket per launch shape -- (n ^ k_pad / 32) & 15 -- so that the launches of a whole GAT or MLP pass keep their stamps apart)
+__device__ unsigned long long g_sb_stamp[16][256][4];
 #define SB_STAMP(SLOT)                                                                              \
     do {                                                                                            \
         if (threadIdx.x == 0) {                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            g_sb_stamp[blockIdx.x & 1023][SLOT] = __builtin_amdgcn_s_memtime();                     \
-            g_sb_stamp[blockIdx.x & 1023][(SLOT) + 1] = __builtin_amdgcn_s_memrealtime();           \
+            unsigned long long *st_ = g_sb_stamp[(n ^ (k_pad >> 5)) & 15][blockIdx.x & 255];        \
+            st_[SLOT] = __builtin_amdgcn_s_memtime();                                               \
+            st_[(SLOT) + 1] = __builtin_amdgcn_s_memrealtime();                                     \
             __builtin_amdgcn_sched_barrier(0);                                                      \
         }                                                                                           \
     } while (0)
@@ -705,9 +707,13 @@ using namespace sb;
 
 #ifdef MPE_SB_CLOCK
 }  // namespace mpe
-extern "C" int mpe_debug_sb_stamps(unsigned long long *out, int n_wg) {      // diagnostic builds only; not part of include/mpe.h
-    if (n_wg > 1024) n_wg = 1024;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mpe::sb::g_sb_stamp), (size_t)n_wg * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+extern "C" int mpe_debug_sb_stamps(unsigned long long *out, int clear) {      // diagnostic builds only; not part of include/mpe.h: [16][256][4]
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mpe::sb::g_sb_stamp), sizeof(mpe::sb::g_sb_stamp)) != hipSuccess) return -1;
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mpe::sb::g_sb_stamp)) != hipSuccess || hipMemset(p, 0, sizeof(mpe::sb::g_sb_stamp)) != hipSuccess) return -1;
+    }
+    return 0;
 }
 namespace mpe {
 using namespace sb;

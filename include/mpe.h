@@ -115,7 +115,8 @@ typedef struct {
  *   kernel selection, each a cross-check path the GPU suite is run under (tools/run_switch_matrix.sh):
  *     MPE_SKINNY_WAVES=<n>        16 x 16 tiles up to which the wave-per-tile GEMM kernels run (default 1024; 0 = tile kernels always)
  *     MPE_GEMM_NARROW=0           narrow outputs (<= 16 / 64 features) on the tile kernels as well
- *     MPE_GAT_ACC64_MINK=<k>      GAT launches with K > k get f64 running sums (default 512: fc2 of layer 0; 0 = never)
+ *     MPE_GAT_ACC64_MINK=<k>      GAT launches with K > k get f64 running sums (default 512: fc2 of layer 0; 0 = never -- that CHANGES the
+ *                                 numerics: the 2e-5 score bound rests on these sums, profiles/r05_switch_matrix.txt; not a cross-check path)
  *     MPE_L0_GROUPED=0            layer-0 fc1 dense over the whole 902-wide row instead of per camera block
  *     MPE_NO_COEF_EPILOGUE        (per call) attention coefficients from k_attn_coef instead of the fc2 epilogue
  *     MPE_NO_FUSED_ATTENTION      (per call) the general attention kernels for every frame size

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import gen_harness_golden as H      # noqa: E402
 
-OUT = os.path.join(ROOT, 'tests', 'golden', 'dropin')
+OUT = os.environ.get('MPE_DROPIN_TRACE_OUT') or os.path.join(ROOT, 'tests', 'golden', 'dropin')      # (the regeneration test writes elsewhere)
 
 PRELUDE = r'''
 import sys, runpy, json

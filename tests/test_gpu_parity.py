@@ -119,6 +119,31 @@ def test_head_features_vs_golden(variant, name):
 
 
 @pytest.mark.parametrize('variant,name', ALL_CASES)
+def test_dense_rows_vs_golden(variant, name):
+    """mpe_dense_rows = graph.ndata['h'] of one frame as the reference builds it (graph_generator.py:444-508, 629-631): EVERY entry of
+    the dense N x F matrix against the reference's (stored sparse in the fixtures): head rows (column 0, the camera's block),
+    edge-node rows (one-hot at column 1), zeros everywhere else."""
+    engine = engine_for(variant)
+    arr, frames = load_case(name, variant)
+    F = env(variant).meta['num_feats']
+    for n, frame in enumerate(frames):
+        p = 'f%d_' % n
+        if (p + 'N') not in arr or int(arr[p + 'N']) == 0:
+            continue
+        db = engine.to_device(engine.pack([_pi(frame)]))
+        if db.n_heads + db.n_edge_nodes == 0:
+            continue
+        got = engine.dense_rows(db).cpu().numpy()
+        N = int(arr[p + 'N'])
+        assert got.shape == (N, F)
+        want = np.zeros((N, F), np.float32)
+        rc = arr[p + 'feat_rc']
+        want[rc[:, 0], rc[:, 1]] = arr[p + 'feat_v']
+        np.testing.assert_allclose(got, want, rtol=0, atol=5e-7)
+        assert np.array_equal(got == 0, want == 0) or np.abs(got[(got == 0) != (want == 0)]).max() < 5e-7
+
+
+@pytest.mark.parametrize('variant,name', ALL_CASES)
 def test_gat_scores_vs_golden(variant, name):
     engine = engine_for(variant)
     arr, frames = load_case(name, variant)

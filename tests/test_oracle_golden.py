@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ALL_CASES, CASES, env, golden_dir, load_case, oracle, pkg
+from conftest import ALL_CASES, CASES, GOLDEN, ROOT, env, golden_dir, load_case, oracle, pkg
 
 
 @pytest.mark.parametrize('variant', ['panoptic', 'arplab', 'arprobot', 'ring23'])
@@ -309,3 +309,22 @@ def test_generated_scenes_oracle_vs_reference_script():
     assert any(len(set(m['nodes_camera'][:m['H']])) < m['H'] for m in exp['graphs'])
     pairs = graphs[0]['pairs'].tolist()
     assert [pairs[0][1], pairs[0][0]] in pairs
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/test'), reason='the reference tree exists in the build container only')
+def test_dropin_call_trace_fixture_is_what_the_reference_script_does(tmp_path):
+    """tests/golden/dropin/call_trace.json -- the sequence of calls (and argument shapes) the reference's per-frame loop makes on
+    the committed pinning file -- regenerated by its committed script (oracle/gen_dropin_trace.py: test/metrics_from_model.py run
+    unchanged under tracing wrappers) is the committed fixture.  The GPU suite holds the package's own one-frame-per-call loop to
+    it (tests/test_gpu_dropin.py::test_frame_loop_calls_the_mirrors_like_the_reference_script)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MPE_DROPIN_TRACE_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'gen_dropin_trace.py')], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    new = json.load(open(tmp_path / 'call_trace.json'))
+    old = json.load(open(os.path.join(GOLDEN, 'dropin', 'call_trace.json')))
+    assert new['frames'] == old['frames'] and len(old['frames']) == 15
+    names = [[e[0] for e in f] for f in old['frames']]
+    assert all(f[0] == 'MergedMultipleHumansDataset' for f in names)
+    assert sum(len(f) for f in names) == 102

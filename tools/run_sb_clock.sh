@@ -1,11 +1,10 @@
+# in-kernel clocks of the split-bf16 launches (diagnostic build: make -C 3d_multi_pose_estimator_amd/csrc exp EXPFLAGS=-DMPE_SB_CLOCK)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/sb32; mkdir -p $O
 cd $R
-export MPE_LIB_VARIANT=exp
-: > $O/clock.txt
-for m in 0 1 5; do
-  MPE_SB_M32=$m timeout -k 10 120 python3 tools/sb_clock_probe.py 3 >> $O/clock.txt 2>> $O/clock.err || { tail -5 $O/clock.err; exit 1; }
+export MPE_LIB_VARIANT=${1:-exp}
+: > $O/clock2.txt
+for w in "mlp 3" "mlp 3 zero" "gat 3" "step 3"; do
+  timeout -k 10 150 python3 tools/sb_clock_probe.py $w >> $O/clock2.txt 2>> $O/clock2.err || { tail -5 $O/clock2.err; exit 1; }
 done
-MPE_SB_M32=0 timeout -k 10 120 python3 tools/sb_clock_probe.py 3 zero >> $O/clock.txt 2>> $O/clock.err || { tail -5 $O/clock.err; exit 1; }
-MPE_SB_M32=5 timeout -k 10 120 python3 tools/sb_clock_probe.py 3 zero >> $O/clock.txt 2>> $O/clock.err || { tail -5 $O/clock.err; exit 1; }
-cat $O/clock.txt
+cat $O/clock2.txt
