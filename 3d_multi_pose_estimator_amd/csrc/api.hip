@@ -764,6 +764,8 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
     L.out_dim = n;
     L.ldw = ldw;
     if (slope_on & 32) {
+        if (lda % 4 || (reinterpret_cast<uintptr_t>(d_a) & 15) || (reinterpret_cast<uintptr_t>(d_w) & 15))
+            return fail(ctx, MPE_ERR_INVALID, "mpe_linear (f64 form): rows must be 16-byte aligned (lda %% 4 == 0)");
         HIPCHK(ctx, launch_linear_f64(static_cast<hipStream_t>(stream), d_a, lda, d_w, ldw, d_bias, d_c, ldc, m, d_m, n, ldw, (slope_on & 1) != 0, slope));
         return MPE_OK;
     }

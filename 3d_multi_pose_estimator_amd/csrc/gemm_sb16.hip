@@ -806,8 +806,15 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     }
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
     // persistent workgroups: one per CU walking its tiles (grid = the CU count rounded down to a multiple of eight, or the tile count)
-    int dev = 0, cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    static int cu_of_device[64];                    // (asked once per device: zero-initialised, benign if two threads ask at once)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int &cu = cu_of_device[dev & 63];
+    if (cu == 0) {
+        int c = 256;
+        (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        cu = c > 0 ? c : 256;
+    }
     const int n_cu = cu >= 8 ? cu / 8 * 8 : 8;
     const bool with_coef = coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !f64;
     // 64-wide feature tiles with f64 sums (with 80 the running sums of the wider wave tile do not fit the 168 registers that three

@@ -11,7 +11,8 @@ are dimensionless shares of the waves' lifetime:
     wait_inst_any   SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   issue stalls (MFMA RAW / pipe busy)
     wait_inst_lds   SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES   of which LDS-issue stalls
     active_any      SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES issuing
-    mfma_busy       SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)
+    mfma_busy       SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)   (share of the cycles the launch really had)
+    eff_clock_ghz   GRBM_GUI_ACTIVE / 8 / duration: the clock the chip held during the launch (reads high on short launches)
     rounds          tiles / (256 CUs x workgroups per CU the kernel's LDS and registers allow)
 """
 import collections
@@ -59,6 +60,10 @@ def main():
                            ('active_vmem', 'SQ_ACTIVE_INST_VMEM')):
                 if cn in per:
                     e[nm] = per[cn] / wc
+        if per.get('GRBM_GUI_ACTIVE'):
+            # effective clock of the dispatch (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE is summed over the 8 XCDs; the
+            # quotient reads HIGH on dispatches shorter than ~0.3 ms (the in-kernel stamps of tools/sb_clock_probe.py are the reference)
+            e['eff_clock_ghz'] = per['GRBM_GUI_ACTIVE'] / 8.0 / (e['avg_us_under_pmc'] * 1e3)
         if per.get('GRBM_GUI_ACTIVE') and 'SQ_VALU_MFMA_BUSY_CYCLES' in per:
             e['mfma_busy'] = per['SQ_VALU_MFMA_BUSY_CYCLES'] / (per['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0)
         if per.get('SQ_VALU_MFMA_BUSY_CYCLES') and 'SQ_VALU_MFMA_COEXEC_CYCLES' in per:
@@ -77,7 +82,7 @@ def main():
         e['rounds'] = e['workgroups'] / (256.0 * e['wg_per_cu'])
         out[key] = e
     json.dump(out, open(out_path, 'w'), indent=1, sort_keys=True)
-    cols = ('rounds', 'avg_us_under_pmc', 'mfma_busy', 'wait_any', 'wait_inst_any', 'wait_inst_lds', 'active_any')
+    cols = ('rounds', 'avg_us_under_pmc', 'eff_clock_ghz', 'mfma_busy', 'wait_any', 'wait_inst_any', 'wait_inst_lds', 'active_any')
     print('%-46s %s' % ('kernel, grid', ' '.join('%13s' % c for c in cols)))
     for key in sorted(out, key=lambda k: -out[k]['avg_us_under_pmc'] * out[k]['launches_seen']):
         e = out[key]
