@@ -533,7 +533,7 @@ def test_mlp_within_1e_3_mm_of_the_exact_network():
     IS the exact network up to the f64 summation order.  Beside it the record holds the default mode and the MAXIMUM-ACCURACY
     mode of the fast form (MLP 4: the split-bf16 form with an f64 flush after every K stage, rms error of a launch 0.13-0.18 ulp
     against 0.24-0.26): it is asserted to be at least as close as the default on every rig and closer than the reference, and
-    reported against the 1e-3 mm line (measured: met on three rigs, 1.19e-3 mm on the fourth) with the layer whose own
+    reported against the 1e-3 mm line (measured: met on three rigs, 1.19e-3 mm on the fourth; mode 5: 0 on all four) with the layer whose own
     deviation is largest.  gpurun_out/mlp_max_accuracy.json -> profiles/r05_mlp_max_accuracy.json."""
     report = {}
     for variant in ('panoptic', 'arplab', 'arprobot', 'ring23'):
