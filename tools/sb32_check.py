@@ -1,7 +1,8 @@
-"""Accuracy of the library's split-bf16 tile kernel in the form the environment selects (MPE_SB_M32=0|1|2|3: the 32 x 32 x 16
-form for the f64-sum / plain launches; MPE_SB_FL1=1: f64 flush per stage) against the layer evaluated in float64, at the shapes
-of the path.  Errors in fp32 ulps of the output scale (max |y|), as tests/test_gpu_parity.py measures them.
-   MPE_SB_M32=3 python tools/sb32_check.py"""
+"""Accuracy of the library's split-bf16 launches against the layer evaluated in float64, at the shapes of the path, and whether five
+rows keep their bits in a batch of five.  Errors in fp32 ulps of the output scale (max |y|), as tests/test_gpu_parity.py measures them.
+(Round 5 ran it under MPE_SB_M32 = 1 | 3 | 5 on commit 80a9985, whose library held the 32 x 32 x 16 kernels: profiles/r05_sb32_forms.txt;
+the switches it prints are gone from the library since.)
+   python tools/sb32_check.py"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
