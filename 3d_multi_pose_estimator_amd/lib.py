@@ -14,8 +14,10 @@ if os.environ.get('MPE_LIB_VARIANT'):      # diagnostics: an experiment build be
 
 # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The engine's pipelines keep 3-4 streams busy
 # (parse / copy / matching / 3D) beside whatever the application has; two of them on one queue serialise (pipeline.py:
-# _make_json_streams has the measurement).  Effective only if HIP has not initialised yet; an explicit setting wins.
-if os.environ.get('MPE_SET_HW_QUEUES', '1') != '0':      # opt out: MPE_SET_HW_QUEUES=0 leaves the host application's environment alone
+# _make_json_streams has the measurement), so a process that streams JSON or pipelines its copies should run with
+# GPU_MAX_HW_QUEUES=8 -- set before HIP initialises.  A library does not rewrite its host's environment on import: since round 5
+# this is OPT-IN (MPE_SET_HW_QUEUES=1 makes the import set it when it is unset); bench.py sets the variable itself.
+if os.environ.get('MPE_SET_HW_QUEUES', '0') == '1':
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 MPE_MAX_CAMERAS = 32

@@ -97,8 +97,8 @@ class Engine:
         leave.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); with the 6-9 streams of
         an application that also pipelines its copies, the parse stream and the compute stream can land on one queue
         and then serialise (measured inside bench.py: 145-159 k or 171 k frames/s depending on the order in which streams
-        were first used).  lib.py therefore asks for 8 hardware queues (GPU_MAX_HW_QUEUES=8, only if the variable is not
-        set and before HIP initialises): 170.5-170.7 k in 5 of 5 runs."""
+        were first used).  With 8 hardware queues (GPU_MAX_HW_QUEUES=8 before HIP initialises: bench.py sets it for itself, lib.py on
+        import when MPE_SET_HW_QUEUES=1 asks for it): 170.5-170.7 k in 5 of 5 runs."""
         if self._json_streams is None:
             self._json_streams = (torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_PARSE_PRIO', '0'))),
                                   torch.cuda.Stream(self.device, priority=int(os.environ.get('MPE_JSON_COMPUTE_PRIO', '-1'))),

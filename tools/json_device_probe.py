@@ -1,6 +1,7 @@
 """Where the time of the device-side JSON parse goes (diagnostic): host staging, H2D, the three kernels.
     python tools/json_device_probe.py [frames] [chunk]"""
 import importlib, json, os, sys, time
+import os as _os; _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before HIP initialises: one hardware queue per busy stream (lib.py leaves the environment alone)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

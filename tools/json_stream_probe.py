@@ -2,6 +2,7 @@
 timeline.  python tools/json_stream_probe.py [frames] [chunk] [parser] [repeats] [contexts]
 `repeats` > 1 runs the same call again in the same process: the first call of a fresh process finds a cool GPU."""
 import importlib, json, os, sys, time
+import os as _os; _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before HIP initialises: one hardware queue per busy stream (lib.py leaves the environment alone)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -11,6 +11,7 @@ bodies_3D ground truth the path does not need):
            the parse of chunk i+1 overlapped with the device work of chunk i
 Writes gpurun_out/json_to_poses.json."""
 import importlib, json, os, sys, time
+import os as _os; _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before HIP initialises: one hardware queue per busy stream (lib.py leaves the environment alone)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -3,6 +3,7 @@ every result compared bit for bit with the first one (a race between windows / c
 difference).  python tools/soak_contexts.py [iterations] [frames per window / batch: 64]
 (500-frame batches put every GEMM of the step on the tile kernels, twelve-wave form included, with two or three steps in flight)"""
 import importlib, json, os, sys, time
+import os as _os; _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before HIP initialises: one hardware queue per busy stream (lib.py leaves the environment alone)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
