@@ -157,6 +157,19 @@ int linear(mpe_ctx *ctx, hipStream_t s, const float *A, int lda, const Linear &L
     return MPE_OK;
 }
 
+// MPE_LATENCY_PATH=0: small batches through the batch path's own small-batch kernels (read per call: tests toggle it)
+bool latency_path_on() {
+    const char *e = getenv("MPE_LATENCY_PATH");
+    return !(e && e[0] == '0');
+}
+
+// MPE_LATENCY_MLP=1: the MLP launches of small batches from the fp32 weights (lat.hip: k_linear_lat_f64).  Off by default: the
+// split of the weight fragments in registers costs what the 2 B per weight save
+bool latency_mlp_on() {
+    const char *e = getenv("MPE_LATENCY_MLP");
+    return latency_path_on() && e && e[0] == '1';
+}
+
 unsigned short f32_to_bf16(float f);
 int ensure_bf16_weights(mpe_ctx *ctx, Linear *L);
 int ensure_split_weights(mpe_ctx *ctx, hipStream_t s, Linear *L);
@@ -226,6 +239,10 @@ void drop_gat_workspace(mpe_ctx *ctx) {
     dev_free(ctx, ctx->cam_count);
     dev_free(ctx, ctx->cam_list);
     ctx->cam_count = ctx->cam_list = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        dev_free(ctx, ctx->gat_pl[i]);
+        ctx->gat_pl[i] = nullptr;
+    }
     for (int c = 0; c < MPE_MAX_CAMERAS; ++c) {
         dev_free(ctx, ctx->l0_fc1[c].w16);          // w / b are views into l0_w / l0_b
         ctx->l0_fc1[c] = Linear();
@@ -371,6 +388,10 @@ int ensure_mlp_workspace(mpe_ctx *ctx) {
         dev_free(ctx, *p);
         *p = nullptr;
     }
+    for (int i = 0; i < 2; ++i) {
+        dev_free(ctx, ctx->mlp_pl[i]);
+        ctx->mlp_pl[i] = nullptr;
+    }
     if (ctx->mlp_layers <= 0) return fail(ctx, MPE_ERR_STATE, "MLP parameters not set");
     for (int l = 0; l < ctx->mlp_layers; ++l)
         if (!ctx->mlp_ready[l]) return fail(ctx, MPE_ERR_STATE, "MLP layer %d has no weights", l);
@@ -391,6 +412,9 @@ int ensure_mlp_workspace(mpe_ctx *ctx) {
     if ((rc = dev_alloc(ctx, &ctx->mlp_rows, rows * ctx->mlp_ld_in))) return rc;
     for (int i = 0; i < 2; ++i)
         if ((rc = dev_alloc(ctx, &ctx->mlp_act[i], rows * ctx->mlp_ld_hidden))) return rc;
+    ctx->mlp_pl_plane = (size_t)linear_lat_max_rows() * ctx->mlp_ld_hidden;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = dev_alloc(ctx, &ctx->mlp_pl[i], 3 * ctx->mlp_pl_plane))) return rc;
     ctx->mlp_ws_ready = true;
     return MPE_OK;
 }
@@ -505,10 +529,111 @@ int gat_topology(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b) {
     return MPE_OK;
 }
 
+// ---- small batches (a few frames; the reference's call pattern is one frame per call, test/metrics_from_model.py:120-300) ----
+constexpr int LAT_MAX_FRAMES = 8;
+constexpr int LAT_MAX_NODES = 16384;
+
+// Can this batch take the latency launches?  Default precision modes, implicit topology, rows featurised on the device, a network
+// whose layers have instantiations (the deployed one: train_skeleton_matching.py:40-57) -- anything else keeps the batch path.
+bool lat_gat_ok(mpe_ctx *ctx, const mpe_batch *b, bool dense_in) {
+    if (!latency_path_on() || dense_in || b->d_en_pair || b->n_frames > LAT_MAX_FRAMES) return false;
+    if (b->n_heads + b->n_edge_nodes > LAT_MAX_NODES || b->n_heads <= 0) return false;
+    if (!ctx->gat_split || ctx->gat_acc64 || ctx->gat_reduced || ctx->gat_attn_fp16 || !ctx->l0_grouped) return false;
+    if (getenv("MPE_NO_COEF_EPILOGUE") || getenv("MPE_GAT_ACC64_MINK")) return false;       // (cross-check switches of the batch path)
+    if (!lat_l0a_available(ctx->cfg.n_joints, ctx->l0_ld)) return false;
+    const GatLayer &g0 = ctx->gat[0];
+    if (g0.out_dim != 40 || g0.in_dim <= 512) return false;      // layer 0: fc2 with f64 sums + the coefficient kernel, as the batch path
+    for (int l = 1; l < ctx->gat_layers; ++l) {
+        const GatLayer &g = ctx->gat[l];
+        if (!lat_gemm_available(g.fc1.ldw, g.in_dim, false, 0) || !lat_gemm_available(g.fc2.ldw, g.heads * g.out_dim, true, g.out_dim)) return false;
+        if (g.in_dim > 512) return false;                        // (such a layer would run with f64 sums)
+    }
+    const size_t shm = (size_t)2 * ((size_t)16 * (ctx->cfg.max_heads_per_frame + 1) + (ctx->cfg.max_heads_per_frame + 1) + 1 +
+                                    (size_t)(ctx->cfg.n_cameras + 1) * (ctx->cfg.n_cameras + 1)) * sizeof(float);
+    return shm <= 40 * 1024;
+}
+
+int ensure_lat_workspace(mpe_ctx *ctx) {
+    if (ctx->gat_pl[0]) return MPE_OK;
+    ctx->lat_rows = ctx->max_nodes < LAT_MAX_NODES ? ctx->max_nodes : LAT_MAX_NODES;
+    ctx->gat_pl_plane = (size_t)ctx->lat_rows * ctx->act_ld;
+    int rc;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = dev_alloc(ctx, &ctx->gat_pl[i], 3 * ctx->gat_pl_plane))) return rc;       // zeroed: pad columns meet zero weights
+    return MPE_OK;
+}
+
+// The matching network for a small batch in 4 + 3 (L - 1) launches instead of ~26: front + layer-0 fc1 (k_lat_l0a), layer-0 fc2 and its
+// coefficients as the batch path has them, then per layer attention (both halves, one launch) -> fc1 -> fc2 with the activations
+// travelling as bf16 planes between them (k_lat_gemm).  Same arithmetic, same summation orders, same bits as the batch kernels.
+int run_gat_lat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en, float *d_scores_heads) {
+    int rc = ensure_lat_workspace(ctx);
+    if (rc) return rc;
+    const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints, hmax = ctx->cfg.max_heads_per_frame;
+    const int n_nodes = b->n_heads + b->n_edge_nodes;
+    if (n_nodes > ctx->lat_rows) return fail(ctx, MPE_ERR_CAPACITY, "latency path: %d nodes exceed %d", n_nodes, ctx->lat_rows);
+    GatLayer &g0 = ctx->gat[0];
+    uint16_t *head_src = getenv("MPE_NO_HEAD_SRC_TABLE") ? nullptr : ctx->head_src;          // read per call: tests toggle it
+    {
+        GemmProf gp(ctx, s, 2.0 * b->n_heads * (double)g0.in_dim * (J * 10), 0, 0);
+        HIPCHK(ctx, launch_lat_l0a(s, ctx->d_cfg, *b, V, J, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair, ctx->head_src, hmax,
+                                   ctx->d_status, ctx->l0_w, (long)weight_rows(g0.in_dim) * ctx->l0_ld, ctx->l0_ld, ctx->l0_b, g0.in_dim, ctx->h0,
+                                   ctx->feat_ld, ctx->gat_alpha));
+    }
+    bool done = false;
+    if ((rc = gat_linear(ctx, s, ctx->h0, ctx->feat_ld, g0.fc2, ctx->act[1], ctx->act_ld, b->n_heads, nullptr, false, 0.f, false, nullptr, nullptr,
+                         -1.0, nullptr, &done)))
+        return rc;
+    HIPCHK(ctx, launch_attn_coef(s, ctx->act[1], ctx->act_ld, b->n_heads, g0.heads, g0.out_dim, g0.attn_l, g0.attn_r, ctx->a12, 0));
+    const int L = ctx->gat_layers;
+    for (int l = 0; l < L; ++l) {
+        GatLayer &g = ctx->gat[l];
+        AggArgs a = gat_agg_args(ctx, l);
+        if (l == 0) {
+            a.ft2 = ctx->act[1];
+            a.en_const_ft2 = ctx->en0_ft2;
+            a.en_const_a = ctx->en0_a;
+        } else {
+            if ((rc = ensure_split_weights(ctx, s, &g.fc1)) || (rc = ensure_split_weights(ctx, s, &g.fc2))) return rc;
+            const int hd = g.heads * g.out_dim;
+            {
+                GemmProf gp(ctx, s, 2.0 * n_nodes * (double)g.in_dim * g.in_dim, 0, 0, 1);
+                HIPCHK(ctx, launch_lat_gemm(s, ctx->gat_pl[0], ctx->act_ld, ctx->gat_pl_plane, g.fc1.w3, (size_t)weight_rows(g.fc1.out_dim) * g.fc1.ldw,
+                                            g.fc1.ldw, g.fc1.b, nullptr, 0, ctx->gat_pl[1], ctx->act_ld, ctx->gat_pl_plane, n_nodes, g.in_dim, g.fc1.ldw,
+                                            false, ctx->gat_alpha, nullptr, nullptr, nullptr, 0));
+            }
+            {
+                GemmProf gp(ctx, s, 2.0 * n_nodes * (double)hd * g.in_dim, 0, 0, 1);
+                HIPCHK(ctx, launch_lat_gemm(s, ctx->gat_pl[1], ctx->act_ld, ctx->gat_pl_plane, g.fc2.w3, (size_t)weight_rows(g.fc2.out_dim) * g.fc2.ldw,
+                                            g.fc2.ldw, g.fc2.b, ctx->act[2], ctx->act_ld, nullptr, 0, 0, n_nodes, hd, g.fc2.ldw, true, 0.f, g.attn_l,
+                                            g.attn_r, ctx->a12, g.out_dim));
+            }
+            a.ft2 = ctx->act[2];
+        }
+        a.a12_ready = 1;
+        if (l == L - 1) {
+            a.out_mode = ctx->gat_out_mode;
+            a.score_mode = 1;
+            a.out = d_scores_en;
+            a.out_heads = d_scores_heads;
+            a.ld_out = 1;
+        } else {
+            a.out_mode = 0;
+            a.out = nullptr;
+            a.out_pl = ctx->gat_pl[0];
+            a.out_pl_plane = ctx->gat_pl_plane;
+            a.ld_out = ctx->act_ld;
+        }
+        HIPCHK(ctx, launch_lat_attention(s, *b, V, hmax, ctx->node_off, ctx->head_frame, ctx->en_frame, ctx->en_pair, a, head_src));
+    }
+    return MPE_OK;
+}
+
 int run_gat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en, float *d_scores_heads,
             const float *d_feats = nullptr, int ld_feats = 0) {
     int rc = ensure_gat_workspace(ctx);
     if (rc) return rc;
+    if (lat_gat_ok(ctx, b, d_feats != nullptr)) return run_gat_lat(ctx, s, b, d_scores_en, d_scores_heads);
     const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints;
     const int n_nodes = b->n_heads + b->n_edge_nodes;
     if ((rc = gat_topology(ctx, s, b))) return rc;
@@ -769,6 +894,13 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
         HIPCHK(ctx, launch_linear_f64(static_cast<hipStream_t>(stream), d_a, lda, d_w, ldw, d_bias, d_c, ldc, m, d_m, n, ldw, (slope_on & 1) != 0, slope));
         return MPE_OK;
     }
+    if (slope_on & 64) {
+        // the small-batch (latency) form of the split-bf16 arithmetic with f64 sums (lat.hip): fp32 weights, split in registers
+        if (m > linear_lat_max_rows()) return fail(ctx, MPE_ERR_INVALID, "mpe_linear (latency form): at most %d rows", linear_lat_max_rows());
+        HIPCHK(ctx, launch_linear_lat_f64(static_cast<hipStream_t>(stream), d_a, lda, 0, d_w, ldw, d_bias, d_c, ldc, 0, m, d_m, n, ldw, (slope_on & 1) != 0, slope,
+                                          (slope_on & 16) ? 1 : 2));
+        return MPE_OK;
+    }
     if (slope_on & 4) {
         // split-bf16 arithmetic (gemm_sb16.hip) on caller-provided weights: the planes are made for this call (a stage-level
         // entry point for tests; the batch entry points keep theirs with the context)
@@ -998,6 +1130,16 @@ static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int 
             if (ld_in < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", ld_in, L.ldw);
             GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0, 3);
             HIPCHK(ctx, launch_linear_f64(s, in, ld_in, L.w, L.ldw, L.b, out, ctx->mlp_ld_hidden, m, d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope));
+        } else if (ctx->mlp_split && latency_mlp_on() && m <= linear_lat_max_rows()) {
+            // small batches: the same arithmetic from the fp32 weights, every fragment of a wave in flight at once (lat.hip)
+            Linear &L = ctx->mlp[l];
+            if (ld_in < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", ld_in, L.ldw);
+            GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0, 1);
+            // fp32 rows in, three bf16 planes between the layers (split once by the producer instead of by every consumer), fp32 rows out
+            const void *a_in = l == 0 ? static_cast<const void *>(in) : ctx->mlp_pl[(l - 1) & 1];
+            void *c_out = last ? static_cast<void *>(out) : ctx->mlp_pl[l & 1];
+            HIPCHK(ctx, launch_linear_lat_f64(s, a_in, l == 0 ? ld_in : ctx->mlp_ld_hidden, ctx->mlp_pl_plane, L.w, L.ldw, L.b, c_out, ctx->mlp_ld_hidden,
+                                              ctx->mlp_pl_plane, m, d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope, ctx->mlp_flush, l > 0, !last));
         } else if (ctx->mlp_split) {
             Linear &L = ctx->mlp[l];
             if ((rc = ensure_split_weights(ctx, s, &L))) return rc;

@@ -16,18 +16,18 @@
 #include <cstdlib>
 
 #include "mpe_internal.h"
+#include "sb_common.h"
 
 namespace mpe {
 
 // ---------------------------------------------------------------------------------------
 // topology tables: node_off[f], head_frame[h], en_frame[m], en_pair[m] = (h1,h2) frame-local
 // ---------------------------------------------------------------------------------------
-__global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head_off,
-                           const int32_t *__restrict__ en_off, const int32_t *__restrict__ slot_n,
-                           int32_t *__restrict__ node_off, int32_t *__restrict__ head_frame,
-                           int32_t *__restrict__ en_frame, int32_t *__restrict__ en_pair, int hmax,
-                           int32_t *__restrict__ status) {
-    const int f = blockIdx.x;
+__device__ __forceinline__ void topology_body(int f, int n_frames, int V, const int32_t *__restrict__ head_off,
+                                              const int32_t *__restrict__ en_off, const int32_t *__restrict__ slot_n,
+                                              int32_t *__restrict__ node_off, int32_t *__restrict__ head_frame,
+                                              int32_t *__restrict__ en_frame, int32_t *__restrict__ en_pair, int hmax,
+                                              int32_t *__restrict__ status) {
     __shared__ int s_n[MPE_MAX_CAMERAS], s_start[MPE_MAX_CAMERAS];
     const int h0 = head_off[f], H = head_off[f + 1] - h0;
     const int e0 = en_off[f], M = en_off[f + 1] - e0;
@@ -58,6 +58,14 @@ __global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head
             }
             base += cnt;
         }
+}
+
+__global__ void k_topology(int n_frames, int V, const int32_t *__restrict__ head_off,
+                           const int32_t *__restrict__ en_off, const int32_t *__restrict__ slot_n,
+                           int32_t *__restrict__ node_off, int32_t *__restrict__ head_frame,
+                           int32_t *__restrict__ en_frame, int32_t *__restrict__ en_pair, int hmax,
+                           int32_t *__restrict__ status) {
+    topology_body(blockIdx.x, n_frames, V, head_off, en_off, slot_n, node_off, head_frame, en_frame, en_pair, hmax, status);
 }
 
 __global__ void k_head_sources(int V, int hmax, const int32_t *__restrict__ head_off,
@@ -185,6 +193,42 @@ hipError_t launch_topology(hipStream_t s, const mpe_batch &b, int V, int32_t *no
 //   c = camera centre (T_i @ [0,0,0,1]), v = (T_i @ [Kinv @ [x,y,1]; 0])[0:3] in f32.
 // dense = true writes the whole zero-padded F-wide row (col 0 = 1, own-camera block at
 // 2 + cam*J*10); dense = false writes only the J*10 block.
+// the ten numbers of joint j of a head (zeros when the skeleton does not hold it)
+__device__ __forceinline__ void head_joint_features(const DevCfg *__restrict__ cfg, int cam, uint32_t mask, int j, const double *__restrict__ pxy,
+                                                    const float *__restrict__ pvp, float *o) {
+#pragma clang fp contract(off)
+    if (mask >> j & 1u) {
+        const double x = pxy[0], y = pxy[1];
+        const double hw = cfg->W / 2.0, hh = cfg->H / 2.0;
+        o[0] = (float)((x - hw) / hw);
+        o[1] = (float)((hh - y) / hh);
+        o[2] = pvp[0];
+        o[3] = pvp[1];
+        const float *Ki = cfg->Kinv[cam];
+        const float *T = cfg->T_i[cam];
+        const float px = (float)x, py = (float)y;
+        float pix[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float a = Ki[r * 3 + 0] * px;
+            a = __builtin_fmaf(Ki[r * 3 + 1], py, a);
+            a = __builtin_fmaf(Ki[r * 3 + 2], 1.0f, a);
+            pix[r] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            o[4 + r] = T[r * 4 + 3];      // T_i @ [0,0,0,1]
+            float a = T[r * 4 + 0] * pix[0];
+            a = __builtin_fmaf(T[r * 4 + 1], pix[1], a);
+            a = __builtin_fmaf(T[r * 4 + 2], pix[2], a);
+            o[7 + r] = a;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) o[k] = 0.f;
+    }
+}
+
 __global__ void k_head_features(const DevCfg *__restrict__ cfg, int n_heads, int J,
                                 const int32_t *__restrict__ head_cam, const uint32_t *__restrict__ joint_mask,
                                 const double *__restrict__ xy, const float *__restrict__ vp,
@@ -200,38 +244,8 @@ __global__ void k_head_features(const DevCfg *__restrict__ cfg, int n_heads, int
     const int cam = head_cam[h];
     const int t = threadIdx.x;
     if (t < J) {
-        const uint32_t mask = joint_mask[h];
         float o[10];
-        if (mask >> t & 1u) {
-            const double x = xy[((size_t)h * J + t) * 2 + 0], y = xy[((size_t)h * J + t) * 2 + 1];
-            const double hw = cfg->W / 2.0, hh = cfg->H / 2.0;
-            o[0] = (float)((x - hw) / hw);
-            o[1] = (float)((hh - y) / hh);
-            o[2] = vp[((size_t)h * J + t) * 2 + 0];
-            o[3] = vp[((size_t)h * J + t) * 2 + 1];
-            const float *Ki = cfg->Kinv[cam];
-            const float *T = cfg->T_i[cam];
-            const float px = (float)x, py = (float)y;
-            float pix[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                float a = Ki[r * 3 + 0] * px;
-                a = __builtin_fmaf(Ki[r * 3 + 1], py, a);
-                a = __builtin_fmaf(Ki[r * 3 + 2], 1.0f, a);
-                pix[r] = a;
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                o[4 + r] = T[r * 4 + 3];      // T_i @ [0,0,0,1]
-                float a = T[r * 4 + 0] * pix[0];
-                a = __builtin_fmaf(T[r * 4 + 1], pix[1], a);
-                a = __builtin_fmaf(T[r * 4 + 2], pix[2], a);
-                o[7 + r] = a;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 10; ++k) o[k] = 0.f;
-        }
+        head_joint_features(cfg, cam, joint_mask[h], t, xy + ((size_t)h * J + t) * 2, vp + ((size_t)h * J + t) * 2, o);
 #pragma unroll
         for (int k = 0; k < 10; ++k) s_f[t * 10 + k] = o[k];
     }
@@ -555,13 +569,11 @@ __device__ __forceinline__ int slot_of_head(const FrameTopo &tp, int V, int v) {
 // In-edge sources of every head of a frame, [hmax][hmax + 1] per frame: entry (h, e) = frame-local id
 // of the source node of in-edge e of head h, 0xFFFF for e >= in-degree and for rows h >= H.  Frames
 // beyond hmax heads (flagged by k_topology) get an all-0xFFFF table.
-__global__ __launch_bounds__(256) void k_head_sources(int V, int hmax, const int32_t *__restrict__ head_off,
-                                                      const int32_t *__restrict__ slot_n,
-                                                      uint16_t *__restrict__ head_src) {
+__device__ __forceinline__ void head_sources_body(int f, int *s_slot, int V, int hmax, const int32_t *__restrict__ head_off,
+                                                  const int32_t *__restrict__ slot_n, uint16_t *__restrict__ head_src) {
     __shared__ int s_topo[MPE_MAX_CAMERAS + 1 + MPE_MAX_CAMERAS * MPE_MAX_CAMERAS];
     __shared__ int s_n[MPE_MAX_CAMERAS];
-    extern __shared__ int s_slot[];                 // [hmax] camera slot of every head
-    const int f = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     const int H = head_off[f + 1] - head_off[f];
     const int max_deg = hmax + 1;
     FrameTopo tp;
@@ -592,6 +604,174 @@ __global__ __launch_bounds__(256) void k_head_sources(int V, int hmax, const int
         }
         dst[i] = (uint16_t)u;
     }
+}
+
+__global__ __launch_bounds__(256) void k_head_sources(int V, int hmax, const int32_t *__restrict__ head_off,
+                                                      const int32_t *__restrict__ slot_n,
+                                                      uint16_t *__restrict__ head_src) {
+    extern __shared__ int s_slot[];                 // [hmax] camera slot of every head
+    head_sources_body(blockIdx.x, s_slot, V, hmax, head_off, slot_n, head_src);
+}
+
+// ---------------------------------------------------------------------------------------
+// Small batches: the front of the matching stage in ONE launch (k_topology + k_head_sources + k_head_features + k_group_heads +
+// the per-camera fc1 launches of layer 0 are nine launches of ~4.5 us each for one 5 x 4 frame).  Workgroups [0, n_frames) write
+// the topology tables of their frame (first read by the attention stage, two launches later); the others are fc1 of layer 0
+// (gat2.py:53-54 on head rows, K = the J * 10 columns of the head's own camera: see the layer-0 de-duplication in DESIGN.md 2) for one
+// (camera, 16 heads of that camera, 64 output features): the heads of a camera are found from the frames' slot tables (ascending
+// head order), their feature rows are computed in place (k_head_features' numbers) into LDS, and four waves multiply them with the
+// camera's weight block -- k_linear_skinny's arithmetic: v_mfma_f32_16x16x4_f32, k ascending, one fp32 chain -- all of a wave's
+// weight fragments requested before the features are computed.
+// ---------------------------------------------------------------------------------------
+constexpr int L0A_NK = 6;           // K stages of 32: J * 10 <= 192
+constexpr int L0A_XS = 196;         // LDS row stride of the feature tile (floats): 16 rows 16 B apart in the banks
+
+__global__ __launch_bounds__(256) void k_lat_l0a(const DevCfg *__restrict__ cfg, int n_frames, int n_heads, int V, int J,
+                                                 const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
+                                                 const int32_t *__restrict__ slot_cam, const int32_t *__restrict__ slot_n,
+                                                 const uint32_t *__restrict__ joint_mask, const double *__restrict__ xy,
+                                                 const float *__restrict__ vp, int32_t *__restrict__ node_off,
+                                                 int32_t *__restrict__ head_frame, int32_t *__restrict__ en_frame,
+                                                 int32_t *__restrict__ en_pair, uint16_t *__restrict__ head_src, int hmax,
+                                                 int32_t *__restrict__ status, const float *__restrict__ l0_w, long w_cam_stride,
+                                                 int l0_ld, const float *__restrict__ l0_b, int n_out, float *__restrict__ h0,
+                                                 int ld_h0, float alpha) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    extern __shared__ int s_dyn_i[];
+    if ((int)blockIdx.x < n_frames) {
+        topology_body(blockIdx.x, n_frames, V, head_off, en_off, slot_n, node_off, head_frame, en_frame, en_pair, hmax, status);
+        if (head_src) {
+            __syncthreads();
+            head_sources_body(blockIdx.x, s_dyn_i, V, hmax, head_off, slot_n, head_src);
+        }
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float s_x[16 * L0A_XS];
+    __shared__ int s_cnt[MPE_MAX_CAMERAS], s_row[16], s_job[2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ntiles = (n_out + 15) / 16, ncg = (ntiles + 3) / 4;
+    const int job = blockIdx.x - n_frames;
+    const int rtg = job / ncg, cg = job - rtg * ncg;
+    // heads per camera, from the slot tables (slot s of frame f holds slot_n heads of camera slot_cam, heads of a frame in slot order)
+    if (t < V) {
+        int c = 0;
+        for (int i = 0; i < n_frames * V; ++i) c += slot_cam[i] == t ? slot_n[i] : 0;
+        s_cnt[t] = c;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int c = 0, acc = 0;
+        for (; c < V; ++c) {
+            const int tl = (s_cnt[c] + 15) / 16;
+            if (rtg < acc + tl) break;
+            acc += tl;
+        }
+        s_job[0] = c;               // camera (V = no such row tile)
+        s_job[1] = rtg - acc;       // row tile within the camera
+    }
+    __syncthreads();
+    const int cam = s_job[0];
+    if (cam >= V) return;
+    // this wave's weight fragments: one burst, before anything that depends on the rows
+    const int ct = cg * 4 + wave;
+    const int fq = lane >> 4, fr = lane & 15;
+    f32x4 wv[L0A_NK][2];
+    {
+        const int ctc = ct < ntiles ? ct : ntiles - 1;
+        const float *pw = l0_w + (size_t)cam * w_cam_stride + (size_t)(ctc * 16 + fr) * l0_ld + 8 * fq;
+#pragma unroll
+        for (int kt = 0; kt < L0A_NK; ++kt) {
+            const int ko = (kt * 32 < l0_ld ? kt : 0) * 32;
+            wv[kt][0] = *reinterpret_cast<const f32x4 *>(pw + ko);
+            wv[kt][1] = *reinterpret_cast<const f32x4 *>(pw + ko + 4);
+        }
+    }
+    if (t < 16) {
+        // the (16 r + t)-th head of the camera, in ascending head order
+        int want = s_job[1] * 16 + t, found = -1;
+        if (want < s_cnt[cam]) {
+            for (int f = 0; f < n_frames && found < 0; ++f) {
+                int start = 0;
+                for (int sl = 0; sl < V; ++sl) {
+                    const int n = slot_n[f * V + sl];
+                    if (slot_cam[f * V + sl] == cam) {
+                        if (want < n) {
+                            found = head_off[f] + start + want;
+                            break;
+                        }
+                        want -= n;
+                    }
+                    start += n;
+                }
+            }
+        }
+        s_row[t] = found;
+    }
+    for (int i = t; i < 16 * (L0A_XS - J * 10); i += 256) {             // columns behind the J * 10 features: zeros (they meet zero weights)
+        const int r = i / (L0A_XS - J * 10), c = J * 10 + (i - r * (L0A_XS - J * 10));
+        s_x[r * L0A_XS + c] = 0.f;
+    }
+    __syncthreads();
+    for (int i = t; i < 16 * J; i += 256) {
+        const int r = i / J, j = i - r * J;
+        const int h = s_row[r];
+        float o[10];
+        if (h >= 0) {
+            head_joint_features(cfg, cam, joint_mask[h], j, xy + ((size_t)h * J + j) * 2, vp + ((size_t)h * J + j) * 2, o);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) o[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s_x[r * L0A_XS + j * 10 + k] = o[k];
+    }
+    __syncthreads();
+    if (ct >= ntiles) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nk = l0_ld / 32;
+#pragma unroll
+    for (int kt = 0; kt < L0A_NK; ++kt) {
+        if (kt < nk) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&s_x[fr * L0A_XS + kt * 32 + 8 * fq]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&s_x[fr * L0A_XS + kt * 32 + 8 * fq + 4]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kt][0][q], a0[q], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kt][1][q], a1[q], acc, 0, 0, 0);
+        }
+    }
+    const int h = s_row[fr];
+    if (h < 0) return;
+    const int nb = ct * 16 + fq * 4;
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(l0_b + nb);
+    f32x4 v = acc + bv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * alpha;
+    float *dst = h0 + (size_t)h * ld_h0 + nb;
+    if (nb + 3 < n_out) {
+        *reinterpret_cast<f32x4 *>(dst) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (nb + i < n_out) dst[i] = v[i];
+    }
+}
+
+bool lat_l0a_available(int J, int l0_ld) { return J * 10 <= L0A_NK * 32 && l0_ld <= L0A_NK * 32 && L0A_XS >= l0_ld; }
+
+hipError_t launch_lat_l0a(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int V, int J, int32_t *node_off, int32_t *head_frame,
+                          int32_t *en_frame, int32_t *en_pair, uint16_t *head_src, int hmax, int32_t *status, const float *l0_w,
+                          long w_cam_stride, int l0_ld, const float *l0_b, int n_out, float *h0, int ld_h0, float alpha) {
+    if (b.n_frames <= 0) return hipSuccess;
+    if (b.d_en_pair || !lat_l0a_available(J, l0_ld)) return hipErrorInvalidValue;
+    if (!head_src_entries(hmax, V)) head_src = nullptr;
+    const int ntiles = (n_out + 15) / 16, ncg = (ntiles + 3) / 4;
+    const int row_tiles = V + (b.n_heads + 15) / 16;                   // >= sum over the cameras of ceil(heads of the camera / 16)
+    const int grid = b.n_frames + (b.n_heads > 0 ? row_tiles * ncg : 0);
+    hipLaunchKernelGGL(k_lat_l0a, dim3(grid), dim3(256), (size_t)hmax * sizeof(int), s, cfg, b.n_frames, b.n_heads, V, J, b.d_frame_head_off,
+                       b.d_frame_en_off, b.d_slot_cam, b.d_slot_n, b.d_joint_mask, b.d_xy, b.d_vp, node_off, head_frame, en_frame, en_pair,
+                       head_src, hmax, status, l0_w, w_cam_stride, l0_ld, l0_b, n_out, h0, ld_h0, alpha);
+    return hipGetLastError();
 }
 
 // Weighted sum over the in-edges of a head destination, canonical order: eight accumulators, the
@@ -648,21 +828,42 @@ constexpr int EN_ROWS = 16;     // edge-node rows per workgroup
 
 // Phase A: one thread per (row, attention head) computes the 3-way softmax weights and one per row
 // the three source rows; phase B: one thread per (row, VEC columns) does the weighted sum from them.
+// rows of the activated output: fp32 rows, or (small batches, lat.hip: the next layer's fc1 takes its activations as the three
+// bf16 planes split8 would make of them) planes only
 template <int VEC>
-__global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *__restrict__ head_off,
-                                                      const int32_t *__restrict__ en_off,
-                                                      const int32_t *__restrict__ node_off,
-                                                      const int32_t *__restrict__ en_frame,
-                                                      const int32_t *__restrict__ en_pair, AggArgs a, int hmax) {
-#pragma clang fp contract(off)
+__device__ __forceinline__ void agg_store_row(const AggArgs &a, size_t row, int c, const float *o) {
+    if (a.out_pl) {
+        unsigned short *d = a.out_pl + row * a.ld_out + c;
+        if (VEC == 4) {
+            sb::f32x4 v = {o[0], o[1], o[2], o[3]};
+            sb::store_planes4(d, a.out_pl_plane, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) sb::store_planes1(d + k, a.out_pl_plane, o[k]);
+        }
+        return;
+    }
     typedef float vecf __attribute__((ext_vector_type(VEC)));
+    vecf v;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = o[k];
+    *reinterpret_cast<vecf *>(a.out + row * a.ld_out + c) = v;
+}
+
+template <int VEC>
+__device__ __forceinline__ void aggregate_en_body(int wg, int n_en, const int32_t *__restrict__ head_off,
+                                                  const int32_t *__restrict__ en_off,
+                                                  const int32_t *__restrict__ node_off,
+                                                  const int32_t *__restrict__ en_frame,
+                                                  const int32_t *__restrict__ en_pair, const AggArgs &a, int hmax) {
+#pragma clang fp contract(off)
     __shared__ float s_w[EN_ROWS][16][3];           // softmax weights of (h1, h2, self) per attention head
     __shared__ int s_over[EN_ROWS];                 // row of a frame beyond max_heads_per_frame (flagged by k_topology): score 0
     __shared__ long s_src[EN_ROWS][3];              // ft2 row of h1, h2, self (self: -1 at layer 0 = the shared row)
     __shared__ long s_dst[EN_ROWS];                 // output row
     const int hd = a.heads * a.out_dim, heads = a.heads;
     const int per_row = (hd + VEC - 1) / VEC;       // a VEC-column group may straddle two attention heads
-    const int m0 = blockIdx.x * EN_ROWS;
+    const int m0 = wg * EN_ROWS;
     const int rows = min(EN_ROWS, n_en - m0);
     const bool l0 = a.en_const_ft2 != nullptr;
     for (int i = threadIdx.x; i < rows * heads; i += blockDim.x) {
@@ -726,7 +927,7 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
             w2[k] = s_w[r][hk][1];
             w3[k] = s_w[r][hk][2];
         }
-        vecf o;
+        float o[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             float acc = v1[k] * w1[k];
@@ -735,8 +936,17 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
             o[k] = agg_activate(acc, a.out_mode, a.out_slope);
         }
         if (a.score_mode) a.out[m0 + r] = s_over[r] ? 0.f : o[0];
-        else *reinterpret_cast<vecf *>(a.out + (size_t)s_dst[r] * a.ld_out + c) = o;
+        else agg_store_row<VEC>(a, (size_t)s_dst[r], c, o);
     }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *__restrict__ head_off,
+                                                      const int32_t *__restrict__ en_off,
+                                                      const int32_t *__restrict__ node_off,
+                                                      const int32_t *__restrict__ en_frame,
+                                                      const int32_t *__restrict__ en_pair, AggArgs a, int hmax) {
+    aggregate_en_body<VEC>(blockIdx.x, n_en, head_off, en_off, node_off, en_frame, en_pair, a, hmax);
 }
 
 // Head destinations, general path: AGG_ROWS head rows per workgroup, two waves per row for the
@@ -746,12 +956,11 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
 constexpr int AGG_ROWS = 2;
 
 template <int VEC>
-__global__ __launch_bounds__(256) void k_aggregate_heads(
-    int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
+__device__ __forceinline__ void aggregate_heads_body(
+    int wg, float *s_dyn, int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
     const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off,
-    const int32_t *__restrict__ head_frame, AggArgs a, const uint16_t *__restrict__ head_src, int src_stride, int hmax) {
+    const int32_t *__restrict__ head_frame, const AggArgs &a, const uint16_t *__restrict__ head_src, int src_stride, int hmax) {
 #pragma clang fp contract(off)
-    extern __shared__ float s_dyn[];
     const int heads = a.heads, hd = a.heads * a.out_dim;
     float *s_w = s_dyn;                                                          // [AGG_ROWS][heads][max_deg]
     int *s_src = reinterpret_cast<int *>(s_w + (size_t)AGG_ROWS * heads * max_deg);   // [AGG_ROWS][max_deg]
@@ -761,7 +970,7 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool l0 = a.en_const_ft2 != nullptr;
     const int r_own = wave & (AGG_ROWS - 1), half = wave / AGG_ROWS;      // row of this wave, which half of the heads
-    const int gh = blockIdx.x * AGG_ROWS + r_own;
+    const int gh = wg * AGG_ROWS + r_own;
     int deg = 0, f = 0, hb = 0, H = 0, v = 0;
     int32_t nb = 0;
     const int32_t *sn = slot_n;
@@ -865,12 +1074,37 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
         if (a.score_mode) {
             a.out_heads[(size_t)hbb + vv] = agg_activate(acc[0], a.out_mode, a.out_slope);
         } else {
-            typedef float vecf __attribute__((ext_vector_type(VEC)));
-            vecf o;
+            float o[VEC];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) o[k] = agg_activate(acc[k], a.out_mode, a.out_slope);
-            *reinterpret_cast<vecf *>(a.out + (size_t)(nbb + vv) * a.ld_out + c) = o;
+            agg_store_row<VEC>(a, (size_t)(nbb + vv), c, o);
         }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_aggregate_heads(
+    int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
+    const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off,
+    const int32_t *__restrict__ head_frame, AggArgs a, const uint16_t *__restrict__ head_src, int src_stride, int hmax) {
+    extern __shared__ float s_dyn[];
+    aggregate_heads_body<VEC>(blockIdx.x, s_dyn, n_heads, V, max_deg, head_off, en_off, slot_n, node_off, head_frame, a, head_src, src_stride, hmax);
+}
+
+// Small batches (a few frames: the reference's own call pattern is one frame per call): BOTH halves of the attention stage in ONE
+// launch -- workgroups [0, n_en_wgs) take edge-node rows, the rest head rows -- with the kernels' own bodies, hence their bits.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_lat_attention(
+    int n_en_wgs, int n_en, int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
+    const int32_t *__restrict__ slot_n, const int32_t *__restrict__ node_off, const int32_t *__restrict__ head_frame,
+    const int32_t *__restrict__ en_frame, const int32_t *__restrict__ en_pair, AggArgs a, const uint16_t *__restrict__ head_src,
+    int src_stride, int hmax) {
+    extern __shared__ float s_dyn[];
+    if ((int)blockIdx.x < n_en_wgs) {
+        aggregate_en_body<VEC>(blockIdx.x, n_en, head_off, en_off, node_off, en_frame, en_pair, a, hmax);
+    } else if (!a.score_mode || a.out_heads) {
+        aggregate_heads_body<VEC>(blockIdx.x - n_en_wgs, s_dyn, n_heads, V, max_deg, head_off, en_off, slot_n, node_off, head_frame, a, head_src,
+                                  src_stride, hmax);
     }
 }
 
@@ -1322,6 +1556,35 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
         if (e != hipSuccess) return e;
     }
     return launch_aggregate(s, b, V, max_heads_per_frame, node_off, head_frame, en_frame, en_pair, a2, head_src, x_deg_cap);
+}
+
+// the general kernels' two halves as one launch (small batches; implicit topology)
+hipError_t launch_lat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame, const int32_t *node_off,
+                                const int32_t *head_frame, const int32_t *en_frame, const int32_t *en_pair, const AggArgs &a,
+                                const uint16_t *head_src) {
+    if (b.d_en_pair || a.ft_half || !a.a12_ready) return hipErrorInvalidValue;
+    const int vec = agg_vec(a);
+    if (!head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
+    const int n_en_wgs = (b.n_edge_nodes + EN_ROWS - 1) / EN_ROWS;
+    const bool heads_on = b.n_heads > 0 && (!a.score_mode || a.out_heads);
+    const int n_h_wgs = heads_on ? (b.n_heads + AGG_ROWS - 1) / AGG_ROWS : 0;
+    if (n_en_wgs + n_h_wgs == 0) return hipSuccess;
+    const int src_stride = max_heads_per_frame + 1;
+    int max_deg = src_stride < 3 ? 3 : src_stride;
+    const size_t shm = (size_t)AGG_ROWS * ((size_t)a.heads * max_deg + max_deg + (V + 1) + (size_t)V * V) * sizeof(float);
+    if (shm > 48 * 1024) return hipErrorInvalidValue;                  // (the caller keeps such rigs on the batch path)
+    const int hd4 = (a.heads * a.out_dim + 3) / 4 * 4;
+    // (one vector width for both halves: the head half needs whole heads per group; per-column arithmetic does not depend on it)
+    (void)hd4;
+#define MPE_LA(V_)                                                                                                              \
+    hipLaunchKernelGGL(k_lat_attention<V_>, dim3(n_en_wgs + n_h_wgs), dim3(256), shm, s, n_en_wgs, b.n_edge_nodes, b.n_heads, V, max_deg, \
+                       b.d_frame_head_off, b.d_frame_en_off, b.d_slot_n, node_off, head_frame, en_frame, en_pair, a, head_src, src_stride, \
+                       max_heads_per_frame)
+    if (vec == 4) MPE_LA(4);
+    else if (vec == 2) MPE_LA(2);
+    else MPE_LA(1);
+#undef MPE_LA
+    return hipGetLastError();
 }
 
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,

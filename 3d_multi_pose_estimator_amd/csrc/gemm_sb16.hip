@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "mpe_internal.h"
+#include "sb_common.h"
 
 #ifndef SB_PRIO_MFMA
 #define SB_PRIO_MFMA 2
@@ -43,12 +44,6 @@ namespace mpe {
 // (kernels in namespace mpe, not an anonymous one: profilers print "(anonymous namespace)::" in front of such names and the
 // tools that cut a kernel name at its first parenthesis then see nothing)
 namespace sb {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
 
 // In-kernel clock of a launch (MI355X_MICROARCH.md, DVFS give-back item 6), DIAGNOSTIC builds only (make exp EXPFLAGS=-DMPE_SB_CLOCK,
 // tools/sb_clock_probe.py): the first MFMA wave of every workgroup stamps the shader clock (s_memtime) and the constant 100 MHz
@@ -69,66 +64,6 @@ __device__ unsigned long long g_sb_stamp[16][256][4];
 #else
 #define SB_STAMP(SLOT) do { } while (0)
 #endif
-
-__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-    bf2 v = {(__bf16)lo, (__bf16)hi};                    // v_cvt_pk_bf16_f32: round to nearest even
-    return __builtin_bit_cast(unsigned, v);
-}
-
-// x - y as ONE v_sub_f32: left to itself the compiler pairs the residual subtractions of split8 into v_pk_add_f32, and a packed
-// fp32 instruction in the shadow of MFMAs costs 13-22 cycles more than the two plain ones it replaces (MI355X_MICROARCH.md, cycle
-// constants: "an anti-lever beside MFMAs").  Not volatile: the scheduler still places it.
-__device__ __forceinline__ float sub1(float x, float y) {
-#ifdef SB_NO_SUB1
-    return x - y;
-#else
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-#endif
-}
-
-// eight fp32 values -> their three bf16 planes (exact: x = p0 + p1 + p2)
-__device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
-    u32x4 q0, q1, q2;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
-        const unsigned u0 = pack2_bf16(a, b);
-        const float ra = sub1(a, __uint_as_float(u0 << 16)), rb = sub1(b, __uint_as_float(u0 & 0xFFFF0000u));
-        const unsigned u1 = pack2_bf16(ra, rb);
-        const float sa = sub1(ra, __uint_as_float(u1 << 16)), sb = sub1(rb, __uint_as_float(u1 & 0xFFFF0000u));
-        q0[j] = u0;
-        q1[j] = u1;
-        q2[j] = pack2_bf16(sa, sb);
-    }
-    p0 = __builtin_bit_cast(bf16x8, q0);
-    p1 = __builtin_bit_cast(bf16x8, q1);
-    p2 = __builtin_bit_cast(bf16x8, q2);
-}
-
-// the six products of one stage, canonical order; a[p], w[p] = plane p (0 = most significant)
-#define SB_STAGE(ACC, A, W)                                                            \
-    do {                                                                               \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[2], (A)[0], ACC, 0, 0, 0);   \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[1], (A)[1], ACC, 0, 0, 0);   \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[1], (A)[0], ACC, 0, 0, 0);   \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[2], ACC, 0, 0, 0);   \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[1], ACC, 0, 0, 0);   \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[0], ACC, 0, 0, 0);   \
-    } while (0)
-
-// the same with the chain started from zero (C operand = the inline constant 0: no accumulator to clear after a flush)
-#define SB_STAGE0(ACC, A, W)                                                                                       \
-    do {                                                                                                           \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[2], (A)[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);     \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[1], (A)[1], ACC, 0, 0, 0);                              \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[1], (A)[0], ACC, 0, 0, 0);                              \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[2], ACC, 0, 0, 0);                              \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[1], ACC, 0, 0, 0);                              \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16((W)[0], (A)[0], ACC, 0, 0, 0);                              \
-    } while (0)
 
 __device__ __forceinline__ int a_swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }   // gemm.hip: dma_swz
 // 64-byte rows (weight planes): chunk c of row r sits at position c ^ w_swz(r).  ds_read_b128 serves its 64 lanes in four

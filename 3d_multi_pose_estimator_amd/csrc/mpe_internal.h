@@ -119,6 +119,9 @@ struct mpe_ctx {
     bool l0_grouped = true;
     float *act[3] = {nullptr, nullptr, nullptr};   // [max_nodes][act_ld]
     float *a12 = nullptr;          // [max_nodes][2*16]
+    unsigned short *gat_pl[2] = {nullptr, nullptr};   // small batches (lat.hip): activations between attention -> fc1 -> fc2 as three bf16 planes [3][lat_rows][act_ld]
+    size_t gat_pl_plane = 0;       // plane stride in elements
+    int lat_rows = 0;
     int32_t *head_frame = nullptr; // [max_heads]
     int32_t *en_frame = nullptr;   // [max_edge_nodes]
     int32_t *en_pair = nullptr;    // [max_edge_nodes][2] frame-local head ids
@@ -133,6 +136,8 @@ struct mpe_ctx {
     int mlp_ld_in = 0, mlp_ld_hidden = 0;
     float *mlp_rows = nullptr;     // [max_frames*Pcap][mlp_ld_in]
     float *mlp_act[2] = {nullptr, nullptr};
+    unsigned short *mlp_pl[2] = {nullptr, nullptr};   // small batches (lat.hip): activations between the layers as three bf16 planes [3][lat rows][mlp_ld_hidden]
+    size_t mlp_pl_plane = 0;       // plane stride in elements
     int32_t *mlp_count = nullptr;
     float *scores_tmp = nullptr;    // [max_edge_nodes]
     int32_t *person_off = nullptr;  // [max_frames+1]
@@ -164,6 +169,16 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
                               bool out_half = false,      // out_half (fp16 ft2 rows, configs[4]): tile kernel, fp32-chain launches without LeakyReLU only; hipErrorInvalidValue otherwise
                               int flush_stages = 2);      // f64 launches: K stages per f64 flush (2 = default, 1 = the maximum-accuracy mode)
 bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64);
+// lat.hip: the small-batch ("latency") forms -- the arithmetic of the split-bf16 kernels (same bits), shortest serial depth:
+// fp32 weights streamed once and split in registers, every weight fragment of a wave requested before its first product
+int linear_lat_max_rows();
+bool lat_gemm_available(int k_pad, int n, bool fc2, int out_dim);
+hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
+                           const float *bias, float *C, int ldc, unsigned short *Cpl, int ldcp, size_t c_plane, int m, int n, int k_pad, bool fc2,
+                           float slope, const float *attn_l, const float *attn_r, float *a12, int out_dim);
+hipError_t launch_linear_lat_f64(hipStream_t s, const void *A, int lda, size_t a_plane, const float *W, int ldw, const float *bias, void *C,
+                                 int ldc, size_t c_plane, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky, float slope,
+                                 int flush_stages, bool a_planes = false, bool c_planes = false);
 // gemm_f64.hip: exact products, f64 accumulation on the f64 matrix pipe (MLP mode 5: the reference-exact form, not the fast path)
 hipError_t launch_linear_f64(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc,
                              int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky, float slope);
@@ -216,11 +231,20 @@ struct AggArgs {
     int ld_out;
     int score_mode;            // last layer: write out[edge-node index] (and heads to out_heads)
     float *out_heads;
+    unsigned short *out_pl;    // small batches (lat.hip): the output as three bf16 planes [3][rows][ld_out] INSTEAD of fp32 rows
+    size_t out_pl_plane;       // plane stride in elements
 };
 hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                             const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
                             const int32_t *en_pair, const AggArgs &a, const uint16_t *head_src, int x_deg_cap = 0);
 
+bool lat_l0a_available(int J, int l0_ld);
+hipError_t launch_lat_l0a(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int V, int J, int32_t *node_off, int32_t *head_frame,
+                          int32_t *en_frame, int32_t *en_pair, uint16_t *head_src, int hmax, int32_t *status, const float *l0_w,
+                          long w_cam_stride, int l0_ld, const float *l0_b, int n_out, float *h0, int ld_h0, float alpha);
+hipError_t launch_lat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame, const int32_t *node_off,
+                                const int32_t *head_frame, const int32_t *en_frame, const int32_t *en_pair, const AggArgs &a,
+                                const uint16_t *head_src);
 hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame,
                                 const int32_t *node_off, const int32_t *head_frame, const int32_t *en_frame,
                                 const int32_t *en_pair, const float *attn_l, const float *attn_r, float *a12,

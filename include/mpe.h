@@ -210,7 +210,8 @@ int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
  * mpe_upload_linear (zero padded).  d_m, if not NULL, overrides M with a device-side count.
  * flags: bit 0 = apply LeakyReLU(slope), bit 1 = f64 running sums (see mpe_set_precision), bit 2 = the split-bf16 form
  * (csrc/gemm_sb16.hip; the planes are made for the call), with bit 3 = without its f64 sums and bit 4 = an f64 flush per K stage;
- * bit 5 = the f64 matrix-pipe form (csrc/gemm_f64.hip). */
+ * bit 5 = the f64 matrix-pipe form (csrc/gemm_f64.hip); bit 6 = the small-batch (latency) form of the split-bf16 arithmetic with f64
+ * sums (csrc/lat.hip: same bits as bit 2, at most 128 rows; bit 4 selects the flush per stage here too). */
 int mpe_upload_linear(mpe_ctx *ctx, const float *w, const float *b, int32_t out_dim, int32_t in_dim,
                       float **d_w, float **d_b, int32_t *ldw);
 int mpe_free_device(mpe_ctx *ctx, void *d_ptr);
