@@ -563,8 +563,8 @@ int ensure_lat_workspace(mpe_ctx *ctx) {
     return MPE_OK;
 }
 
-// The matching network for a small batch in 4 + 3 (L - 1) launches instead of ~26: front + layer-0 fc1 (k_lat_l0a), layer-0 fc2 and its
-// coefficients as the batch path has them, then per layer attention (both halves, one launch) -> fc1 -> fc2 with the activations
+// The matching network for a small batch in 3 + 3 (L - 1) launches instead of ~26: front + layer-0 fc1 (k_lat_l0a), layer-0 fc2 as the
+// batch path has it, then per layer attention (both halves, one launch) -> fc1 -> fc2 with the activations
 // travelling as bf16 planes between them (k_lat_gemm).  Same arithmetic, same summation orders, same bits as the batch kernels.
 int run_gat_lat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en, float *d_scores_heads) {
     int rc = ensure_lat_workspace(ctx);
@@ -584,11 +584,13 @@ int run_gat_lat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores
     if ((rc = gat_linear(ctx, s, ctx->h0, ctx->feat_ld, g0.fc2, ctx->act[1], ctx->act_ld, b->n_heads, nullptr, false, 0.f, false, nullptr, nullptr,
                          -1.0, nullptr, &done)))
         return rc;
-    HIPCHK(ctx, launch_attn_coef(s, ctx->act[1], ctx->act_ld, b->n_heads, g0.heads, g0.out_dim, g0.attn_l, g0.attn_r, ctx->a12, 0));
     const int L = ctx->gat_layers;
     for (int l = 0; l < L; ++l) {
         GatLayer &g = ctx->gat[l];
         AggArgs a = gat_agg_args(ctx, l);
+        a.attn_l = g.attn_l;
+        a.attn_r = g.attn_r;
+        bool coef = false;                                   // a1 | a2 already in a12?  (otherwise the attention kernel computes them from the rows)
         if (l == 0) {
             a.ft2 = ctx->act[1];
             a.en_const_ft2 = ctx->en0_ft2;
@@ -606,11 +608,11 @@ int run_gat_lat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores
                 GemmProf gp(ctx, s, 2.0 * n_nodes * (double)hd * g.in_dim, 0, 0, 1);
                 HIPCHK(ctx, launch_lat_gemm(s, ctx->gat_pl[1], ctx->act_ld, ctx->gat_pl_plane, g.fc2.w3, (size_t)weight_rows(g.fc2.out_dim) * g.fc2.ldw,
                                             g.fc2.ldw, g.fc2.b, ctx->act[2], ctx->act_ld, nullptr, 0, 0, n_nodes, hd, g.fc2.ldw, true, 0.f, g.attn_l,
-                                            g.attn_r, ctx->a12, g.out_dim));
+                                            g.attn_r, ctx->a12, g.out_dim, &coef));
             }
             a.ft2 = ctx->act[2];
         }
-        a.a12_ready = 1;
+        a.a12_ready = coef ? 1 : 0;
         if (l == L - 1) {
             a.out_mode = ctx->gat_out_mode;
             a.score_mode = 1;
@@ -1118,7 +1120,8 @@ int mpe_mlp_input_rows(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int
 }
 
 static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int m, const int32_t *d_m, float **y_out,
-                     int *ld_y) {
+                     int *ld_y, const DecodeEpi *dec = nullptr, bool *dec_done = nullptr) {
+    if (dec_done) *dec_done = false;
     const float *in = x;
     int ld_in = ld_x;
     int rc;
@@ -1146,7 +1149,8 @@ static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int 
             if (ld_in < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", ld_in, L.ldw);
             GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0, 1);
             HIPCHK(ctx, launch_linear_sb16(s, in, ld_in, L.w3, (size_t)weight_rows(L.out_dim) * L.ldw, L.ldw, L.b, out, ctx->mlp_ld_hidden, m,
-                                           d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope, true, nullptr, nullptr, false, ctx->mlp_flush));
+                                           d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope, true, nullptr, nullptr, false, ctx->mlp_flush,
+                                           last ? dec : nullptr, last ? dec_done : nullptr));
         } else if (ctx->mlp_bf16) {
             Linear &L = ctx->mlp[l];
             if ((rc = ensure_bf16_weights(ctx, &L))) return rc;
@@ -1194,16 +1198,25 @@ int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_
     if (!d_persons || !d_n_persons || !d_poses) return fail(ctx, MPE_ERR_INVALID, "mpe_mlp3d_batch: NULL argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int pcap = ctx->cfg.max_persons_per_frame;
-    HIPCHK(ctx, launch_person_scan(s, b->n_frames, pcap, d_n_persons, ctx->person_off, ctx->mlp_count));
-    HIPCHK(ctx, launch_mlp_rows(s, ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints, *b, d_persons, d_n_persons,
-                                ctx->person_off, pcap, ctx->mlp_rows, ctx->mlp_ld_in, d_valid ? d_valid : ctx->valid_tmp));
-    float *y;
-    int ldy;
-    if ((rc = mlp_chain(ctx, s, ctx->mlp_rows, ctx->mlp_ld_in, b->n_frames * pcap, ctx->mlp_count, &y, &ldy))) return rc;
     const int n_out = ctx->mlp[ctx->mlp_layers - 1].out_dim;
     if (n_out != ctx->cfg.n_joints * 3)
         return fail(ctx, MPE_ERR_INVALID, "MLP output width %d != 3*J", n_out);
-    HIPCHK(ctx, launch_decode(s, b->n_frames, pcap, n_out, 10.f, d_n_persons, ctx->person_off, y, ldy, d_poses));
+    // small batches: the persons' prefix inside the row kernel, the decode inside the last layer's launch (two launches fewer)
+    const bool small = latency_path_on() && b->n_frames <= LAT_MAX_FRAMES;
+    if (small) {
+        HIPCHK(ctx, launch_mlp_rows(s, ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints, *b, d_persons, d_n_persons, nullptr, pcap, ctx->mlp_rows,
+                                    ctx->mlp_ld_in, d_valid ? d_valid : ctx->valid_tmp, ctx->person_off, ctx->mlp_count, d_poses, n_out));
+    } else {
+        HIPCHK(ctx, launch_person_scan(s, b->n_frames, pcap, d_n_persons, ctx->person_off, ctx->mlp_count));
+        HIPCHK(ctx, launch_mlp_rows(s, ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints, *b, d_persons, d_n_persons,
+                                    ctx->person_off, pcap, ctx->mlp_rows, ctx->mlp_ld_in, d_valid ? d_valid : ctx->valid_tmp));
+    }
+    float *y;
+    int ldy;
+    const DecodeEpi dec{ctx->person_off, b->n_frames, pcap, n_out, 10.f, d_poses};
+    bool decoded = false;
+    if ((rc = mlp_chain(ctx, s, ctx->mlp_rows, ctx->mlp_ld_in, b->n_frames * pcap, ctx->mlp_count, &y, &ldy, small ? &dec : nullptr, &decoded))) return rc;
+    if (!decoded) HIPCHK(ctx, launch_decode(s, b->n_frames, pcap, n_out, 10.f, d_n_persons, ctx->person_off, y, ldy, d_poses));
     return MPE_OK;
 }
 

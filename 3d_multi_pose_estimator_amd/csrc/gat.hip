@@ -850,21 +850,61 @@ __device__ __forceinline__ void agg_store_row(const AggArgs &a, size_t row, int 
     *reinterpret_cast<vecf *>(a.out + row * a.ld_out + c) = v;
 }
 
-template <int VEC>
+// a1 | a2 of one attention head of a feature row, when no GEMM epilogue left them in a12 (small batches: the layer-0 rows and the
+// 30-wide heads): the canonical orders -- coef40 for 40-wide heads (parity = the head's place in its 80-wide tile), one chain otherwise
+__device__ __forceinline__ void row_coef(const float *__restrict__ fv, const AggArgs &a, int hh, float &x1, float &x2) {
+    const float *al = a.attn_l + hh * a.out_dim, *ar = a.attn_r + hh * a.out_dim;
+    if (a.out_dim == 40) {
+        // the forty values first (ten 16-byte requests in flight), then the chains: left to the chains, every value is a request of
+        // its own behind the previous one's wait
+        float v[40];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const float4 x = *reinterpret_cast<const float4 *>(fv + 4 * q);
+            v[4 * q] = x.x;
+            v[4 * q + 1] = x.y;
+            v[4 * q + 2] = x.z;
+            v[4 * q + 3] = x.w;
+        }
+        coef40([&](int d) { return v[d]; }, al, ar, hh & 1, x1, x2);
+    } else if (a.out_dim == 30) {
+        float v[30];                                       // (a 30-wide head starts at a multiple of 120 bytes: 8-byte requests)
+#pragma unroll
+        for (int q = 0; q < 15; ++q) {
+            const float2 x = *reinterpret_cast<const float2 *>(fv + 2 * q);
+            v[2 * q] = x.x;
+            v[2 * q + 1] = x.y;
+        }
+        x1 = x2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 30; ++d) {
+            x1 = __builtin_fmaf(v[d], al[d], x1);
+            x2 = __builtin_fmaf(v[d], ar[d], x2);
+        }
+    } else {
+        x1 = x2 = 0.f;
+        for (int d = 0; d < a.out_dim; ++d) {
+            x1 = __builtin_fmaf(fv[d], al[d], x1);
+            x2 = __builtin_fmaf(fv[d], ar[d], x2);
+        }
+    }
+}
+
+template <int VEC, int ER = 16>
 __device__ __forceinline__ void aggregate_en_body(int wg, int n_en, const int32_t *__restrict__ head_off,
                                                   const int32_t *__restrict__ en_off,
                                                   const int32_t *__restrict__ node_off,
                                                   const int32_t *__restrict__ en_frame,
                                                   const int32_t *__restrict__ en_pair, const AggArgs &a, int hmax) {
 #pragma clang fp contract(off)
-    __shared__ float s_w[EN_ROWS][16][3];           // softmax weights of (h1, h2, self) per attention head
-    __shared__ int s_over[EN_ROWS];                 // row of a frame beyond max_heads_per_frame (flagged by k_topology): score 0
-    __shared__ long s_src[EN_ROWS][3];              // ft2 row of h1, h2, self (self: -1 at layer 0 = the shared row)
-    __shared__ long s_dst[EN_ROWS];                 // output row
+    __shared__ float s_w[ER][16][3];                // softmax weights of (h1, h2, self) per attention head
+    __shared__ int s_over[ER];                      // row of a frame beyond max_heads_per_frame (flagged by k_topology): score 0
+    __shared__ long s_src[ER][3];                   // ft2 row of h1, h2, self (self: -1 at layer 0 = the shared row)
+    __shared__ long s_dst[ER];                      // output row
     const int hd = a.heads * a.out_dim, heads = a.heads;
     const int per_row = (hd + VEC - 1) / VEC;       // a VEC-column group may straddle two attention heads
-    const int m0 = wg * EN_ROWS;
-    const int rows = min(EN_ROWS, n_en - m0);
+    const int m0 = wg * ER;
+    const int rows = min(ER, n_en - m0);
     const bool l0 = a.en_const_ft2 != nullptr;
     for (int i = threadIdx.x; i < rows * heads; i += blockDim.x) {
         const int r = i / heads, hh = i - r * heads;
@@ -884,8 +924,26 @@ __device__ __forceinline__ void aggregate_en_body(int wg, int n_en, const int32_
             ra2 = a.a12 + (size_t)(nb + h2) * 32;
             ra3 = a.a12 + (size_t)(nb + v) * 32;
         }
-        const float a2v = ra3[16 + hh];
-        float e1 = ra1[hh] + a2v, e2 = ra2[hh] + a2v, e3 = ra3[hh] + a2v;
+        float a2v, c1, c2, c3;
+        if (a.a12_ready) {
+            a2v = ra3[16 + hh];
+            c1 = ra1[hh];
+            c2 = ra2[hh];
+            c3 = ra3[hh];
+        } else {
+            // no coefficients in a12: from the rows themselves (fp32 rows; the shared layer-0 row has its own constants)
+            const size_t rb = (size_t)(l0 ? hb : nb);
+            float unused;
+            row_coef(a.ft2 + (rb + h1) * a.ld + hh * a.out_dim, a, hh, c1, unused);
+            row_coef(a.ft2 + (rb + h2) * a.ld + hh * a.out_dim, a, hh, c2, unused);
+            if (l0) {
+                c3 = a.en_const_a[hh];
+                a2v = a.en_const_a[16 + hh];
+            } else {
+                row_coef(a.ft2 + (rb + v) * a.ld + hh * a.out_dim, a, hh, c3, a2v);
+            }
+        }
+        float e1 = c1 + a2v, e2 = c2 + a2v, e3 = c3 + a2v;
         e1 = e1 > 0.f ? e1 : e1 * a.alpha;
         e2 = e2 > 0.f ? e2 : e2 * a.alpha;
         e3 = e3 > 0.f ? e3 : e3 * a.alpha;
@@ -946,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_aggregate_en(int n_en, const int32_t *_
                                                       const int32_t *__restrict__ node_off,
                                                       const int32_t *__restrict__ en_frame,
                                                       const int32_t *__restrict__ en_pair, AggArgs a, int hmax) {
-    aggregate_en_body<VEC>(blockIdx.x, n_en, head_off, en_off, node_off, en_frame, en_pair, a, hmax);
+    aggregate_en_body<VEC, EN_ROWS>(blockIdx.x, n_en, head_off, en_off, node_off, en_frame, en_pair, a, hmax);
 }
 
 // Head destinations, general path: AGG_ROWS head rows per workgroup, two waves per row for the
@@ -1020,19 +1078,49 @@ __device__ __forceinline__ void aggregate_heads_body(
     }
     if (half == 0 && lane == 0) s_deg[r_own] = deg;
     __syncthreads();
+    float *s_a2 = reinterpret_cast<float *>(s_topo + AGG_ROWS * (V + 1 + V * V));           // [AGG_ROWS][16] (only without coefficients in a12)
+    if (!a.a12_ready) {
+        // No coefficients in a12 (small batches, lat.hip): ALL of them first, one (in-edge, attention head) pair per thread of the
+        // row's two waves -- a1 of every source into its slot of the weight table, a2 of the row itself beside it -- so that the
+        // requests of a whole row are in flight together (inside the per-head loop below they would be two round trips per head).
+        if (live) {
+            const int *src = s_src + r_own * max_deg;
+            const size_t rb = (size_t)(l0 ? hb : nb);
+            for (int i = lane + 64 * half; i < (deg + 1) * heads; i += 64 * (4 / AGG_ROWS)) {
+                const int e = i / heads, hh = i - e * heads;
+                float c1, c2;
+                if (e == deg) {
+                    row_coef(a.ft2 + (rb + v) * a.ld + hh * a.out_dim, a, hh, c1, c2);
+                    s_a2[r_own * 16 + hh] = c2;
+                } else {
+                    const int u = src[e];
+                    if (l0 && u >= H) c1 = a.en_const_a[hh];
+                    else row_coef(a.ft2 + (rb + u) * a.ld + hh * a.out_dim, a, hh, c1, c2);
+                    s_w[((size_t)r_own * heads + hh) * max_deg + e] = c1;
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (live) {
         const int *src = s_src + r_own * max_deg;
         const float *a_dst = l0 ? a.a12 + (size_t)(hb + v) * 32 : a.a12 + (size_t)(nb + v) * 32;
         for (int hh = half; hh < heads; hh += 4 / AGG_ROWS) {
-            const float a2v = a_dst[16 + hh];
+            const float a2v = a.a12_ready ? a_dst[16 + hh] : s_a2[r_own * 16 + hh];
             float *w = s_w + ((size_t)r_own * heads + hh) * max_deg;
             float mx = -INFINITY;
             for (int e = lane; e < deg; e += 64) {
                 const int u = src[e];
-                const float *a_src;
-                if (l0) a_src = u >= H ? a.en_const_a : a.a12 + (size_t)(hb + u) * 32;
-                else a_src = a.a12 + (size_t)(nb + u) * 32;
-                float x = a_src[hh] + a2v;
+                float a1u;
+                if (a.a12_ready) {
+                    const float *a_src;
+                    if (l0) a_src = u >= H ? a.en_const_a : a.a12 + (size_t)(hb + u) * 32;
+                    else a_src = a.a12 + (size_t)(nb + u) * 32;
+                    a1u = a_src[hh];
+                } else {
+                    a1u = w[e];
+                }
+                float x = a1u + a2v;
                 x = x > 0.f ? x : x * a.alpha;
                 w[e] = x;
                 mx = fmaxf(mx, x);
@@ -1093,6 +1181,9 @@ __global__ __launch_bounds__(256) void k_aggregate_heads(
 
 // Small batches (a few frames: the reference's own call pattern is one frame per call): BOTH halves of the attention stage in ONE
 // launch -- workgroups [0, n_en_wgs) take edge-node rows, the rest head rows -- with the kernels' own bodies, hence their bits.
+// Two edge-node rows per workgroup: every thread then has ONE group of columns (with sixteen rows a thread walks seven groups one
+// after the other, each a round trip to L2: 11 us per launch for one 5 x 4 frame).
+constexpr int LAT_EN_ROWS = 2;
 template <int VEC>
 __global__ __launch_bounds__(256) void k_lat_attention(
     int n_en_wgs, int n_en, int n_heads, int V, int max_deg, const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
@@ -1101,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_lat_attention(
     int src_stride, int hmax) {
     extern __shared__ float s_dyn[];
     if ((int)blockIdx.x < n_en_wgs) {
-        aggregate_en_body<VEC>(blockIdx.x, n_en, head_off, en_off, node_off, en_frame, en_pair, a, hmax);
+        aggregate_en_body<VEC, LAT_EN_ROWS>(blockIdx.x, n_en, head_off, en_off, node_off, en_frame, en_pair, a, hmax);
     } else if (!a.score_mode || a.out_heads) {
         aggregate_heads_body<VEC>(blockIdx.x - n_en_wgs, s_dyn, n_heads, V, max_deg, head_off, en_off, slot_n, node_off, head_frame, a, head_src,
                                   src_stride, hmax);
@@ -1554,6 +1645,7 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
     if (!a.a12_ready) {
         hipError_t e = launch_attn_coef(s, a.ft2, a.ld, n_rows_ft2, a.heads, a.out_dim, attn_l, attn_r, a12, a.ft_half);
         if (e != hipSuccess) return e;
+        a2.a12_ready = 1;                  // (the general kernels compute the coefficients themselves when this reads 0: small batches only)
     }
     return launch_aggregate(s, b, V, max_heads_per_frame, node_off, head_frame, en_frame, en_pair, a2, head_src, x_deg_cap);
 }
@@ -1562,16 +1654,16 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
 hipError_t launch_lat_attention(hipStream_t s, const mpe_batch &b, int V, int max_heads_per_frame, const int32_t *node_off,
                                 const int32_t *head_frame, const int32_t *en_frame, const int32_t *en_pair, const AggArgs &a,
                                 const uint16_t *head_src) {
-    if (b.d_en_pair || a.ft_half || !a.a12_ready) return hipErrorInvalidValue;
+    if (b.d_en_pair || a.ft_half || (!a.a12_ready && (!a.attn_l || !a.attn_r))) return hipErrorInvalidValue;
     const int vec = agg_vec(a);
     if (!head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
-    const int n_en_wgs = (b.n_edge_nodes + EN_ROWS - 1) / EN_ROWS;
+    const int n_en_wgs = (b.n_edge_nodes + LAT_EN_ROWS - 1) / LAT_EN_ROWS;
     const bool heads_on = b.n_heads > 0 && (!a.score_mode || a.out_heads);
     const int n_h_wgs = heads_on ? (b.n_heads + AGG_ROWS - 1) / AGG_ROWS : 0;
     if (n_en_wgs + n_h_wgs == 0) return hipSuccess;
     const int src_stride = max_heads_per_frame + 1;
     int max_deg = src_stride < 3 ? 3 : src_stride;
-    const size_t shm = (size_t)AGG_ROWS * ((size_t)a.heads * max_deg + max_deg + (V + 1) + (size_t)V * V) * sizeof(float);
+    const size_t shm = (size_t)AGG_ROWS * ((size_t)a.heads * max_deg + max_deg + (V + 1) + (size_t)V * V + 16) * sizeof(float);
     if (shm > 48 * 1024) return hipErrorInvalidValue;                  // (the caller keeps such rigs on the batch path)
     const int hd4 = (a.heads * a.out_dim + 3) / 4 * 4;
     // (one vector width for both halves: the head half needs whole heads per group; per-column arithmetic does not depend on it)
@@ -1616,7 +1708,7 @@ hipError_t launch_aggregate(hipStream_t s, const mpe_batch &b, int V, int max_he
         const int src_stride = xpl ? x_deg_cap : max_heads_per_frame + 1;     // row stride of the in-edge source table
         int max_deg = src_stride;
         if (max_deg < 3) max_deg = 3;
-        const size_t shm = (size_t)AGG_ROWS * ((size_t)a.heads * max_deg + max_deg + (V + 1) + (size_t)V * V) * sizeof(float);
+        const size_t shm = (size_t)AGG_ROWS * ((size_t)a.heads * max_deg + max_deg + (V + 1) + (size_t)V * V + 16) * sizeof(float);
         if (shm > 64 * 1024) {
             static PerDeviceFlag attr;
             if (!attr.test()) {

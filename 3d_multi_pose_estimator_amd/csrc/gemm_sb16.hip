@@ -574,7 +574,8 @@ template <bool LEAKY, int KS>
 __global__ __launch_bounds__(64 * KS) void k_linear_sb_ks(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
                                                           size_t w_plane, int ldw, const float *__restrict__ bias,
                                                           float *__restrict__ C, int ldc, int m_cap,
-                                                          const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16, int fl) {
+                                                          const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16, int fl,
+                                                          DecodeEpi dec) {
     extern __shared__ __attribute__((aligned(16))) float s_part[];       // [pairs][64 lanes][4]
     int M = m_cap;
     if (d_m) {
@@ -617,6 +618,17 @@ __global__ __launch_bounds__(64 * KS) void k_linear_sb_ks(const float *__restric
     float v = (float)(run + (double)bias[nb]);
     if (LEAKY) v = v > 0.f ? v : v * slope;
     C[(size_t)m * ldc + nb] = v;
+    if (dec.poses) {
+        // k_decode from here: the frame of row m by bisection of the persons' prefix, then y * scale into the (frame, person) slot
+        int lo = 0, hi = dec.n_frames;                       // person_off[lo] <= m < person_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (dec.person_off[mid] <= m) lo = mid;
+            else hi = mid;
+        }
+        const int pp = m - dec.person_off[lo];
+        if (pp < dec.pcap && nb < dec.n_out) dec.poses[((size_t)lo * dec.pcap + pp) * dec.n_out + nb] = v * dec.scale;
+    }
 }
 
 // fp32 weights [rows][ld] -> three bf16 planes [3][rows][ld]
@@ -683,8 +695,10 @@ bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64) {
 
 hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
-                              float slope, bool f64, const AttnCoef *coef, bool *coef_done, bool out_half, int flush_stages) {
+                              float slope, bool f64, const AttnCoef *coef, bool *coef_done, bool out_half, int flush_stages,
+                              const DecodeEpi *dec, bool *dec_done) {
     if (coef_done) *coef_done = false;
+    if (dec_done) *dec_done = false;
     if (m_cap <= 0 || n <= 0) return hipSuccess;
     if (flush_stages != 1 && flush_stages != 2) return hipErrorInvalidValue;
     const int skinny_waves = sb_skinny_waves();
@@ -707,12 +721,15 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
             if (e != hipSuccess) return e;
             attr_done.set();
         }
+        DecodeEpi de{};
+        if (dec) de = *dec;
         if (leaky)
             hipLaunchKernelGGL((k_linear_sb_ks<true, 8>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C,
-                               ldc, m_cap, d_m, n, k_pad, slope, nt16, flush_stages);
+                               ldc, m_cap, d_m, n, k_pad, slope, nt16, flush_stages, de);
         else
             hipLaunchKernelGGL((k_linear_sb_ks<false, 8>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C,
-                               ldc, m_cap, d_m, n, k_pad, slope, nt16, flush_stages);
+                               ldc, m_cap, d_m, n, k_pad, slope, nt16, flush_stages, de);
+        if (dec && dec_done) *dec_done = true;
         return hipGetLastError();
     }
     if (waves16 <= skinny_waves || narrow) {

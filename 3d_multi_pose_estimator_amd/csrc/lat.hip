@@ -367,9 +367,9 @@ static int lat_gemm_form(int k_pad, int n, bool fc2, int out_dim) {
         if (nk == 5 && n <= 160) return 3;                   // 150 -> 150: one workgroup of ten waves per row tile
         return 0;
     }
-    if (nk == 13 && out_dim == 40 && n % 80 == 0) return 4;  // 400 -> H x 40
-    if (nk == 10 && n <= 160) return 5;                      // 320 -> 5 x 30: all heads in one workgroup
-    if (nk == 5 && n <= 16) return 6;                        // 150 -> 1
+    if (nk == 13 && out_dim == 40 && n % 80 == 0) return 4;  // 400 -> H x 40, coefficients from the epilogue
+    if (nk == 10) return 5;                                  // 320 -> 5 x 30: fp32 rows only (80-column workgroups cut the 30-wide heads; the attention kernel computes a1 | a2)
+    if (nk == 5 && n <= 16) return 6;                        // 150 -> 1, coefficients from the epilogue
     return 0;
 }
 
@@ -377,9 +377,11 @@ bool lat_gemm_available(int k_pad, int n, bool fc2, int out_dim) { return lat_ge
 
 hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
                            const float *bias, float *C, int ldc, unsigned short *Cpl, int ldcp, size_t c_plane, int m, int n, int k_pad, bool fc2,
-                           float slope, const float *attn_l, const float *attn_r, float *a12, int out_dim) {
+                           float slope, const float *attn_l, const float *attn_r, float *a12, int out_dim, bool *coef_done) {
+    if (coef_done) *coef_done = false;
     if (m <= 0 || n <= 0) return hipSuccess;
     const int form = lat_gemm_form(k_pad, n, fc2, out_dim);
+    if (coef_done) *coef_done = form == 4 || form == 6;
     const int ntm = (m + 15) / 16;
 #define MPE_LG(NK_, NT_, L_, O_, C_)                                                                                                         \
     hipLaunchKernelGGL((lat::k_lat_gemm<NK_, NT_, L_, O_, C_>), dim3((unsigned)(ntm * ((n + NT_ * 16 - 1) / (NT_ * 16)))), dim3(64 * NT_), 0, s, Apl, lda, \
@@ -389,7 +391,7 @@ hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, si
     case 2: MPE_LG(10, 5, true, true, false); break;
     case 3: MPE_LG(5, 10, true, true, false); break;
     case 4: MPE_LG(13, 5, false, false, true); break;
-    case 5: MPE_LG(10, 10, false, false, true); break;
+    case 5: MPE_LG(10, 5, false, false, false); break;
     case 6: MPE_LG(5, 1, false, false, true); break;
     default: return hipErrorInvalidValue;
     }

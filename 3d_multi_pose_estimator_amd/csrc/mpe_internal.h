@@ -163,11 +163,20 @@ struct AttnCoef {              // fc2 of a graph-attention layer: also emit a1|a
     float *a12;                     // [rows][32]: a1[0..15] | a2[0..15]
     int heads, out_dim;
 };
+// the decode of the MLP output (metrics_from_model.py:281-294) from the epilogue of the last layer's launch: row m of the compacted
+// rows is person m - person_off[f] of the frame f with person_off[f] <= m < person_off[f + 1]
+struct DecodeEpi {
+    const int32_t *person_off;     // [n_frames + 1]
+    int n_frames, pcap, n_out;
+    float scale;
+    float *poses;                  // [n_frames][pcap][n_out]
+};
 hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
                               const float *bias, float *C, int ldc, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky,
                               float slope, bool f64 = true, const AttnCoef *coef = nullptr, bool *coef_done = nullptr,
                               bool out_half = false,      // out_half (fp16 ft2 rows, configs[4]): tile kernel, fp32-chain launches without LeakyReLU only; hipErrorInvalidValue otherwise
-                              int flush_stages = 2);      // f64 launches: K stages per f64 flush (2 = default, 1 = the maximum-accuracy mode)
+                              int flush_stages = 2,       // f64 launches: K stages per f64 flush (2 = default, 1 = the maximum-accuracy mode)
+                              const DecodeEpi *dec = nullptr, bool *dec_done = nullptr);   // the K-split kernel can also store the decoded poses (*dec_done says whether it did)
 bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64);
 // lat.hip: the small-batch ("latency") forms -- the arithmetic of the split-bf16 kernels (same bits), shortest serial depth:
 // fp32 weights streamed once and split in registers, every weight fragment of a wave requested before its first product
@@ -175,7 +184,7 @@ int linear_lat_max_rows();
 bool lat_gemm_available(int k_pad, int n, bool fc2, int out_dim);
 hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
                            const float *bias, float *C, int ldc, unsigned short *Cpl, int ldcp, size_t c_plane, int m, int n, int k_pad, bool fc2,
-                           float slope, const float *attn_l, const float *attn_r, float *a12, int out_dim);
+                           float slope, const float *attn_l, const float *attn_r, float *a12, int out_dim, bool *coef_done = nullptr);
 hipError_t launch_linear_lat_f64(hipStream_t s, const void *A, int lda, size_t a_plane, const float *W, int ldw, const float *bias, void *C,
                                  int ldc, size_t c_plane, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky, float slope,
                                  int flush_stages, bool a_planes = false, bool c_planes = false);
@@ -231,6 +240,7 @@ struct AggArgs {
     int ld_out;
     int score_mode;            // last layer: write out[edge-node index] (and heads to out_heads)
     float *out_heads;
+    const float *attn_l, *attn_r;   // [heads*out_dim]: for the kernels that compute a1 | a2 themselves when a12_ready == 0 (general path, small batches)
     unsigned short *out_pl;    // small batches (lat.hip): the output as three bf16 planes [3][rows][ld_out] INSTEAD of fp32 rows
     size_t out_pl_plane;       // plane stride in elements
 };
@@ -264,7 +274,9 @@ hipError_t launch_person_scan(hipStream_t s, int n_frames, int pcap, const int32
                               int32_t *total);
 hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                            const int32_t *persons, const int32_t *n_persons, const int32_t *person_off, int pcap,
-                           float *rows, int ld_rows, uint8_t *valid);
+                           float *rows, int ld_rows, uint8_t *valid, int32_t *scan_out = nullptr, int32_t *total_out = nullptr,
+                           float *zero_poses = nullptr, int n_out = 0);
+
 hipError_t launch_triangulate(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                               const int32_t *persons, const int32_t *n_persons, int pcap, double *poses,
                               uint8_t *joint_valid, uint32_t out_mask, bool positive_ids_only = false);

@@ -179,7 +179,9 @@ __global__ __launch_bounds__(NT) void k_mlp_rows(const DevCfg *__restrict__ cfg,
                                                   const int32_t *__restrict__ persons,
                                                   const int32_t *__restrict__ n_persons,
                                                   const int32_t *__restrict__ person_off, float *__restrict__ rows,
-                                                  int ld_rows, uint8_t *__restrict__ valid) {
+                                                  int ld_rows, uint8_t *__restrict__ valid,
+                                                  int32_t *__restrict__ scan_out, int32_t *__restrict__ total_out, int n_frames,
+                                                  float *__restrict__ zero_poses, int n_out) {
 #pragma clang fp contract(off)
     extern __shared__ double s_dyn64[];
     const int f = blockIdx.x / pcap, p = blockIdx.x - f * pcap;
@@ -193,11 +195,32 @@ __global__ __launch_bounds__(NT) void k_mlp_rows(const DevCfg *__restrict__ cfg,
     __shared__ float s_red[NT];
     const int np_f = n_persons[f];
     const size_t slot = (size_t)f * pcap + p;
+    // scan_out (small batches): the exclusive prefix of the persons per frame is computed HERE (k_person_scan is a launch of its own
+    // for a handful of numbers); the first workgroup of a frame writes the frame's entry for the kernels behind this one
+    __shared__ int s_off;
+    if (scan_out) {
+        if (threadIdx.x == 0) {
+            int acc = 0;
+            for (int g = 0; g < f; ++g) acc += min(max(n_persons[g], 0), pcap);
+            s_off = acc;
+            if (p == 0) {
+                scan_out[f] = acc;
+                if (f == n_frames - 1) {
+                    const int tot = acc + min(max(np_f, 0), pcap);
+                    scan_out[n_frames] = tot;
+                    if (total_out) *total_out = tot;
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (p >= np_f) {
         if (threadIdx.x == 0 && valid) valid[slot] = 0;
+        if (zero_poses)                      // the pose slots nobody fills (k_decode's job when it runs)
+            for (int k = threadIdx.x; k < n_out; k += blockDim.x) zero_poses[slot * n_out + k] = 0.f;
         return;
     }
-    const size_t r = person_off ? (size_t)person_off[f] + p : slot;
+    const size_t r = scan_out ? (size_t)s_off + p : person_off ? (size_t)person_off[f] + p : slot;
     const int h0 = head_off[f];
     if (threadIdx.x < V) {
         const int lh = persons[slot * V + threadIdx.x];
@@ -330,7 +353,7 @@ hipError_t launch_person_scan(hipStream_t s, int n_frames, int pcap, const int32
 
 hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                            const int32_t *persons, const int32_t *n_persons, const int32_t *person_off, int pcap,
-                           float *rows, int ld_rows, uint8_t *valid) {
+                           float *rows, int ld_rows, uint8_t *valid, int32_t *scan_out, int32_t *total_out, float *zero_poses, int n_out) {
     if (b.n_frames <= 0) return hipSuccess;
     const size_t shm = ((size_t)V * J * 2 + (size_t)J * (V * (V - 1) / 2) * 3) * sizeof(double) + (size_t)ld_rows * sizeof(float) + 16;
     if (shm > 40 * 1024) {
@@ -342,12 +365,12 @@ hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const
         }
         hipLaunchKernelGGL(k_mlp_rows<1024>, dim3(b.n_frames * pcap), dim3(1024), shm, s, cfg, pcap, b.d_frame_head_off,
                            b.d_joint_mask, b.d_tri_mask, b.d_xy, b.d_vp, persons, n_persons, person_off, rows, ld_rows,
-                           valid);
+                           valid, scan_out, total_out, b.n_frames, zero_poses, n_out);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_mlp_rows<256>, dim3(b.n_frames * pcap), dim3(256), shm, s, cfg, pcap, b.d_frame_head_off,
                        b.d_joint_mask, b.d_tri_mask, b.d_xy, b.d_vp, persons, n_persons, person_off, rows, ld_rows,
-                       valid);
+                       valid, scan_out, total_out, b.n_frames, zero_poses, n_out);
     return hipGetLastError();
 }
 

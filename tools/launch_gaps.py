@@ -12,7 +12,7 @@ n = len(rows)
 # the timed region: the last `steps` repetitions of the chain; a chain starts at the kernel named by MARK (the first launch of
 # mpe_match_batch: the topology / front kernel)
 import os
-mark = os.environ.get('MARK', 'k_topology,k_lat_front').split(',')
+mark = os.environ.get('MARK', 'k_topology,k_lat_l0a').split(',')
 idx = [i for i, r in enumerate(rows) if any(m in r['Kernel_Name'] for m in mark)]
 if len(idx) > steps + 1:
     use = rows[idx[-steps - 1]:idx[-1]]
