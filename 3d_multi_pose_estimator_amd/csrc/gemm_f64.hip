@@ -115,8 +115,10 @@ hipError_t launch_linear_f64(hipStream_t s, const float *A, int lda, const float
     const int ntm = (m_cap + f64mm::BM - 1) / f64mm::BM, ntn = (n + f64mm::BN - 1) / f64mm::BN;
     const dim3 grid((unsigned)(ntm * ntn)), block(256);
     // The slope arrives as the fp32 number the C ABI carries; the network's own parameter is the decimal the caller wrote
-    // (nn.LeakyReLU(0.1): utils/mlp.py:11), which an f64 evaluation multiplies by as a double.  Take that decimal (seven digits)
-    // when it rounds to the fp32 value given, the fp32 value itself otherwise.
+    // (nn.LeakyReLU(0.1): utils/mlp.py:11), which an f64 evaluation of the NETWORK multiplies by as a double.  Take that decimal
+    // (seven digits) when it rounds to the fp32 value given, the fp32 value itself otherwise.  This is the rule include/mpe.h
+    // documents for MLP mode 5: the mode evaluates the network in f64 ("f64-evaluated network", what tests call the exact network),
+    // it does not replay the reference's fp32 kernel, which multiplies by (float)0.1.
     double slope_d = (double)slope;
     const double dec = __builtin_nearbyint(slope_d * 1e7) / 1e7;
     if ((float)dec == slope) slope_d = dec;

@@ -570,12 +570,13 @@ __global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restric
 // The stage PAIRS of a tile (= the units between two f64 flushes) dealt round-robin to the KS waves of a workgroup; fp32 pair
 // results parked in LDS, then every element summed over the pairs in pair order in f64: the additions of k_linear_sb in the
 // same order (and exact anyway: fp32 terms in an f64 sum).
-template <bool LEAKY, int KS>
+template <bool LEAKY, int KS, int FL>
 __global__ __launch_bounds__(64 * KS) void k_linear_sb_ks(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
                                                           size_t w_plane, int ldw, const float *__restrict__ bias,
                                                           float *__restrict__ C, int ldc, int m_cap,
-                                                          const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16, int fl,
+                                                          const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16,
                                                           DecodeEpi dec) {
+    constexpr int fl = FL;                                   // K stages per f64 flush (a template argument: with one stage per unit the second fragment is not even requested)
     extern __shared__ __attribute__((aligned(16))) float s_part[];       // [pairs][64 lanes][4]
     int M = m_cap;
     if (d_m) {
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(64 * KS) void k_linear_sb_ks(const float *__restric
         SbFrag f0, f1;
         const int k0 = fl * j, k1 = fl * j + 1 < nk ? fl * j + 1 : nk - 1;
         sb_load(f0, pa, pw, w_plane, k0 * GEMM_BK);
-        sb_load(f1, pa, pw, w_plane, k1 * GEMM_BK);
+        if (FL == 2) sb_load(f1, pa, pw, w_plane, k1 * GEMM_BK);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         bf16x8 ap[3];
         split8(f0.a0, f0.a1, ap[0], ap[1], ap[2]);
@@ -713,22 +714,23 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         const size_t shm = (size_t)((nk + flush_stages - 1) / flush_stages) * 1024;
         static PerDeviceFlag attr_done;
         if (!attr_done.test()) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_sb_ks<true, 8>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_sb_ks<false, 8>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            hipError_t e = hipSuccess;
+            const void *fns[] = {reinterpret_cast<const void *>(k_linear_sb_ks<true, 8, 2>), reinterpret_cast<const void *>(k_linear_sb_ks<false, 8, 2>),
+                                 reinterpret_cast<const void *>(k_linear_sb_ks<true, 8, 1>), reinterpret_cast<const void *>(k_linear_sb_ks<false, 8, 1>)};
+            for (const void *fn : fns)
+                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) return e;
             attr_done.set();
         }
         DecodeEpi de{};
         if (dec) de = *dec;
-        if (leaky)
-            hipLaunchKernelGGL((k_linear_sb_ks<true, 8>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C,
-                               ldc, m_cap, d_m, n, k_pad, slope, nt16, flush_stages, de);
-        else
-            hipLaunchKernelGGL((k_linear_sb_ks<false, 8>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C,
-                               ldc, m_cap, d_m, n, k_pad, slope, nt16, flush_stages, de);
+#define MPE_KS(L_, F_) \
+    hipLaunchKernelGGL((k_linear_sb_ks<L_, 8, F_>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, nt16, de)
+        if (leaky && flush_stages == 2) MPE_KS(true, 2);
+        else if (leaky) MPE_KS(true, 1);
+        else if (flush_stages == 2) MPE_KS(false, 2);
+        else MPE_KS(false, 1);
+#undef MPE_KS
         if (dec && dec_done) *dec_done = true;
         return hipGetLastError();
     }

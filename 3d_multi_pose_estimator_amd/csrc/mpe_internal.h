@@ -188,7 +188,7 @@ hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, si
 hipError_t launch_linear_lat_f64(hipStream_t s, const void *A, int lda, size_t a_plane, const float *W, int ldw, const float *bias, void *C,
                                  int ldc, size_t c_plane, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky, float slope,
                                  int flush_stages, bool a_planes = false, bool c_planes = false);
-// gemm_f64.hip: exact products, f64 accumulation on the f64 matrix pipe (MLP mode 5: the reference-exact form, not the fast path)
+// gemm_f64.hip: exact products, f64 accumulation on the f64 matrix pipe (MLP mode 5: the f64-evaluated network, not the fast path; the slope rule is in include/mpe.h)
 hipError_t launch_linear_f64(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc,
                              int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky, float slope);
 hipError_t launch_linear(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias,

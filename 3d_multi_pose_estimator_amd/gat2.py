@@ -61,11 +61,12 @@ class GAT2(nn.Module):
             layer.g = g
 
     def _state_version(self):
-        # (the module tree is fixed after construction: walking it for every forward cost 0.13 ms per frame in the one-frame-per-call loop)
-        ps = self.__dict__.get('_param_list')
-        if ps is None:
-            ps = self.__dict__['_param_list'] = list(self.parameters())
-        return tuple((p.data_ptr(), p._version) for p in ps)
+        # (walking the module tree for every forward cost 0.13 ms per frame in the one-frame-per-call loop: runtime.ParamWatch keeps
+        # the walk and checks per call that it still describes the tree)
+        w = self.__dict__.get('_param_watch')
+        if w is None:
+            w = self.__dict__['_param_watch'] = runtime.ParamWatch(self)
+        return w.version()
 
     def _ensure_engine(self, n_graphs=1):
         ver = self._state_version()

@@ -23,10 +23,10 @@ class PoseEstimatorMLP(nn.Module):
         self._version = None
 
     def _ensure_engine(self):
-        ps = self.__dict__.get('_param_list')
-        if ps is None:
-            ps = self.__dict__['_param_list'] = list(self.parameters())
-        ver = tuple((p.data_ptr(), p._version) for p in ps)
+        w = self.__dict__.get('_param_watch')
+        if w is None:
+            w = self.__dict__['_param_watch'] = runtime.ParamWatch(self)      # (gat2.GAT2._state_version)
+        ver = w.version()
         if self._engine is not None and ver == self._version:
             return self._engine
         if self._engine is not None:

@@ -846,7 +846,7 @@ class Engine:
         # instead of 0.24-0.26 ulp of its output scale, the MLP launches ~7 % slower.
         if mlp_split is None:
             mlp_split = bool(mlp_acc64) and not mlp_bf16
-        # mlp_f64: the reference-exact form (MLP mode 5): exact products, f64 accumulation on the f64 matrix pipe; several times slower.
+        # mlp_f64: the f64-evaluated network (MLP mode 5; LeakyReLU slope as the decimal double, include/mpe.h): exact products, f64 accumulation on the f64 matrix pipe; several times slower.
         if mlp_max_accuracy and (mlp_bf16 or not mlp_split or mlp_f64):
             raise ValueError('mlp_max_accuracy is a mode of the split-bf16 MLP (mlp_acc64=True, not mlp_bf16, mlp_split not False)')
         if mlp_f64 and mlp_bf16:

@@ -12,6 +12,50 @@ import numpy as np
 _shared = {}
 
 
+class ParamWatch:
+    """(data_ptr, version) of every parameter of a module tree, without walking the tree per call (0.13 ms per forward in the
+    one-frame-per-call loop) and without trusting that the tree never changes: the walk's result is kept, and every call checks
+    with plain dict lookups that it still describes the tree -- every module still sits under its parent's name, every parameter
+    still IS the object registered under its owner's name, no module gained or lost a child or a parameter.  A swapped submodule,
+    `layer.fc1.weight = nn.Parameter(...)`, a pruning re-parametrisation or `register_parameter` rebuilds the snapshot; an
+    in-place update or a `.to()` changes the tuple as before."""
+
+    def __init__(self, root):
+        self.root = root
+        self.links = None        # (parent, name, child, n_children of child, n_parameters of child)
+        self.slots = None        # (owner, name, parameter)
+
+    def _rebuild(self):
+        self.links, self.slots = [], []
+        stack = [self.root]
+        self.root_counts = (len(self.root._modules), len(self.root._parameters))
+        while stack:
+            mod = stack.pop()
+            for name, p in mod._parameters.items():
+                if p is not None:
+                    self.slots.append((mod, name, p))
+            for name, child in mod._modules.items():
+                if child is not None:
+                    self.links.append((mod, name, child, len(child._modules), len(child._parameters)))
+                    stack.append(child)
+
+    def _valid(self):
+        if (len(self.root._modules), len(self.root._parameters)) != self.root_counts:
+            return False
+        for parent, name, child, n_mod, n_par in self.links:
+            if parent._modules.get(name) is not child or len(child._modules) != n_mod or len(child._parameters) != n_par:
+                return False
+        for owner, name, p in self.slots:
+            if owner._parameters.get(name) is not p:
+                return False
+        return True
+
+    def version(self):
+        if self.links is None or not self._valid():
+            self._rebuild()
+        return tuple((p.data_ptr(), p._version) for _, _, p in self.slots)
+
+
 def max_persons_per_camera():
     return int(os.environ.get('MPE_MAX_PERSONS_PER_CAMERA', '10'))
 

@@ -8,8 +8,8 @@ With --mode tri the 3D stage is the DLT triangulation path (configs[2]).
 Launch.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N
 rank processes ITSELF (fresh children; the parent makes no HIP call and does not import torch; RANK /
 LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relays rank 0's JSON line; under
-torchrun (`python -m torch.distributed.run ... bench.py --gpus N`) the ranks already exist and
-are used as they are.  One process per GPU, RCCL (`--backend nccl`) for the only exchange of the
+torchrun (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) the ranks already exist
+and are used; `--gpus` must equal WORLD_SIZE (a mismatch exits 3 before any GPU work).  One process per GPU, RCCL (`--backend nccl`) for the only exchange of the
 path: one all-gather of the 3D poses per step.
 
 Scaling modes.  Default (weak): every rank processes its own `--frames`-frame shard per step.
@@ -66,7 +66,16 @@ PKG = '3d_multi_pose_estimator_amd'
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_TBS = 8.0
-TRAFFIC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+def traffic_files():
+    """profiles/rNN_pmc_traffic.json, newest round first (the record of THIS round when its profile pass has been committed)."""
+    import glob
+    import re
+    found = []
+    for path in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')):
+        m = re.match(r'r(\d+)_pmc_traffic\.json$', os.path.basename(path))
+        if m:
+            found.append((int(m.group(1)), os.path.basename(path)))
+    return [name for _, name in sorted(found, reverse=True)]
 
 
 def parse_args(argv=None):
@@ -74,6 +83,7 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--regions', type=int, default=3, help='timed regions of --steps steps each; value = the median region')
     ap.add_argument('--frames', type=int, default=1000, help='frames per rank and step (weak scaling)')
     ap.add_argument('--total-frames', type=int, default=0,
                     help='strong scaling: this many frames per step in total, sharded over the ranks (configs[3]: 100000 with --persons 10)')
@@ -231,10 +241,13 @@ def run_rank(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
+    if args.gpus != world and not os.environ.get('MPE_BENCH_FORCE_DIST'):
+        # one contract: the ranks that exist ARE the job, and --gpus must say so (the driver always passes the same number to the
+        # launcher and to bench.py).  A mismatch ends here, before any GPU work, instead of after a full step in the self-check.
         if rank == 0:
-            print('bench.py: --gpus %d but WORLD_SIZE=%d; the launcher decides: running %d ranks'
-                  % (args.gpus, world, world), file=sys.stderr)
+            print('bench.py: --gpus %d but WORLD_SIZE=%d: start as many ranks as --gpus names (python bench.py --gpus N spawns them itself; '
+                  'under torchrun pass --nproc-per-node N and --gpus N)' % (args.gpus, world), file=sys.stderr)
+        return 3
     # MPE_BENCH_FORCE_DIST=1: initialise the process group even at world size 1 (rehearses the RCCL
     # init / barrier / all-gather path on a one-GPU box)
     distributed = world > 1 or bool(os.environ.get('MPE_BENCH_FORCE_DIST'))
@@ -412,7 +425,14 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
 
-    elapsed, (poses, n_persons) = timed(lambda i: step(), args.steps)
+    # The headline region is timed `--regions` times (3) in this process, each EXACTLY --steps steps between barrier + synchronize;
+    # `value` is the MEDIAN region, value_min / value_max the slowest / fastest: one region of 20 steps is 75 ms, and a single
+    # sample of it moved by 2 % between boards and runs without any code change (BENCH_r04 / r05).
+    regions = []
+    for _ in range(max(1, args.regions)):
+        dt_r, (poses, n_persons) = timed(lambda i: step(), args.steps)
+        regions.append(dt_r)
+    elapsed = sorted(regions)[len(regions) // 2]
 
     # the exchange once more, checked: every rank finds its own shard, bit for bit, at its place in what it received
     gathered_ok = None
@@ -502,6 +522,9 @@ def run_rank(args):
         'metric': 'frames/sec (5-view Panoptic, 4 persons) at 1/2/4/8 GPUs; MPJPE vs ref',
         'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
+        'value_min': total * args.steps / max(regions), 'value_max': total * args.steps / min(regions),
+        'timed_regions': {'n': len(regions), 'steps_each': args.steps, 'ms_per_step': [1e3 * r / args.steps for r in regions],
+                          'value_is': 'the median region'},
         'vs_baseline': None,
         'dtype': 'bf16 GEMMs / f16 attention rows' if args.reduced else 'f32 GAT GEMMs / f16 attention rows / bf16 MLP' if args.cfg4
                  else ('bf16 (MLP) / f32' if args.bf16_mlp else 'f32'),
@@ -840,7 +863,7 @@ def pmc_traffic():
     """Fabric bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
     (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 2x FETCH correction).  PMC cannot be sampled
     from inside the process: this is an OFFLINE measurement and says which file it came from."""
-    for name in TRAFFIC_FILES:
+    for name in traffic_files():
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as fh:
                 d = json.load(fh)

@@ -155,9 +155,12 @@ int mpe_set_mlp_layer(mpe_ctx *ctx, int32_t layer, int32_t in_dim, int32_t out_d
  * six significant partial products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulators flushed into f64 sums every second
  * stage (csrc/gemm_sb16.hip; measured error against exactly evaluated dot products: that of mode 1 or below, 1.35x faster
  * launches).  MLP mode 4 = mode 3 with an f64 flush after EVERY stage: the maximum-accuracy form (rms error of a launch 0.13-0.18
- * instead of 0.24-0.26 ulp of its output scale; the MLP launches take ~7 % longer).  MLP mode 5 = the reference-exact form: exact
- * fp32 x fp32 products accumulated in f64 over the whole K on the f64 matrix pipe (v_mfma_f64_16x16x4_f64, csrc/gemm_f64.hip), i.e. the
- * network evaluated in f64 with fp32 rounding between layers; several times slower, for parity work.  Defaults: GAT 4 (below), MLP 3 (the MLP's K is up to 3072 and its 3D output is compared with the reference at the
+ * instead of 0.24-0.26 ulp of its output scale; the MLP launches take ~7 % longer).  MLP mode 5 = the f64-evaluated network: exact
+ * fp32 x fp32 products accumulated in f64 over the whole K on the f64 matrix pipe (v_mfma_f64_16x16x4_f64, csrc/gemm_f64.hip), bias and
+ * LeakyReLU in f64, fp32 rounding between layers; several times slower, for parity work.  Its LeakyReLU multiplies by the network's
+ * parameter as a double: the seven-digit decimal that rounds to the fp32 slope given to mpe_set_mlp_params (0.1 for
+ * nn.LeakyReLU(0.1), utils/mlp.py:11), or that fp32 value itself when no such decimal exists -- the network, not a replay of the
+ * reference's fp32 kernel (which multiplies by (float)0.1).  Defaults: GAT 4 (below), MLP 3 (the MLP's K is up to 3072 and its 3D output is compared with the reference at the
  * micrometre level: DESIGN.md section 5; mode 1 stays selectable).  MLP mode 2 is the
  * reduced-precision variant of BASELINE.json configs[4]: weights and staged activations in
  * bf16, v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~3 significant digits; not parity).

@@ -276,3 +276,32 @@ def test_frame_loop_calls_the_mirrors_like_the_reference_script(calib):
         for eg, ew in zip(g, w):
             assert eg == ew, (n, eg, ew)
     assert out['frames'] == sum(1 for w in want['frames'] if len(w) > 1)       # frames without a graph end after the first call
+
+
+def test_gat2_forward_raises_for_a_frame_beyond_capacity_without_a_device_round_trip(dropin, calib, monkeypatch):
+    """GAT2.forward skips the device status word for a single implicit-topology graph (0.2 ms per frame): the host check
+    (FrameGraph.device_batch -> Engine.check_capacity) must then cover everything k_topology can flag for such a frame, i.e. more
+    skeletons than max_heads_per_frame (gat.hip:topology_body raises status bit 0 for exactly H > hmax).  A frame of 15 skeletons on a
+    mirror built for 10 raises from forward() itself, before anything is launched, and leaves no stale status bit behind."""
+    d = dropin
+    import importlib
+    syn = importlib.import_module('3d_multi_pose_estimator_amd.synthetic')
+    monkeypatch.setenv('MPE_MAX_PERSONS_PER_CAMERA', '2')               # a fresh mirror: capacity 5 cameras x 2 = 10 skeletons per frame
+    prm = d['prm']
+    model = d['GAT'](None, prm['gnn_layers'], prm['num_feats'], prm['n_classes'], prm['num_hidden'], prm['heads'], torch.nn.LeakyReLU(),
+                     torch.nn.Sigmoid(), prm['in_drop'], prm['attn_drop'], prm['alpha'], prm['residual'], bias=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in d['sd'].items()})
+    def graph(persons, index):
+        frame = syn.make_frame(calib, index, syn.FrameSpec(persons=persons))[0]
+        pi = {c: [frame[c][0], 0] for c in frame if json.loads(frame[c][0])}
+        return d['MergedMultipleHumansDataset'](pi, mode='test', limit=10000, debug=True, alt='3', verbose=False).graphs[0]
+    ok = graph(2, 700)
+    out = model(ok.ndata['h'].cuda(), ok)
+    assert out.shape[0] == ok.num_nodes()
+    big = graph(3, 701)                                                   # 15 skeletons
+    with pytest.raises(ValueError, match='capacity'):
+        model(None, big)
+    model._engine.sync_status()                                           # nothing was launched for it: the status word is clean
+    again = model(ok.ndata['h'].cuda(), ok)
+    assert torch.equal(again, out)
+    model._engine.close()

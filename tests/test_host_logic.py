@@ -354,6 +354,61 @@ def test_bench_under_external_launcher_uses_its_world():
     assert not [l for l in outs[1][0].splitlines() if l.startswith('{')]      # only rank 0 prints
 
 
+def test_param_watch_sees_replaced_parameters_and_modules():
+    """runtime.ParamWatch (the mirrors' cheap "did my weights change" check): same tuple while nothing changes; a new tuple
+    after an in-place update, after `module.weight = nn.Parameter(...)`, after a swapped submodule, after register_parameter, after
+    a pruning-style re-registration."""
+    from torch import nn
+    rt = pkg('runtime')
+    net = nn.Sequential(nn.Linear(4, 3), nn.LeakyReLU(0.1), nn.Sequential(nn.Linear(3, 2)))
+    w = rt.ParamWatch(net)
+    v0 = w.version()
+    assert w.version() == v0 and len(v0) == 4
+    with torch.no_grad():
+        net[0].weight.add_(1.0)                                   # in place: version counter
+    v1 = w.version()
+    assert v1 != v0
+    net[0].weight = nn.Parameter(torch.zeros(3, 4))                # a NEW Parameter object under the same name
+    v2 = w.version()
+    assert v2 != v1 and any(ptr == net[0].weight.data_ptr() for ptr, _ in v2)
+    net[2][0] = nn.Linear(3, 2)                                    # a swapped submodule
+    v3 = w.version()
+    assert v3 != v2 and any(ptr == net[2][0].weight.data_ptr() for ptr, _ in v3)
+    net[2].register_parameter('extra', nn.Parameter(torch.ones(1)))
+    v4 = w.version()
+    assert len(v4) == 5
+    orig = net[0].weight                                           # pruning-style: the parameter moves to another name
+    del net[0]._parameters['weight']
+    net[0].register_parameter('weight_orig', orig)
+    assert w.version() != v4
+    assert w.version() == w.version()
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus_before_any_gpu_work():
+    """One contract for the launch: the ranks that exist are the job and --gpus must name their number; a mismatch exits 3
+    at once -- no process group, no device -- with a message that says what to pass."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')
+    env.pop('MPE_BENCH_FORCE_DIST', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--dry-run', '--steps', '1', '--frames', '5'],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    assert '--gpus 1 but WORLD_SIZE=2' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_bench_reads_the_newest_pmc_traffic_record():
+    """roofline.traffic_source names the newest profiles/rNN_pmc_traffic.json (the line cited a round-4 file while a
+    round-5 one existed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    names = bench.traffic_files()
+    have = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json'))
+    assert names and sorted(names) == have and names[0] == have[-1]
+
+
 def test_projection_helpers_match_reference_formulas():
     """pose_estimator_utils.apply_distortion / from_homogeneous(2) / get_distortion_coefficients:
     host-side tensor helpers of the reprojection check (reference pose_estimator_utils.py:32-50).
