@@ -111,7 +111,8 @@ typedef struct {
 } mpe_batch;
 
 /* ---- environment switches of the library (diagnostics; none is needed in production) -------------------------------------------
- * The list is FROZEN (round 5): these are all the variables csrc/ reads.  Read once per process unless marked "per call".
+ * The list is FROZEN (round 5; round 6 added the two MPE_LATENCY_* switches with the small-batch launches): these are all the variables
+ * csrc/ reads.  Read once per process unless marked "per call".
  *   kernel selection, each a cross-check path the GPU suite is run under (tools/run_switch_matrix.sh):
  *     MPE_SKINNY_WAVES=<n>        16 x 16 tiles up to which the wave-per-tile GEMM kernels run (default 1024; 0 = tile kernels always)
  *     MPE_GEMM_NARROW=0           narrow outputs (<= 16 / 64 features) on the tile kernels as well
@@ -125,6 +126,11 @@ typedef struct {
  *     MPE_CLUSTER_KERNEL=wave|block|lds|big   (per call) clustering kernel
  *     MPE_HALF_VEC=4              fp16 rows of the general attention kernels read 4 columns per thread instead of 8
  *     MPE_JSON_WGS=<n>            workgroups of the device-side JSON walk
+ *     MPE_LATENCY_PATH=0          (per call) batches of at most 8 frames through the batch path's own small-batch kernels instead of the
+ *                                 latency launches of csrc/lat.hip / gat.hip (k_lat_l0a, k_lat_gemm, k_lat_attention; persons' prefix and
+ *                                 decode folded into their neighbours): same bits either way (tests/test_gpu_latency.py)
+ *     MPE_LATENCY_MLP=1           (per call) the MLP launches of such batches from the fp32 weights, split in registers (k_linear_lat_f64):
+ *                                 same bits; measured slower than the plane kernels, kept as the record of that experiment
  *   host packer (threads, timing prints): MPE_PACK_THREADS, MPE_SCAN_THREADS, MPE_SCAN_CHUNK_KB, MPE_PACK_NO_SIMD, MPE_PACK_TIMING,
  *     MPE_STAGE_TIMING
  * Gone since round 5 (their code left the library): MPE_GEMM_TUNE, MPE_GEMM_BN, MPE_GEMM_LOADER, MPE_SB_GAT_MW, MPE_SB_PERS,
