@@ -473,17 +473,25 @@ __global__ __launch_bounds__(64) void k_cluster_wave(const DevCfg *__restrict__ 
     uint32_t *s_pair = reinterpret_cast<uint32_t *>(s_keys + n_pow2);
     const float thr = cfg->threshold;
     const int min_views = cfg->min_views;
-    int n = 64;
-    while (n < M) n <<= 1;
-    for (int m = lane; m < n; m += 64) {
+    // Only the matchings above the threshold are sorted (compacted to the front in index order by wave ballots; the keys are
+    // unique, so what the sort returns does not depend on where it found them): a 5 x 4 frame has 160 candidates and a few dozen
+    // matchings, i.e. 21 compare-exchange passes over 64 keys instead of 36 over 256 -- a third of this kernel's time for one frame.
+    int n_valid = 0;
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        const int m = m0 + lane;
         uint64_t key = KEY_NONE;
         if (m < M) {
             const int h1 = en_pair[2 * (size_t)(e0 + m)], h2 = en_pair[2 * (size_t)(e0 + m) + 1];
             s_pair[m] = ((uint32_t)h1 << 16) | (uint32_t)h2;
             key = make_key(scores[e0 + m], thr, m);
         }
-        s_keys[m] = key;
+        const unsigned long long live = __ballot(key != KEY_NONE);
+        if (key != KEY_NONE) s_keys[n_valid + __popcll(live & ((1ull << lane) - 1ull))] = key;
+        n_valid += __popcll(live);
     }
+    int n = 64;
+    while (n < n_valid) n <<= 1;
+    for (int m = n_valid + lane; m < n; m += 64) s_keys[m] = KEY_NONE;
     __syncthreads();
     for (int k = 2; k <= n; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
