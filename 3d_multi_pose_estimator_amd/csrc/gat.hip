@@ -1228,6 +1228,23 @@ __device__ __forceinline__ void lds_barrier_raw() { asm volatile("s_waitcnt lgkm
 
 constexpr int FUSED_PIECES = 8;     // LDS-DMA pieces per wave of the overlapped staging (8 x 4 x 1 KiB = 32 KiB image)
 
+// Where a workgroup of k_gat_fused spends its life (DIAGNOSTIC builds only: make exp EXPFLAGS=-DMPE_FUSED_CLOCK, tools/fused_clock_probe.py):
+// thread 0 of every workgroup stores the 100 MHz clock between its phase boundaries into the workgroup's own slot (plain stores: a
+// shared counter would serialise 34 000 workgroups per forward on one address and measure itself).
+#ifdef MPE_FUSED_CLOCK
+__device__ unsigned int g_fused_stamp[16384][4];
+#define FUSED_STAMP(SLOT)                                                                \
+    do {                                                                                 \
+        if (threadIdx.x == 0) {                                                          \
+            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();            \
+            g_fused_stamp[blockIdx.x & 16383][SLOT] = (unsigned int)(now_ - fused_t_);   \
+            fused_t_ = now_;                                                             \
+        }                                                                                \
+    } while (0)
+#else
+#define FUSED_STAMP(SLOT) do { } while (0)
+#endif
+
 template <int VEC, int G>
 __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int hmax, int n_cap, int m_cap,
                                                    const int32_t *__restrict__ head_off,
@@ -1244,6 +1261,9 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int hmax,
     // XCD-aware order: workgroups with equal (id % 8) share an L2; the attention heads of one
     // frame read neighbouring 160-byte pieces of the same rows, so they go to the same XCD
     const int bid = blockIdx.x, nwg = gridDim.x;
+#ifdef MPE_FUSED_CLOCK
+    unsigned long long fused_t_ = __builtin_amdgcn_s_memrealtime();
+#endif
     const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
     const int vid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int f = vid / a.heads, hh = vid - f * a.heads;
@@ -1285,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int hmax,
     // consecutive chunks of the dense image, every lane with its own source address), so all of a
     // thread's requests are in flight at once; other shapes are staged through registers, four
     // requests at a time.
-    if (VEC == 4 && overlap) {
+    if (VEC == 4 && (overlap & 1)) {
         // Small frames with coefficients from the GEMM (the production case).  Every global load the
         // softmax phase depends on is issued FIRST, then exactly FUSED_PIECES image pieces per wave;
         // vmcnt counts in issue order, so `s_waitcnt vmcnt(FUSED_PIECES)` means "my table values are
@@ -1368,6 +1388,7 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int hmax,
             s_src[2 * t] = lo == 0xFFFF ? -1 : lo;
             s_src[2 * t + 1] = hi == 0xFFFF ? -1 : hi;
         }
+        FUSED_STAMP(0);                    // issue of the loads + landing of the table values
         lds_barrier_raw();
     } else {
     if (VEC == 4 && !a.ft_half) {
@@ -1514,9 +1535,67 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int hmax,
             if (gl == 0) s_deg[h] = deg;
         }
     }
+    FUSED_STAMP(1);                        // softmax phase (under the landing image)
     __syncthreads();
+    FUSED_STAMP(2);                        // what was left of the image's landing + the barrier
     // phase 3: weighted sums in edge order, activation, store
     const int first = (a.score_mode && !a.out_heads) ? H : 0;
+    if (VEC == 4 && !a.score_mode && (DV & 1) == 0 && !(overlap & 2)) {
+        // The production shape (40- / 80-wide heads, feature rows out).  An item of the edge-node rows is TWO 16-byte column groups
+        // of one row: its pair, its three weights and its index arithmetic are fetched once for eight columns instead of once for
+        // four -- measured with in-kernel stamps (tools/fused_clock_probe.py, profiles/r06_fused_phases.txt): phase 3 is 6.5 of a
+        // workgroup's 17.3 us and is instruction-bound (seven passes of ~70 instructions per thread), the image has long landed.
+        // Head rows (up to 17 sources per item) keep one group per item.  Per column the arithmetic is what it was: same bits.
+        const int DV2 = DV / 2;
+        const int n_head_items = H * DV, n_items = n_head_items + M * DV2;
+        for (int i = t; i < n_items; i += blockDim.x) {
+            if (i >= n_head_items) {
+                const int j = i - n_head_items;
+                const int m = j / DV2, d = (j - m * DV2) * 8;
+                const int node = H + m;
+                const int pr = s_pair[m];
+                const int h1 = pr >> 16, h2 = pr & 0xFFFF;
+                const float w1 = s_wen[m * 3 + 0], w2 = s_wen[m * 3 + 1], w3 = s_wen[m * 3 + 2];
+                const float *p1 = s_ft + h1 * Dp + d, *p2 = s_ft + h2 * Dp + d, *p3 = s_ft + node * Dp + d;
+                float *dst = a.out + (size_t)(nb + node) * a.ld_out + c0 + d;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const vecf f1 = *reinterpret_cast<const vecf *>(p1 + 4 * g);
+                    const vecf f2 = *reinterpret_cast<const vecf *>(p2 + 4 * g);
+                    const vecf f3 = *reinterpret_cast<const vecf *>(p3 + 4 * g);
+                    vecf o;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        float acc = f1[k] * w1;
+                        acc = acc + f2[k] * w2;
+                        acc = acc + f3[k] * w3;
+                        o[k] = agg_activate(acc, a.out_mode, a.out_slope);
+                    }
+                    *reinterpret_cast<vecf *>(dst + 4 * g) = o;
+                }
+            } else {
+                const int node = i / DV, d = (i - node * DV) * VEC;
+                const int deg = s_deg[node];
+                const int *src = s_src + node * max_deg;
+                const float *w = s_wh + node * max_deg;
+                float acc[VEC];
+                weighted_sum8<VEC>(
+                    deg,
+                    [&](int e, float *fv) {
+                        const vecf x = *reinterpret_cast<const vecf *>(s_ft + src[e] * Dp + d);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) fv[k] = x[k];
+                    },
+                    [&](int e) { return w[e]; }, acc);
+                vecf o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o[k] = agg_activate(acc[k], a.out_mode, a.out_slope);
+                *reinterpret_cast<vecf *>(a.out + (size_t)(nb + node) * a.ld_out + c0 + d) = o;
+            }
+        }
+        FUSED_STAMP(3);
+        return;
+    }
     for (int i = first * DV + t; i < N * DV; i += blockDim.x) {
         const int node = i / DV, d = (i - node * DV) * VEC;
         vecf o;
@@ -1558,7 +1637,21 @@ __global__ __launch_bounds__(256) void k_gat_fused(int V, int max_deg, int hmax,
             *reinterpret_cast<vecf *>(a.out + (size_t)(nb + node) * a.ld_out + c0 + d) = o;
         }
     }
+    FUSED_STAMP(3);                        // phase 3: weighted sums, activation, stores issued
 }
+
+#ifdef MPE_FUSED_CLOCK
+}  // namespace mpe
+extern "C" int mpe_debug_fused_stamps(unsigned int *out, int clear) {            // [16384][4]      // diagnostic builds only; not part of include/mpe.h
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mpe::g_fused_stamp), sizeof(mpe::g_fused_stamp)) != hipSuccess) return -1;
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mpe::g_fused_stamp)) != hipSuccess || hipMemset(p, 0, sizeof(mpe::g_fused_stamp)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace mpe {
+#endif
 
 // LDS bytes of k_gat_fused for frames of up to `hmax` heads.  Implicit topology: at most hmax^2 (V-1) / 2V edge-nodes
 // and hmax + 1 in-edges per head; explicit pair lists (x_m_cap > 0): the caller's caps.
@@ -1607,14 +1700,21 @@ hipError_t launch_gat_attention(hipStream_t s, const mpe_batch &b, int V, int ma
     if (shm <= FUSED_LDS_LIMIT && !no_fuse && b.n_frames > 0) {
         const int vec = agg_vec(a);
         // lane-group width of the head softmax: the largest in-degree a head can have
-        const int grp = max_deg <= 16 ? 16 : max_deg <= 32 ? 32 : 64;
+        // A lane takes the in-edges j, j + G, ... in ascending order before the butterfly.  With at most 2 G in-edges that is the
+        // canonical 64-lane tree itself (its first level adds lane j to lane j + 32, its second the result to lane j + 16's: for
+        // in-degrees up to 32 the first addition of lane j is x_j + x_(j+16), whichever form runs), so sixteen lanes serve heads of
+        // up to 32 in-edges and thirty-two lanes heads of up to 64 -- sixteen heads per pass instead of eight at 5 x 4
+        // (tests/test_gpu_stages.py::test_attention_paths_give_identical_bits compares with the 64-lane general kernel).
+        const int grp = max_deg <= 32 ? 16 : max_deg <= 64 ? 32 : 64;
         // overlapped staging: coefficients from the GEMM, fp32 rows of 16-byte chunks, tables of at most one
         // entry per thread, image of at most FUSED_PIECES x 256 chunks
         if (!xpl && !head_src_entries(max_heads_per_frame, V)) head_src = nullptr;
         // (the source table then travels as at most one dword = two entries per thread)
-        const int overlap = (!xpl && vec == 4 && a.a12_ready && !a.ft_half && n_cap <= 256 && m_cap <= 256 && head_src &&
-                             max_heads_per_frame * (max_heads_per_frame + 1) <= 512 &&
-                             n_cap * (a.out_dim / 4) <= FUSED_PIECES * 256 && !getenv("MPE_FUSED_NO_OVERLAP")) ? 1 : 0;
+        // (bit 1: MPE_FUSED_NO_OVERLAP also selects the one-group-per-item form of phase 3 -- the switch is the kernel's plain form)
+        const int overlap = ((!xpl && vec == 4 && a.a12_ready && !a.ft_half && n_cap <= 256 && m_cap <= 256 && head_src &&
+                              max_heads_per_frame * (max_heads_per_frame + 1) <= 512 &&
+                              n_cap * (a.out_dim / 4) <= FUSED_PIECES * 256 && !getenv("MPE_FUSED_NO_OVERLAP")) ? 1 : 0) |
+                            (getenv("MPE_FUSED_NO_OVERLAP") ? 2 : 0);
         const void *fn = nullptr;
 #define MPE_FUSED(V_, G_)                                                                                     \
     do {                                                                                                      \
