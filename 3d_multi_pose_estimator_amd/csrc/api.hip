@@ -539,7 +539,9 @@ bool lat_gat_ok(mpe_ctx *ctx, const mpe_batch *b, bool dense_in) {
     if (!latency_path_on() || dense_in || b->d_en_pair || b->n_frames > LAT_MAX_FRAMES) return false;
     if (b->n_heads + b->n_edge_nodes > LAT_MAX_NODES || b->n_heads <= 0) return false;
     if (!ctx->gat_split || ctx->gat_acc64 || ctx->gat_reduced || ctx->gat_attn_fp16 || !ctx->l0_grouped) return false;
-    if (getenv("MPE_NO_COEF_EPILOGUE") || getenv("MPE_GAT_ACC64_MINK")) return false;       // (cross-check switches of the batch path)
+    // (cross-check switches of the batch path: a run that asks for the tile kernels at every batch size, for the coefficient kernel or
+    // for another f64 threshold means the batch path's kernels)
+    if (getenv("MPE_NO_COEF_EPILOGUE") || getenv("MPE_GAT_ACC64_MINK") || getenv("MPE_SKINNY_WAVES") || getenv("MPE_GEMM_NARROW")) return false;
     if (!lat_l0a_available(ctx->cfg.n_joints, ctx->l0_ld)) return false;
     const GatLayer &g0 = ctx->gat[0];
     if (g0.out_dim != 40 || g0.in_dim <= 512) return false;      // layer 0: fc2 with f64 sums + the coefficient kernel, as the batch path
