@@ -568,7 +568,18 @@ int ensure_lat_workspace(mpe_ctx *ctx) {
 // The matching network for a small batch in 3 + 3 (L - 1) launches instead of ~26: front + layer-0 fc1 (k_lat_l0a), layer-0 fc2 as the
 // batch path has it, then per layer attention (both halves, one launch) -> fc1 -> fc2 with the activations
 // travelling as bf16 planes between them (k_lat_gemm).  Same arithmetic, same summation orders, same bits as the batch kernels.
-int run_gat_lat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en, float *d_scores_heads) {
+// *tail (optional): the attention stage of the LAST layer is left to the caller's tail launch (k_lat_tail: scores + clustering in one
+// launch) when the layer's coefficients come from the fc2 epilogue; *tail says whether it was, and describes the stage.
+struct LatTail {
+    bool deferred = false;
+    const float *ft2 = nullptr;
+    int ld = 0;
+    float alpha = 0.f, out_slope = 0.f;
+    int out_mode = 0;
+};
+
+int run_gat_lat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores_en, float *d_scores_heads, LatTail *tail = nullptr) {
+    if (tail) tail->deferred = false;
     int rc = ensure_lat_workspace(ctx);
     if (rc) return rc;
     const int V = ctx->cfg.n_cameras, J = ctx->cfg.n_joints, hmax = ctx->cfg.max_heads_per_frame;
@@ -600,6 +611,15 @@ int run_gat_lat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores
         } else {
             if ((rc = ensure_split_weights(ctx, s, &g.fc1)) || (rc = ensure_split_weights(ctx, s, &g.fc2))) return rc;
             const int hd = g.heads * g.out_dim;
+            if (lat_gemm_fusable(g.fc1.ldw, g.in_dim, g.fc2.ldw, hd, g.out_dim)) {
+                // the last layer: fc1 and the one-row fc2 in one launch (k_lat_gemm<.., FUSE2>)
+                GemmProf gp(ctx, s, 2.0 * n_nodes * (double)g.in_dim * (g.in_dim + hd), 0, 0, 1);
+                HIPCHK(ctx, launch_lat_gemm_fused(s, ctx->gat_pl[0], ctx->act_ld, ctx->gat_pl_plane, g.fc1.w3, (size_t)weight_rows(g.fc1.out_dim) * g.fc1.ldw,
+                                                  g.fc1.ldw, g.fc1.b, n_nodes, g.in_dim, ctx->gat_alpha, g.fc2.w3,
+                                                  (size_t)weight_rows(g.fc2.out_dim) * g.fc2.ldw, g.fc2.ldw, g.fc2.b, ctx->act[2], ctx->act_ld, g.attn_l, g.attn_r,
+                                                  ctx->a12));
+                coef = true;
+            } else {
             {
                 GemmProf gp(ctx, s, 2.0 * n_nodes * (double)g.in_dim * g.in_dim, 0, 0, 1);
                 HIPCHK(ctx, launch_lat_gemm(s, ctx->gat_pl[0], ctx->act_ld, ctx->gat_pl_plane, g.fc1.w3, (size_t)weight_rows(g.fc1.out_dim) * g.fc1.ldw,
@@ -612,6 +632,7 @@ int run_gat_lat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores
                                             g.fc2.ldw, g.fc2.b, ctx->act[2], ctx->act_ld, nullptr, 0, 0, n_nodes, hd, g.fc2.ldw, true, 0.f, g.attn_l,
                                             g.attn_r, ctx->a12, g.out_dim, &coef));
             }
+            }
             a.ft2 = ctx->act[2];
         }
         a.a12_ready = coef ? 1 : 0;
@@ -621,6 +642,15 @@ int run_gat_lat(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b, float *d_scores
             a.out = d_scores_en;
             a.out_heads = d_scores_heads;
             a.ld_out = 1;
+            if (tail && coef && !d_scores_heads && g.heads == 1 && g.out_dim == 1) {
+                tail->deferred = true;
+                tail->ft2 = a.ft2;
+                tail->ld = a.ld;
+                tail->alpha = a.alpha;
+                tail->out_slope = a.out_slope;
+                tail->out_mode = a.out_mode;
+                return MPE_OK;
+            }
         } else {
             a.out_mode = 0;
             a.out = nullptr;
@@ -1099,7 +1129,39 @@ int mpe_match_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_sco
     if (!scores) {
         scores = ctx->scores_tmp;
     }
-    if ((rc = run_gat(ctx, s, b, scores, nullptr))) return rc;
+    const int hmax = ctx->cfg.max_heads_per_frame;
+    if ((rc = ensure_gat_workspace(ctx))) return rc;
+    for (int k = 0; k < 2; ++k)                               // whatever route this call takes: pairs solved for an older batch in these arrays are stale
+        if (ctx->pair_key[k] == b->d_xy) ctx->pair_key[k] = nullptr;
+    if (lat_gat_ok(ctx, b, false) && lat_tail_available(hmax, ctx->cl_keys_per_frame) && b->n_edge_nodes > 0) {
+        // small batch: the last layer's scores and the clustering in ONE launch, and beside them every cross-camera pair of the batch
+        // solved for the row kernel of mpe_mlp3d_batch (which recognises the batch by the tag left here)
+        LatTail tail;
+        if ((rc = run_gat_lat(ctx, s, b, scores, nullptr, &tail))) return rc;
+        if (tail.deferred) {
+            const int J = ctx->cfg.n_joints;
+            const int slot = ctx->pair_next;
+            const size_t need = (size_t)LAT_MAX_FRAMES * hmax * hmax * J * 3;
+            // (the buffer is indexed by the batch's head number: a batch whose frames are within capacity has at most 8 hmax of them;
+            // anything else -- flagged on the device, rejected by Engine.check_capacity -- gets no pair solves and no tag)
+            const bool pairs_ok = (size_t)b->n_heads <= (size_t)LAT_MAX_FRAMES * hmax;
+            if (pairs_ok && !ctx->pair_pts[slot] && (rc = dev_alloc(ctx, &ctx->pair_pts[slot], need, false))) return rc;
+            for (int k = 0; k < 2; ++k)                       // one tag per input array at most: an older batch in the same arrays is gone
+                if (k == slot || ctx->pair_key[k] == b->d_xy) ctx->pair_key[k] = nullptr;
+            HIPCHK(ctx, launch_lat_tail(s, ctx->d_cfg, *b, J, ctx->en_pair, ctx->en_frame, tail.ft2, tail.ld, ctx->a12, tail.alpha, tail.out_slope,
+                                        tail.out_mode, ctx->node_off, scores, ctx->cfg.max_persons_per_frame, hmax, ctx->cl_keys_per_frame, d_persons,
+                                        d_n_persons, pairs_ok ? ctx->pair_pts[slot] : nullptr));
+            if (pairs_ok) {
+                ctx->pair_key[slot] = b->d_xy;
+                ctx->pair_heads[slot] = b->n_heads;
+                ctx->pair_en[slot] = b->n_edge_nodes;
+                ctx->pair_next = slot ^ 1;
+            }
+            return MPE_OK;
+        }
+    } else if ((rc = run_gat(ctx, s, b, scores, nullptr))) {
+        return rc;
+    }
     HIPCHK(ctx, launch_cluster(s, ctx->d_cfg, *b, ctx->en_pair, scores, ctx->cfg.max_persons_per_frame,
                                ctx->cfg.max_heads_per_frame, ctx->cl_keys, ctx->cl_keys_per_frame, ctx->cl_scratch,
                                ctx->cl_scratch_per_frame, d_persons, d_n_persons));
@@ -1206,8 +1268,14 @@ int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, const int32_
     // small batches: the persons' prefix inside the row kernel, the decode inside the last layer's launch (two launches fewer)
     const bool small = latency_path_on() && b->n_frames <= LAT_MAX_FRAMES;
     if (small) {
+        // the batch whose pairs mpe_match_batch left solved (same input arrays, same sizes)?  then the row kernel fetches them
+        const double *pairs = nullptr;
+        for (int k = 0; k < 2; ++k)
+            if (ctx->pair_key[k] && ctx->pair_key[k] == b->d_xy && ctx->pair_heads[k] == b->n_heads && ctx->pair_en[k] == b->n_edge_nodes)
+                pairs = ctx->pair_pts[k];
         HIPCHK(ctx, launch_mlp_rows(s, ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints, *b, d_persons, d_n_persons, nullptr, pcap, ctx->mlp_rows,
-                                    ctx->mlp_ld_in, d_valid ? d_valid : ctx->valid_tmp, ctx->person_off, ctx->mlp_count, d_poses, n_out));
+                                    ctx->mlp_ld_in, d_valid ? d_valid : ctx->valid_tmp, ctx->person_off, ctx->mlp_count, d_poses, n_out, pairs,
+                                    ctx->cfg.max_heads_per_frame));
     } else {
         HIPCHK(ctx, launch_person_scan(s, b->n_frames, pcap, d_n_persons, ctx->person_off, ctx->mlp_count));
         HIPCHK(ctx, launch_mlp_rows(s, ctx->d_cfg, ctx->cfg.n_cameras, ctx->cfg.n_joints, *b, d_persons, d_n_persons,

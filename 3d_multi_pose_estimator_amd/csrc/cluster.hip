@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include "mpe_internal.h"
+#include "dlt_common.h"
 
 namespace mpe {
 
@@ -449,16 +450,12 @@ __device__ inline bool rs_add(RegSet &s, int key) {
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_cluster_wave(const DevCfg *__restrict__ cfg, int n_frames,
-                                                     const int32_t *__restrict__ head_off,
-                                                     const int32_t *__restrict__ en_off,
-                                                     const int32_t *__restrict__ head_cam,
-                                                     const int32_t *__restrict__ en_pair,
-                                                     const float *__restrict__ scores, int pcap, int n_pow2,
-                                                     int hmax, int32_t *__restrict__ persons,
-                                                     int32_t *__restrict__ n_persons) {
-    extern __shared__ uint64_t s_keys[];
-    const int f = blockIdx.x;
+// (the body of k_cluster_wave: one wave, lane = threadIdx.x < 64; also run by the small-batch tail launch k_lat_tail)
+__device__ __forceinline__ void cluster_wave_body(uint64_t *s_keys, int f, const DevCfg *__restrict__ cfg, int n_frames,
+                                                  const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
+                                                  const int32_t *__restrict__ head_cam, const int32_t *__restrict__ en_pair,
+                                                  const float *__restrict__ scores, int pcap, int n_pow2, int hmax,
+                                                  int32_t *__restrict__ persons, int32_t *__restrict__ n_persons) {
     if (f >= n_frames) return;
     const int V = cfg->V;
     const int lane = threadIdx.x;
@@ -669,6 +666,128 @@ __global__ __launch_bounds__(64) void k_cluster_wave(const DevCfg *__restrict__ 
         }
     }
     if (lane == 0) n_persons[f] = np;
+}
+
+__global__ __launch_bounds__(64) void k_cluster_wave(const DevCfg *__restrict__ cfg, int n_frames,
+                                                     const int32_t *__restrict__ head_off,
+                                                     const int32_t *__restrict__ en_off,
+                                                     const int32_t *__restrict__ head_cam,
+                                                     const int32_t *__restrict__ en_pair,
+                                                     const float *__restrict__ scores, int pcap, int n_pow2,
+                                                     int hmax, int32_t *__restrict__ persons,
+                                                     int32_t *__restrict__ n_persons) {
+    extern __shared__ uint64_t s_keys[];
+    cluster_wave_body(s_keys, blockIdx.x, cfg, n_frames, head_off, en_off, head_cam, en_pair, scores, pcap, n_pow2, hmax, persons, n_persons);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Small batches: the tail of the matching stage in ONE launch.  Workgroup f < n_frames (its first wave): the scores of the frame's
+// edge-nodes -- the attention stage of the LAST layer (one attention head, one feature: gat2.py:57-66 + the final activation,
+// :145-148), k_lat_attention's edge-node half written out for one column: same expressions, same order, same bits -- and then the
+// frame's clustering (cluster_wave_body).  The other workgroups solve, BESIDE that (the clustering is 20 us of sequential rules on
+// one wave; the rest of the chip is idle), every cross-camera skeleton pair of the batch for every joint: one DLT solve per
+// (edge-node, joint) with the arguments in camera order, as the row kernel's person_front would call it
+// (pose_estimator_dataset_from_json.py:63-101) -- which of them a person needs is only known after the clustering, that they
+// are all of this form is known before.  k_mlp_rows then fetches its pairs (pair_pts) instead of solving them: 21 -> 8 us.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct TailScores {                // the last layer's attention stage (AggArgs of that layer, the fields an N x 1 layer needs)
+    const float *ft2;              // [n_nodes][ld]: column 0
+    int ld;
+    const float *a12;              // [n_nodes][32]: a1 at [0], a2 at [16]
+    float alpha, out_slope;
+    int out_mode;
+    const int32_t *node_off;
+    float *scores;                 // [n_edge_nodes] (written here, read by the clustering of the same workgroup)
+};
+
+__global__ __launch_bounds__(256) void k_lat_tail(const DevCfg *__restrict__ cfg, int n_frames, int n_en, int J,
+                                                  const int32_t *__restrict__ head_off, const int32_t *__restrict__ en_off,
+                                                  const int32_t *__restrict__ head_cam, const int32_t *__restrict__ en_pair,
+                                                  const int32_t *__restrict__ en_frame, TailScores ts, int pcap, int n_pow2, int hmax,
+                                                  int32_t *__restrict__ persons, int32_t *__restrict__ n_persons,
+                                                  const uint32_t *__restrict__ tri_mask, const double *__restrict__ xy,
+                                                  double *__restrict__ pair_pts) {
+#pragma clang fp contract(off)
+    extern __shared__ uint64_t s_keys[];
+    if ((int)blockIdx.x < n_frames) {
+        if (threadIdx.x >= 64) return;                          // (one wave: the other three leave before any barrier)
+        const int f = blockIdx.x, lane = threadIdx.x;
+        const int hb = head_off[f], H = head_off[f + 1] - hb;
+        const int e0 = en_off[f], M = en_off[f + 1] - e0;
+        const int nb = ts.node_off[f];
+        for (int m = lane; m < M; m += 64) {
+            // gat.hip: aggregate_en_body<1> for one attention head of width one, score mode
+            const int h1 = en_pair[2 * (size_t)(e0 + m)], h2 = en_pair[2 * (size_t)(e0 + m) + 1], v = H + m;
+            const float *ra1 = ts.a12 + (size_t)(nb + h1) * 32, *ra2 = ts.a12 + (size_t)(nb + h2) * 32, *ra3 = ts.a12 + (size_t)(nb + v) * 32;
+            const float a2v = ra3[16];
+            float e1 = ra1[0] + a2v, e2 = ra2[0] + a2v, e3 = ra3[0] + a2v;
+            e1 = e1 > 0.f ? e1 : e1 * ts.alpha;
+            e2 = e2 > 0.f ? e2 : e2 * ts.alpha;
+            e3 = e3 > 0.f ? e3 : e3 * ts.alpha;
+            const float mx = fmaxf(fmaxf(e1, e2), e3);
+            const float x1 = expf(e1 - mx), x2 = expf(e2 - mx), x3 = expf(e3 - mx);
+            const float sum = (x1 + x2) + x3;
+            const float w1 = x1 / sum, w2 = x2 / sum, w3 = x3 / sum;
+            const float v1 = ts.ft2[(size_t)(nb + h1) * ts.ld], v2 = ts.ft2[(size_t)(nb + h2) * ts.ld], v3 = ts.ft2[(size_t)(nb + v) * ts.ld];
+            float acc = v1 * w1;
+            acc = acc + v2 * w2;
+            acc = acc + v3 * w3;
+            float o = acc;
+            if (ts.out_mode == 0) o = acc > 0.f ? acc : acc * ts.out_slope;
+            else if (ts.out_mode == 1) o = 1.f / (1.f + expf(-acc));
+            ts.scores[e0 + m] = H > hmax ? 0.f : o;
+        }
+        __syncthreads();                                        // (the wave's own stores, visible to its own loads)
+        cluster_wave_body(s_keys, f, cfg, n_frames, head_off, en_off, head_cam, en_pair, ts.scores, pcap, n_pow2, hmax, persons, n_persons);
+        return;
+    }
+    // every (edge-node, joint) of the batch: the pair's two skeletons, lower camera first
+    const size_t i = (size_t)(blockIdx.x - n_frames) * 256 + threadIdx.x;
+    if (i >= (size_t)n_en * J) return;
+    const int m = (int)(i / J), j = (int)(i - (size_t)m * J);
+    const int f = en_frame[m];
+    const int hb = head_off[f], H = head_off[f + 1] - hb;
+    if (H > hmax) return;
+    int la = en_pair[2 * (size_t)m], lb = en_pair[2 * (size_t)m + 1];
+    int ca = head_cam[hb + la], cb = head_cam[hb + lb];
+    if (ca > cb) {
+        const int t = la;
+        la = lb;
+        lb = t;
+        const int c = ca;
+        ca = cb;
+        cb = c;
+    }
+    const int ga = hb + la, gb = hb + lb;
+    if (!((tri_mask[ga] >> j) & 1u) || !((tri_mask[gb] >> j) & 1u)) return;
+    double ua, va, ub, vb;
+    dltc::undistort_point(cfg, ca, xy[((size_t)ga * J + j) * 2], xy[((size_t)ga * J + j) * 2 + 1], &ua, &va);
+    dltc::undistort_point(cfg, cb, xy[((size_t)gb * J + j) * 2], xy[((size_t)gb * J + j) * 2 + 1], &ub, &vb);
+    dltc::dlt_solve(cfg->P[ca], cfg->P[cb], ua, va, ub, vb, pair_pts + (((size_t)ga * hmax + lb) * J + j) * 3);
+}
+
+// Can the tail launch serve this context's frames?  (the one-wave clustering kernel: at most 64 skeletons per frame)
+bool lat_tail_available(int hmax, size_t keys_per_frame) {
+    if (getenv("MPE_CLUSTER_KERNEL") || hmax > 64) return false;
+    int n_pow2 = 64;
+    while ((size_t)n_pow2 < keys_per_frame) n_pow2 <<= 1;
+    return (size_t)n_pow2 * (sizeof(uint64_t) + sizeof(uint32_t)) + 256 * sizeof(int32_t) <= 48 * 1024;
+}
+
+hipError_t launch_lat_tail(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, const int32_t *en_pair, const int32_t *en_frame,
+                           const float *ft2, int ld, const float *a12, float alpha, float out_slope, int out_mode, const int32_t *node_off,
+                           float *scores, int pcap, int hmax, size_t keys_per_frame, int32_t *persons, int32_t *n_persons, double *pair_pts) {
+    if (b.n_frames <= 0) return hipSuccess;
+    int n_pow2 = 64;
+    while ((size_t)n_pow2 < keys_per_frame) n_pow2 <<= 1;
+    const size_t shm = (size_t)n_pow2 * (sizeof(uint64_t) + sizeof(uint32_t)) + 256 * sizeof(int32_t);
+    TailScores ts{ft2, ld, a12, alpha, out_slope, out_mode, node_off, scores};
+    const size_t items = pair_pts ? (size_t)b.n_edge_nodes * J : 0;
+    const unsigned grid = (unsigned)(b.n_frames + (items + 255) / 256);
+    hipLaunchKernelGGL(k_lat_tail, dim3(grid), dim3(256), shm, s, cfg, b.n_frames, pair_pts ? b.n_edge_nodes : 0, J, b.d_frame_head_off,
+                       b.d_frame_en_off, b.d_head_cam, en_pair, en_frame, ts, pcap, n_pow2, hmax, persons, n_persons, b.d_tri_mask, b.d_xy,
+                       pair_pts);
+    return hipGetLastError();
 }
 
 // ---- workgroup variant for large frames (> 64 heads: 5 x 10+, 23 cameras) ----------------

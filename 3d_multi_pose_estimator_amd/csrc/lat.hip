@@ -206,13 +206,28 @@ __device__ __forceinline__ void coef40_lat(const float *fv, const float *__restr
     o2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
 }
 
-template <int NK, int NT, bool LEAKY, bool OPL, bool COEF>
+// FUSE2 (the last layer: fc1 150 -> 150 in ONE workgroup per row tile, then fc2 150 -> 1): the workgroup keeps its fc1 rows as planes
+// in LDS and its first wave multiplies them with fc2's one weight row right away -- fp32 column 0 and a1 | a2 of the single
+// one-wide head out, the arithmetic of this kernel's own <NK, 1, false, false, true> form; one launch and one round trip fewer.
+struct LatFc2 {
+    const unsigned short *W3;      // fc2's planes [3][weight_rows(1)][ldw]
+    size_t w_plane;
+    int ldw;
+    const float *bias;
+    float *C;                      // [rows][ldc] fp32: column 0
+    int ldc;
+    const float *attn_l, *attn_r;  // [1]
+    float *a12;
+};
+
+template <int NK, int NT, bool LEAKY, bool OPL, bool COEF, bool FUSE2 = false>
 __global__ __launch_bounds__(64 * NT) void k_lat_gemm(const unsigned short *__restrict__ Apl, int lda, size_t a_plane,
                                                        const unsigned short *__restrict__ W3, size_t w_plane, int ldw,
                                                        const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                        unsigned short *__restrict__ Cpl, int ldcp, size_t c_plane, int M, int n,
                                                        float slope, const float *__restrict__ attn_l, const float *__restrict__ attn_r,
-                                                       float *__restrict__ a12, int out_dim) {
+                                                       float *__restrict__ a12, int out_dim, LatFc2 f2 = LatFc2()) {
+    static_assert(!FUSE2 || (OPL && !COEF && NT * 16 == NK * 32), "fused fc2: one workgroup holds whole fc1 rows, as wide as its own K");
     constexpr int KS = NK * 32 + 8;                          // LDS row stride of an activation plane (bf16 elements): rows 16 B apart in the banks
     constexpr int NTHR = 64 * NT;
     constexpr int A_CHUNKS = 3 * 16 * NK * 4;                // 16-byte chunks of the activation tile (3 planes x 16 rows x NK * 64 B)
@@ -232,6 +247,14 @@ __global__ __launch_bounds__(64 * NT) void k_lat_gemm(const unsigned short *__re
         for (int kt = 0; kt < NK; ++kt)
 #pragma unroll
             for (int p = 0; p < 3; ++p) wv[kt][p] = *reinterpret_cast<const bf16x8 *>(pw + p * w_plane + kt * GEMM_BK);
+    }
+    bf16x8 wv2[FUSE2 ? NK : 1][3];                         // fc2's fragments (its sixteen output "columns" are one real row + zero padding)
+    if (FUSE2 && wave == 0) {
+        const unsigned short *pw2 = f2.W3 + (size_t)fr * f2.ldw + 8 * fq;
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wv2[kt][p] = *reinterpret_cast<const bf16x8 *>(pw2 + p * f2.w_plane + kt * GEMM_BK);
     }
     // the activation tile (shared by the NT waves): global -> registers -> LDS
     {
@@ -273,6 +296,41 @@ __global__ __launch_bounds__(64 * NT) void k_lat_gemm(const unsigned short *__re
     for (int i = 0; i < 4; ++i) {
         v[i] = (acc[i] + acc_odd[i]) + bv[i];
         if (LEAKY) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+    }
+    if (FUSE2) {
+        // this workgroup's fc1 rows (all NT x 16 columns; the ones behind n are exact zeros: zero weight rows, zero bias) as planes into
+        // the LDS tile the activation planes came through, then fc2 on them by the first wave
+        __syncthreads();
+        {
+            const unsigned a0 = pack2_lat(v[0], v[1]), a1 = pack2_lat(v[2], v[3]);
+            const float r0 = sub1(v[0], __uint_as_float(a0 << 16)), r1 = sub1(v[1], __uint_as_float(a0 & 0xFFFF0000u));
+            const float r2 = sub1(v[2], __uint_as_float(a1 << 16)), r3 = sub1(v[3], __uint_as_float(a1 & 0xFFFF0000u));
+            const unsigned b0 = pack2_lat(r0, r1), b1 = pack2_lat(r2, r3);
+            const float s0 = sub1(r0, __uint_as_float(b0 << 16)), s1 = sub1(r1, __uint_as_float(b0 & 0xFFFF0000u));
+            const float s2 = sub1(r2, __uint_as_float(b1 << 16)), s3 = sub1(r3, __uint_as_float(b1 & 0xFFFF0000u));
+            unsigned short *d = &s_a[fr * KS + wave * 16 + fq * 4];
+            *reinterpret_cast<uint2 *>(d) = make_uint2(a0, a1);
+            *reinterpret_cast<uint2 *>(d + 16 * KS) = make_uint2(b0, b1);
+            *reinterpret_cast<uint2 *>(d + 32 * KS) = make_uint2(pack2_lat(s0, s1), pack2_lat(s2, s3));
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            bf16x8 ap[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ap[p] = *reinterpret_cast<const bf16x8 *>(&s_a[(p * 16 + fr) * KS + kt * GEMM_BK + 8 * fq]);
+            if (kt & 1) SB_STAGE(o, ap, wv2[kt]);
+            else SB_STAGE(e, ap, wv2[kt]);
+        }
+        if (fq == 0 && m < M) {                              // output column 0 of the row
+            const float y = (e[0] + o[0]) + f2.bias[0];
+            f2.C[(size_t)m * f2.ldc] = y;
+            f2.a12[(size_t)m * 32] = __builtin_fmaf(y, f2.attn_l[0], 0.f);
+            f2.a12[(size_t)m * 32 + 16] = __builtin_fmaf(y, f2.attn_r[0], 0.f);
+        }
+        return;
     }
     if (OPL) {
         if (m < M && nb + 3 < n) {
@@ -374,6 +432,22 @@ static int lat_gemm_form(int k_pad, int n, bool fc2, int out_dim) {
 }
 
 bool lat_gemm_available(int k_pad, int n, bool fc2, int out_dim) { return lat_gemm_form(k_pad, n, fc2, out_dim) != 0; }
+
+// fc1 (150 -> 150) and fc2 (150 -> 1) of the last layer as one launch?
+bool lat_gemm_fusable(int k1_pad, int n1, int k2_pad, int n2, int out_dim2) {
+    return lat_gemm_form(k1_pad, n1, false, 0) == 3 && lat_gemm_form(k2_pad, n2, true, out_dim2) == 6 && n2 == 1 && out_dim2 == 1 && k2_pad == 160 && n1 <= 160;
+}
+
+hipError_t launch_lat_gemm_fused(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
+                                 const float *bias, int m, int n, float slope, const unsigned short *W3b, size_t w_plane_b, int ldw_b, const float *bias_b,
+                                 float *C2, int ldc2, const float *attn_l, const float *attn_r, float *a12) {
+    if (m <= 0) return hipSuccess;
+    lat::LatFc2 f2{W3b, w_plane_b, ldw_b, bias_b, C2, ldc2, attn_l, attn_r, a12};
+    const int ntm = (m + 15) / 16;
+    hipLaunchKernelGGL((lat::k_lat_gemm<5, 10, true, true, false, true>), dim3((unsigned)ntm), dim3(640), 0, s, Apl, lda, a_plane, W3, w_plane, ldw, bias,
+                       nullptr, 0, nullptr, 0, 0, m, n, slope, nullptr, nullptr, nullptr, 0, f2);
+    return hipGetLastError();
+}
 
 hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
                            const float *bias, float *C, int ldc, unsigned short *Cpl, int ldcp, size_t c_plane, int m, int n, int k_pad, bool fc2,

@@ -119,6 +119,11 @@ struct mpe_ctx {
     bool l0_grouped = true;
     float *act[3] = {nullptr, nullptr, nullptr};   // [max_nodes][act_ld]
     float *a12 = nullptr;          // [max_nodes][2*16]
+    // small batches: every cross-camera pair of a batch solved beside the clustering (cluster.hip: k_lat_tail) for the row kernel of the
+    // SAME batch to fetch: two buffers [heads][hmax][J][3] f64, each tagged with the batch it holds (the batch's d_xy pointer and sizes)
+    double *pair_pts[2] = {nullptr, nullptr};
+    const void *pair_key[2] = {nullptr, nullptr};
+    int pair_heads[2] = {0, 0}, pair_en[2] = {0, 0}, pair_next = 0;
     unsigned short *gat_pl[2] = {nullptr, nullptr};   // small batches (lat.hip): activations between attention -> fc1 -> fc2 as three bf16 planes [3][lat_rows][act_ld]
     size_t gat_pl_plane = 0;       // plane stride in elements
     int lat_rows = 0;
@@ -185,6 +190,10 @@ bool lat_gemm_available(int k_pad, int n, bool fc2, int out_dim);
 hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
                            const float *bias, float *C, int ldc, unsigned short *Cpl, int ldcp, size_t c_plane, int m, int n, int k_pad, bool fc2,
                            float slope, const float *attn_l, const float *attn_r, float *a12, int out_dim, bool *coef_done = nullptr);
+bool lat_gemm_fusable(int k1_pad, int n1, int k2_pad, int n2, int out_dim2);
+hipError_t launch_lat_gemm_fused(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
+                                 const float *bias, int m, int n, float slope, const unsigned short *W3b, size_t w_plane_b, int ldw_b, const float *bias_b,
+                                 float *C2, int ldc2, const float *attn_l, const float *attn_r, float *a12);
 hipError_t launch_linear_lat_f64(hipStream_t s, const void *A, int lda, size_t a_plane, const float *W, int ldw, const float *bias, void *C,
                                  int ldc, size_t c_plane, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky, float slope,
                                  int flush_stages, bool a_planes = false, bool c_planes = false);
@@ -269,13 +278,19 @@ hipError_t launch_cluster(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, 
                           size_t keys_per_frame, int32_t *scratch, size_t scratch_per_frame,
                           int32_t *persons, int32_t *n_persons);
 
+// the small-batch tail launch (cluster.hip: k_lat_tail): last layer's scores + clustering per frame, every cross-camera pair solved beside it
+bool lat_tail_available(int hmax, size_t keys_per_frame);
+hipError_t launch_lat_tail(hipStream_t s, const DevCfg *cfg, const mpe_batch &b, int J, const int32_t *en_pair, const int32_t *en_frame,
+                           const float *ft2, int ld, const float *a12, float alpha, float out_slope, int out_mode, const int32_t *node_off,
+                           float *scores, int pcap, int hmax, size_t keys_per_frame, int32_t *persons, int32_t *n_persons, double *pair_pts);
+
 // pose3d.hip
 hipError_t launch_person_scan(hipStream_t s, int n_frames, int pcap, const int32_t *n_persons, int32_t *person_off,
                               int32_t *total);
 hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                            const int32_t *persons, const int32_t *n_persons, const int32_t *person_off, int pcap,
                            float *rows, int ld_rows, uint8_t *valid, int32_t *scan_out = nullptr, int32_t *total_out = nullptr,
-                           float *zero_poses = nullptr, int n_out = 0);
+                           float *zero_poses = nullptr, int n_out = 0, const double *pair_pts = nullptr, int pair_hmax = 0);
 
 hipError_t launch_triangulate(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                               const int32_t *persons, const int32_t *n_persons, int pcap, double *poses,

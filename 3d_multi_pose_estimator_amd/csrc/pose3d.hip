@@ -14,116 +14,11 @@
 // close as possible to the CPU evaluation order, except inside the Jacobi SVD (an iteration to
 // convergence whose result does not depend on the rounding of single steps beyond a few ulp).
 #include "mpe_internal.h"
+#include "dlt_common.h"
 
 namespace mpe {
 
-namespace {
-
-__device__ inline void undistort_point(const DevCfg *cfg, int cam, double u, double v, double *ox, double *oy) {
-#pragma clang fp contract(off)
-    const float *K = cfg->K[cam];
-    const double fx = (double)K[0], fy = (double)K[4], cx = (double)K[2], cy = (double)K[5];
-    const double *d = cfg->dist[cam];
-    const double k1 = d[0], k2 = d[1], p1 = d[2], p2 = d[3], k3 = d[4];
-    const double ifx = 1.0 / fx, ify = 1.0 / fy;
-    double x = (u - cx) * ifx, y = (v - cy) * ify;
-    const double x0 = x, y0 = y;
-    for (int it = 0; it < 5; ++it) {
-        const double r2 = x * x + y * y;
-        const double icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2);
-        if (icdist < 0) {
-            x = x0;
-            y = y0;
-            break;
-        }
-        const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
-        const double dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
-        x = (x0 - dx) * icdist;
-        y = (y0 - dy) * icdist;
-    }
-    *ox = x;
-    *oy = y;
-}
-
-// Right singular vector of the smallest singular value of the 4x4 DLT matrix, dehomogenised.
-__device__ inline void dlt_solve(const double *P1, const double *P2, double x1, double y1, double x2, double y2,
-                                 double *out) {
-#pragma clang fp contract(fast)
-    double A[4][4], Vm[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        A[0][k] = x1 * P1[8 + k] - P1[k];
-        A[1][k] = y1 * P1[8 + k] - P1[4 + k];
-        A[2][k] = x2 * P2[8 + k] - P2[k];
-        A[3][k] = y2 * P2[8 + k] - P2[4 + k];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Vm[k][j] = (k == j) ? 1.0 : 0.0;
-    }
-    // converged when every column pair is orthogonal to a few ulp: |<a_p,a_q>| <= 4e-16 |a_p||a_q|
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        bool rotated = false;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 4; ++q) {
-                double al = 0, be = 0, ga = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    al += A[i][p] * A[i][p];
-                    be += A[i][q] * A[i][q];
-                    ga += A[i][p] * A[i][q];
-                }
-                if (ga * ga <= 1.6e-31 * (al * be) || ga == 0.0) continue;
-                rotated = true;
-                // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (be - al) / (2 ga), written with one
-                // division and one square root; c = 1 / sqrt(1 + t^2)
-                const double d = be - al, g2 = 2.0 * fabs(ga);
-                const double sg = (d == 0.0 || (d > 0.0) == (ga > 0.0)) ? 1.0 : -1.0;
-                const double t = sg * g2 / (fabs(d) + sqrt(d * d + g2 * g2));
-                const double c = rsqrt(1.0 + t * t), s = c * t;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const double ap = A[i][p], aq = A[i][q];
-                    A[i][p] = c * ap - s * aq;
-                    A[i][q] = s * ap + c * aq;
-                    const double vp = Vm[i][p], vq = Vm[i][q];
-                    Vm[i][p] = c * vp - s * vq;
-                    Vm[i][q] = s * vp + c * vq;
-                }
-            }
-        if (!rotated) break;
-    }
-    int jm = 0;
-    double best = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        double nn = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nn += A[i][j] * A[i][j];
-        if (j == 0 || nn < best) {
-            best = nn;
-            jm = j;
-        }
-    }
-    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (j == jm) {
-            v0 = Vm[0][j];
-            v1 = Vm[1][j];
-            v2 = Vm[2][j];
-            v3 = Vm[3][j];
-        }
-    out[0] = v0 / v3;
-    out[1] = v1 / v3;
-    out[2] = v2 / v3;
-}
-
-__device__ inline int pair_index(int c1, int c2, int V) {   // lexicographic index of (c1<c2)
-    return c1 * V - c1 * (c1 + 1) / 2 + (c2 - c1 - 1);
-}
-
-}  // namespace
+using namespace dltc;
 
 // ---------------------------------------------------------------------------------------
 // shared front end: heads of the person, undistorted points, all pair solves into LDS
@@ -134,9 +29,12 @@ struct PersonCtx {
 };
 
 // s_und [V][J][2], s_pts [J][npairs][3], s_head[V] (global head index or -1)
+// pair_pts (small batches, cluster.hip: k_lat_tail): every cross-camera pair of the frame has ALREADY been solved, beside the
+// clustering -- [global head of the lower camera][frame-local head of the other][J][3] -- and a pair is fetched instead of solved
+// (the same function on the same arguments: the same bits).
 __device__ inline void person_front(const DevCfg *cfg, const PersonCtx &pc, const int32_t *s_head,
                                     const uint32_t *s_mask, const double *__restrict__ xy, double *s_und,
-                                    double *s_pts) {
+                                    double *s_pts, const double *__restrict__ pair_pts = nullptr, int pair_hmax = 0) {
     const int V = pc.V, J = pc.J;
     for (int i = threadIdx.x; i < V * J; i += blockDim.x) {
         const int c = i / J, j = i - c * J;
@@ -157,8 +55,15 @@ __device__ inline void person_front(const DevCfg *cfg, const PersonCtx &pc, cons
         while (rem >= V - 1 - c1) { rem -= V - 1 - c1; ++c1; }
         const int c2 = c1 + 1 + rem;
         if (s_head[c1] >= 0 && s_head[c2] >= 0 && (s_mask[c1] >> j & 1u) && (s_mask[c2] >> j & 1u)) {
-            dlt_solve(cfg->P[c1], cfg->P[c2], s_und[(c1 * J + j) * 2], s_und[(c1 * J + j) * 2 + 1],
-                      s_und[(c2 * J + j) * 2], s_und[(c2 * J + j) * 2 + 1], s_pts + (size_t)i * 3);
+            if (pair_pts) {
+                const double *src = pair_pts + (((size_t)s_head[c1] * pair_hmax + (s_head[c2] - pc.h0)) * J + j) * 3;
+                s_pts[(size_t)i * 3] = src[0];
+                s_pts[(size_t)i * 3 + 1] = src[1];
+                s_pts[(size_t)i * 3 + 2] = src[2];
+            } else {
+                dlt_solve(cfg->P[c1], cfg->P[c2], s_und[(c1 * J + j) * 2], s_und[(c1 * J + j) * 2 + 1],
+                          s_und[(c2 * J + j) * 2], s_und[(c2 * J + j) * 2 + 1], s_pts + (size_t)i * 3);
+            }
         }
     }
     __syncthreads();
@@ -181,7 +86,8 @@ __global__ __launch_bounds__(NT) void k_mlp_rows(const DevCfg *__restrict__ cfg,
                                                   const int32_t *__restrict__ person_off, float *__restrict__ rows,
                                                   int ld_rows, uint8_t *__restrict__ valid,
                                                   int32_t *__restrict__ scan_out, int32_t *__restrict__ total_out, int n_frames,
-                                                  float *__restrict__ zero_poses, int n_out) {
+                                                  float *__restrict__ zero_poses, int n_out,
+                                                  const double *__restrict__ pair_pts, int pair_hmax) {
 #pragma clang fp contract(off)
     extern __shared__ double s_dyn64[];
     const int f = blockIdx.x / pcap, p = blockIdx.x - f * pcap;
@@ -233,7 +139,7 @@ __global__ __launch_bounds__(NT) void k_mlp_rows(const DevCfg *__restrict__ cfg,
     for (int c = threadIdx.x; c < ld_rows; c += blockDim.x) row[c] = 0.f;
     __syncthreads();
     PersonCtx pc{f, p, V, J, npairs, h0};
-    person_front(cfg, pc, s_head, s_tmask, xy, s_und, s_pts);   // pair solves on the tri mask
+    person_front(cfg, pc, s_head, s_tmask, xy, s_und, s_pts, pair_pts, pair_hmax);   // pair solves on the tri mask (or the pairs solved beside the clustering)
     // undistorted points of joints outside the tri mask (joint 0) are still needed for the rays
     for (int i = threadIdx.x; i < V * J; i += blockDim.x) {
         const int c = i / J, j = i - c * J;
@@ -353,7 +259,8 @@ hipError_t launch_person_scan(hipStream_t s, int n_frames, int pcap, const int32
 
 hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const mpe_batch &b,
                            const int32_t *persons, const int32_t *n_persons, const int32_t *person_off, int pcap,
-                           float *rows, int ld_rows, uint8_t *valid, int32_t *scan_out, int32_t *total_out, float *zero_poses, int n_out) {
+                           float *rows, int ld_rows, uint8_t *valid, int32_t *scan_out, int32_t *total_out, float *zero_poses, int n_out,
+                           const double *pair_pts, int pair_hmax) {
     if (b.n_frames <= 0) return hipSuccess;
     const size_t shm = ((size_t)V * J * 2 + (size_t)J * (V * (V - 1) / 2) * 3) * sizeof(double) + (size_t)ld_rows * sizeof(float) + 16;
     if (shm > 40 * 1024) {
@@ -365,12 +272,12 @@ hipError_t launch_mlp_rows(hipStream_t s, const DevCfg *cfg, int V, int J, const
         }
         hipLaunchKernelGGL(k_mlp_rows<1024>, dim3(b.n_frames * pcap), dim3(1024), shm, s, cfg, pcap, b.d_frame_head_off,
                            b.d_joint_mask, b.d_tri_mask, b.d_xy, b.d_vp, persons, n_persons, person_off, rows, ld_rows,
-                           valid, scan_out, total_out, b.n_frames, zero_poses, n_out);
+                           valid, scan_out, total_out, b.n_frames, zero_poses, n_out, pair_pts, pair_hmax);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_mlp_rows<256>, dim3(b.n_frames * pcap), dim3(256), shm, s, cfg, pcap, b.d_frame_head_off,
                        b.d_joint_mask, b.d_tri_mask, b.d_xy, b.d_vp, persons, n_persons, person_off, rows, ld_rows,
-                       valid, scan_out, total_out, b.n_frames, zero_poses, n_out);
+                       valid, scan_out, total_out, b.n_frames, zero_poses, n_out, pair_pts, pair_hmax);
     return hipGetLastError();
 }
 

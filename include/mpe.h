@@ -197,7 +197,11 @@ int mpe_match_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
 /* 3D stage A: PoseEstimatorDataset dict branch (pose_estimator_dataset_from_json.py:237-298,
  * incl. get_3D_from_triangulation :63-101) + PoseEstimatorMLP + x10 decode
  * (metrics_from_model.py:243-294).
- *   d_poses [n_frames][Pcap][J][3] f32 metres, d_valid [n_frames][Pcap] 1 = person row kept */
+ *   d_poses [n_frames][Pcap][J][3] f32 metres, d_valid [n_frames][Pcap] 1 = person row kept
+ * Small batches (<= 8 frames): when mpe_match_batch has just run on the SAME batch arrays (same d_xy pointer, same head and edge-node
+ * counts), it has already solved every cross-camera skeleton pair of the batch beside its clustering launch, and the row kernel here
+ * fetches them instead of solving (same function, same arguments: same bits).  The arrays must not change in between -- which the
+ * call order of the pipeline implies anyway. */
 int mpe_mlp3d_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
                     const int32_t *d_persons, const int32_t *d_n_persons,
                     float *d_poses, uint8_t *d_valid);

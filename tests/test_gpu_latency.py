@@ -97,3 +97,26 @@ def test_small_batches_on_the_latency_launches_give_the_batch_paths_bits(engine,
     assert np.array_equal(lat[0][:m_tot], big[0][:m_tot]), np.abs(lat[0][:m_tot] - big[0][:m_tot]).max()
     for k in (1, 2, 3):
         assert np.array_equal(lat[k], big[k][:n_frames])
+
+
+def test_row_kernel_fetches_pairs_only_for_the_batch_they_were_solved_for(engine, calib, monkeypatch):
+    """mpe_match_batch of a small batch solves every cross-camera pair of that batch beside its clustering launch and tags the buffer
+    with the batch's arrays; mpe_mlp3d_batch fetches the pairs when it is handed the tagged batch and solves them itself otherwise.
+    Either way the poses are those of the route without any of this (MPE_LATENCY_PATH=0)."""
+    fa, fb = _frames(calib, 3, start=500), _frames(calib, 3, persons=(5, 3, 4), start=600)
+    monkeypatch.setenv('MPE_LATENCY_PATH', '0')
+    dba, dbb = engine.to_device(engine.pack(fa)), engine.to_device(engine.pack(fb))
+    want = {}
+    for name, db in (('a', dba), ('b', dbb)):
+        _, p, n = engine.match(db)
+        want[name] = (p.clone(), n.clone(), engine.mlp3d(db, p, n)[0].clone())
+    monkeypatch.delenv('MPE_LATENCY_PATH', raising=False)
+    _, pb, nb = engine.match(dbb)                      # tags one buffer with batch b
+    assert torch.equal(pb, want['b'][0]) and torch.equal(nb, want['b'][1])
+    _, pa, na = engine.match(dba)                      # tags the other with batch a
+    assert torch.equal(engine.mlp3d(dbb, pb, nb)[0], want['b'][2])          # fetched from b's buffer
+    assert torch.equal(engine.mlp3d(dba, pa, na)[0], want['a'][2])          # fetched from a's
+    engine.match(dba)
+    engine.match(dba)                                  # both buffers have held batch a since: b's tag is gone
+    assert torch.equal(engine.mlp3d(dbb, pb, nb)[0], want['b'][2])          # solved by the row kernel itself
+    engine.sync_status()
