@@ -163,19 +163,6 @@ bool latency_path_on() {
     return !(e && e[0] == '0');
 }
 
-// MPE_LATENCY_MLP=1: the MLP launches of small batches from the fp32 weights (lat.hip: k_linear_lat_f64).  Off by default: the
-// split of the weight fragments in registers costs what the 2 B per weight save
-bool latency_mlp_on() {
-    const char *e = getenv("MPE_LATENCY_MLP");
-    return latency_path_on() && e && e[0] == '1';
-}
-
-// MPE_MLP_CHAIN=0: the MLP of a batch of at most 16 rows as one launch per layer instead of ONE launch (lat.hip: k_mlp_chain)
-bool mlp_chain_on() {
-    const char *e = getenv("MPE_MLP_CHAIN");
-    return latency_path_on() && !(e && e[0] == '0');
-}
-
 unsigned short f32_to_bf16(float f);
 int ensure_bf16_weights(mpe_ctx *ctx, Linear *L);
 int ensure_split_weights(mpe_ctx *ctx, hipStream_t s, Linear *L);
@@ -394,14 +381,6 @@ int ensure_mlp_workspace(mpe_ctx *ctx) {
         dev_free(ctx, *p);
         *p = nullptr;
     }
-    for (int i = 0; i < 2; ++i) {
-        dev_free(ctx, ctx->mlp_pl[i]);
-        ctx->mlp_pl[i] = nullptr;
-        dev_free(ctx, ctx->mlp_chain_act[i]);
-        ctx->mlp_chain_act[i] = nullptr;
-    }
-    dev_free(ctx, ctx->mlp_chain_ctl);
-    ctx->mlp_chain_ctl = nullptr;
     if (ctx->mlp_layers <= 0) return fail(ctx, MPE_ERR_STATE, "MLP parameters not set");
     for (int l = 0; l < ctx->mlp_layers; ++l)
         if (!ctx->mlp_ready[l]) return fail(ctx, MPE_ERR_STATE, "MLP layer %d has no weights", l);
@@ -422,13 +401,6 @@ int ensure_mlp_workspace(mpe_ctx *ctx) {
     if ((rc = dev_alloc(ctx, &ctx->mlp_rows, rows * ctx->mlp_ld_in))) return rc;
     for (int i = 0; i < 2; ++i)
         if ((rc = dev_alloc(ctx, &ctx->mlp_act[i], rows * ctx->mlp_ld_hidden))) return rc;
-    ctx->mlp_chain_plane = (size_t)(ctx->mlp_ld_hidden / 16 + 1) * 256;
-    for (int i = 0; i < 2; ++i)
-        if ((rc = dev_alloc(ctx, &ctx->mlp_chain_act[i], 3 * ctx->mlp_chain_plane))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->mlp_chain_ctl, 64))) return rc;
-    ctx->mlp_pl_plane = (size_t)linear_lat_max_rows() * ctx->mlp_ld_hidden;
-    for (int i = 0; i < 2; ++i)
-        if ((rc = dev_alloc(ctx, &ctx->mlp_pl[i], 3 * ctx->mlp_pl_plane))) return rc;
     ctx->mlp_ws_ready = true;
     return MPE_OK;
 }
@@ -942,13 +914,6 @@ int mpe_linear(mpe_ctx *ctx, void *stream, const float *d_a, int32_t lda, const 
         HIPCHK(ctx, launch_linear_f64(static_cast<hipStream_t>(stream), d_a, lda, d_w, ldw, d_bias, d_c, ldc, m, d_m, n, ldw, (slope_on & 1) != 0, slope));
         return MPE_OK;
     }
-    if (slope_on & 64) {
-        // the small-batch (latency) form of the split-bf16 arithmetic with f64 sums (lat.hip): fp32 weights, split in registers
-        if (m > linear_lat_max_rows()) return fail(ctx, MPE_ERR_INVALID, "mpe_linear (latency form): at most %d rows", linear_lat_max_rows());
-        HIPCHK(ctx, launch_linear_lat_f64(static_cast<hipStream_t>(stream), d_a, lda, 0, d_w, ldw, d_bias, d_c, ldc, 0, m, d_m, n, ldw, (slope_on & 1) != 0, slope,
-                                          (slope_on & 16) ? 1 : 2));
-        return MPE_OK;
-    }
     if (slope_on & 4) {
         // split-bf16 arithmetic (gemm_sb16.hip) on caller-provided weights: the planes are made for this call (a stage-level
         // entry point for tests; the batch entry points keep theirs with the context)
@@ -1023,9 +988,6 @@ int mpe_sync_status(mpe_ctx *ctx, void *stream) {
     HIPCHK(ctx, hipMemcpyAsync(&st, ctx->d_status, sizeof st, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof st, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
-    if (st & 4)
-        return fail(ctx, MPE_ERR_HIP, "the one-launch MLP (k_mlp_chain) gave up waiting for a layer's tiles; its output is undefined "
-                    "(MPE_MLP_CHAIN=0 selects one launch per layer)");
     if (st & 2)
         return fail(ctx, MPE_ERR_INVALID, "an explicit edge-node list held a pair outside its frame (or h1 == h2), or repeated pairs "
                     "beyond the in-degree capacity 2 * max_heads_per_frame; such pairs were replaced / dropped");
@@ -1206,42 +1168,6 @@ static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int 
     const float *in = x;
     int ld_in = ld_x;
     int rc;
-    if (ctx->mlp_split && !ctx->mlp_f64mm && mlp_chain_on() && m <= 16) {
-        // at most 16 rows (one frame): the whole chain in one launch
-        const int nl = ctx->mlp_layers;
-        const unsigned short *W3[MPE_MAX_MLP_LAYERS];
-        size_t wpl[MPE_MAX_MLP_LAYERS];
-        int ldw[MPE_MAX_MLP_LAYERS], nn[MPE_MAX_MLP_LAYERS];
-        const float *bias[MPE_MAX_MLP_LAYERS];
-        for (int l = 0; l < nl; ++l) {
-            ldw[l] = ctx->mlp[l].ldw;
-            nn[l] = ctx->mlp[l].out_dim;
-        }
-        if (mlp_chain_available(nl, ldw, nn, m) && ld_x >= ldw[0]) {
-            for (int l = 0; l < nl; ++l) {
-                if ((rc = ensure_split_weights(ctx, s, &ctx->mlp[l]))) return rc;
-                W3[l] = ctx->mlp[l].w3;
-                wpl[l] = (size_t)weight_rows(ctx->mlp[l].out_dim) * ctx->mlp[l].ldw;
-                bias[l] = ctx->mlp[l].b;
-            }
-            static int n_cu = 0;
-            if (!n_cu) {
-                int c = 256;
-                (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, ctx->device);
-                n_cu = c > 0 ? c : 256;
-            }
-            double flop = 0;
-            for (int l = 0; l < nl; ++l) flop += 2.0 * (double)nn[l] * ctx->mlp[l].in_dim;
-            GemmProf gp(ctx, s, d_m ? 0.0 : flop * m, 0, 0, 1);
-            float *y = ctx->mlp_act[0];
-            HIPCHK(ctx, launch_mlp_chain(s, nl, W3, wpl, ldw, bias, nn, x, ld_x, ctx->mlp_chain_act[0], ctx->mlp_chain_act[1], ctx->mlp_chain_plane,
-                                         ctx->mlp_chain_ctl, ctx->d_status, m, d_m, ctx->mlp_slope, y, ctx->mlp_ld_hidden, dec, ctx->mlp_flush, n_cu));
-            if (dec && dec_done) *dec_done = true;
-            *y_out = y;
-            *ld_y = ctx->mlp_ld_hidden;
-            return MPE_OK;
-        }
-    }
     for (int l = 0; l < ctx->mlp_layers; ++l) {
         float *out = ctx->mlp_act[l & 1];
         const bool last = l == ctx->mlp_layers - 1;
@@ -1250,16 +1176,6 @@ static int mlp_chain(mpe_ctx *ctx, hipStream_t s, const float *x, int ld_x, int 
             if (ld_in < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", ld_in, L.ldw);
             GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0, 3);
             HIPCHK(ctx, launch_linear_f64(s, in, ld_in, L.w, L.ldw, L.b, out, ctx->mlp_ld_hidden, m, d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope));
-        } else if (ctx->mlp_split && latency_mlp_on() && m <= linear_lat_max_rows()) {
-            // small batches: the same arithmetic from the fp32 weights, every fragment of a wave in flight at once (lat.hip)
-            Linear &L = ctx->mlp[l];
-            if (ld_in < L.ldw) return fail(ctx, MPE_ERR_INVALID, "activation stride %d < padded K %d", ld_in, L.ldw);
-            GemmProf gp(ctx, s, d_m ? 0.0 : 2.0 * m * (double)L.out_dim * L.in_dim, d_m ? L.out_dim : 0, d_m ? L.in_dim : 0, 1);
-            // fp32 rows in, three bf16 planes between the layers (split once by the producer instead of by every consumer), fp32 rows out
-            const void *a_in = l == 0 ? static_cast<const void *>(in) : ctx->mlp_pl[(l - 1) & 1];
-            void *c_out = last ? static_cast<void *>(out) : ctx->mlp_pl[l & 1];
-            HIPCHK(ctx, launch_linear_lat_f64(s, a_in, l == 0 ? ld_in : ctx->mlp_ld_hidden, ctx->mlp_pl_plane, L.w, L.ldw, L.b, c_out, ctx->mlp_ld_hidden,
-                                              ctx->mlp_pl_plane, m, d_m, L.out_dim, L.ldw, !last, ctx->mlp_slope, ctx->mlp_flush, l > 0, !last));
         } else if (ctx->mlp_split) {
             Linear &L = ctx->mlp[l];
             if ((rc = ensure_split_weights(ctx, s, &L))) return rc;

@@ -141,11 +141,6 @@ struct mpe_ctx {
     int mlp_ld_in = 0, mlp_ld_hidden = 0;
     float *mlp_rows = nullptr;     // [max_frames*Pcap][mlp_ld_in]
     float *mlp_act[2] = {nullptr, nullptr};
-    unsigned short *mlp_pl[2] = {nullptr, nullptr};   // small batches (lat.hip): activations between the layers as three bf16 planes [3][lat rows][mlp_ld_hidden]
-    size_t mlp_pl_plane = 0;       // plane stride in elements
-    unsigned short *mlp_chain_act[2] = {nullptr, nullptr};   // k_mlp_chain: activations between the layers, [3 planes][tiles][16][16] bf16
-    size_t mlp_chain_plane = 0;
-    int32_t *mlp_chain_ctl = nullptr;                        // its ticket / done counters (zero between launches)
     int32_t *mlp_count = nullptr;
     float *scores_tmp = nullptr;    // [max_edge_nodes]
     int32_t *person_off = nullptr;  // [max_frames+1]
@@ -186,9 +181,7 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
                               int flush_stages = 2,       // f64 launches: K stages per f64 flush (2 = default, 1 = the maximum-accuracy mode)
                               const DecodeEpi *dec = nullptr, bool *dec_done = nullptr);   // the K-split kernel can also store the decoded poses (*dec_done says whether it did)
 bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64);
-// lat.hip: the small-batch ("latency") forms -- the arithmetic of the split-bf16 kernels (same bits), shortest serial depth:
-// fp32 weights streamed once and split in registers, every weight fragment of a wave requested before its first product
-int linear_lat_max_rows();
+// lat.hip: the small-batch ("latency") forms -- the arithmetic of the split-bf16 kernels (same bits), shortest serial depth
 bool lat_gemm_available(int k_pad, int n, bool fc2, int out_dim);
 hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
                            const float *bias, float *C, int ldc, unsigned short *Cpl, int ldcp, size_t c_plane, int m, int n, int k_pad, bool fc2,
@@ -197,15 +190,6 @@ bool lat_gemm_fusable(int k1_pad, int n1, int k2_pad, int n2, int out_dim2);
 hipError_t launch_lat_gemm_fused(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
                                  const float *bias, int m, int n, float slope, const unsigned short *W3b, size_t w_plane_b, int ldw_b, const float *bias_b,
                                  float *C2, int ldc2, const float *attn_l, const float *attn_r, float *a12);
-// lat.hip: the whole MLP of a small batch (at most 16 rows) in one launch (k_mlp_chain)
-bool mlp_chain_available(int n_layers, const int *k_pad, const int *n, int m_cap);
-hipError_t launch_mlp_chain(hipStream_t s, int n_layers, const unsigned short *const *W3, const size_t *w_plane, const int *ldw, const float *const *bias,
-                            const int *n, const float *A0, int lda0, unsigned short *act0, unsigned short *act1, size_t act_plane, int32_t *ctl,
-                            int32_t *status, int m_cap, const int32_t *d_m, float slope, float *y, int ldy, const DecodeEpi *dec, int flush_stages,
-                            int n_workgroups);
-hipError_t launch_linear_lat_f64(hipStream_t s, const void *A, int lda, size_t a_plane, const float *W, int ldw, const float *bias, void *C,
-                                 int ldc, size_t c_plane, int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky, float slope,
-                                 int flush_stages, bool a_planes = false, bool c_planes = false);
 // gemm_f64.hip: exact products, f64 accumulation on the f64 matrix pipe (MLP mode 5: the f64-evaluated network, not the fast path; the slope rule is in include/mpe.h)
 hipError_t launch_linear_f64(hipStream_t s, const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc,
                              int m_cap, const int32_t *d_m, int n, int k_pad, bool leaky, float slope);

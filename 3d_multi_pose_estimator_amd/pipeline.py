@@ -856,7 +856,7 @@ class Engine:
         for e in self._siblings:
             e.set_precision(gat_acc64, mlp_acc64, mlp_bf16, gat_reduced, attn_fp16, mlp_split, gat_split, mlp_max_accuracy, mlp_f64)
 
-    def linear(self, x, w, b, slope=None, acc64=False, split=False, split_f64=True, split_flush_per_stage=False, f64mm=False, lat=False):
+    def linear(self, x, w, b, slope=None, acc64=False, split=False, split_f64=True, split_flush_per_stage=False, f64mm=False):
         """act(x @ w.T + b) through the MFMA GEMM (parity tests). x device [m,k]; w,b host.  split: the split-bf16
         arithmetic of csrc/gemm_sb16.hip."""
         w = _np32(w)
@@ -872,7 +872,7 @@ class Engine:
             ldc = (n + 3) // 4 * 4
             y = torch.empty((m, ldc), dtype=torch.float32, device=self.device)
             self._chk(self.lib.mpe_linear(self.ctx, self._stream(), _ptr(xp), ldw.value, dw, ldw.value, dbias,
-                                          _ptr(y), ldc, m, None, n, k, (0 if slope is None else 1) | (2 if acc64 else 0) | (4 if split else 0) | (0 if split_f64 else 8) | (16 if split_flush_per_stage else 0) | (32 if f64mm else 0) | (64 if lat else 0),
+                                          _ptr(y), ldc, m, None, n, k, (0 if slope is None else 1) | (2 if acc64 else 0) | (4 if split else 0) | (0 if split_f64 else 8) | (16 if split_flush_per_stage else 0) | (32 if f64mm else 0),
                                           0.0 if slope is None else float(slope)))
             torch.cuda.synchronize(self.device)
             return y[:, :n].contiguous()

@@ -129,13 +129,13 @@ typedef struct {
  *     MPE_LATENCY_PATH=0          (per call) batches of at most 8 frames through the batch path's own small-batch kernels instead of the
  *                                 latency launches of csrc/lat.hip / gat.hip (k_lat_l0a, k_lat_gemm, k_lat_attention; persons' prefix and
  *                                 decode folded into their neighbours): same bits either way (tests/test_gpu_latency.py)
- *     MPE_LATENCY_MLP=1           (per call) the MLP launches of such batches from the fp32 weights, split in registers (k_linear_lat_f64):
- *                                 same bits; measured slower than the plane kernels, kept as the record of that experiment
  *   host packer (threads, timing prints): MPE_PACK_THREADS, MPE_SCAN_THREADS, MPE_SCAN_CHUNK_KB, MPE_PACK_NO_SIMD, MPE_PACK_TIMING,
  *     MPE_STAGE_TIMING
  * Gone since round 5 (their code left the library): MPE_GEMM_TUNE, MPE_GEMM_BN, MPE_GEMM_LOADER, MPE_SB_GAT_MW, MPE_SB_PERS,
  * MPE_SB_LDS_PAD, and the compile-time ablation switches MPE_EXP / MPE_SBEXP.  `make exp EXPFLAGS=-DMPE_SB_CLOCK` builds the one
- * diagnostic variant left: in-kernel clock stamps of the split-bf16 tile kernel (tools/sb_clock_probe.py). */
+ * diagnostic variant left: in-kernel clock stamps of the split-bf16 tile kernel (tools/sb_clock_probe.py).
+ * Round 6 built and removed two experiments with their switches (MPE_LATENCY_MLP, MPE_MLP_CHAIN, mpe_linear flag bit 6): the records are
+ * profiles/r06_mlp_fp32_weights_experiment.txt and profiles/r06_mlp_chain_experiment.txt, the code is in commit 102284c. */
 
 /* ---- lifetime ------------------------------------------------------------------------ */
 int mpe_create(const mpe_config *cfg, mpe_ctx **out);
@@ -223,8 +223,7 @@ int mpe_triangulate_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
  * mpe_upload_linear (zero padded).  d_m, if not NULL, overrides M with a device-side count.
  * flags: bit 0 = apply LeakyReLU(slope), bit 1 = f64 running sums (see mpe_set_precision), bit 2 = the split-bf16 form
  * (csrc/gemm_sb16.hip; the planes are made for the call), with bit 3 = without its f64 sums and bit 4 = an f64 flush per K stage;
- * bit 5 = the f64 matrix-pipe form (csrc/gemm_f64.hip); bit 6 = the small-batch (latency) form of the split-bf16 arithmetic with f64
- * sums (csrc/lat.hip: same bits as bit 2, at most 128 rows; bit 4 selects the flush per stage here too). */
+ * bit 5 = the f64 matrix-pipe form (csrc/gemm_f64.hip). */
 int mpe_upload_linear(mpe_ctx *ctx, const float *w, const float *b, int32_t out_dim, int32_t in_dim,
                       float **d_w, float **d_b, int32_t *ldw);
 int mpe_free_device(mpe_ctx *ctx, void *d_ptr);

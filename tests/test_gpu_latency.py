@@ -20,25 +20,9 @@ def engine(calib, gat_weights, mlp_weights):
     eng.close()
 
 
-@pytest.mark.parametrize('k,n,slope', [(1260, 3072, 0.1), (3072, 2048, 0.1), (1024, 54, None), (902, 400, None), (6016, 64, 0.1), (96, 48, 0.1)])
-def test_latency_linear_gives_the_tile_kernels_bits(engine, k, n, slope):
-    """k_linear_lat_f64 (fp32 weights split in registers, all fragments of a wave requested at once, units dealt to eight waves,
-    ordered f64 reduction) against k_linear_sb (three bf16 planes, 256-row tiles): identical rows at 1 ... 128 rows, in both flush
-    cadences; K = 6016 runs two rounds per workgroup (four with a flush per stage), K = 902 has an odd stage count."""
-    g = torch.Generator().manual_seed(k * 7 + n)
-    x = torch.randn(3000, k, generator=g)
-    w = (torch.randn(n, k, generator=g) / np.sqrt(k)).numpy()
-    b = torch.randn(n, generator=g).numpy()
-    for per_stage in (False, True):
-        big = engine.linear(x.cuda(), w, b, slope, split=True, split_flush_per_stage=per_stage).cpu()
-        for m in (1, 4, 16, 17, 40, 128):
-            small = engine.linear(x[:m].cuda(), w, b, slope, lat=True, split_flush_per_stage=per_stage).cpu()
-            assert torch.equal(small, big[:m]), (per_stage, m, (small - big[:m]).abs().max().item())
-
-
-def test_mlp_small_batches_take_the_latency_kernels_and_keep_their_bits(engine, mlp_weights, monkeypatch):
-    """mpe_mlp_forward routes batches of at most 128 rows to lat.hip: same rows as in a batch of 1600 (tile kernels) and as with the
-    route switched off, in the default and in the maximum-accuracy mode."""
+def test_mlp_small_batches_keep_their_bits_on_either_route(engine, mlp_weights, monkeypatch):
+    """mpe_mlp_forward at 1 ... 128 rows (the K-split plane kernel k_linear_sb_ks): same rows as in a batch of 1600 (tile kernels),
+    with the small-batch route on and off, in the default and in the maximum-accuracy mode."""
     g = torch.Generator().manual_seed(5)
     x = torch.randn(1600, 1260, generator=g) * 0.3            # (the engine holds 64 frames x 25 persons)
     try:
