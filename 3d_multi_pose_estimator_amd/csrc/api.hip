@@ -760,6 +760,7 @@ int mpe_create(const mpe_config *cfg, mpe_ctx **out) {
     do {
         if ((rc = dev_alloc(ctx, &ctx->d_cfg, 1))) break;
         if ((rc = dev_alloc(ctx, &ctx->d_status, 1))) break;
+        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { rc = MPE_ERR_NOMEM; break; }
         if (hipMemcpy(ctx->d_cfg, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) { rc = MPE_ERR_HIP; break; }
         if ((rc = dev_alloc(ctx, &ctx->head_frame, (size_t)cfg->max_heads))) break;
         if ((rc = dev_alloc(ctx, &ctx->en_frame, (size_t)cfg->max_edge_nodes))) break;
@@ -799,6 +800,7 @@ void mpe_destroy(mpe_ctx *ctx) {
     DeviceGuard dg(ctx);
     (void)hipDeviceSynchronize();
     for (void *p : ctx->owned) (void)hipFree(p);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (auto &r : ctx->prof) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
@@ -980,14 +982,7 @@ int mpe_set_gat_output(mpe_ctx *ctx, int32_t mode) {
     return MPE_OK;
 }
 
-int mpe_sync_status(mpe_ctx *ctx, void *stream) {
-    if (!ctx) return MPE_ERR_INVALID;
-    DeviceGuard dg(ctx);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    int32_t st = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&st, ctx->d_status, sizeof st, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof st, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
+static int report_status(mpe_ctx *ctx, int32_t st) {
     if (st & 2)
         return fail(ctx, MPE_ERR_INVALID, "an explicit edge-node list held a pair outside its frame (or h1 == h2), or repeated pairs "
                     "beyond the in-degree capacity 2 * max_heads_per_frame; such pairs were replaced / dropped");
@@ -995,6 +990,42 @@ int mpe_sync_status(mpe_ctx *ctx, void *stream) {
         return fail(ctx, MPE_ERR_CAPACITY, "a frame holds more than max_heads_per_frame = %d skeletons (or, with an explicit edge-node list, more "
                     "than %d edge-nodes); its scores are zero and it produced no persons", ctx->cfg.max_heads_per_frame, ctx->x_m_cap);
     return MPE_OK;
+}
+
+// mpe_sync_status in two halves, for a caller that has more to do before it waits (the per-frame mirrors: the read-back of the status
+// word joins the chain it belongs to instead of starting a chain of its own after the wait): mpe_status_queue orders the read-back and
+// the reset behind everything queued so far, mpe_status_wait synchronises and reports it.
+int mpe_status_queue(mpe_ctx *ctx, void *stream) {
+    if (!ctx) return MPE_ERR_INVALID;
+    DeviceGuard dg(ctx);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ctx->status_queued) {                       // an earlier half nobody waited for: its word must not be lost
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        ctx->status_carry |= *ctx->h_status;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t), s));
+    ctx->status_queued = true;
+    return MPE_OK;
+}
+
+int mpe_status_wait(mpe_ctx *ctx, void *stream) {
+    if (!ctx) return MPE_ERR_INVALID;
+    if (!ctx->status_queued) {
+        const int rc = mpe_status_queue(ctx, stream);
+        if (rc) return rc;
+    }
+    DeviceGuard dg(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    ctx->status_queued = false;
+    const int32_t st = *ctx->h_status | ctx->status_carry;
+    ctx->status_carry = 0;
+    return report_status(ctx, st);
+}
+
+int mpe_sync_status(mpe_ctx *ctx, void *stream) {
+    const int rc = mpe_status_queue(ctx, stream);
+    return rc ? rc : mpe_status_wait(ctx, stream);
 }
 
 static int stage_layer_checks(mpe_ctx *ctx, const mpe_batch *b, int32_t layer, const void *in, int32_t ld_in, int cols_in,

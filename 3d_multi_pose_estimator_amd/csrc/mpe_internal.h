@@ -71,6 +71,9 @@ struct ProfileRec {
 struct mpe_ctx {
     mpe_config cfg;
     int device = 0;                // HIP device the context was created on (every entry point switches to it)
+    int32_t *h_status = nullptr;   // page-locked twin of the status word (mpe_sync_status reads it back without a staging copy)
+    bool status_queued = false;    // mpe_status_queue has ordered a read-back nobody has waited for yet
+    int32_t status_carry = 0;      // bits of read-backs that were overtaken by a later mpe_status_queue
     int32_t *d_status = nullptr;   // device-side status word: bit 0 = a frame exceeded max_heads_per_frame
     bool gat_ws_ready = false;     // set only after the LAST step of ensure_gat_workspace succeeded
     bool mlp_ws_ready = false;

@@ -55,6 +55,7 @@ struct FrameOut {                    // compact per-frame result (J values per h
     std::vector<double> xy;          // [heads][J][2]
     std::vector<float> vp;           // [heads][J][2]
     std::vector<int32_t> slot_cam, slot_n;
+    std::vector<int32_t> extent;     // optional (mpe_pack_views_into): [heads][2] byte offsets of each skeleton object in its camera text
     std::string error;
 };
 
@@ -412,7 +413,7 @@ bool parse_skeleton(Cursor &c, int J, Head *h, std::string *err) {
 
 // the camera entry's first element: a JSON string holding the skeleton list (or, leniently,
 // the list itself)
-bool parse_skeleton_list(Cursor &c, int J, int cam, FrameOut *fo, int *n_here) {
+bool parse_skeleton_list(Cursor &c, int J, int cam, FrameOut *fo, int *n_here, const char *extent_base = nullptr) {
     skip_ws(c);
     Cursor in = c;
     bool quoted = false;
@@ -435,8 +436,14 @@ bool parse_skeleton_list(Cursor &c, int J, int cam, FrameOut *fo, int *n_here) {
             Head h;
             h.cam = cam;
             h.skeleton_index = idx++;
+            skip_ws(in);
+            const char *sk_begin = in.p;
             if (!parse_skeleton(in, J, &h, &fo->error)) return false;
             if (h.joint_mask) {
+                if (extent_base) {
+                    fo->extent.push_back((int32_t)(sk_begin - extent_base));
+                    fo->extent.push_back((int32_t)(in.p - extent_base));
+                }
                 fo->heads.push_back({h.cam, h.joint_mask, h.tri_mask, h.skeleton_index});
                 for (int j = 0; j < J; ++j) {
                     fo->xy.push_back(h.xy[j][0]);
@@ -1203,6 +1210,57 @@ int mpe_pack_json_into(const char *json, size_t len, const char *const *camera_n
     *n_frames = (int32_t)fo.size();
     *n_heads = (int32_t)H;
     *n_edge_nodes = dst->frame_en_off[fo.size()];
+    return MPE_OK;
+}
+
+// One frame as the reference's per-frame callers hold it (test/metrics_from_model.py:182-199: a dict camera -> [text of the skeleton
+// list, timestamp]): the camera texts themselves, no outer document -- the one-frame-per-call mirrors no longer serialise the frame
+// again just to have it parsed.  Same grammar, same head order and same numbers as parse_frame gives for the same texts.
+int mpe_pack_views_into(const char *const *texts, const size_t *lens, const int32_t *cams, int32_t n_views, int32_t n_cameras,
+                        int32_t n_joints, const mpe_pack_dst *dst, int32_t *n_heads, int32_t *n_edge_nodes, int32_t *extents) {
+    if (!dst || !n_heads || !n_edge_nodes || !dst->frame_head_off || !dst->frame_en_off || !dst->slot_cam || !dst->slot_n ||
+        !dst->head_cam || !dst->skeleton_index || !dst->joint_mask || !dst->tri_mask || !dst->xy || !dst->vp || dst->max_frames < 1 ||
+        dst->max_heads < 1 || n_views < 0 || (n_views > 0 && (!texts || !lens || !cams)) || n_cameras < 1 || n_cameras > MPE_MAX_CAMERAS ||
+        n_views > n_cameras || n_joints < 1 || n_joints > MPE_MAX_JOINTS) {
+        g_pack_error = "mpe_pack_views_into: bad argument";
+        return MPE_ERR_INVALID;
+    }
+    std::vector<FrameOut> fo(1);
+    FrameOut &f = fo[0];
+    f.heads.reserve(32);
+    f.xy.reserve((size_t)32 * n_joints * 2);
+    f.vp.reserve((size_t)32 * n_joints * 2);
+    for (int i = 0; i < n_views; ++i) {
+        if (cams[i] < 0 || cams[i] >= n_cameras || !texts[i]) {
+            g_pack_error = "mpe_pack_views_into: bad camera index";
+            return MPE_ERR_INVALID;
+        }
+        Cursor c{texts[i], texts[i] + lens[i], false};
+        skip_ws(c);
+        int n_here = 0;
+        if (c.p < c.end && *c.p == '"') f.error = "skeleton list expected";       // (a string inside the string: not what json.loads would turn into a list)
+        if (!f.error.empty() || !parse_skeleton_list(c, n_joints, cams[i], &f, &n_here, extents ? texts[i] : nullptr)) {
+            g_pack_error = "view " + std::to_string(i) + ": " + f.error;
+            return MPE_ERR_INVALID;
+        }
+        skip_ws(c);
+        if (c.p != c.end) {
+            g_pack_error = "view " + std::to_string(i) + ": text behind the skeleton list";
+            return MPE_ERR_INVALID;
+        }
+        f.slot_cam.push_back(cams[i]);
+        f.slot_n.push_back(n_here);
+    }
+    const size_t H = f.heads.size();
+    if (H > (size_t)dst->max_heads) {
+        g_pack_error = "mpe_pack_views_into: " + std::to_string(H) + " skeletons exceed the destination's max_heads = " + std::to_string(dst->max_heads);
+        return MPE_ERR_CAPACITY;
+    }
+    assemble(fo, n_cameras, n_joints, dst->frame_head_off, dst->frame_en_off, dst->slot_cam, dst->slot_n, dst->head_cam, dst->skeleton_index,
+             dst->joint_mask, dst->tri_mask, dst->xy, dst->vp);
+    if (extents && !f.extent.empty()) memcpy(extents, f.extent.data(), f.extent.size() * sizeof(int32_t));
+    *n_heads = (int32_t)H;
+    *n_edge_nodes = dst->frame_en_off[1];
     return MPE_OK;
 }
 

@@ -102,7 +102,23 @@ class GAT2(nn.Module):
             # re-derived on the device from the packed skeletons instead
             if not (own is not None and inputs.shape == own.shape and torch.equal(inputs.to(own.device).float(), own)):
                 feats = inputs
+        one = getattr(g, 'batch_size', 1) == 1
+        if one and feats is None and runtime.prefetch_enabled():
+            fs = runtime.queued_scores(g, eng, self.final_activation is not None)
+            if fs is not None:           # this engine already scored the frame when the dataset was built (runtime.start_frame)
+                g._ahead = fs.ahead
+                return fs.out
         eng.set_gat_output(sigmoid=self.final_activation is not None)     # None: raw logits (gat2.py:146-148)
+        if one and db.n_edge_nodes > 0 and getattr(g.packed, 'en_pair', None) is None:
+            out, sc = eng.gat_scores_joined(db, feats=feats)
+            out = out.reshape(-1, 1, 1)
+            # the reference's caller clusters these scores next and builds one MLP row per person (metrics_from_model.py:214-277):
+            # both are queued behind the scores now (runtime.queue_proposals) and used only if the caller does exactly that
+            g._ahead = None
+            if runtime.prefetch_enabled():
+                g._ahead = runtime.queue_proposals(eng, db, sc, out)
+                runtime.note_matcher(eng)
+            return out
         sc, sh = eng.gat_scores(db, heads=True, feats=feats)
         # A graph beyond the engine's per-frame capacity must raise instead of scoring 0.  For the implicit topology of a packed
         # frame that was decided on the host (FrameGraph.device_batch -> Engine.check_capacity raises before anything is
@@ -110,7 +126,7 @@ class GAT2(nn.Module):
         # -- needs the status word, i.e. a stream synchronisation (0.2 ms per frame in the one-frame-per-call loop).
         if getattr(g.packed, 'en_pair', None) is not None or getattr(g, 'batch_size', 1) != 1:
             eng.sync_status()
-        if getattr(g, 'batch_size', 1) == 1:
+        if one:
             return torch.cat([sh, sc]).reshape(-1, 1, 1)
         # a batch of graphs (graph_generator.batch = the reference's dgl.batch): node order graph by graph, heads then edge-nodes
         parts, h0, e0 = [], 0, 0

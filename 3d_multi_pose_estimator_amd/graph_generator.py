@@ -91,6 +91,7 @@ class FrameGraph:
         self.packed = packed                 # PackedBatch, one frame per graph
         self.params = params
         self._dev = {}
+        self._fits = set()
         self.ndata = _NData(self)
         self.edata = {}
         self.batch_size = packed.n_frames
@@ -138,11 +139,15 @@ class FrameGraph:
     def device_batch(self, engine):
         """The graph's arrays on the engine's device: uploaded once per device (the GAT2 / clustering / dataset mirrors
         each own an engine), capacity checked per engine."""
-        engine.check_capacity(self.packed)
-        key = str(engine.device)
-        if key not in self._dev:
-            self._dev[key] = self.packed.to(engine.device)
-        return self._dev[key]
+        cap = (engine.max_frames, engine.hpf, engine.V, engine.J, engine.m_frame)
+        if cap not in self._fits:                # (per capacity, not per call: three engines see every frame of the per-frame loop)
+            engine.check_capacity(self.packed)
+            self._fits.add(cap)
+        key = engine.device
+        dev = self._dev.get(key)
+        if dev is None:
+            dev = self._dev[key] = self.packed.to(key)
+        return dev
 
     def _dense_features(self):
         """graph.ndata['h']: the dense N x F rows (reference :444-508, 629-631), assembled ON THE DEVICE from the featurisation
@@ -207,20 +212,31 @@ class _LazyHeadJsons(dict):
         be cut safely (then the caller's string is rebuilt with json.dumps)."""
         if not hasattr(self, '_texts'):
             self._texts = {}
-            sm = list(parameters.used_cameras_skeleton_matching)
+            sm = parameters.used_cameras_skeleton_matching
             pb = self._packed
             k = 0
-            for s in range(pb.slot_cam.shape[1]):
-                c, n = int(pb.slot_cam[0, s]), int(pb.slot_n[0, s])
+            index_of = pb.skeleton_index.tolist()
+            ext = getattr(pb, 'skeleton_extent', None)
+            ext = ext.tolist() if ext is not None else None
+            for c, n in zip(pb.slot_cam[0].tolist(), pb.slot_n[0].tolist()):
                 if c < 0 or n == 0:
                     continue
                 text = self._frame[sm[c]][0]
+                if ext is not None:
+                    # the native packer's byte extents of the skeleton objects: a slice of the caller's own text.  Whether that slice is
+                    # what json.dumps([jsons_for_head[h]]) writes is for the comparison in runtime._RecentRows to find out -- a key that
+                    # differs is a miss (the dataset computes the row itself), never a wrong row
+                    for _ in range(n):
+                        a, b = ext[k]
+                        self._texts[k] = '[' + text[a:b] + ']'
+                        k += 1
+                    continue
                 pieces = None
                 # skeleton dicts hold lists of numbers only (no nested dict): '}, {' separates them; an "ID" member may hold anything
                 if text.startswith('[{') and text.endswith('}]') and '"ID"' not in text and '\\' not in text:
                     pieces = text[2:-2].split('}, {')
                 for _ in range(n):
-                    i = int(pb.skeleton_index[k])
+                    i = index_of[k]
                     self._texts[k] = '[{' + pieces[i] + '}]' if pieces is not None and i < len(pieces) else None
                     k += 1
         return self._texts.get(h)
@@ -257,17 +273,17 @@ class _LazyHeadJsons(dict):
 
 
 def _pack_one(frame):
-    """One frame dict -> PackedBatch through the native packer (csrc/packer.cpp: the Python loops over 20 skeletons x 18
-    joints cost more than the frame's kernels); frames it declines (keys outside the configured joints, non-string
-    entries, ...) go through the Python packer, which defines the accepted language and the error messages."""
+    """One frame dict -> PackedBatch through the native packer (csrc/packer.cpp, mpe_pack_views_into: the camera texts as the
+    caller holds them -- the Python loops over 20 skeletons x 18 joints cost more than the frame's kernels, and so did
+    serialising the frame into a document for mpe_pack_json); frames it declines (keys outside the configured joints,
+    non-string entries, more skeletons than the engines hold, ...) go through the Python packer, which defines the accepted
+    language and the error messages."""
     try:
-        from .packing import pack_json
-        if all(isinstance(frame[c][0], str) for c in frame):
-            pb = pack_json(json.dumps([frame]), parameters, n_threads=1)
-            if pb.n_frames == 1:
-                pb.jsons_for_head = [_LazyHeadJsons(frame, pb)]
-                return pb
-    except (ValueError, ImportError, TypeError, KeyError):
+        from .packing import pack_views
+        pb = pack_views(frame, parameters, len(parameters.used_cameras_skeleton_matching) * runtime.max_persons_per_camera())
+        pb.jsons_for_head = [_LazyHeadJsons(frame, pb)]
+        return pb
+    except (ValueError, ImportError, TypeError, KeyError, AttributeError, IndexError):
         pass
     return pack_frames([frame], parameters, keep_json=True)
 
@@ -348,6 +364,8 @@ class MergedMultipleHumansDataset:
                 self.labels.append(torch.zeros((M, 1), dtype=torch.float64))
                 self.data['edge_nodes_indices'].append(torch.arange(H, H + M, dtype=torch.int64).unsqueeze(1))
                 self.data['nodes_camera'].append([sm[int(c)] for c in packed.head_cam] + [''] * M)
+                if iterate_over is self.inputs:           # one frame dict (the per-frame loop of metrics_from_model.py:178-209): its scores are wanted next
+                    runtime.start_frame(self.graphs[-1])
 
     def sample_scenes(self):
         """The generator of process_training (reference :674-693): per scene `random.randint(1, n_files)` people, taken

@@ -65,11 +65,14 @@ class MirrorCalls:
     """Every call into the package goes through here: host seconds inside the mirrors, optionally the sequence of calls."""
     seconds: float = 0.0
     trace: list = None
+    by_symbol: dict = field(default_factory=dict)
 
     def __call__(self, name, fn, *args, **kwargs):
         t0 = time.perf_counter()
         out = fn(*args, **kwargs)
-        self.seconds += time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        self.seconds += dt
+        self.by_symbol[name] = self.by_symbol.get(name, 0.0) + dt
         if self.trace is not None and not name.startswith('graph.'):      # (attribute reads of the graph object are not calls of the script)
             self.trace.append([name, [_describe(a) for a in args], {k: _describe(v) for k, v in sorted(kwargs.items())}])
         return out
@@ -154,6 +157,7 @@ def run(frames, matcher, lifter, warmup=3, device=None, trace=None):
         if index == warmup:                                  # everything before is warm-up: clocks start here
             torch.cuda.synchronize()
             calls.seconds = 0.0
+            calls.by_symbol = {}
             clk = Clocks()
         if trace is not None:
             calls.trace = []
@@ -183,4 +187,5 @@ def run(frames, matcher, lifter, warmup=3, device=None, trace=None):
             # host time inside the package's symbols per frame; the remainder is the caller's own Python (decoding and encoding
             # every camera list and every person, tensor reshapes, waiting for the MLP kernels in .to('cpu'), numpy boxing)
             'inside_mirrors_ms': 1e3 * calls.seconds / n,
+            'inside_mirrors_by_symbol_ms': {k: round(1e3 * v / n, 4) for k, v in calls.by_symbol.items()},
             'reference_readme_ms': README_MS, 'last': last}

@@ -107,6 +107,8 @@ SYMBOLS = {
     'mpe_edge_softmax_aggregate': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_int32, C.c_void_p,
                                              C.c_int32, C.c_void_p, C.c_int32]),
     'mpe_sync_status': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mpe_status_queue': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mpe_status_wait': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mpe_set_threshold': (C.c_int, [C.c_void_p, C.c_float]),
     'mpe_cluster_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(mpe_batch), C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
@@ -120,6 +122,8 @@ SYMBOLS = {
     'mpe_pack_json_into': (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.POINTER(mpe_pack_dst), C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'mpe_pack_views_into': (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(mpe_pack_dst), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
     'mpe_json_index_create': (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     'mpe_json_index_free': (None, [C.c_void_p]),
     'mpe_pack_indexed_into': (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -298,6 +298,102 @@ def pack_json_into(text, params, arena, frame_start=0, frame_step=1, max_frames=
     return pb
 
 
+class _ViewPacker:
+    """Per-thread ctypes state of `pack_views` (argument arrays, destination struct, array offsets of a one-frame layout): built once
+    per (cameras, joints, capacity)."""
+
+    def __init__(self, sm, J, max_heads):
+        import ctypes as C
+
+        from . import lib as L
+        self.lib = L.load()
+        self.sm, self.V, self.J, self.max_heads = list(sm), len(sm), J, int(max_heads)
+        self.cam_index = {c: i for i, c in enumerate(self.sm)}
+        V = self.V
+        self.texts, self.lens, self.cams = (C.c_char_p * V)(), (C.c_size_t * V)(), (C.c_int32 * V)()
+        self.dst = L.mpe_pack_dst()
+        self.dst.max_frames, self.dst.max_heads = 1, self.max_heads
+        self.nh, self.ne = C.c_int32(), C.c_int32()
+        self.p_dst, self.p_nh, self.p_ne = C.byref(self.dst), C.byref(self.nh), C.byref(self.ne)
+        count = {'F1': 2, 'FV': V, 'H': self.max_heads, 'HJ2': self.max_heads * J * 2}
+        self.offsets, off = [], 0
+        for name, dt, kind in CapacityArena.FIELDS:
+            self.offsets.append((name, off, np.dtype(dt), kind))
+            off += (count[kind] * np.dtype(dt).itemsize + 255) // 256 * 256
+        self.nbytes = off
+        self.void_p = C.c_void_p
+        self.pin = None
+
+
+_view_packers = None
+
+
+def pack_views(frame, params, max_heads):
+    """ONE frame dict {camera: [text of the skeleton list, ...]} -> PackedBatch through the native packer (`mpe_pack_views_into`),
+    without serialising the frame into a document first.  The arrays are views of one byte buffer laid out like the device copy
+    (`pb.upload_layout`), so the batch travels to the device as it lies.  ValueError where the packer declines the text."""
+    global _view_packers
+    import threading
+    if _view_packers is None:
+        _view_packers = threading.local()
+    sm = params.used_cameras_skeleton_matching
+    J = len(params.joint_list)
+    key = (tuple(sm), J, int(max_heads))
+    st = getattr(_view_packers, 'state', None)
+    if st is None or st[0] != key:
+        st = _view_packers.state = (key, _ViewPacker(sm, J, max_heads))
+    vp = st[1]
+    n = 0
+    keep = []
+    ascii_only = True
+    for cam, entry in frame.items():
+        c = vp.cam_index.get(cam)
+        if c is None:
+            continue
+        if n >= vp.V:
+            raise ValueError('frame lists more cameras than configured')
+        t = entry[0].encode()          # (AttributeError for a non-string entry: the caller falls back to the Python packer)
+        keep.append(t)
+        ascii_only = ascii_only and len(t) == len(entry[0])
+        vp.texts[n], vp.lens[n], vp.cams[n] = t, len(t), c
+        n += 1
+    # page-locked where a GPU is present (torch's caching host allocator: a few microseconds once warm, and it keeps a block away from
+    # reuse while an asynchronous copy out of it is in flight): the upload is then one asynchronous copy, not a staged blocking one
+    pinned = None
+    if vp.pin is None:
+        import torch
+        vp.pin = bool(torch.cuda.is_available())
+    if vp.pin:
+        import torch
+        pinned = torch.empty(vp.nbytes, dtype=torch.uint8, pin_memory=True)
+        buf = pinned.numpy()
+    else:
+        buf = np.empty(vp.nbytes, np.uint8)
+    base = buf.ctypes.data
+    dst = vp.dst
+    for name, off, _, _ in vp.offsets:
+        setattr(dst, name, vp.void_p(base + off))
+    extents = np.empty((vp.max_heads, 2), np.int32)
+    rc = vp.lib.mpe_pack_views_into(vp.texts, vp.lens, vp.cams, n, vp.V, J, vp.p_dst, vp.p_nh, vp.p_ne, extents.ctypes.data)
+    if rc != 0:
+        raise ValueError('mpe_pack_views_into: %s' % vp.lib.mpe_pack_last_error().decode())
+    H = vp.nh.value
+    V = vp.V
+    size = {'F1': 2, 'FV': V, 'H': H, 'HJ2': H * J * 2}
+    pb = PackedBatch(V, J)
+    pb.n_frames = 1
+    layout = {}
+    for name, off, dt, kind in vp.offsets:
+        layout[name] = off
+        setattr(pb, name, buf[off: off + size[kind] * dt.itemsize].view(dt))
+    pb.slot_cam, pb.slot_n = pb.slot_cam.reshape(1, V), pb.slot_n.reshape(1, V)
+    pb.xy, pb.vp = pb.xy.reshape(H, J, 2), pb.vp.reshape(H, J, 2)
+    pb.upload_layout = (buf, layout, pinned)
+    # [begin, end) of every head's skeleton object inside its camera's text (character = byte offsets: ASCII texts only)
+    pb.skeleton_extent = extents[:H] if ascii_only else None
+    return pb
+
+
 class DeviceBatch:
     def __init__(self, pb, device, arena=None):
         """arena = None: nine independent device tensors uploaded from pageable numpy arrays
@@ -313,7 +409,18 @@ class DeviceBatch:
         self.arena = arena
         s = L.mpe_batch()
         s.n_frames, s.n_heads, s.n_edge_nodes = pb.n_frames, pb.n_heads, pb.n_edge_nodes
-        if arena is None:
+        lay = getattr(pb, 'upload_layout', None)
+        if arena is None and lay is not None and pb.en_pair is None:
+            # a frame packed by `pack_views`: its arrays already lie in one buffer, 256-byte aligned -- it travels as it is
+            if lay[2] is not None and self.device.type == 'cuda':
+                self.buf = torch.empty(lay[0].size, dtype=torch.uint8, device=self.device)
+                self.buf.copy_(lay[2], non_blocking=True)
+            else:
+                self.buf = torch.from_numpy(lay[0]).to(self.device)
+            base = self.buf.data_ptr()
+            for name, _ in ARRAYS:
+                setattr(s, 'd_' + name, C.c_void_p(base + lay[1][name]))
+        elif arena is None:
             # ONE pageable buffer, one H2D copy (the per-frame mirrors upload a batch per call: nine small copies cost more
             # than the batch's kernels); 256-byte aligned pieces like the arenas
             parts, off = [], 0

@@ -666,6 +666,8 @@ class Engine:
         batch beyond them must be rejected here (the C ABI cannot see per-frame counts)."""
         if pb.n_frames > self.max_frames:
             raise ValueError('batch of %d frames exceeds max_frames=%d' % (pb.n_frames, self.max_frames))
+        if pb.n_frames == 1 and pb.n_heads <= self.hpf and pb.V == self.V and pb.J == self.J and getattr(pb, 'en_pair', None) is None:
+            return                           # (one frame of the per-frame mirrors: nothing below can fail)
         if pb.n_frames and pb.max_heads_per_frame() > self.hpf:
             raise ValueError('a frame holds %d skeletons, capacity is %d (raise max_persons_per_camera / '
                              'max_heads_per_frame)' % (pb.max_heads_per_frame(), self.hpf))
@@ -717,6 +719,21 @@ class Engine:
                                            _ptr(sc), _ptr(sh)))
         return (sc[:db.n_edge_nodes], sh[:db.n_heads]) if heads else sc[:db.n_edge_nodes]
 
+    def gat_scores_joined(self, db, feats=None):
+        """GAT2.forward of a one-graph batch in the node order of the reference's output (heads, then edge-nodes): both halves are
+        written into ONE [n_heads + n_edge_nodes] buffer (the last layer's rows are single floats: no alignment beyond 4 bytes is
+        asked of either half).  -> (all scores, the edge-node part as a view)."""
+        H, M = db.n_heads, db.n_edge_nodes
+        out = torch.empty(H + M, dtype=torch.float32, device=self.device)
+        ld = 0
+        if feats is not None:
+            feats = feats.to(self.device, torch.float32).contiguous()
+            ld = feats.shape[1]
+        base = out.data_ptr()
+        self._chk(self.lib.mpe_gat_forward(self.ctx, self._stream(), C.byref(db.struct), _ptr(feats), ld,
+                                           C.c_void_p(base + 4 * H), C.c_void_p(base)))
+        return out, out[H:]
+
     def set_gat_output(self, sigmoid=True):
         """Last-layer activation: sigmoid (deployed model) or identity (final_activation=None)."""
         if self._state.get('gat_output', True) == bool(sigmoid):
@@ -748,6 +765,14 @@ class Engine:
         """Synchronise and raise MpeError(MPE_ERR_CAPACITY) if a frame of a batch since the last
         call exceeded max_heads_per_frame (detected on the device)."""
         self._chk(self.lib.mpe_sync_status(self.ctx, self._stream()))
+
+    def status_queue(self):
+        """First half of sync_status: the read-back of the status word joins what is queued so far (mpe_status_queue)."""
+        self._chk(self.lib.mpe_status_queue(self.ctx, self._stream()))
+
+    def status_wait(self):
+        """Second half: synchronise and raise what the read-back saw (mpe_status_wait)."""
+        self._chk(self.lib.mpe_status_wait(self.ctx, self._stream()))
 
     def set_threshold(self, thr):
         if self._state.get('threshold', self._made_with['threshold']) == float(thr):
@@ -792,10 +817,20 @@ class Engine:
         """x [m, in_dim] f32 (device) -> [m, out_dim]."""
         m, k = x.shape
         ld = (k + 127) // 128 * 128
-        xp = torch.zeros((m, ld), dtype=torch.float32, device=self.device)
-        xp[:, :k] = x
+        stream = self._stream()
+        st = self.__dict__.get('_mlp_stage')
+        if m <= 64 and (st is None or st[0].shape[1] != ld or st[1] != stream.value):
+            # small batches (the one-frame-per-call mirrors): one padded staging buffer per engine and stream, zeroed once -- the pad
+            # columns stay zero, a call costs one copy instead of a fill and a copy
+            st = self.__dict__['_mlp_stage'] = (torch.zeros((64, ld), dtype=torch.float32, device=self.device), stream.value)
+        if m <= 64:
+            xp = st[0][:m]
+            xp[:, :k].copy_(x)
+        else:
+            xp = torch.zeros((m, ld), dtype=torch.float32, device=self.device)
+            xp[:, :k] = x
         y = torch.empty((m, self.mlp_out), dtype=torch.float32, device=self.device)
-        self._chk(self.lib.mpe_mlp_forward(self.ctx, self._stream(), _ptr(xp), ld, m, _ptr(y), self.mlp_out))
+        self._chk(self.lib.mpe_mlp_forward(self.ctx, stream, _ptr(xp), ld, m, _ptr(y), self.mlp_out))
         return y
 
     def mlp3d(self, db, persons, n_persons):

@@ -13,6 +13,19 @@ def get_person_proposal_from_network_output(outputs, subgraph, indices, nodes_ca
     be a tensor or a Python list of per-node scores; only edge-node entries are read."""
     if getattr(subgraph, 'batch_size', 1) != 1:
         raise ValueError('one graph per call (the reference function walks one graph, skeleton_matching_utils.py:33-55)')
+    cams = list(parameters.used_cameras_skeleton_matching)
+    ahead = getattr(subgraph, '_ahead', None)
+    if ahead is not None and ahead.matches(outputs, CLASSIFICATION_THRESHOLD) and ahead.engine.params is parameters:
+        # the scores GAT2.forward returned for this very graph, untouched: clustering and the persons' MLP rows were queued behind them
+        # (runtime.queue_proposals) -- provided the indices are the graph's own edge-node ids, as below
+        idx = torch.as_tensor(indices).reshape(-1)
+        own = subgraph.__dict__.get('_en_ids')
+        if own is None:
+            own = subgraph.__dict__['_en_ids'] = torch.arange(subgraph.H, subgraph.H + subgraph.M, dtype=torch.int64)
+        if idx.device.type == 'cpu' and idx.dtype == torch.int64 and idx.numel() == own.numel() and torch.equal(idx, own):
+            rows = runtime.take_proposals(ahead, jsons_for_head, cams)
+            if rows is not None:
+                return [{cam: (None if row[c] < 0 else row[c]) for c, cam in enumerate(cams)} for row in rows]
     eng = runtime.shared_engine()
     db = subgraph.device_batch(eng)
     if type(outputs) is list:
@@ -34,7 +47,6 @@ def get_person_proposal_from_network_output(outputs, subgraph, indices, nodes_ca
     eng.sync_status()
     n = int(n_persons[0])
     rows = persons[0, :n].cpu().tolist()
-    cams = list(parameters.used_cameras_skeleton_matching)
     if ahead is not None and n:
         runtime.prefetch_mlp_rows(eng, db, persons, n_persons, rows, jsons_for_head, cams, launched=ahead)
     return [{cam: (None if row[c] < 0 else row[c]) for c, cam in enumerate(cams)} for row in rows]

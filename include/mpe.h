@@ -275,6 +275,11 @@ int mpe_edge_softmax_aggregate(mpe_ctx *ctx, void *stream, const mpe_batch *b, i
  * such a frame (MPE_ERR_INVALID if an explicit edge-node list held a bad pair; MPE_OK otherwise) and clears the bits.  Limits that mpe_create enforces:
  * max_heads_per_frame < 32768, n_cameras <= 32, n_joints <= 32, attention heads <= 16. */
 int mpe_sync_status(mpe_ctx *ctx, void *stream);
+/* The same in two halves: mpe_status_queue orders the read-back (into page-locked memory) and the reset of the word behind everything
+ * queued on `stream` so far and returns at once; mpe_status_wait synchronises `stream` and reports what the read-back saw (it queues
+ * one itself if none is pending).  Bits raised by work queued after mpe_status_queue are reported by the next call. */
+int mpe_status_queue(mpe_ctx *ctx, void *stream);
+int mpe_status_wait(mpe_ctx *ctx, void *stream);
 
 /* CLASSIFICATION_THRESHOLD of get_person_proposal_from_network_output (default from mpe_config) */
 int mpe_set_threshold(mpe_ctx *ctx, float threshold);
@@ -332,6 +337,15 @@ int mpe_pack_json_into(const char *json, size_t len, const char *const *camera_n
                        int32_t n_joints, int32_t frame_start, int32_t frame_step, int32_t max_frames,
                        int32_t n_threads, const mpe_pack_dst *dst, int32_t *n_frames, int32_t *n_heads,
                        int32_t *n_edge_nodes);
+/* ONE frame as the reference's per-frame callers hold it after json.load (test/metrics_from_model.py:182-199; what
+ * MergedMultipleHumansDataset(mode='test') receives, graph_generator.py:813-876): per configured camera the TEXT of its skeleton list
+ * (frame[cam][0]), in the frame dict's order; cams[i] = that camera's index in the configured list.  Same grammar, head order and numbers
+ * as mpe_pack_json_into gives for the document [frame]; dst as there with max_frames >= 1.  extents (NULL or dst->max_heads * 2 entries)
+ * receives per head the byte offsets [begin, end) of its skeleton object inside its camera text (the per-frame callers hand single
+ * skeletons on as text, metrics_from_model.py:250-252).  MPE_ERR_INVALID with mpe_pack_last_error for text the packer declines,
+ * MPE_ERR_CAPACITY beyond dst->max_heads. */
+int mpe_pack_views_into(const char *const *texts, const size_t *lens, const int32_t *cams, int32_t n_views, int32_t n_cameras,
+                        int32_t n_joints, const mpe_pack_dst *dst, int32_t *n_heads, int32_t *n_edge_nodes, int32_t *extents);
 /* A document that is consumed in windows (frame_start, max_frames): the index scans the document for
  * its frame extents ONCE, in a background thread it starts at creation, ahead of the windows; a window
  * is parsed as its frames are published (n_threads = 0: as many workers as the process may use: the

@@ -146,6 +146,44 @@ def test_native_json_packer_equals_python_packer(name, calib):
     assert e.n_frames == 1 and np.array_equal(e.xy, packing.pack_frames(frames[:1], calib.params).xy)
 
 
+@pytest.mark.parametrize('name', CASES)
+def test_native_view_packer_equals_python_packer(name, calib):
+    """mpe_pack_views_into (the per-frame mirrors: one frame dict, the camera texts as the caller holds them) against
+    packing.pack_frames, frame by frame; the arrays lie in one buffer at the offsets the device copy uses."""
+    packing = pkg('packing')
+    if not os.path.exists(pkg('lib').LIB_PATH):
+        pytest.skip('library not built')
+    arr, frames = load_case(name)
+    fields = ('frame_head_off', 'frame_en_off', 'slot_cam', 'slot_n', 'head_cam', 'skeleton_index', 'joint_mask', 'tri_mask', 'xy', 'vp')
+    for frame in frames:
+        ref = packing.pack_frames([frame], calib.params)
+        got = packing.pack_views(frame, calib.params, max_heads=max(1, ref.n_heads))
+        buf, layout = got.upload_layout[:2]
+        for f in fields:
+            a, b = np.asarray(getattr(ref, f)), np.asarray(getattr(got, f))
+            assert a.shape == b.shape and np.array_equal(a, b), f
+            assert layout[f] % 256 == 0 and getattr(got, f).ctypes.data == buf.ctypes.data + layout[f] or b.size == 0
+        if ref.n_heads > 1:
+            with pytest.raises(ValueError, match='exceed'):
+                packing.pack_views(frame, calib.params, max_heads=ref.n_heads - 1)
+
+
+def test_native_view_packer_declines_what_json_loads_would_not_turn_into_a_list(calib):
+    packing = pkg('packing')
+    if not os.path.exists(pkg('lib').LIB_PATH):
+        pytest.skip('library not built')
+    P = calib.params
+    good = '[{"5": [5, 1.5, 2.5, 1, 0.25]}]'
+    ok = packing.pack_views({'zzz': ['[]', 0], 'trackerb': ['  ' + good + ' \n', 0.0], 'trackera': ['[]', 0.0]}, P, 8)
+    assert ok.n_heads == 1 and ok.slot_cam[0].tolist()[:2] == [1, 0] and ok.slot_n[0].tolist()[:2] == [1, 0] and ok.xy[0, 5].tolist() == [1.5, 2.5]
+    for bad in (good + ' x', json.dumps(good), '', '{"5": [5, 1, 2, 1, 1]}', good[:-1], '[{"99": [1, 2, 3, 4, 5]}]'):
+        with pytest.raises(ValueError):
+            packing.pack_views({'trackera': [bad, 0.0]}, P, 8)
+    with pytest.raises(AttributeError):                       # (graph_generator._pack_one hands such frames to the Python packer)
+        packing.pack_views({'trackera': [[{"5": [5, 1.5, 2.5, 1, 0.25]}], 0.0]}, P, 8)
+    assert packing.pack_views({}, P, 8).n_heads == 0
+
+
 def test_native_json_packer_rejects_garbage(calib):
     packing = pkg('packing')
     if not os.path.exists(pkg('lib').LIB_PATH):
