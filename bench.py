@@ -508,8 +508,16 @@ def run_rank(args):
         loop = importlib.import_module(PKG + '.harness.dropin_loop')
         model_, mlp_ = loop.build_models(gat_sd, prm, mlp_sd)
         n_dl = args.dropin_frames
-        res = loop.run([wire[i % uniq] for i in range(n_dl + 10)], model_, mlp_, warmup=10, device=device)
-        res.pop('last', None)
+        # three passes over the same frames, the one with the median time inside the mirrors reported (the loop is host-bound: a single
+        # pass moves by +-10 % with whatever else the host is doing), all three kept beside it
+        passes = []
+        for _ in range(3):
+            r_ = loop.run([wire[i % uniq] for i in range(n_dl + 10)], model_, mlp_, warmup=10, device=device)
+            r_.pop('last', None)
+            passes.append(r_)
+        res = sorted(passes, key=lambda r_: r_['inside_mirrors_ms'])[1]
+        res['inside_mirrors_ms_passes'] = [round(r_['inside_mirrors_ms'], 4) for r_ in passes]
+        res['ms_per_frame_passes'] = [round(r_['ms_per_frame'], 4) for r_ in passes]
         res['what'] = ("the loop body of the reference's test/metrics_from_model.py:178-294, one frame per call, over the package's "
                        'mirrors of its symbols (INTEGRATION.md section 2), timed with the reference\'s own two timers; '
                        'reference_readme_ms = what the reference README quotes for its own path on its authors\' GPU')

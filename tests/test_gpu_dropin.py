@@ -305,3 +305,128 @@ def test_gat2_forward_raises_for_a_frame_beyond_capacity_without_a_device_round_
     again = model(ok.ndata['h'].cuda(), ok)
     assert torch.equal(again, out)
     model._engine.close()
+
+
+def _frame_inputs(d, names=CASES):
+    frames = [f for name in names for f in load_case(name)[1]]
+    out = []
+    for input_element in frames:
+        processed = {}
+        for cam in input_element:
+            data = json.loads(input_element[cam][0])
+            if data:
+                processed[cam] = [json.dumps(data), input_element[cam][1]]
+        out.append(processed)
+    return out
+
+
+def _one_frame(d, processed, model=None, threshold=0.5, touch=None, indices=None):
+    """One pass of the per-frame loop up to the persons' MLP rows -> (scores, proposals, rows, scenario)."""
+    parameters = d['parameters']
+    scenario = d['MergedMultipleHumansDataset'](processed, mode='test', limit=10000, debug=True, alt=parameters.graph_alternative, verbose=False)
+    if not scenario.graphs:
+        return None
+    g = scenario.graphs[0]
+    outputs = torch.squeeze((model or d['model'])(g.ndata['h'].float(), g))
+    if touch is not None:
+        outputs = touch(outputs)
+    idx = torch.squeeze(scenario.data['edge_nodes_indices'][0], 1) if indices is None else indices(scenario)
+    persons = d['get_person_proposal_from_network_output'](outputs, g, idx, scenario.data['nodes_camera'][0], scenario.jsons_for_head, threshold)
+    rows = []
+    for person in persons:
+        views = {cam: [json.dumps([scenario.jsons_for_head[person[cam]]])] for cam in parameters.used_cameras if person[cam] is not None}
+        ds = d['PoseEstimatorDataset'](views, parameters.cameras, parameters.joint_list, save=False)
+        rows.append(ds[0][0].clone() if len(ds) else None)
+    return outputs.detach().cpu().clone(), persons, rows, scenario
+
+
+def _same(a, b):
+    assert torch.equal(a[0], b[0]) and a[1] == b[1] and len(a[2]) == len(b[2])
+    for x, y in zip(a[2], b[2]):
+        assert (x is None) == (y is None) and (x is None or torch.equal(x, y))
+
+
+def test_queued_frame_results_are_the_step_by_step_results(dropin, monkeypatch):
+    """The per-frame mirrors queue a frame's scores when its dataset is built (on the engine of the matcher that scored the previous
+    frame) and its clustering + MLP rows right behind them (runtime.start_frame / queue_proposals): scores, proposals and rows must
+    be the bits of the step-by-step route (MPE_DROPIN_PREFETCH=0), frame after frame, and the queued results must really be the ones
+    handed out."""
+    d = dropin
+    runtime = __import__('importlib').import_module('3d_multi_pose_estimator_amd.runtime')
+    inputs = _frame_inputs(d)
+    monkeypatch.setenv('MPE_DROPIN_PREFETCH', '0')
+    want = [_one_frame(d, p) for p in inputs]
+    monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+    _one_frame(d, inputs[0])                               # the matcher's engine becomes the one frames are queued on
+    used = 0
+    for p, w in zip(inputs, want):
+        got = _one_frame(d, p)
+        assert (got is None) == (w is None)
+        if got is None:
+            continue
+        _same(got, w)
+        g = got[3].graphs[0]
+        fs = g.__dict__.get('_scored')
+        assert fs is not None and fs.ahead is g._ahead and fs.out.data_ptr() == d['model'](None, g).data_ptr()      # (a second call hands the same scores out)
+        used += 1
+    assert used >= 4
+
+
+def test_queued_frame_results_are_dropped_when_the_caller_departs_from_the_script(dropin, gat_weights, monkeypatch):
+    """Queued results are used only for exactly what they were computed from: another matcher (other weights, or no final activation),
+    scores the caller changed, another threshold, other indices -- each must give what the step-by-step route gives for THAT call."""
+    d = dropin
+    parameters = d['parameters']
+    inputs = [p for p in _frame_inputs(d) if p][:3]
+    sd, prm = gat_weights
+    monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+    _one_frame(d, inputs[0])
+
+    def both(**kw):
+        monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+        _one_frame(d, inputs[0])                           # (re-arms the hint with the fixture's matcher)
+        fast = _one_frame(d, inputs[1], **kw)
+        monkeypatch.setenv('MPE_DROPIN_PREFETCH', '0')
+        slow = _one_frame(d, inputs[1], **kw)
+        monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+        _same(fast, slow)
+        return fast
+    base = both()
+    # another matcher: same architecture, different weights, and one without the final activation
+    GAT = d['GAT']
+    other = GAT(None, prm['gnn_layers'], prm['num_feats'], prm['n_classes'], prm['num_hidden'], prm['heads'], torch.nn.LeakyReLU(), torch.nn.Sigmoid(),
+                prm['in_drop'], prm['attn_drop'], prm['alpha'], prm['residual'], bias=True)
+    other.load_state_dict({k: torch.from_numpy(v * (0.5 if k.endswith('fc2.weight') else 1.0)) for k, v in sd.items()})
+    o = both(model=other)
+    assert not torch.equal(o[0], base[0])
+    raw = GAT(None, prm['gnn_layers'], prm['num_feats'], prm['n_classes'], prm['num_hidden'], prm['heads'], torch.nn.LeakyReLU(), None,
+              prm['in_drop'], prm['attn_drop'], prm['alpha'], prm['residual'], bias=True)
+    raw.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    r = both(model=raw, threshold=0.0)
+    assert float(r[0].min()) < 0.0 or float(r[0].max()) > 1.0           # logits, not probabilities
+    # weights changed in place between two frames: the matcher builds a new engine, the frame queued on the old one is not used
+    with torch.no_grad():
+        d['model'].layers[1].fc2.weight.mul_(1.0)
+    both()
+    # scores changed by the caller (in place, and as a new tensor), another threshold
+    both(touch=lambda s: s.mul_(0.5))
+    both(touch=lambda s: s * 0.5)
+    both(threshold=0.9)
+    both(threshold=0.999999)
+    # indices that are not the graph's own edge-node ids: refused on either route
+    for prefetch in ('1', '0'):
+        monkeypatch.setenv('MPE_DROPIN_PREFETCH', prefetch)
+        with pytest.raises(ValueError):
+            _one_frame(d, inputs[1], indices=lambda sc: torch.squeeze(sc.data['edge_nodes_indices'][0], 1)[:-1])
+    monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+    # more frames queued than the ring holds before anybody asks for their proposals: the overwritten ones take the step-by-step route
+    scen = [d['MergedMultipleHumansDataset'](p, mode='test', limit=10000, debug=True, alt=parameters.graph_alternative, verbose=False) for p in (inputs * 3)[:7]]
+    for sc_, p in zip(scen, (inputs * 3)[:7]):
+        g = sc_.graphs[0]
+        outputs = torch.squeeze(d['model'](None, g))
+        got = d['get_person_proposal_from_network_output'](outputs, g, torch.squeeze(sc_.data['edge_nodes_indices'][0], 1), sc_.data['nodes_camera'][0],
+                                                           sc_.jsons_for_head, 0.5)
+        monkeypatch.setenv('MPE_DROPIN_PREFETCH', '0')
+        want = _one_frame(d, p)
+        monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+        assert got == want[1] and torch.equal(outputs.cpu(), want[0])
