@@ -570,34 +570,50 @@ __global__ __launch_bounds__(256) void k_linear_sb_skinny(const float *__restric
 // The stage PAIRS of a tile (= the units between two f64 flushes) dealt round-robin to the KS waves of a workgroup; fp32 pair
 // results parked in LDS, then every element summed over the pairs in pair order in f64: the additions of k_linear_sb in the
 // same order (and exact anyway: fp32 terms in an f64 sum).
-template <bool LEAKY, int KS, int FL>
+// RT = 2: a workgroup takes TWO 16-row tiles with one fetch of the weight fragments (17 ... 128 rows: eight frames per call, the MLP of
+// a few dozen persons): every row tile used to be a workgroup of its own that streamed the layer's planes again.
+template <bool LEAKY, int KS, int FL, int RT = 1>
 __global__ __launch_bounds__(64 * KS) void k_linear_sb_ks(const float *__restrict__ A, int lda, const unsigned short *__restrict__ W3,
                                                           size_t w_plane, int ldw, const float *__restrict__ bias,
                                                           float *__restrict__ C, int ldc, int m_cap,
                                                           const int32_t *__restrict__ d_m, int n, int k_pad, float slope, int nt16,
                                                           DecodeEpi dec) {
     constexpr int fl = FL;                                   // K stages per f64 flush (a template argument: with one stage per unit the second fragment is not even requested)
-    extern __shared__ __attribute__((aligned(16))) float s_part[];       // [pairs][64 lanes][4]
+    extern __shared__ __attribute__((aligned(16))) float s_part[];       // [pairs][RT][64 lanes][4]
     int M = m_cap;
     if (d_m) {
         const int dm = *d_m;
         M = dm < m_cap ? dm : m_cap;
     }
-    const int tm = blockIdx.x / nt16, tn = blockIdx.x - tm * nt16;
+    const int tg = blockIdx.x / nt16, tn = blockIdx.x - tg * nt16;
+    const int tm = tg * RT;                                  // first row tile of the workgroup
     if (tm * 16 >= M) return;                                // whole workgroup leaves: no barrier reached
+    const bool two = RT == 2 && (tm + 1) * 16 < M;           // (uniform) the second row tile holds rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fq = lane >> 4, fr = lane & 15;
     int grow = tm * 16 + fr;
     grow = grow < M ? grow : M - 1;
     const float *pa = A + (size_t)grow * lda + 8 * fq;
+    int grow2 = (tm + 1) * 16 + fr;
+    grow2 = grow2 < M ? grow2 : M - 1;
+    const float *pa2 = A + (size_t)grow2 * lda + 8 * fq;
     const unsigned short *pw = W3 + (size_t)(tn * 16 + fr) * ldw + 8 * fq;
     // (fl = K stages per f64 flush: the units are stage pairs, or single stages in the flush-per-stage mode)
     const int nk = k_pad / GEMM_BK, npair = (nk + fl - 1) / fl;
     for (int j = wave; j < npair; j += KS) {
         SbFrag f0, f1;
+        f32x4 b00 = {0.f, 0.f, 0.f, 0.f}, b01 = b00, b10 = b00, b11 = b00;         // the second row tile's activation fragments
         const int k0 = fl * j, k1 = fl * j + 1 < nk ? fl * j + 1 : nk - 1;
         sb_load(f0, pa, pw, w_plane, k0 * GEMM_BK);
         if (FL == 2) sb_load(f1, pa, pw, w_plane, k1 * GEMM_BK);
+        if (RT == 2 && two) {
+            b00 = *reinterpret_cast<const f32x4 *>(pa2 + k0 * GEMM_BK);
+            b01 = *reinterpret_cast<const f32x4 *>(pa2 + k0 * GEMM_BK + 4);
+            if (FL == 2) {
+                b10 = *reinterpret_cast<const f32x4 *>(pa2 + k1 * GEMM_BK);
+                b11 = *reinterpret_cast<const f32x4 *>(pa2 + k1 * GEMM_BK + 4);
+            }
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         bf16x8 ap[3];
         split8(f0.a0, f0.a1, ap[0], ap[1], ap[2]);
@@ -606,15 +622,26 @@ __global__ __launch_bounds__(64 * KS) void k_linear_sb_ks(const float *__restric
             split8(f1.a0, f1.a1, ap[0], ap[1], ap[2]);
             SB_STAGE(acc, ap, f1.w);
         }
-        *reinterpret_cast<f32x4 *>(&s_part[(j * 64 + lane) * 4]) = acc;
+        *reinterpret_cast<f32x4 *>(&s_part[((j * RT) * 64 + lane) * 4]) = acc;
+        if (RT == 2 && two) {
+            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+            split8(b00, b01, ap[0], ap[1], ap[2]);
+            SB_STAGE(acc2, ap, f0.w);
+            if (fl == 2 && 2 * j + 1 < nk) {
+                split8(b10, b11, ap[0], ap[1], ap[2]);
+                SB_STAGE(acc2, ap, f1.w);
+            }
+            *reinterpret_cast<f32x4 *>(&s_part[((j * RT + 1) * 64 + lane) * 4]) = acc2;
+        }
     }
     __syncthreads();
     const int t = threadIdx.x;
-    if (t >= 256) return;
+    const int rt = t >> 8, tt = t & 255;                     // row tile of the workgroup, element of its 16 x 16 tile
+    if (rt >= RT || (rt == 1 && !two)) return;
     double run = 0.0;
-    for (int j = 0; j < npair; ++j) run += (double)s_part[j * 256 + t];  // pair order, as the tile kernel
-    const int el = t >> 2, i = t & 3;                        // element (lane el, component i) of the MFMA tile
-    const int m = tm * 16 + (el & 15), nb = tn * 16 + (el >> 4) * 4 + i;
+    for (int j = 0; j < npair; ++j) run += (double)s_part[(j * RT + rt) * 256 + tt];  // pair order, as the tile kernel
+    const int el = tt >> 2, i = tt & 3;                      // element (lane el, component i) of the MFMA tile
+    const int m = (tm + rt) * 16 + (el & 15), nb = tn * 16 + (el >> 4) * 4 + i;
     if (m >= M || nb >= n) return;
     float v = (float)(run + (double)bias[nb]);
     if (LEAKY) v = v > 0.f ? v : v * slope;
@@ -674,6 +701,19 @@ hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsi
     return hipGetLastError();
 }
 
+static int device_cu_count() {
+    static int cu_of_device[64];                    // (asked once per device: zero-initialised, benign if two threads ask at once)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int &cu = cu_of_device[dev & 63];
+    if (cu == 0) {
+        int c = 256;
+        (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        cu = c > 0 ? c : 256;
+    }
+    return cu;
+}
+
 // Same dispatch rules as launch_linear's f64-sum branch (gemm.hip): K split over eight waves / one wave per 16 x 16 tile for
 // small batches and for outputs of at most four 16-wide tiles at any batch size, the tile kernel otherwise.
 static int sb_skinny_waves() {
@@ -711,12 +751,22 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     // launch rather than store fp32 rows into a buffer the caller strides in halves
     if (out_half && (f64 || leaky || waves16 <= skinny_waves || narrow)) return hipErrorInvalidValue;
     if (f64 && (waves16 <= skinny_waves || narrow) && nk <= 128 * flush_stages && nk >= 8) {
-        const size_t shm = (size_t)((nk + flush_stages - 1) / flush_stages) * 1024;
+        // two row tiles per workgroup, the weight fragments fetched once for both (LDS: 2 KB per unit then) -- where two row tiles as
+        // workgroups of their own would be more workgroups than the chip has CUs (eight frames: 32 rows x 3072 features = 384), so
+        // that the second tile would wait for a CU anyway; below that the tiles run side by side and share the weights through the
+        // L2, and a workgroup that takes both only serialises them (measured at eight 5 x 4 frames: 14.9 / 30.0 us as one tile per
+        // workgroup, 12.5 / 23.4 as two on the 3072-wide layers; 17.3 against 22.6 on the 2048-wide ones).  The rows a batch really
+        // holds are a device-side count: the rule looks at the layer's width only.
+        const int row_tiles = (m_cap + 15) / 16;
+        const bool rt2 = row_tiles > 1 && 2 * nt16 > device_cu_count() && (size_t)((nk + flush_stages - 1) / flush_stages) * 2048 <= 128 * 1024;
+        const size_t shm = (size_t)((nk + flush_stages - 1) / flush_stages) * (rt2 ? 2048 : 1024);
         static PerDeviceFlag attr_done;
         if (!attr_done.test()) {
             hipError_t e = hipSuccess;
             const void *fns[] = {reinterpret_cast<const void *>(k_linear_sb_ks<true, 8, 2>), reinterpret_cast<const void *>(k_linear_sb_ks<false, 8, 2>),
-                                 reinterpret_cast<const void *>(k_linear_sb_ks<true, 8, 1>), reinterpret_cast<const void *>(k_linear_sb_ks<false, 8, 1>)};
+                                 reinterpret_cast<const void *>(k_linear_sb_ks<true, 8, 1>), reinterpret_cast<const void *>(k_linear_sb_ks<false, 8, 1>),
+                                 reinterpret_cast<const void *>(k_linear_sb_ks<true, 8, 2, 2>), reinterpret_cast<const void *>(k_linear_sb_ks<false, 8, 2, 2>),
+                                 reinterpret_cast<const void *>(k_linear_sb_ks<true, 8, 1, 2>), reinterpret_cast<const void *>(k_linear_sb_ks<false, 8, 1, 2>)};
             for (const void *fn : fns)
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) return e;
@@ -724,8 +774,12 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
         }
         DecodeEpi de{};
         if (dec) de = *dec;
-#define MPE_KS(L_, F_) \
-    hipLaunchKernelGGL((k_linear_sb_ks<L_, 8, F_>), dim3((unsigned)waves16), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, nt16, de)
+        const unsigned grid = (unsigned)((rt2 ? (row_tiles + 1) / 2 : row_tiles) * nt16);
+#define MPE_KS(L_, F_)                                                                                                                          \
+    do {                                                                                                                                        \
+        if (rt2) hipLaunchKernelGGL((k_linear_sb_ks<L_, 8, F_, 2>), dim3(grid), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, nt16, de); \
+        else hipLaunchKernelGGL((k_linear_sb_ks<L_, 8, F_, 1>), dim3(grid), dim3(512), shm, s, A, lda, W3, w_plane, ldw, bias, C, ldc, m_cap, d_m, n, k_pad, slope, nt16, de);     \
+    } while (0)
         if (leaky && flush_stages == 2) MPE_KS(true, 2);
         else if (leaky) MPE_KS(true, 1);
         else if (flush_stages == 2) MPE_KS(false, 2);
@@ -760,15 +814,7 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     }
     const int n_major = (size_t)n * k_pad * sizeof(float) > (size_t)(2u << 20) ? 1 : 0;
     // persistent workgroups: one per CU walking its tiles (grid = the CU count rounded down to a multiple of eight, or the tile count)
-    static int cu_of_device[64];                    // (asked once per device: zero-initialised, benign if two threads ask at once)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    int &cu = cu_of_device[dev & 63];
-    if (cu == 0) {
-        int c = 256;
-        (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
-        cu = c > 0 ? c : 256;
-    }
+    const int cu = device_cu_count();
     const int n_cu = cu >= 8 ? cu / 8 * 8 : 8;
     const bool with_coef = coef && coef->out_dim == 40 && n == coef->heads * 40 && !leaky && !f64;
     // 64-wide feature tiles with f64 sums (with 80 the running sums of the wider wave tile do not fit the 168 registers that three
