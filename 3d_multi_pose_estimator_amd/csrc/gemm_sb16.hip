@@ -701,7 +701,7 @@ hipError_t launch_split_planes(hipStream_t s, const float *w, size_t count, unsi
     return hipGetLastError();
 }
 
-static int device_cu_count() {
+int device_cu_count() {
     static int cu_of_device[64];                    // (asked once per device: zero-initialised, benign if two threads ask at once)
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -86,7 +86,7 @@ struct LatFc2 {
     float *a12;
 };
 
-template <int NK, int NT, bool LEAKY, bool OPL, bool COEF, bool FUSE2 = false>
+template <int NK, int NT, bool LEAKY, bool OPL, bool COEF, bool FUSE2 = false, bool LOOP = false>
 __global__ __launch_bounds__(64 * NT) void k_lat_gemm(const unsigned short *__restrict__ Apl, int lda, size_t a_plane,
                                                        const unsigned short *__restrict__ W3, size_t w_plane, int ldw,
                                                        const float *__restrict__ bias, float *__restrict__ C, int ldc,
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64 * NT) void k_lat_gemm(const unsigned short *__re
     constexpr int TS = NT * 16 + 4;                          // row stride of the result tile (floats) for the coefficient epilogue
     __shared__ __attribute__((aligned(16))) unsigned short s_a[3 * 16 * KS > 2 * 16 * TS ? 3 * 16 * KS : 2 * 16 * TS];
     const int ngrp = (n + NT * 16 - 1) / (NT * 16);
-    const int tm = blockIdx.x / ngrp, tg = blockIdx.x - tm * ngrp;
+    const int tm0 = blockIdx.x / ngrp, tg = blockIdx.x - tm0 * ngrp;
+    const int tm_step = gridDim.x / ngrp, ntm = (M + 15) / 16;      // LOOP: a workgroup walks the row tiles tm0, tm0 + tm_step, ... with its weight fragments in registers
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fq = lane >> 4, fr = lane & 15;
     const int ct = tg * NT + wave;                           // this wave's 16-column tile (padded weight rows cover a tile that starts below n)
@@ -122,6 +123,10 @@ __global__ __launch_bounds__(64 * NT) void k_lat_gemm(const unsigned short *__re
 #pragma unroll
             for (int p = 0; p < 3; ++p) wv2[kt][p] = *reinterpret_cast<const bf16x8 *>(pw2 + p * f2.w_plane + kt * GEMM_BK);
     }
+    int tm = tm0 - tm_step;
+    do {                                                     // (one pass without LOOP: the code of a single tile, no loop-carried registers)
+    tm += tm_step;
+    if (LOOP && tm != tm0) __syncthreads();                  // everybody is done with the previous tile's LDS image
     // the activation tile (shared by the NT waves): global -> registers -> LDS
     {
         u32x4 stage[A_PER];
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(64 * NT) void k_lat_gemm(const unsigned short *__re
             *reinterpret_cast<uint2 *>(d + 32 * KS) = make_uint2(pack2_lat(s0, s1), pack2_lat(s2, s3));
         }
         __syncthreads();
-        if (wave != 0) return;
+        if (wave != 0) continue;
         f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(64 * NT) void k_lat_gemm(const unsigned short *__re
             f2.a12[(size_t)m * 32] = __builtin_fmaf(y, f2.attn_l[0], 0.f);
             f2.a12[(size_t)m * 32 + 16] = __builtin_fmaf(y, f2.attn_r[0], 0.f);
         }
-        return;
+        continue;
     }
     if (OPL) {
         if (m < M && nb + 3 < n) {
@@ -248,9 +253,22 @@ __global__ __launch_bounds__(64 * NT) void k_lat_gemm(const unsigned short *__re
             a12[(size_t)mm * 32 + 16 + h] = x2;
         }
     }
+    } while (LOOP && tm + tm_step < ntm);                    // row tiles of the workgroup
 }
 
 }  // namespace lat
+
+// Row-tile groups of an fc1 launch: one workgroup per (row tile, column group) while that fits the chip in one round (the kernels hold
+// 150-200 registers: one workgroup per CU); beyond that (eight frames: 90 row tiles x 5 column groups) as many groups as give one
+// workgroup per CU, each walking several row tiles with its weight fragments in registers -- a second round would fetch them again
+// and pay the kernel's whole serial depth twice (fc1 of eight frames: 14.6 -> 11.8 us, 16.0 -> 11.4 on the 320-wide layer).  Only
+// the fc1 forms: with the coefficient epilogue the loop form needs more registers than the wave has (29 spilled: 18.2 -> 20.5 us).
+static int lat_row_groups(int ntm, int ngrp) {
+    const int cu = device_cu_count();
+    if (ntm * ngrp <= cu) return ntm;
+    const int g = cu / ngrp;
+    return g < 1 ? 1 : g < ntm ? g : ntm;
+}
 
 // Does a layer of this shape have an instantiation of k_lat_gemm?  fc1 (leaky, planes out) / fc2 (fp32 out + coefficients):
 // K stages and columns per workgroup as the deployed network has them (train_skeleton_matching.py:40-57: 400 / 320 / 150 wide).
@@ -297,15 +315,26 @@ hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, si
 #define MPE_LG(NK_, NT_, L_, O_, C_)                                                                                                         \
     hipLaunchKernelGGL((lat::k_lat_gemm<NK_, NT_, L_, O_, C_>), dim3((unsigned)(ntm * ((n + NT_ * 16 - 1) / (NT_ * 16)))), dim3(64 * NT_), 0, s, Apl, lda, \
                        a_plane, W3, w_plane, ldw, bias, C, ldc, Cpl, ldcp, c_plane, m, n, slope, attn_l, attn_r, a12, out_dim)
+    // fc1 of the wide layers at several frames: more (row tile, column group) pairs than CUs -> as many row-tile groups as give one
+    // workgroup per CU, each walking its row tiles with the weight fragments in registers (lat_row_groups)
+#define MPE_LG_LOOP(NK_, NT_)                                                                                                                \
+    do {                                                                                                                                     \
+        const int ngrp_ = (n + NT_ * 16 - 1) / (NT_ * 16), g_ = lat_row_groups(ntm, ngrp_);                                                  \
+        if (g_ < ntm)                                                                                                                        \
+            hipLaunchKernelGGL((lat::k_lat_gemm<NK_, NT_, true, true, false, false, true>), dim3((unsigned)(g_ * ngrp_)), dim3(64 * NT_), 0, s, Apl, lda,     \
+                               a_plane, W3, w_plane, ldw, bias, C, ldc, Cpl, ldcp, c_plane, m, n, slope, attn_l, attn_r, a12, out_dim);      \
+        else MPE_LG(NK_, NT_, true, true, false);                                                                                            \
+    } while (0)
     switch (form) {
-    case 1: MPE_LG(13, 5, true, true, false); break;
-    case 2: MPE_LG(10, 5, true, true, false); break;
+    case 1: MPE_LG_LOOP(13, 5); break;
+    case 2: MPE_LG_LOOP(10, 5); break;
     case 3: MPE_LG(5, 10, true, true, false); break;
     case 4: MPE_LG(13, 5, false, false, true); break;
     case 5: MPE_LG(10, 5, false, false, false); break;
     case 6: MPE_LG(5, 1, false, false, true); break;
     default: return hipErrorInvalidValue;
     }
+#undef MPE_LG_LOOP
 #undef MPE_LG
     return hipGetLastError();
 }

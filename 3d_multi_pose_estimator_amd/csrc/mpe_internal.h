@@ -184,6 +184,8 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
                               int flush_stages = 2,       // f64 launches: K stages per f64 flush (2 = default, 1 = the maximum-accuracy mode)
                               const DecodeEpi *dec = nullptr, bool *dec_done = nullptr);   // the K-split kernel can also store the decoded poses (*dec_done says whether it did)
 bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64);
+int device_cu_count();        // gemm_sb16.hip: CUs of the current device (asked once per device)
+
 // lat.hip: the small-batch ("latency") forms -- the arithmetic of the split-bf16 kernels (same bits), shortest serial depth
 bool lat_gemm_available(int k_pad, int n, bool fc2, int out_dim);
 hipError_t launch_lat_gemm(hipStream_t s, const unsigned short *Apl, int lda, size_t a_plane, const unsigned short *W3, size_t w_plane, int ldw,
