@@ -213,6 +213,8 @@ class FrameAhead:
     def matches(self, outputs, threshold):
         import torch
         out = self.out
+        if not getattr(self.engine, 'ctx', None):          # the matcher has replaced its engine since (new weights): nothing to wait on
+            return False
         return (isinstance(outputs, torch.Tensor) and outputs.data_ptr() == out.data_ptr() and outputs.numel() == out.numel()
                 and outputs.dtype == out.dtype and outputs._version == self.version and float(threshold) == self.threshold
                 and self.slot.gen == self.gen)

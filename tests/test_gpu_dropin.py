@@ -408,6 +408,17 @@ def test_queued_frame_results_are_dropped_when_the_caller_departs_from_the_scrip
     with torch.no_grad():
         d['model'].layers[1].fc2.weight.mul_(1.0)
     both()
+    # ... and proposals asked for scores of the OLD engine after the matcher has replaced it: the step-by-step route, no dead context
+    sc_old = d['MergedMultipleHumansDataset'](inputs[1], mode='test', limit=10000, debug=True, alt=parameters.graph_alternative, verbose=False)
+    g_old = sc_old.graphs[0]
+    out_old = torch.squeeze(d['model'](None, g_old))
+    with torch.no_grad():
+        d['model'].layers[1].fc2.weight.mul_(1.0)
+    d['model'](None, d['MergedMultipleHumansDataset'](inputs[2], mode='test', limit=10000, debug=True, alt=parameters.graph_alternative, verbose=False).graphs[0])
+    assert g_old._ahead is not None and not g_old._ahead.engine.ctx
+    got_old = d['get_person_proposal_from_network_output'](out_old, g_old, torch.squeeze(sc_old.data['edge_nodes_indices'][0], 1), sc_old.data['nodes_camera'][0],
+                                                           sc_old.jsons_for_head, 0.5)
+    assert got_old == base[1]
     # scores changed by the caller (in place, and as a new tensor), another threshold
     both(touch=lambda s: s.mul_(0.5))
     both(touch=lambda s: s * 0.5)
