@@ -441,3 +441,29 @@ def test_queued_frame_results_are_dropped_when_the_caller_departs_from_the_scrip
         want = _one_frame(d, p)
         monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
         assert got == want[1] and torch.equal(outputs.cpu(), want[0])
+
+
+def test_queued_frame_results_on_random_frames(dropin, calib, monkeypatch):
+    """The same comparison (queued against step by step) on 40 random frames: 1 ... 6 persons, dropped joints, an empty camera now and then."""
+    import importlib
+    syn = importlib.import_module('3d_multi_pose_estimator_amd.synthetic')
+    loop = importlib.import_module('3d_multi_pose_estimator_amd.harness.dropin_loop')
+    d = dropin
+    cams = list(d['parameters'].used_cameras_skeleton_matching)
+    inputs = []
+    for i in range(40):
+        spec = syn.FrameSpec(persons=1 + i % 6, empty_cameras=(cams[i % len(cams)],) if i % 5 == 2 else (), joint_drop=(0.0, 0.2)[i % 2], noise_px=1.0)
+        inputs.append(loop.cameras_with_skeletons(syn.make_frame(calib, 9000 + i, spec)[0]))
+    monkeypatch.setenv('MPE_DROPIN_PREFETCH', '0')
+    want = [_one_frame(d, p) for p in inputs]
+    monkeypatch.setenv('MPE_DROPIN_PREFETCH', '1')
+    _one_frame(d, inputs[0])
+    persons = 0
+    for p, w in zip(inputs, want):
+        got = _one_frame(d, p)
+        assert (got is None) == (w is None)
+        if got is not None:
+            _same(got, w)
+            assert got[3].graphs[0].__dict__.get('_scored') is not None
+            persons += len(got[1])
+    assert persons > 60

@@ -104,3 +104,57 @@ def test_row_kernel_fetches_pairs_only_for_the_batch_they_were_solved_for(engine
     engine.match(dba)                                  # both buffers have held batch a since: b's tag is gone
     assert torch.equal(engine.mlp3d(dbb, pb, nb)[0], want['b'][2])          # solved by the row kernel itself
     engine.sync_status()
+
+
+def test_small_batch_routes_on_a_random_sweep_of_frames(calib, gat_weights, mlp_weights):
+    """240 random frames (1 ... 6 persons, dropped joints, pixel noise, empty cameras, single-camera frames that have no graph) in groups
+    of 1 ... 8 through the latency launches against the same frames in ONE batch of 240 (tile kernels, fused attention, the wave
+    clustering kernel, the row kernel's own pair solves): scores, persons and poses bit for bit, frame by frame -- the last layer's
+    scores + clustering + pair solves of k_lat_tail and the plane-fed GEMMs on shapes the golden frames do not hold."""
+    syn = pkg('synthetic')
+    from conftest import oracle
+    eng = pkg('pipeline').Engine(calib.params, calib, max_frames=240, max_persons_per_camera=6)
+    sd, prm = gat_weights
+    eng.load_gat(sd, prm)
+    eng.load_mlp(mlp_weights)
+    try:
+        cams = list(calib.params.used_cameras_skeleton_matching)
+        frames = []
+        for i in range(240):
+            empty = ()
+            if i % 7 == 3:
+                empty = (cams[i % len(cams)],)
+            elif i % 31 == 5:
+                empty = tuple(cams[1:])                      # one camera left: heads, no edge-node
+            elif i % 43 == 9:
+                empty = tuple(cams)                          # nothing at all
+            spec = syn.FrameSpec(persons=1 + i % 6, empty_cameras=empty, joint_drop=(0.0, 0.15, 0.4)[i % 3], noise_px=(0.0, 1.0, 3.0)[(i // 3) % 3])
+            frames.append(oracle().processed_input(syn.make_frame(calib, 7000 + i, spec)[0]))
+        db = eng.to_device(eng.pack(frames))
+        sc, pe, npers = eng.match(db)
+        po, va = eng.mlp3d(db, pe, npers)
+        eng.sync_status()
+        sc, pe, npers, po, va = sc.cpu().numpy(), pe.cpu().numpy(), npers.cpu().numpy(), po.cpu().numpy(), va.cpu().numpy()
+        off = [db.host.frame_counts(f) for f in range(len(frames))]
+        sizes, i, k, groups = (1, 2, 3, 5, 8, 4, 1, 7, 6, 8), 0, 0, 0
+        while i < len(frames):
+            n = min(sizes[k % len(sizes)], len(frames) - i)
+            k += 1
+            g = eng.to_device(eng.pack(frames[i:i + n]))
+            s2, p2, n2 = eng.match(g)
+            q2, v2 = eng.mlp3d(g, p2, n2)
+            eng.sync_status()
+            s2, p2, n2, q2, v2 = s2.cpu().numpy(), p2.cpu().numpy(), n2.cpu().numpy(), q2.cpu().numpy(), v2.cpu().numpy()
+            e = 0
+            for j in range(n):
+                _, _, e0, M = off[i + j]
+                assert np.array_equal(s2[e:e + M], sc[e0:e0 + M]), (i + j, n)
+                e += M
+                cnt = int(npers[i + j])
+                assert n2[j] == cnt and np.array_equal(p2[j, :cnt], pe[i + j, :cnt]), (i + j, n)
+                assert np.array_equal(v2[j], va[i + j]) and np.array_equal(q2[j][v2[j] != 0], po[i + j][va[i + j] != 0]), (i + j, n)
+            i += n
+            groups += 1
+        assert groups >= 50 and int(npers.sum()) > 300
+    finally:
+        eng.close()
