@@ -280,7 +280,6 @@ def start_frame(graph):
     try:
         if eng is None or not getattr(eng, 'ctx', None) or graph.batch_size != 1 or graph.M < 1 or getattr(graph.packed, 'en_pair', None) is not None:
             return
-        import torch
         db = graph.device_batch(eng)
         out, sc = eng.gat_scores_joined(db)
         fs = FrameScores()
