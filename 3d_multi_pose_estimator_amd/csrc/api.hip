@@ -516,7 +516,9 @@ int gat_topology(mpe_ctx *ctx, hipStream_t s, const mpe_batch *b) {
 }
 
 // ---- small batches (a few frames; the reference's call pattern is one frame per call, test/metrics_from_model.py:120-300) ----
-constexpr int LAT_MAX_FRAMES = 8;
+// (sixteen: measured against the batch path with one context on one stream -- 9 frames 336 against 429 us per call, 12: 389 / 456,
+// 16: 427 / 449; 24: 577 / 531, 32: 657 / 558: the plane-fed GEMMs run one workgroup per CU and take a round per 256 of them)
+constexpr int LAT_MAX_FRAMES = 16;
 constexpr int LAT_MAX_NODES = 16384;
 
 // Can this batch take the latency launches?  Default precision modes, implicit topology, rows featurised on the device, a network
@@ -1152,7 +1154,7 @@ int mpe_match_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b, float *d_sco
             const int J = ctx->cfg.n_joints;
             const int slot = ctx->pair_next;
             const size_t need = (size_t)LAT_MAX_FRAMES * hmax * hmax * J * 3;
-            // (the buffer is indexed by the batch's head number: a batch whose frames are within capacity has at most 8 hmax of them;
+            // (the buffer is indexed by the batch's head number: a batch whose frames are within capacity has at most 16 hmax of them;
             // anything else -- flagged on the device, rejected by Engine.check_capacity -- gets no pair solves and no tag)
             const bool pairs_ok = (size_t)b->n_heads <= (size_t)LAT_MAX_FRAMES * hmax;
             if (pairs_ok && !ctx->pair_pts[slot] && (rc = dev_alloc(ctx, &ctx->pair_pts[slot], need, false))) return rc;

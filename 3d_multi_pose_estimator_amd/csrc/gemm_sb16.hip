@@ -725,13 +725,22 @@ static int sb_narrow_on() {
     return v;
 }
 
+// Row tiles (of CAPACITY: the rows a batch really holds are a device-side count, typically a third of it) up to which the K-split
+// kernel takes an f64-sum launch instead of the tile kernel.  Measured per row tile that holds rows against the tile kernel's time
+// for up to 256 rows: 7 against 102 us on the 3072 x 3072 layer, 4.8 against 70 on 2048 x 2048, 1.5 against 37 on 1024 x 1024 -- the
+// tile kernel puts N / 64 workgroups on the chip, each streaming its weights alone.  Thresholds from the sweep of frames per call
+// (5 x 4 frames, capacity 10 persons per frame; us per call before / after): 33 frames 835 / 626, 40: ~850 / 653, 48: 858 / 708,
+// 64: 892 / 795, 96: 986 / 981 (profiles/r06_frames_per_call.txt).
+static int few_rows_tiles(int nt16) { return nt16 >= 128 ? 32 : 48; }
+
 // Does launch_linear_sb16 take the tile kernel for this shape?  (Only the tile kernel stores fp16 rows: callers that want
 // `out_half` ask here first and keep the launch on the fp32 MFMA otherwise.)
 bool linear_sb16_uses_tile_kernel(int m_cap, int n, bool f64) {
     const int nt16 = (n + 15) / 16;
     const long waves16 = (long)((m_cap + 15) / 16) * nt16;
     const bool narrow = sb_narrow_on() && nt16 <= (f64 ? 4 : 1);
-    return !(waves16 <= sb_skinny_waves() || narrow);
+    const bool few_rows = f64 && sb_skinny_waves() > 0 && (m_cap + 15) / 16 <= few_rows_tiles(nt16) && nt16 > 4;      // (launch_linear_sb16)
+    return !(waves16 <= sb_skinny_waves() || narrow || few_rows);
 }
 
 hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsigned short *W3, size_t w_plane, int ldw,
@@ -750,7 +759,13 @@ hipError_t launch_linear_sb16(hipStream_t s, const float *A, int lda, const unsi
     // fp16 result rows (fc2 launches of the fp16-attention mode) exist in the tile kernel's fp32-chain forms only: refuse the
     // launch rather than store fp32 rows into a buffer the caller strides in halves
     if (out_half && (f64 || leaky || waves16 <= skinny_waves || narrow)) return hipErrorInvalidValue;
-    if (f64 && (waves16 <= skinny_waves || narrow) && nk <= 128 * flush_stages && nk >= 8) {
+    // A few row tiles of a WIDE layer (the MLP of 9 ... 32 frames: capacity 90 ... 320 rows, a fraction of them persons): the tile kernel
+    // would put 48 workgroups on the chip, each streaming its 64 features' weights alone (100 us for the 3072 x 3072 layer whatever the
+    // rows: 16 frames spent 315 of their 673 us there); the K-split kernel streams the layer once per two row tiles THAT HOLD ROWS
+    // (workgroups of empty tiles leave at once), 25 us at 64 rows.  At capacity it can be up to 2x behind the tile kernel, at the
+    // usual third of it 1.3-2x ahead.  MPE_SKINNY_WAVES=0 still means the tile kernel everywhere.  (few_rows_tiles: the break-even per width.)
+    const bool few_rows = f64 && skinny_waves > 0 && (m_cap + 15) / 16 <= few_rows_tiles(nt16) && nt16 > 4;
+    if (f64 && (waves16 <= skinny_waves || narrow || few_rows) && nk <= 128 * flush_stages && nk >= 8) {
         // two row tiles per workgroup, the weight fragments fetched once for both (LDS: 2 KB per unit then) -- where two row tiles as
         // workgroups of their own would be more workgroups than the chip has CUs (eight frames: 32 rows x 3072 features = 384), so
         // that the second tile would wait for a CU anyway; below that the tiles run side by side and share the weights through the

@@ -126,7 +126,7 @@ typedef struct {
  *     MPE_CLUSTER_KERNEL=wave|block|lds|big   (per call) clustering kernel
  *     MPE_HALF_VEC=4              fp16 rows of the general attention kernels read 4 columns per thread instead of 8
  *     MPE_JSON_WGS=<n>            workgroups of the device-side JSON walk
- *     MPE_LATENCY_PATH=0          (per call) batches of at most 8 frames through the batch path's own small-batch kernels instead of the
+ *     MPE_LATENCY_PATH=0          (per call) batches of at most 16 frames through the batch path's own small-batch kernels instead of the
  *                                 latency launches of csrc/lat.hip / gat.hip (k_lat_l0a, k_lat_gemm, k_lat_attention; persons' prefix and
  *                                 decode folded into their neighbours): same bits either way (tests/test_gpu_latency.py)
  *   host packer (threads, timing prints): MPE_PACK_THREADS, MPE_SCAN_THREADS, MPE_SCAN_CHUNK_KB, MPE_PACK_NO_SIMD, MPE_PACK_TIMING,
@@ -198,7 +198,7 @@ int mpe_match_batch(mpe_ctx *ctx, void *stream, const mpe_batch *b,
  * incl. get_3D_from_triangulation :63-101) + PoseEstimatorMLP + x10 decode
  * (metrics_from_model.py:243-294).
  *   d_poses [n_frames][Pcap][J][3] f32 metres, d_valid [n_frames][Pcap] 1 = person row kept
- * Small batches (<= 8 frames): when mpe_match_batch has just run on the SAME batch arrays (same d_xy pointer, same head and edge-node
+ * Small batches (<= 16 frames): when mpe_match_batch has just run on the SAME batch arrays (same d_xy pointer, same head and edge-node
  * counts), it has already solved every cross-camera skeleton pair of the batch beside its clustering launch, and the row kernel here
  * fetches them instead of solving (same function, same arguments: same bits).  The arrays must not change in between -- which the
  * call order of the pipeline implies anyway. */
