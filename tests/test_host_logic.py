@@ -694,6 +694,54 @@ def test_split_bf16_tile_kernel_occupancy_pins(tmp_path):
         mfma = set(re.findall(r'(v_mfma_\S+)', body))
         assert mfma == {'v_mfma_f32_16x16x32_bf16'}, (name, mfma)
     assert 'MPE_SBEXP' not in open(src).read()
+    # the K-split kernel of the small and mid-size batches (one and two row tiles per workgroup x flush cadence x LeakyReLU): no spills,
+    # and few enough registers for FOUR eight-wave workgroups per CU -- its one unit in flight per wave is hidden by the other waves
+    # (profiles/r06_ks_ahead_experiment.txt: the run-ahead form with 138 registers was slower)
+    ks = {k: v for k, v in meta.items() if k.startswith('_ZN3mpe2sb14k_linear_sb_ksIL')}
+    assert len(ks) == 8, sorted(ks)
+    for name, (threads, vgpr, spills) in ks.items():
+        assert spills == 0 and threads == 512 and vgpr <= 128, (name, threads, vgpr, spills)
+        body = text[text.index(name + ':'):]
+        body = body[:body.index('s_endpgm')]
+        assert not re.search(r'scratch_', body), name
+        assert set(re.findall(r'(v_mfma_\S+)', body)) == {'v_mfma_f32_16x16x32_bf16'}, name
+
+
+def test_latency_gemm_kernels_fit_their_workgroup(tmp_path):
+    """Static pins of the small-batch GEMM launches (csrc/lat.hip: k_lat_gemm, fc1 / fc2 of gat2.py:53-55 for <= 16 frames), read from
+    the gfx950 assembly (no GPU): every instantiation the host code can launch exists, none spills or touches scratch (the loop form
+    WITH the coefficient epilogue spilled 29 registers and was taken out: lat.hip, lat_row_groups), a workgroup's waves fit one CU's
+    register file (512 per SIMD lane), and the matrix instruction is the split-bf16 form's v_mfma_f32_16x16x32_bf16."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, '3d_multi_pose_estimator_amd', 'csrc', 'lat.hip')
+    out = str(tmp_path / 'lat.s')
+    subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-S', '--cuda-device-only', '-o', out, src],
+                   check=True, capture_output=True, timeout=900)
+    text = open(out).read()
+    meta = {}
+    for m in re.finditer(r'\.max_flat_workgroup_size: (\d+)\n\s+\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count: (\d+)', text):
+        meta[m.group(2)] = (int(m.group(1)), int(m.group(3)), int(m.group(4)))
+    lat = {k: v for k, v in meta.items() if k.startswith('_ZN3mpe3lat10k_lat_gemmIL')}
+    # <NK, NT, LEAKY, OPL, COEF, FUSE2, LOOP>: fc1 400 / 320 wide (single tile and loop forms), fc1 150 wide, fc1 + fc2 of the last layer
+    # in one launch, fc2 400 -> H x 40 with coefficients, fc2 320 -> 5 x 30, fc2 150 -> 1 with coefficients
+    want = ['Li13ELi5ELb1ELb1ELb0ELb0ELb0E', 'Li13ELi5ELb1ELb1ELb0ELb0ELb1E', 'Li10ELi5ELb1ELb1ELb0ELb0ELb0E', 'Li10ELi5ELb1ELb1ELb0ELb0ELb1E',
+            'Li5ELi10ELb1ELb1ELb0ELb0ELb0E', 'Li5ELi10ELb1ELb1ELb0ELb1ELb0E', 'Li13ELi5ELb0ELb0ELb1ELb0ELb0E', 'Li10ELi5ELb0ELb0ELb0ELb0ELb0E',
+            'Li5ELi1ELb0ELb0ELb1ELb0ELb0E']
+    assert len(lat) == len(want), sorted(lat)
+    for w in want:
+        assert any(('k_lat_gemmI' + w) in k for k in lat), w
+    for name, (threads, vgpr, spills) in lat.items():
+        assert spills == 0, (name, spills)
+        waves_per_simd = (threads // 64 + 3) // 4
+        assert vgpr * waves_per_simd <= 512, (name, threads, vgpr)
+        body = text[text.index(name + ':'):]
+        body = body[:body.index('s_endpgm')]
+        assert not re.search(r'scratch_', body), name
+        assert set(re.findall(r'(v_mfma_\S+)', body)) == {'v_mfma_f32_16x16x32_bf16'}, name
 
 
 def test_no_product_kernel_loads_into_registers_from_inline_asm_without_its_wait():
