@@ -1,0 +1,289 @@
+// A plain C++ host of libmpe_hip.so: no Python, no torch -- the C ABI of include/mpe.h and the HIP runtime API only.
+// Reads a case file (configuration + calibration, network weights, a wire-format JSON document), runs
+//   mpe_create -> mpe_set_gat_* / mpe_set_mlp_* -> mpe_pack_json (host) -> hipMemcpy -> mpe_match_batch -> mpe_mlp3d_batch
+//   -> mpe_triangulate_batch -> mpe_sync_status
+// and writes what came back.  tests/test_gpu_native_abi.py builds the case from a live Engine, runs this program and compares its
+// output bit for bit with the Python binding's on the same input: the boundary the reference's callers would bind
+// (test/metrics_from_model.py:120-300 is the loop body these three entry points replace) is the library, not the binding.
+// Also the example INTEGRATION.md points a C / C++ host at.
+//
+// Case / result file: records of  u32 name length | name | u8 dtype (0 u8, 1 i32, 2 f32, 3 f64) | u32 ndim | u64 dims[ndim] | raw bytes.
+//
+//   hipcc -O2 -std=c++17 -I include tests/native/abi_roundtrip.cpp -L 3d_multi_pose_estimator_amd -lmpe_hip -o abi_roundtrip
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "mpe.h"
+
+namespace {
+
+struct Blob {
+    int dtype = 0;
+    std::vector<uint64_t> dims;
+    std::vector<char> data;
+    size_t count() const {
+        size_t n = 1;
+        for (uint64_t d : dims) n *= (size_t)d;
+        return n;
+    }
+    template <typename T>
+    const T *as() const { return reinterpret_cast<const T *>(data.data()); }
+};
+
+const size_t kSize[4] = {1, 4, 4, 8};
+
+bool load(const char *path, std::map<std::string, Blob> *out) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    for (;;) {
+        uint32_t nl = 0;
+        if (fread(&nl, 4, 1, f) != 1) break;
+        std::string name(nl, '\0');
+        Blob b;
+        uint8_t dt = 0;
+        uint32_t nd = 0;
+        if (fread(&name[0], 1, nl, f) != nl || fread(&dt, 1, 1, f) != 1 || fread(&nd, 4, 1, f) != 1 || dt > 3 || nd > 8) return fclose(f), false;
+        b.dtype = dt;
+        b.dims.resize(nd);
+        if (nd && fread(b.dims.data(), 8, nd, f) != nd) return fclose(f), false;
+        b.data.resize(b.count() * kSize[dt]);
+        if (!b.data.empty() && fread(b.data.data(), 1, b.data.size(), f) != b.data.size()) return fclose(f), false;
+        (*out)[name] = std::move(b);
+    }
+    fclose(f);
+    return true;
+}
+
+void put(FILE *f, const char *name, int dtype, std::vector<uint64_t> dims, const void *data) {
+    const uint32_t nl = (uint32_t)strlen(name), nd = (uint32_t)dims.size();
+    const uint8_t dt = (uint8_t)dtype;
+    size_t n = kSize[dtype];
+    for (uint64_t d : dims) n *= (size_t)d;
+    fwrite(&nl, 4, 1, f);
+    fwrite(name, 1, nl, f);
+    fwrite(&dt, 1, 1, f);
+    fwrite(&nd, 4, 1, f);
+    if (nd) fwrite(dims.data(), 8, nd, f);
+    if (n) fwrite(data, 1, n, f);
+}
+
+#define HIP(expr)                                                                                \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            fprintf(stderr, "%s: %s (line %d)\n", #expr, hipGetErrorString(e_), __LINE__);       \
+            return 2;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+#define MPE(expr)                                                                                            \
+    do {                                                                                                     \
+        int rc_ = (expr);                                                                                    \
+        if (rc_ != MPE_OK) {                                                                                 \
+            fprintf(stderr, "%s -> %d: %s (line %d)\n", #expr, rc_, ctx ? mpe_last_error(ctx) : "", __LINE__); \
+            return 3;                                                                                        \
+        }                                                                                                    \
+    } while (0)
+
+template <typename T>
+hipError_t to_device(const T *host, size_t count, T **dev) {
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(dev), (count ? count : 1) * sizeof(T));
+    if (e != hipSuccess || !count) return e;
+    return hipMemcpy(*dev, host, count * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 3) {
+        fprintf(stderr, "usage: %s case.bin result.bin\n", argv[0]);
+        return 1;
+    }
+    std::map<std::string, Blob> in;
+    if (!load(argv[1], &in)) {
+        fprintf(stderr, "cannot read %s\n", argv[1]);
+        return 1;
+    }
+    auto need = [&](const std::string &k) -> const Blob & {
+        auto it = in.find(k);
+        if (it == in.end()) {
+            fprintf(stderr, "case file has no record '%s'\n", k.c_str());
+            exit(1);
+        }
+        return it->second;
+    };
+    mpe_ctx *ctx = nullptr;
+
+    // ---- configuration (parameters + calibration globals of the reference's hot-path modules) ----
+    const double *c = need("cfg").as<double>();          // the scalar fields of mpe_config in declaration order
+    mpe_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.n_cameras = (int32_t)c[0];
+    cfg.n_joints = (int32_t)c[1];
+    cfg.image_width = (int32_t)c[2];
+    cfg.image_height = (int32_t)c[3];
+    cfg.numbers_per_joint = (int32_t)c[4];
+    cfg.min_views = (int32_t)c[5];
+    cfg.median_axis = (int32_t)c[6];
+    cfg.used_joint_mask = (uint32_t)c[7];
+    cfg.threshold = (float)c[8];
+    cfg.median_window = (float)c[9];
+    cfg.max_frames = (int32_t)c[10];
+    cfg.max_heads = (int32_t)c[11];
+    cfg.max_edge_nodes = (int32_t)c[12];
+    cfg.max_heads_per_frame = (int32_t)c[13];
+    cfg.max_persons_per_frame = (int32_t)c[14];
+    cfg.Kinv = need("Kinv").as<float>();
+    cfg.K = need("K").as<float>();
+    cfg.T_i = need("T_i").as<float>();
+    cfg.P = need("P").as<double>();
+    cfg.dist = need("dist").as<double>();
+    const int V = cfg.n_cameras, J = cfg.n_joints, P = cfg.max_persons_per_frame;
+    MPE(mpe_create(&cfg, &ctx));
+
+    // ---- weights: GAT2 state dict (gat2.py:18-48), PoseEstimatorMLP (utils/mlp.py:8-28) ----
+    const double *gp = need("gat_params").as<double>();  // layers, alpha, slope of the hidden LeakyReLU
+    const int gat_layers = (int)gp[0];
+    MPE(mpe_set_gat_params(ctx, gat_layers, (float)gp[1], (float)gp[2]));
+    for (int l = 0; l < gat_layers; ++l) {
+        const std::string p = "gat" + std::to_string(l) + "_";
+        const int32_t *d = need(p + "dims").as<int32_t>();          // in_dim, heads, out_dim
+        MPE(mpe_set_gat_layer(ctx, l, d[0], d[1], d[2], need(p + "fc1_w").as<float>(), need(p + "fc1_b").as<float>(),
+                              need(p + "fc2_w").as<float>(), need(p + "fc2_b").as<float>(), need(p + "attn_l").as<float>(),
+                              need(p + "attn_r").as<float>()));
+    }
+    const double *mp = need("mlp_params").as<double>();  // layers, slope
+    const int mlp_layers = (int)mp[0];
+    MPE(mpe_set_mlp_params(ctx, mlp_layers, (float)mp[1]));
+    for (int l = 0; l < mlp_layers; ++l) {
+        const Blob &w = need("mlp" + std::to_string(l) + "_w");      // [out][in]
+        MPE(mpe_set_mlp_layer(ctx, l, (int32_t)w.dims[1], (int32_t)w.dims[0], w.as<float>(), need("mlp" + std::to_string(l) + "_b").as<float>()));
+    }
+
+    // ---- the frames: wire-format JSON -> packed host arrays (no GPU involved) -> device ----
+    const Blob &names = need("cameras");                  // camera names, '\n'-separated, in configured order
+    std::vector<std::string> cam;
+    {
+        std::string all(names.as<char>(), names.data.size()), cur;
+        for (char ch : all) {
+            if (ch == '\n') {
+                cam.push_back(cur);
+                cur.clear();
+            } else {
+                cur.push_back(ch);
+            }
+        }
+        if (!cur.empty()) cam.push_back(cur);
+    }
+    if ((int)cam.size() != V) {
+        fprintf(stderr, "%zu camera names for %d cameras\n", cam.size(), V);
+        return 1;
+    }
+    std::vector<const char *> cam_p;
+    for (const std::string &s : cam) cam_p.push_back(s.c_str());
+    const Blob &json = need("json");
+    mpe_packed *pk = nullptr;
+    if (mpe_pack_json(json.as<char>(), json.data.size(), cam_p.data(), V, J, 0, 1, 0, 2, &pk) != MPE_OK) {
+        fprintf(stderr, "mpe_pack_json: %s\n", mpe_pack_last_error());
+        return 3;
+    }
+    mpe_packed_arrays a;
+    MPE(mpe_packed_view(pk, &a));
+    const int B = a.n_frames, H = a.n_heads, M = a.n_edge_nodes;
+    if (B > cfg.max_frames || H > cfg.max_heads || M > cfg.max_edge_nodes) {
+        fprintf(stderr, "the document (%d frames, %d skeletons, %d pairs) exceeds the context's capacity\n", B, H, M);
+        return 1;
+    }
+    int32_t *d_fho, *d_feo, *d_scam, *d_sn, *d_hcam;
+    uint32_t *d_jm, *d_tm;
+    double *d_xy;
+    float *d_vp;
+    HIP(to_device(a.frame_head_off, (size_t)B + 1, &d_fho));
+    HIP(to_device(a.frame_en_off, (size_t)B + 1, &d_feo));
+    HIP(to_device(a.slot_cam, (size_t)B * V, &d_scam));
+    HIP(to_device(a.slot_n, (size_t)B * V, &d_sn));
+    HIP(to_device(a.head_cam, (size_t)H, &d_hcam));
+    HIP(to_device(a.joint_mask, (size_t)H, &d_jm));
+    HIP(to_device(a.tri_mask, (size_t)H, &d_tm));
+    HIP(to_device(a.xy, (size_t)H * J * 2, &d_xy));
+    HIP(to_device(a.vp, (size_t)H * J * 2, &d_vp));
+    mpe_batch b;
+    memset(&b, 0, sizeof b);
+    b.n_frames = B;
+    b.n_heads = H;
+    b.n_edge_nodes = M;
+    b.d_frame_head_off = d_fho;
+    b.d_frame_en_off = d_feo;
+    b.d_slot_cam = d_scam;
+    b.d_slot_n = d_sn;
+    b.d_head_cam = d_hcam;
+    b.d_joint_mask = d_jm;
+    b.d_tri_mask = d_tm;
+    b.d_xy = d_xy;
+    b.d_vp = d_vp;
+    b.d_en_pair = nullptr;                                // the implicit topology of process_test (graph_generator.py:854-864)
+
+    // ---- the path: matching, then both 3D stages, on a stream of this program's own ----
+    hipStream_t s;
+    HIP(hipStreamCreate(&s));
+    float *d_scores, *d_poses;
+    int32_t *d_persons, *d_np;
+    uint8_t *d_valid, *d_jv;
+    double *d_tri;
+    HIP(hipMalloc(reinterpret_cast<void **>(&d_scores), (size_t)(M ? M : 1) * sizeof(float)));
+    HIP(hipMalloc(reinterpret_cast<void **>(&d_persons), (size_t)(B ? B : 1) * P * V * sizeof(int32_t)));
+    HIP(hipMalloc(reinterpret_cast<void **>(&d_np), (size_t)(B ? B : 1) * sizeof(int32_t)));
+    HIP(hipMalloc(reinterpret_cast<void **>(&d_poses), (size_t)(B ? B : 1) * P * J * 3 * sizeof(float)));
+    HIP(hipMalloc(reinterpret_cast<void **>(&d_valid), (size_t)(B ? B : 1) * P));
+    HIP(hipMalloc(reinterpret_cast<void **>(&d_tri), (size_t)(B ? B : 1) * P * J * 3 * sizeof(double)));
+    HIP(hipMalloc(reinterpret_cast<void **>(&d_jv), (size_t)(B ? B : 1) * P * J));
+    MPE(mpe_match_batch(ctx, s, &b, d_scores, d_persons, d_np));
+    MPE(mpe_mlp3d_batch(ctx, s, &b, d_persons, d_np, d_poses, d_valid));
+    MPE(mpe_triangulate_batch(ctx, s, &b, d_persons, d_np, d_tri, d_jv, 0));
+    MPE(mpe_sync_status(ctx, s));                         // waits for the stream; a frame beyond the per-frame capacity is reported here
+
+    std::vector<float> scores((size_t)M), poses((size_t)B * P * J * 3);
+    std::vector<int32_t> persons((size_t)B * P * V), np_((size_t)B);
+    std::vector<uint8_t> valid((size_t)B * P), jv((size_t)B * P * J);
+    std::vector<double> tri((size_t)B * P * J * 3);
+    if (M) HIP(hipMemcpy(scores.data(), d_scores, scores.size() * sizeof(float), hipMemcpyDeviceToHost));
+    if (B) {
+        HIP(hipMemcpy(persons.data(), d_persons, persons.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(np_.data(), d_np, np_.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(poses.data(), d_poses, poses.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(valid.data(), d_valid, valid.size(), hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(tri.data(), d_tri, tri.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(jv.data(), d_jv, jv.size(), hipMemcpyDeviceToHost));
+    }
+
+    FILE *f = fopen(argv[2], "wb");
+    if (!f) {
+        fprintf(stderr, "cannot write %s\n", argv[2]);
+        return 1;
+    }
+    const int32_t counts[3] = {B, H, M};
+    put(f, "counts", 1, {3}, counts);
+    put(f, "scores", 2, {(uint64_t)M}, scores.data());
+    put(f, "persons", 1, {(uint64_t)B, (uint64_t)P, (uint64_t)V}, persons.data());
+    put(f, "n_persons", 1, {(uint64_t)B}, np_.data());
+    put(f, "poses", 2, {(uint64_t)B, (uint64_t)P, (uint64_t)J, 3}, poses.data());
+    put(f, "valid", 0, {(uint64_t)B, (uint64_t)P}, valid.data());
+    put(f, "tri_poses", 3, {(uint64_t)B, (uint64_t)P, (uint64_t)J, 3}, tri.data());
+    put(f, "tri_valid", 0, {(uint64_t)B, (uint64_t)P, (uint64_t)J}, jv.data());
+    fclose(f);
+
+    void *dev[] = {d_fho, d_feo, d_scam, d_sn, d_hcam, d_jm, d_tm, d_xy, d_vp, d_scores, d_persons, d_np, d_poses, d_valid, d_tri, d_jv};
+    for (void *p : dev) (void)hipFree(p);
+    mpe_packed_free(pk);
+    (void)hipStreamDestroy(s);
+    mpe_destroy(ctx);
+    printf("abi_roundtrip: %s, %d frames, %d skeletons, %d pairs\n", mpe_version(), B, H, M);
+    return 0;
+}
