@@ -10,8 +10,11 @@
 // Case / result file: records of  u32 name length | name | u8 dtype (0 u8, 1 i32, 2 f32, 3 f64) | u32 ndim | u64 dims[ndim] | raw bytes.
 //
 //   hipcc -O2 -std=c++17 -I include tests/native/abi_roundtrip.cpp -L 3d_multi_pose_estimator_amd -lmpe_hip -o abi_roundtrip
+//   ./abi_roundtrip case.bin result.bin [calls]      calls > 0: after the pass that is written out, time that many further
+//                                                    match + MLP-3D calls (one synchronisation each) and print us per call
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -261,6 +264,25 @@ int main(int argc, char **argv) {
         HIP(hipMemcpy(valid.data(), d_valid, valid.size(), hipMemcpyDeviceToHost));
         HIP(hipMemcpy(tri.data(), d_tri, tri.size() * sizeof(double), hipMemcpyDeviceToHost));
         HIP(hipMemcpy(jv.data(), d_jv, jv.size(), hipMemcpyDeviceToHost));
+    }
+
+    const int calls = argc > 3 ? atoi(argv[3]) : 0;
+    if (calls > 0 && B > 0) {
+        // the call pattern of the reference's loop from a native host: one batch in, its poses out, then the next
+        for (int i = 0; i < 20; ++i) {
+            MPE(mpe_match_batch(ctx, s, &b, nullptr, d_persons, d_np));
+            MPE(mpe_mlp3d_batch(ctx, s, &b, d_persons, d_np, d_poses, d_valid));
+        }
+        HIP(hipStreamSynchronize(s));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < calls; ++i) {
+            MPE(mpe_match_batch(ctx, s, &b, nullptr, d_persons, d_np));
+            MPE(mpe_mlp3d_batch(ctx, s, &b, d_persons, d_np, d_poses, d_valid));
+            HIP(hipStreamSynchronize(s));
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
+        MPE(mpe_sync_status(ctx, s));
+        printf("abi_roundtrip: %d calls of %d frame(s): %.1f us per call, %.0f frames/s\n", calls, B, us, B * 1e6 / us);
     }
 
     FILE *f = fopen(argv[2], "wb");

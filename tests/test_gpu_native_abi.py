@@ -117,8 +117,14 @@ def test_cpp_host_gets_the_python_bindings_bits(tmp_path, calib, gat_weights, ml
         eng.close()
     exe = _build(tmp_path)
     env = {k: v for k, v in os.environ.items() if not k.startswith('MPE_')}
-    r = subprocess.run([exe, case, res], capture_output=True, text=True, timeout=300, env=env)
+    # (one and three frames: 300 further timed calls -- the reference's call pattern from a native host; the line goes to
+    # gpurun_out/native_host_latency.txt, nothing is asserted about it)
+    r = subprocess.run([exe, case, res] + (['300'] if n_frames <= 3 else []), capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
+    if n_frames <= 3:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'native_host_latency.txt'), 'a') as fh:
+            fh.write(''.join(l + '\n' for l in r.stdout.splitlines() if 'us per call' in l))
     got = _read(res)
     assert np.array_equal(got['counts'], want['counts'])
     assert int(want['n_persons'].sum()) >= n_frames
