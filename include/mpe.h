@@ -24,6 +24,7 @@
 #ifndef MPE_H
 #define MPE_H
 
+#include <stddef.h>     /* size_t */
 #include <stdint.h>
 
 #ifdef __cplusplus

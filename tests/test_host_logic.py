@@ -69,6 +69,46 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), name
 
 
+def test_header_is_plain_c_and_a_c_host_packs_like_the_binding(tmp_path, calib):
+    """include/mpe.h is what a cgo / JNI / N-API binding includes: it has to be valid C on its own (C99 and C++11, -pedantic -Werror;
+    round 6 found it leaning on a C++ translation unit's <cstddef> for size_t).  And a plain C program that includes it
+    (tests/native/c_host_packer.c) packs a wire-format document through mpe_pack_json -- the host side of the boundary, no GPU -- into
+    the same arrays as the Python binding (graph_generator.py:573-605 is the order they restate)."""
+    import json
+    import shutil
+    import subprocess
+    gcc, gxx = shutil.which('gcc'), shutil.which('g++')
+    if not gcc or not gxx:
+        pytest.skip('gcc / g++ not available')
+    inc = os.path.join(ROOT, 'include')
+    (tmp_path / 'h.c').write_text('#include "mpe.h"\nint main(void) { mpe_config c; mpe_batch b; mpe_pack_dst d; (void)c; (void)b; (void)d; return 0; }\n')
+    (tmp_path / 'h.cpp').write_text('#include "mpe.h"\nint main() { mpe_config c; (void)c; return 0; }\n')
+    subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', inc, '-fsyntax-only', str(tmp_path / 'h.c')], check=True, capture_output=True)
+    subprocess.run([gxx, '-std=c++11', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', inc, '-fsyntax-only', str(tmp_path / 'h.cpp')], check=True, capture_output=True)
+    lib = pkg('lib')
+    if not os.path.exists(lib.LIB_PATH):
+        pytest.skip('library not built yet (run __graft_entry__.build())')
+    libdir, exe = os.path.dirname(lib.LIB_PATH), str(tmp_path / 'c_host_packer')
+    hip_lib = '/opt/rocm/lib'
+    subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', inc, os.path.join(ROOT, 'tests', 'native', 'c_host_packer.c'),
+                    '-L', libdir, '-lmpe_hip', '-Wl,-rpath,' + libdir, '-Wl,-rpath,' + hip_lib, '-o', exe], check=True, capture_output=True, timeout=300)
+    syn, packing = pkg('synthetic'), pkg('packing')
+    frames = [syn.make_frame(calib, 10 + i, syn.FrameSpec(persons=2 + i, empty_cameras=(calib.params.used_cameras_skeleton_matching[2],) if i == 1 else ()))[0]
+              for i in range(3)]
+    text = json.dumps(frames)
+    (tmp_path / 'doc.json').write_text(text)
+    r = subprocess.run([exe, str(tmp_path / 'doc.json'), str(len(calib.params.joint_list))] + list(calib.params.used_cameras_skeleton_matching),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r'frames (\d+) heads (\d+) edge_nodes (\d+) sum (\S+) masks (\d+) last_off (\d+)', r.stdout)
+    assert m, r.stdout
+    pb = packing.pack_json(text.encode(), calib.params)
+    assert (int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(6))) == (pb.n_frames, pb.n_heads, pb.n_edge_nodes, pb.n_heads)
+    t = np.asarray(pb.xy, np.float64).reshape(-1) + np.asarray(pb.vp, np.float32).reshape(-1).astype(np.float64)
+    assert float(m.group(4)) == float(np.cumsum(t)[-1])          # the C loop's sequential sum, to the last bit
+    assert int(m.group(5)) == int(sum(int(x) % 1000003 for x in pb.joint_mask) + int(np.asarray(pb.head_cam, np.int64).sum()))
+
+
 def test_no_product_import_of_oracle():
     """The product must not route through the oracle or any CPU fallback."""
     pkg_dir = os.path.join(ROOT, '3d_multi_pose_estimator_amd')
