@@ -109,6 +109,31 @@ def test_header_is_plain_c_and_a_c_host_packs_like_the_binding(tmp_path, calib):
     assert int(m.group(5)) == int(sum(int(x) % 1000003 for x in pb.joint_mask) + int(np.asarray(pb.head_cam, np.int64).sum()))
 
 
+def test_every_entry_point_refuses_null_arguments_without_crashing():
+    """The error behaviour of the boundary, without a GPU: every function include/mpe.h declares, called with a NULL context / NULL
+    pointers / zero sizes, returns MPE_ERR_INVALID (or does nothing, for the void ones) -- no entry point dereferences before it checks.
+    In a child process: a crash there is an exit code here, not the end of the test run."""
+    import subprocess
+    import sys
+    lib = pkg('lib')
+    if not os.path.exists(lib.LIB_PATH):
+        pytest.skip('library not built yet (run __graft_entry__.build())')
+    code = (
+        "import ctypes as C, importlib, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "L = importlib.import_module('3d_multi_pose_estimator_amd.lib')\n"
+        "lib = L.load()\n"
+        "for name, (res, args) in L.SYMBOLS.items():\n"
+        "    vals = [0 if a in (C.c_int32, C.c_int, C.c_uint32, C.c_size_t) else 0.0 if a is C.c_float else None for a in args]\n"
+        "    r = getattr(lib, name)(*vals)\n"
+        "    if res is C.c_int:\n"
+        "        assert r == -1, (name, r)\n"
+        "assert lib.mpe_last_error(None) == b'null context'\n"
+        "print('ok', len(L.SYMBOLS))\n" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith('ok'), r.stdout + r.stderr
+
+
 def test_no_product_import_of_oracle():
     """The product must not route through the oracle or any CPU fallback."""
     pkg_dir = os.path.join(ROOT, '3d_multi_pose_estimator_amd')
