@@ -10,8 +10,10 @@
 // Case / result file: records of  u32 name length | name | u8 dtype (0 u8, 1 i32, 2 f32, 3 f64) | u32 ndim | u64 dims[ndim] | raw bytes.
 //
 //   hipcc -O2 -std=c++17 -I include tests/native/abi_roundtrip.cpp -L 3d_multi_pose_estimator_amd -lmpe_hip -o abi_roundtrip
-//   ./abi_roundtrip case.bin result.bin [calls]      calls > 0: after the pass that is written out, time that many further
-//                                                    match + MLP-3D calls (one synchronisation each) and print us per call
+//   ./abi_roundtrip case.bin result.bin [calls [device]]
+//        calls > 0: after the pass that is written out, time that many further match + MLP-3D calls (one synchronisation each)
+//        device:    the skeleton strings are parsed ON THE DEVICE (mpe_json_index_create -> mpe_json_stage_window ->
+//                   mpe_json_parse_device) instead of by the host packer (mpe_pack_json): same arrays, same results
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
@@ -192,33 +194,105 @@ int main(int argc, char **argv) {
     std::vector<const char *> cam_p;
     for (const std::string &s : cam) cam_p.push_back(s.c_str());
     const Blob &json = need("json");
+    const bool device_parse = argc > 4 && !strcmp(argv[4], "device");
+    hipStream_t s;
+    HIP(hipStreamCreate(&s));
     mpe_packed *pk = nullptr;
-    if (mpe_pack_json(json.as<char>(), json.data.size(), cam_p.data(), V, J, 0, 1, 0, 2, &pk) != MPE_OK) {
-        fprintf(stderr, "mpe_pack_json: %s\n", mpe_pack_last_error());
-        return 3;
-    }
-    mpe_packed_arrays a;
-    MPE(mpe_packed_view(pk, &a));
-    const int B = a.n_frames, H = a.n_heads, M = a.n_edge_nodes;
-    if (B > cfg.max_frames || H > cfg.max_heads || M > cfg.max_edge_nodes) {
-        fprintf(stderr, "the document (%d frames, %d skeletons, %d pairs) exceeds the context's capacity\n", B, H, M);
-        return 1;
-    }
-    int32_t *d_fho, *d_feo, *d_scam, *d_sn, *d_hcam;
-    uint32_t *d_jm, *d_tm;
-    double *d_xy;
-    float *d_vp;
-    HIP(to_device(a.frame_head_off, (size_t)B + 1, &d_fho));
-    HIP(to_device(a.frame_en_off, (size_t)B + 1, &d_feo));
-    HIP(to_device(a.slot_cam, (size_t)B * V, &d_scam));
-    HIP(to_device(a.slot_n, (size_t)B * V, &d_sn));
-    HIP(to_device(a.head_cam, (size_t)H, &d_hcam));
-    HIP(to_device(a.joint_mask, (size_t)H, &d_jm));
-    HIP(to_device(a.tri_mask, (size_t)H, &d_tm));
-    HIP(to_device(a.xy, (size_t)H * J * 2, &d_xy));
-    HIP(to_device(a.vp, (size_t)H * J * 2, &d_vp));
+    mpe_json_index *ix = nullptr;
+    int B = 0, H = 0, M = 0;
+    int32_t *d_fho = nullptr, *d_feo = nullptr, *d_scam = nullptr, *d_sn = nullptr, *d_hcam = nullptr, *d_skel = nullptr, *d_totals = nullptr, *d_fent = nullptr;
+    uint32_t *d_jm = nullptr, *d_tm = nullptr;
+    double *d_xy = nullptr;
+    float *d_vp = nullptr;
+    char *d_text = nullptr;
+    mpe_json_entry *d_entries = nullptr;
+    void *d_scratch = nullptr;
     mpe_batch b;
     memset(&b, 0, sizeof b);
+    if (!device_parse) {
+        if (mpe_pack_json(json.as<char>(), json.data.size(), cam_p.data(), V, J, 0, 1, 0, 2, &pk) != MPE_OK) {
+            fprintf(stderr, "mpe_pack_json: %s\n", mpe_pack_last_error());
+            return 3;
+        }
+        mpe_packed_arrays a;
+        MPE(mpe_packed_view(pk, &a));
+        B = a.n_frames, H = a.n_heads, M = a.n_edge_nodes;
+        if (B > cfg.max_frames || H > cfg.max_heads || M > cfg.max_edge_nodes) {
+            fprintf(stderr, "the document (%d frames, %d skeletons, %d pairs) exceeds the context's capacity\n", B, H, M);
+            return 1;
+        }
+        HIP(to_device(a.frame_head_off, (size_t)B + 1, &d_fho));
+        HIP(to_device(a.frame_en_off, (size_t)B + 1, &d_feo));
+        HIP(to_device(a.slot_cam, (size_t)B * V, &d_scam));
+        HIP(to_device(a.slot_n, (size_t)B * V, &d_sn));
+        HIP(to_device(a.head_cam, (size_t)H, &d_hcam));
+        HIP(to_device(a.joint_mask, (size_t)H, &d_jm));
+        HIP(to_device(a.tri_mask, (size_t)H, &d_tm));
+        HIP(to_device(a.xy, (size_t)H * J * 2, &d_xy));
+        HIP(to_device(a.vp, (size_t)H * J * 2, &d_vp));
+    } else {
+        // The other half of f1: the host keeps the first level of the format only -- frame extents (the index) and, per
+        // configured camera, the extent of the STRING that holds its skeleton list (mpe_json_stage_window) -- and the strings are parsed
+        // on the device into arrays this program allocated (mpe_json_parse_device), bit for bit what the host packer gives.
+        if (mpe_json_index_create(json.as<char>(), json.data.size(), &ix) != MPE_OK) {
+            fprintf(stderr, "mpe_json_index_create: %s\n", mpe_pack_last_error());
+            return 3;
+        }
+        const int Fcap = cfg.max_frames, Hcap = cfg.max_heads, kcap = cfg.max_heads_per_frame, ecap = Fcap * V;
+        const size_t text_cap = json.data.size() + (size_t)16 * ecap + 256;
+        std::vector<char> text(text_cap);
+        std::vector<mpe_json_entry> entries((size_t)ecap);
+        std::vector<int32_t> fent((size_t)Fcap + 1);
+        int32_t nf = 0, ne = 0;
+        size_t text_bytes = 0;
+        if (mpe_json_stage_window(ix, cam_p.data(), V, 0, 1, Fcap, 1, text.data(), text_cap, entries.data(), ecap, fent.data(), &nf, &ne, &text_bytes) != MPE_OK) {
+            fprintf(stderr, "mpe_json_stage_window: %s\n", mpe_pack_last_error());
+            return 3;
+        }
+        B = nf;
+        HIP(to_device(text.data(), text_bytes, &d_text));
+        HIP(to_device(entries.data(), (size_t)ne, &d_entries));
+        HIP(to_device(fent.data(), (size_t)nf + 1, &d_fent));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_fho), ((size_t)Fcap + 1) * sizeof(int32_t)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_feo), ((size_t)Fcap + 1) * sizeof(int32_t)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_scam), (size_t)Fcap * V * sizeof(int32_t)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_sn), (size_t)Fcap * V * sizeof(int32_t)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_hcam), (size_t)Hcap * sizeof(int32_t)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_skel), (size_t)Hcap * sizeof(int32_t)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_jm), (size_t)Hcap * sizeof(uint32_t)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_tm), (size_t)Hcap * sizeof(uint32_t)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_xy), (size_t)Hcap * J * 2 * sizeof(double)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_vp), (size_t)Hcap * J * 2 * sizeof(float)));
+        HIP(hipMalloc(reinterpret_cast<void **>(&d_totals), 4 * sizeof(int32_t)));
+        const size_t scratch_bytes = mpe_json_scratch_bytes(ecap, kcap, J);
+        HIP(hipMalloc(&d_scratch, scratch_bytes));
+        mpe_batch out;
+        memset(&out, 0, sizeof out);
+        out.n_frames = nf;
+        out.d_frame_head_off = d_fho;
+        out.d_frame_en_off = d_feo;
+        out.d_slot_cam = d_scam;
+        out.d_slot_n = d_sn;
+        out.d_head_cam = d_hcam;
+        out.d_joint_mask = d_jm;
+        out.d_tri_mask = d_tm;
+        out.d_xy = d_xy;
+        out.d_vp = d_vp;
+        MPE(mpe_json_parse_device(ctx, s, d_text, d_entries, d_fent, ne, nf, Hcap, kcap, d_scratch, scratch_bytes, &out, d_skel, d_totals));
+        int32_t totals[4] = {0, 0, 0, 0};
+        HIP(hipStreamSynchronize(s));
+        HIP(hipMemcpy(totals, d_totals, sizeof totals, hipMemcpyDeviceToHost));
+        if (totals[2] != 0) {                             // bit 0: a string for the host parser; bit 1: more skeletons than the arrays hold
+            fprintf(stderr, "the device-side parser handed the window back (status %d): pack it with mpe_pack_indexed_into\n", totals[2]);
+            return 4;
+        }
+        H = totals[0];
+        M = totals[1];
+        if (M > cfg.max_edge_nodes) {
+            fprintf(stderr, "%d pairs exceed the context's capacity\n", M);
+            return 1;
+        }
+    }
     b.n_frames = B;
     b.n_heads = H;
     b.n_edge_nodes = M;
@@ -234,8 +308,6 @@ int main(int argc, char **argv) {
     b.d_en_pair = nullptr;                                // the implicit topology of process_test (graph_generator.py:854-864)
 
     // ---- the path: matching, then both 3D stages, on a stream of this program's own ----
-    hipStream_t s;
-    HIP(hipStreamCreate(&s));
     float *d_scores, *d_poses;
     int32_t *d_persons, *d_np;
     uint8_t *d_valid, *d_jv;
@@ -301,11 +373,14 @@ int main(int argc, char **argv) {
     put(f, "tri_valid", 0, {(uint64_t)B, (uint64_t)P, (uint64_t)J}, jv.data());
     fclose(f);
 
-    void *dev[] = {d_fho, d_feo, d_scam, d_sn, d_hcam, d_jm, d_tm, d_xy, d_vp, d_scores, d_persons, d_np, d_poses, d_valid, d_tri, d_jv};
-    for (void *p : dev) (void)hipFree(p);
-    mpe_packed_free(pk);
+    void *dev[] = {d_fho, d_feo, d_scam, d_sn, d_hcam, d_jm, d_tm, d_xy, d_vp, d_scores, d_persons, d_np, d_poses, d_valid, d_tri, d_jv,
+                   d_skel, d_totals, d_fent, d_text, d_entries, d_scratch};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    if (pk) mpe_packed_free(pk);
+    if (ix) mpe_json_index_free(ix);
     (void)hipStreamDestroy(s);
     mpe_destroy(ctx);
-    printf("abi_roundtrip: %s, %d frames, %d skeletons, %d pairs\n", mpe_version(), B, H, M);
+    printf("abi_roundtrip: %s, %d frames, %d skeletons, %d pairs (%s parse)\n", mpe_version(), B, H, M, device_parse ? "device" : "host");
     return 0;
 }

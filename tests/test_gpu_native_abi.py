@@ -89,10 +89,12 @@ def _write_case(path, eng, gat_weights, mlp_weights, text):
         _put(fh, 'json', np.frombuffer(text, np.uint8))
 
 
-@pytest.mark.parametrize('n_frames', [1, 3, 40])
-def test_cpp_host_gets_the_python_bindings_bits(tmp_path, calib, gat_weights, mlp_weights, n_frames):
+@pytest.mark.parametrize('n_frames,parse', [(1, 'host'), (3, 'host'), (40, 'host'), (3, 'device'), (40, 'device')])
+def test_cpp_host_gets_the_python_bindings_bits(tmp_path, calib, gat_weights, mlp_weights, n_frames, parse):
     """1 and 3 frames (the small-batch launches), 40 (the batch kernels with the K-split MLP): scores, persons, MLP poses and
-    triangulated poses of the C++ host equal the Python binding's, bit for bit; frames with 1 ... 5 persons, one with an empty camera."""
+    triangulated poses of the C++ host equal the Python binding's, bit for bit; frames with 1 ... 5 persons, one with an empty camera.
+    parse = 'device': the program stages the document's first level on the host and has the skeleton strings parsed on the GPU
+    (mpe_json_stage_window -> mpe_json_parse_device) instead of packing it with mpe_pack_json."""
     syn = pkg('synthetic')
     eng = pkg('pipeline').Engine(calib.params, calib, max_frames=48, max_persons_per_camera=6)
     try:
@@ -119,9 +121,11 @@ def test_cpp_host_gets_the_python_bindings_bits(tmp_path, calib, gat_weights, ml
     env = {k: v for k, v in os.environ.items() if not k.startswith('MPE_')}
     # (one and three frames: 300 further timed calls -- the reference's call pattern from a native host; the line goes to
     # gpurun_out/native_host_latency.txt, nothing is asserted about it)
-    r = subprocess.run([exe, case, res] + (['300'] if n_frames <= 3 else []), capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stdout + r.stderr
-    if n_frames <= 3:
+    timed = n_frames <= 3 and parse == 'host'
+    r = subprocess.run([exe, case, res, '300' if timed else '0'] + (['device'] if parse == 'device' else []), capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0 and ('(%s parse)' % parse) in r.stdout, r.stdout + r.stderr
+    if timed:
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', 'native_host_latency.txt'), 'a') as fh:
             fh.write(''.join(l + '\n' for l in r.stdout.splitlines() if 'us per call' in l))
