@@ -158,3 +158,54 @@ def test_small_batch_routes_on_a_random_sweep_of_frames(calib, gat_weights, mlp_
         assert groups >= 30 and int(npers.sum()) > 300
     finally:
         eng.close()
+
+
+def test_small_batch_routes_at_the_largest_frames_they_take(calib, gat_weights, mlp_weights, monkeypatch):
+    """5 x 10-person frames (BASELINE configs[3]'s frame: 50 skeletons, 1000 cross-camera pairs, 1050 graph nodes) in groups of 1, 2, 8, 15
+    and 16: up to 15 frames = 15 750 nodes the latency launches take the batch (their row-tile loop forms, the tail launch with 50-head
+    frames and 45 x 45 pair solves per frame), 16 frames = 16 800 nodes exceed their row capacity and go to the batch kernels.  Scores,
+    persons and poses equal the same frames inside one batch of 32, and the route switched off, bit for bit."""
+    syn = pkg('synthetic')
+    from conftest import oracle
+    eng = pkg('pipeline').Engine(calib.params, calib, max_frames=32, max_persons_per_camera=10)
+    sd, prm = gat_weights
+    eng.load_gat(sd, prm)
+    eng.load_mlp(mlp_weights)
+    try:
+        frames = [oracle().processed_input(syn.make_frame(calib, 8800 + i, syn.FrameSpec(persons=10 if i % 4 else 9, joint_drop=0.05 * (i % 3)))[0])
+                  for i in range(32)]
+        db = eng.to_device(eng.pack(frames))
+        assert db.n_heads >= 32 * 40 and db.n_edge_nodes >= 32 * 700
+        sc, pe, npers = eng.match(db)
+        po, va = eng.mlp3d(db, pe, npers)
+        eng.sync_status()
+        sc, pe, npers, po, va = sc.cpu().numpy(), pe.cpu().numpy(), npers.cpu().numpy(), po.cpu().numpy(), va.cpu().numpy()
+        off = [db.host.frame_counts(f) for f in range(len(frames))]
+        assert int(npers.sum()) >= 32 * 5
+        for route in ('1', '0'):
+            monkeypatch.setenv('MPE_LATENCY_PATH', route)
+            i = 0
+            for n in (1, 2, 8, 15, 6):                   # 32 frames; then 16 from the start
+                g = eng.to_device(eng.pack(frames[i:i + n]))
+                s2, p2, n2 = eng.match(g)
+                q2, v2 = eng.mlp3d(g, p2, n2)
+                eng.sync_status()
+                s2, p2, n2, q2, v2 = s2.cpu().numpy(), p2.cpu().numpy(), n2.cpu().numpy(), q2.cpu().numpy(), v2.cpu().numpy()
+                e = 0
+                for j in range(n):
+                    _, _, e0, M = off[i + j]
+                    assert np.array_equal(s2[e:e + M], sc[e0:e0 + M]), (route, i + j, n)
+                    e += M
+                    cnt = int(npers[i + j])
+                    assert n2[j] == cnt and np.array_equal(p2[j, :cnt], pe[i + j, :cnt]), (route, i + j, n)
+                    assert np.array_equal(v2[j], va[i + j]) and np.array_equal(q2[j][v2[j] != 0], po[i + j][va[i + j] != 0]), (route, i + j, n)
+                i += n
+            g = eng.to_device(eng.pack(frames[:16]))
+            s2, p2, n2 = eng.match(g)
+            q2, v2 = eng.mlp3d(g, p2, n2)
+            eng.sync_status()
+            M16 = sum(off[j][3] for j in range(16))
+            assert np.array_equal(s2.cpu().numpy()[:M16], sc[:M16]) and np.array_equal(n2.cpu().numpy(), npers[:16]), route
+            assert np.array_equal(q2.cpu().numpy()[v2.cpu().numpy() != 0], po[:16][va[:16] != 0]), route
+    finally:
+        eng.close()
