@@ -70,8 +70,14 @@ def new_engine(params=None, calib=None, max_frames=1):
     p = params or default_params
     hpf = len(p.used_cameras_skeleton_matching) * max_persons_per_camera()
     # the mirrors also take the graphs of mode='test_generated' (explicit edge-node lists: up to explicit_m_cap per graph)
-    return Engine(params, calib, max_frames=max_frames, max_persons_per_camera=max_persons_per_camera(),
-                  device=device(), max_edge_nodes_per_frame=explicit_m_cap(hpf) or None)
+    eng = Engine(params, calib, max_frames=max_frames, max_persons_per_camera=max_persons_per_camera(),
+                 device=device(), max_edge_nodes_per_frame=explicit_m_cap(hpf) or None)
+    if os.environ.get('MPE_GAT_ACC64', '0') == '1':
+        # opt-in for callers of the mirrors, who have no Engine to call set_precision on: f64 running sums in EVERY GAT GEMM (scores then sit
+        # closer to the float64 network than the reference's own fp32 evaluation on every frame measured, profiles/r06_shape_fuzz_seeds.txt;
+        # the matching network's GEMMs take ~10 % longer and small batches leave the latency launches for the batch path's kernels)
+        eng.set_precision(gat_acc64=True)
+    return eng
 
 
 def shared_engine(params=None, calib=None, max_frames=1):

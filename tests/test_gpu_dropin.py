@@ -307,6 +307,44 @@ def test_gat2_forward_raises_for_a_frame_beyond_capacity_without_a_device_round_
     model._engine.close()
 
 
+def test_mirrors_take_f64_sums_in_the_matching_network_on_request(dropin, calib, gat_weights, monkeypatch):
+    """MPE_GAT_ACC64=1 (read when a mirror builds its engine): GAT2.forward's scores are those of an Engine with
+    set_precision(gat_acc64=True) -- f64 running sums in every GAT GEMM -- bit for bit, and not the default precision's."""
+    d = dropin
+    import importlib
+    syn = importlib.import_module('3d_multi_pose_estimator_amd.synthetic')
+    pipeline = importlib.import_module('3d_multi_pose_estimator_amd.pipeline')
+    prm = d['prm']
+    frame = syn.make_frame(calib, 905, syn.FrameSpec(persons=4))[0]
+    pi = {c: [frame[c][0], 0] for c in frame if json.loads(frame[c][0])}
+
+    def mirror_scores():
+        model = d['GAT'](None, prm['gnn_layers'], prm['num_feats'], prm['n_classes'], prm['num_hidden'], prm['heads'], torch.nn.LeakyReLU(),
+                         torch.nn.Sigmoid(), prm['in_drop'], prm['attn_drop'], prm['alpha'], prm['residual'], bias=True)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in d['sd'].items()})
+        g = d['MergedMultipleHumansDataset'](pi, mode='test', limit=10000, debug=True, alt='3', verbose=False).graphs[0]
+        out = model(g.ndata['h'].cuda(), g).reshape(-1).cpu().numpy().copy()
+        model._engine.close()
+        return out
+
+    plain = mirror_scores()
+    monkeypatch.setenv('MPE_GAT_ACC64', '1')
+    acc = mirror_scores()
+    eng = pipeline.Engine(calib.params, calib, max_frames=1, max_persons_per_camera=10)
+    try:
+        sd, p2 = gat_weights
+        eng.load_gat(sd, p2)
+        eng.set_precision(gat_acc64=True)
+        from conftest import oracle
+        db = eng.to_device(eng.pack([oracle().processed_input(frame)]))
+        sc, sh = eng.gat_scores(db, heads=True)
+        want = np.concatenate([sh.cpu().numpy(), sc.cpu().numpy()])
+    finally:
+        eng.close()
+    assert acc.shape == want.shape and np.array_equal(acc, want)
+    assert plain.shape == acc.shape and not np.array_equal(plain, acc) and np.abs(plain - acc).max() < 1e-4
+
+
 def _frame_inputs(d, names=CASES):
     frames = [f for name in names for f in load_case(name)[1]]
     out = []
