@@ -72,11 +72,16 @@ def new_engine(params=None, calib=None, max_frames=1):
     # the mirrors also take the graphs of mode='test_generated' (explicit edge-node lists: up to explicit_m_cap per graph)
     eng = Engine(params, calib, max_frames=max_frames, max_persons_per_camera=max_persons_per_camera(),
                  device=device(), max_edge_nodes_per_frame=explicit_m_cap(hpf) or None)
-    if os.environ.get('MPE_GAT_ACC64', '0') == '1':
-        # opt-in for callers of the mirrors, who have no Engine to call set_precision on: f64 running sums in EVERY GAT GEMM (scores then sit
-        # closer to the float64 network than the reference's own fp32 evaluation on every frame measured, profiles/r06_shape_fuzz_seeds.txt;
-        # the matching network's GEMMs take ~10 % longer and small batches leave the latency launches for the batch path's kernels)
-        eng.set_precision(gat_acc64=True)
+    # opt-ins for callers of the mirrors, who have no Engine to call set_precision on.  MPE_GAT_ACC64=1: f64 running sums in EVERY GAT GEMM
+    # (scores then sit closer to the float64 network than the reference's own fp32 evaluation on every frame measured,
+    # profiles/r06_shape_fuzz_seeds.txt; the matching network's GEMMs take ~10 % longer and small batches leave the latency launches for the
+    # batch path's kernels).  MPE_MLP_PRECISION=max_accuracy | f64: the MLP with an f64 flush per K stage (mode 4) or evaluated on the f64
+    # matrix pipe (mode 5: every output of every golden row bit-equal to the network evaluated in f64; several times slower).
+    acc, mlp = os.environ.get('MPE_GAT_ACC64', '0') == '1', os.environ.get('MPE_MLP_PRECISION', '')
+    if mlp not in ('', 'default', 'max_accuracy', 'f64'):
+        raise ValueError("MPE_MLP_PRECISION must be 'max_accuracy' or 'f64' (or unset), not %r" % mlp)
+    if acc or mlp in ('max_accuracy', 'f64'):
+        eng.set_precision(gat_acc64=acc, mlp_max_accuracy=mlp == 'max_accuracy', mlp_f64=mlp == 'f64')
     return eng
 
 

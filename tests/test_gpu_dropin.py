@@ -345,6 +345,40 @@ def test_mirrors_take_f64_sums_in_the_matching_network_on_request(dropin, calib,
     assert plain.shape == acc.shape and not np.array_equal(plain, acc) and np.abs(plain - acc).max() < 1e-4
 
 
+@pytest.mark.parametrize('mode', ['max_accuracy', 'f64'])
+def test_mlp_mirror_takes_its_precision_mode_on_request(dropin, calib, mlp_weights, monkeypatch, mode):
+    """MPE_MLP_PRECISION=max_accuracy | f64 (read when the PoseEstimatorMLP mirror builds its engine): forward() gives the rows of an
+    Engine with set_precision(mlp_max_accuracy=True) / (mlp_f64=True), bit for bit."""
+    import importlib
+    pipeline = importlib.import_module('3d_multi_pose_estimator_amd.pipeline')
+    d = dropin
+    in_dim = int(np.asarray(mlp_weights['layers.1.weight']).shape[1])          # the reference's module tree: Flatten, then Linear at 1, 3, ..., 17
+    x = torch.from_numpy(np.random.RandomState(5).uniform(-1.0, 1.0, (7, in_dim)).astype(np.float32))
+
+    def mirror():
+        m = d['PoseEstimatorMLP'](in_dim, 54)
+        m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in mlp_weights.items()})
+        y = m(x.cuda()).cpu().numpy().copy()
+        m._engine.close()
+        return y
+
+    plain = mirror()
+    monkeypatch.setenv('MPE_MLP_PRECISION', mode)
+    got = mirror()
+    eng = pipeline.Engine(calib.params, calib, max_frames=4, max_persons_per_camera=10)
+    try:
+        eng.load_mlp(mlp_weights)
+        eng.set_precision(mlp_max_accuracy=mode == 'max_accuracy', mlp_f64=mode == 'f64')
+        want = eng.mlp_forward(x.cuda()).cpu().numpy()
+    finally:
+        eng.close()
+    assert np.array_equal(got, want)
+    assert plain.shape == got.shape and np.abs(plain - got).max() <= 1e-3 * max(1.0, np.abs(plain).max())
+    monkeypatch.setenv('MPE_MLP_PRECISION', 'fast')
+    with pytest.raises(ValueError, match='MPE_MLP_PRECISION'):
+        mirror()
+
+
 def _frame_inputs(d, names=CASES):
     frames = [f for name in names for f in load_case(name)[1]]
     out = []
