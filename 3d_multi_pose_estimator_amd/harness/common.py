@@ -44,6 +44,10 @@ def build_parser(description):
                    help='synthetic frames only: replace the GAT scores by the ground-truth pairing (isolates the 3D stage)')
     p.add_argument('--noise-px', type=float, default=0.0)
     p.add_argument('--persons', type=int, default=4)
+    p.add_argument('--gat-acc64', action='store_true',
+                   help='f64 running sums in every GEMM of the matching network (Engine.set_precision(gat_acc64=True); default: single fp32 chains for K <= 512)')
+    p.add_argument('--mlp-precision', choices=['default', 'max_accuracy', 'f64'], default='default',
+                   help='MLP mode 3 (default: f64 sums every second K stage), 4 (an f64 flush per stage) or 5 (the network evaluated on the f64 matrix pipe)')
     return p
 
 
@@ -276,6 +280,9 @@ def run(args, mode):
     work = collect_work(args, calib)
     eng = Engine(parameters, calib, max_frames=args.batch,
                  max_persons_per_camera=max(4, args.persons + 1, max_skeletons_per_camera(work)))
+    if getattr(args, 'gat_acc64', False) or getattr(args, 'mlp_precision', 'default') != 'default':
+        eng.set_precision(gat_acc64=bool(getattr(args, 'gat_acc64', False)), mlp_max_accuracy=getattr(args, 'mlp_precision', '') == 'max_accuracy',
+                          mlp_f64=getattr(args, 'mlp_precision', '') == 'f64')
     load_models(eng, args, need_mlp=(mode == 'mlp'))
     T_i1 = torch.from_numpy(calib.T_i32[1])
     J = eng.J

@@ -31,6 +31,24 @@ def test_harness_reproduces_the_reference_scripts_report(script, key, tmp_path):
         assert out['ap'][th] == pytest.approx(triple, rel=1e-12, abs=1e-12), (th, out['ap'][th], triple)
 
 
+@pytest.mark.parametrize('extra', [['--gat-acc64'], ['--mlp-precision', 'f64'], ['--gat-acc64', '--mlp-precision', 'max_accuracy']])
+def test_harness_precision_flags_keep_the_reference_scripts_report(extra, tmp_path):
+    """The harness's own precision flags (f64 sums in every GAT GEMM; the MLP in mode 4 / 5) on the committed test file: the report of
+    /root/reference/test/metrics_from_model.py for the same files is reproduced under each -- AP / precision / recall exactly, MPJPE within
+    0.01 mm (a14 / a15 with the more accurate arithmetic)."""
+    hd = os.path.join(GOLDEN, 'harness')
+    with open(os.path.join(hd, 'harness_expected.json')) as fh:
+        exp = json.load(fh)
+    mdir = harness_model_files(str(tmp_path), exp['inputs'])
+    m = importlib.import_module('3d_multi_pose_estimator_amd.harness.metrics_from_model')
+    out = m.main(['--testfiles', os.path.join(hd, exp['inputs']['testfile']), '--tmdir', hd, '--modelsdir', mdir,
+                  '--datastep', str(exp['inputs']['datastep']), '--batch', '7'] + extra)
+    want = exp['model']
+    assert abs(out['mpjpe_mm'] - want['mpjpe_mm']) < 0.01, (out['mpjpe_mm'], want['mpjpe_mm'])
+    for th, triple in want['ap'].items():
+        assert out['ap'][th] == pytest.approx(triple, rel=1e-12, abs=1e-12), (th, out['ap'][th], triple)
+
+
 def test_triangulation_harness_recovers_ground_truth():
     """With the ground-truth pairing as scores, undistort + DLT must recover the synthetic 3D
     joints: MPJPE far below a millimetre on noise-free projections (the lens model of the
