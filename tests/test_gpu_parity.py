@@ -213,6 +213,55 @@ def test_cluster_known_answers_bit_exact(engine, calib, variant, monkeypatch):
             assert np.array_equal(persons[f, :len(want)], want), i
 
 
+@pytest.mark.parametrize('kernel', [None, 'wave', 'block', 'lds', 'big'])
+def test_cluster_fresh_known_answers_bit_exact(calib, kernel, monkeypatch):
+    """The 1500 further known answers of the reference's clustering function (tests/golden/cluster_cases_fuzz.npz, written by
+    oracle/gen_cluster_fuzz.py from the reference's own file: near-threshold scores in float32 steps, saturated ties, confidently wrong
+    links, up to ten skeletons per camera) through the default kernel choice and through each of the four clustering kernels: the
+    reference's persons, bit for bit (a8)."""
+    arr = np.load(os.path.join(GOLDEN, 'cluster_cases_fuzz.npz'))
+    packing = pkg('packing')
+    engine = pkg('pipeline').Engine(calib.params, calib, max_frames=64, max_persons_per_camera=10)
+    if kernel:
+        monkeypatch.setenv('MPE_CLUSTER_KERNEL', kernel)
+    try:
+        V, n_cases = engine.V, int(arr['n'])
+        for start in range(0, n_cases, 64):
+            chunk = list(range(start, min(start + 64, n_cases)))
+            pb = packing.PackedBatch(V, engine.J)
+            B = len(chunk)
+            pb.n_frames = B
+            pb.slot_cam = np.full((B, V), -1, np.int32)
+            pb.slot_n = np.zeros((B, V), np.int32)
+            head_off, en_off, head_cam, scores = [0], [0], [], []
+            for f, i in enumerate(chunk):
+                sc_, sn_ = arr['c%d_slot_cam' % i], arr['c%d_slot_n' % i]
+                pb.slot_cam[f, :len(sc_)] = sc_
+                pb.slot_n[f, :len(sn_)] = sn_
+                tot = int(sn_.sum())
+                head_off.append(head_off[-1] + tot)
+                en_off.append(en_off[-1] + (tot * tot - int((sn_ * sn_).sum())) // 2)
+                head_cam += [int(c) for c, k in zip(sc_, sn_) for _ in range(k)]
+                scores.append(arr['c%d_scores' % i])
+            n = head_off[-1]
+            pb.frame_head_off = np.array(head_off, np.int32)
+            pb.frame_en_off = np.array(en_off, np.int32)
+            pb.head_cam = np.array(head_cam, np.int32)
+            pb.joint_mask = np.ones(n, np.uint32)
+            pb.tri_mask = np.ones(n, np.uint32)
+            pb.xy = np.zeros((n, engine.J, 2))
+            pb.vp = np.zeros((n, engine.J, 2), np.float32)
+            db = engine.to_device(pb)
+            persons, n_persons = engine.cluster(db, torch.from_numpy(np.concatenate(scores)))
+            persons, n_persons = persons.cpu().numpy(), n_persons.cpu().numpy()
+            for f, i in enumerate(chunk):
+                want = arr['c%d_persons' % i]
+                assert n_persons[f] == len(want), (kernel, i)
+                assert np.array_equal(persons[f, :len(want)], want), (kernel, i)
+    finally:
+        engine.close()
+
+
 def test_cluster_large_frames_vs_oracle(monkeypatch):
     """23 cameras x 10 skeletons = 230 heads, 25 300 edge-nodes per frame: more matchings above
     the threshold than the LDS sort holds (global-scratch sort of k_cluster_block), long chains of

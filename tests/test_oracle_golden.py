@@ -98,6 +98,33 @@ def test_cluster_known_answers(variant):
     assert nonempty > (300 if variant == 'panoptic' else 100)
 
 
+def test_cluster_fresh_known_answers():
+    """1500 further known answers of the reference's get_person_proposal_from_network_output (skeleton_matching_utils.py:12-132; the real
+    function through oracle/refenv.py, oracle/gen_cluster_fuzz.py): near-threshold scores in float32 steps, confidently wrong links
+    (components with repeated cameras), up to ten skeletons per camera -- the oracle's restatement gives the reference's persons on
+    every one."""
+    import os
+    onp = oracle()
+    calib = env('panoptic').calib
+    arr = np.load(os.path.join(golden_dir('panoptic'), 'cluster_cases_fuzz.npz'))
+    sm = list(calib.params.used_cameras_skeleton_matching)
+    nonempty = multi = 0
+    for i in range(int(arr['n'])):
+        slot_cam, slot_n = arr['c%d_slot_cam' % i], arr['c%d_slot_n' % i]
+        slots, hid = [], 0
+        for c, k in zip(slot_cam, slot_n):
+            slots.append((sm[c], list(range(hid, hid + k))))
+            hid += k
+        N, src, dst, pairs = onp.topology(slots)
+        head_cam = [int(c) for c, k in zip(slot_cam, slot_n) for _ in range(k)]
+        persons = onp.cluster(arr['c%d_scores' % i], pairs, hid, head_cam, len(sm))
+        want = arr['c%d_persons' % i]
+        assert np.array_equal(np.array(persons, np.int32).reshape(-1, len(sm)), want), i
+        nonempty += len(want) > 0
+        multi += len(want) > 3
+    assert int(arr['n']) == 1500 and nonempty > 1200 and multi > 300
+
+
 @pytest.mark.parametrize('variant,name', ALL_CASES)
 def test_stage3d(variant, name):
     onp = oracle()
