@@ -166,6 +166,10 @@ def main(variant='panoptic'):
         ('c2_3x2', F(persons=2, cameras=['trackerb', 'trackerd', 'trackere']), [6]),
         ('c4_5x10', F(persons=10, noise_px=1.0), [7]),
       ]
+      # round 6: frames of RANDOM shape through the reference (the GPU path and the oracle had met such frames only against each other,
+      # tests/checkers/shape_fuzz.py): camera subsets and orders, empty cameras, spurious skeletons, dropped joints, "ID" keys, noise.
+      # One spec per frame; every frame keeps at least two cameras with skeletons (the reference builds no graph otherwise).
+      cases.append(('fz_random_shapes', random_shape_specs(names, 40, 606), list(range(600, 640))))
     meta = {'gat_seed': GAT_SEED, 'mlp_seed': MLP_SEED, 'logit_gain': LOGIT_GAIN, 'logit_shift': shift,
             'num_feats': nf, 'mlp_in': in_dim, 'variant': variant, 'cases': {},
             'room_mlp': {'kind': 'decoder', 'noise_seed': ROOM_NOISE_SEED, 'noise_bound': ROOM_NOISE}}
@@ -173,7 +177,7 @@ def main(variant='panoptic'):
         frames_json = []
         arrays = {}
         for n, fi in enumerate(idxs):
-            frame, gt = syn.make_frame(calib, fi, spec)
+            frame, gt = syn.make_frame(calib, fi, spec[n] if isinstance(spec, list) else spec)
             frames_json.append(frame)
             # ---- callers' pre-processing (metrics_from_model.py:182-191)
             pi = {}
@@ -285,6 +289,25 @@ def main(variant='panoptic'):
             "the triangulation gather reads person.get(camera) where test/metrics_from_triangulation.py:240 reads person[camera]: with this preset the reference's own statement raises KeyError for the cameras outside used_cameras_skeleton_matching, so these fixtures pin the builder's reading of the script, not an unmodified run"]
     with open(os.path.join(OUT, 'meta.json'), 'w') as fh:
         json.dump(meta, fh, indent=1)
+
+
+def random_shape_specs(names, n, seed):
+    """n FrameSpecs of random shape (the generator of tests/checkers/shape_fuzz.py, restricted to frames the reference builds a graph
+    for: at least two cameras that hold skeletons, at least one person)."""
+    from importlib import import_module
+    syn = import_module('3d_multi_pose_estimator_amd.synthetic')
+    rng = np.random.RandomState(seed)
+    specs = []
+    while len(specs) < n:
+        k = rng.randint(2, len(names) + 1) if rng.rand() < 0.7 else len(names)
+        cams = [str(c) for c in rng.permutation(names)[:k]]
+        empty = tuple(c for c in cams if rng.rand() < 0.15)
+        if len(cams) - len(empty) < 2:
+            continue
+        specs.append(syn.FrameSpec(persons=int(rng.randint(1, 7)), cameras=cams, noise_px=float(rng.choice([0.0, 1.0, 3.0])),
+                                   joint_drop=float(rng.choice([0.0, 0.2, 0.5])), add_id_key=bool(rng.rand() < 0.3),
+                                   spurious=int(rng.randint(0, 3)), empty_cameras=empty, float_conf=bool(rng.rand() < 0.7)))
+    return specs
 
 
 class _G:

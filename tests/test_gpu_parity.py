@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ALL_CASES, CASES, GOLDEN, ROOT, env, load_case, oracle, pkg
+from conftest import ALL_CASES, ALL_CASES_FZ, CASES, GOLDEN, ROOT, env, load_case, oracle, pkg
 
 pytestmark = pytest.mark.gpu
 
@@ -97,7 +97,7 @@ def test_linear_small_batch_rows_identical(engine, k, n, slope):
             assert torch.equal(small, big[:m]), (acc64, m, (small - big[:m]).abs().max().item())
 
 
-@pytest.mark.parametrize('variant,name', ALL_CASES)
+@pytest.mark.parametrize('variant,name', ALL_CASES_FZ)
 def test_head_features_vs_golden(variant, name):
     engine = engine_for(variant)
     arr, frames = load_case(name, variant)
@@ -118,7 +118,7 @@ def test_head_features_vs_golden(variant, name):
             assert dense[h, 0] == 1.0
 
 
-@pytest.mark.parametrize('variant,name', ALL_CASES)
+@pytest.mark.parametrize('variant,name', ALL_CASES_FZ)
 def test_dense_rows_vs_golden(variant, name):
     """mpe_dense_rows = graph.ndata['h'] of one frame as the reference builds it (graph_generator.py:444-508, 629-631): EVERY entry of
     the dense N x F matrix against the reference's (stored sparse in the fixtures): head rows (column 0, the camera's block),
@@ -143,7 +143,7 @@ def test_dense_rows_vs_golden(variant, name):
         assert np.array_equal(got == 0, want == 0) or np.abs(got[(got == 0) != (want == 0)]).max() < 5e-7
 
 
-@pytest.mark.parametrize('variant,name', ALL_CASES)
+@pytest.mark.parametrize('variant,name', ALL_CASES_FZ)
 def test_gat_scores_vs_golden(variant, name):
     engine = engine_for(variant)
     arr, frames = load_case(name, variant)
@@ -307,7 +307,7 @@ def test_cluster_large_frames_vs_oracle(monkeypatch):
     engine.close()
 
 
-@pytest.mark.parametrize('variant,name', ALL_CASES)
+@pytest.mark.parametrize('variant,name', ALL_CASES_FZ)
 def test_match_and_3d_vs_golden(variant, name):
     """End to end per golden frame: clusters bit-exact, MLP rows / poses / triangulation
     within tolerance (see test_mlp_error_budget for the 3D bound)."""

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ALL_CASES, ROOT, env, load_case, oracle, pkg
+from conftest import ALL_CASES, ALL_CASES_FZ, ROOT, env, load_case, oracle, pkg
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,7 @@ def _close(a, b, tol):
     return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max()) <= tol
 
 
-@pytest.mark.parametrize('variant,name', ALL_CASES)
+@pytest.mark.parametrize('variant,name', ALL_CASES_FZ)
 def test_gat_layers_vs_reference_activations(variant, name):
     """mpe_gat_layer, layer by layer, on the reference graph's own feature rows: the hidden
     activations the REFERENCE computed (fixtures act{l}_head / act{l}_en, first four heads and

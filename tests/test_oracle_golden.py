@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ALL_CASES, CASES, GOLDEN, ROOT, env, golden_dir, load_case, oracle, pkg
+from conftest import ALL_CASES, ALL_CASES_FZ, CASES, GOLDEN, ROOT, env, golden_dir, load_case, oracle, pkg
 
 
 @pytest.mark.parametrize('variant', ['panoptic', 'arplab', 'arprobot', 'ring23'])
@@ -29,7 +29,7 @@ def test_calibration_matches_reference_globals(variant):
     assert len(g['features']) == 2 + len(sm) * 18 * 10 == e.meta['num_feats']
 
 
-@pytest.mark.parametrize('variant,name', ALL_CASES)
+@pytest.mark.parametrize('variant,name', ALL_CASES_FZ)
 def test_graph_and_gat(variant, name):
     onp = oracle()
     calib = env(variant).calib
@@ -61,7 +61,7 @@ def test_graph_and_gat(variant, name):
             np.testing.assert_allclose(a[H:H + 4].numpy(), arr[p + 'act%d_en' % l], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize('variant,name', ALL_CASES)
+@pytest.mark.parametrize('variant,name', ALL_CASES_FZ)
 def test_cluster_on_golden_scores(variant, name):
     onp = oracle()
     calib = env(variant).calib
@@ -125,7 +125,7 @@ def test_cluster_fresh_known_answers():
     assert int(arr['n']) == 1500 and nonempty > 1200 and multi > 300
 
 
-@pytest.mark.parametrize('variant,name', ALL_CASES)
+@pytest.mark.parametrize('variant,name', ALL_CASES_FZ)
 def test_stage3d(variant, name):
     onp = oracle()
     calib = env(variant).calib
