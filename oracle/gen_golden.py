@@ -148,7 +148,8 @@ def main(variant='panoptic'):
     names = list(rparams.camera_names)
     if variant == 'arplab':
         cases = [('arp_6x3', F(persons=3, add_id_key=True, noise_px=1.0, float_conf=False), [0, 1]),
-                 ('arp_robot_pair', F(persons=2, cameras=['orinbot_r', 'orinbot_l']), [2])]
+                 ('arp_robot_pair', F(persons=2, cameras=['orinbot_r', 'orinbot_l']), [2]),
+                 ('fz_random_shapes', random_shape_specs(names, 30, 707), list(range(700, 730)))]      # round 6, as for PANOPTIC below
     elif variant == 'arprobot':
         cases = [('arp_robot_only', F(persons=3, cameras=['orinbot_l', 'orinbot_r'], noise_px=1.0), [0, 1]),
                  ('arp_robot_only_all_streams', F(persons=2, add_id_key=True), [3])]   # the other four cameras' skeletons arrive too

@@ -23,7 +23,7 @@ def engine_for(variant, ppc=None):
     if key not in _engines:
         e = env(variant)
         eng = pkg('pipeline').Engine(e.params, e.calib, max_frames=4,
-                                     max_persons_per_camera=ppc or (10 if variant == 'panoptic' else 3))
+                                     max_persons_per_camera=ppc or (10 if variant in ('panoptic', 'arplab') else 3))
         eng.load_gat(*e.gat)
         eng.load_mlp(e.mlp)
         _engines[key] = eng

@@ -53,8 +53,14 @@ def test_graph_and_gat(variant, name):
         assert torch.equal(dense[:, ~ray], g['feats'][:, ~ray])
         np.testing.assert_allclose(g['feats'][:, ray].numpy(), dense[:, ray].numpy(), rtol=0, atol=1.2e-7)
         scores, inter = onp.gat_forward(sd, prm, g['feats'], g['src'], g['dst'], keep=True)
-        # same torch CPU kernels on the same machine -> equal to a few ulp at most
-        np.testing.assert_allclose(scores.numpy(), arr[p + 'scores'], rtol=2e-5, atol=1e-7)
+        # same torch CPU kernels on the same machine -> equal to a few ulp at most on the hand-made cases.  On the random-shape frames
+        # (round 6) the two fp32 evaluations -- the reference's own modules over the DGL stand-in, and the oracle's restatement --
+        # differ by up to 1.17e-5 in a score (ARPLAB frame 5, at a score of 0.369; bit-equal on all 40 PANOPTIC frames): operation order, amplified by
+        # the fixture weights' logit gain of 25.  That is the size of the noise the 2e-5 bound of the GPU tests is about.
+        if name.startswith('fz_'):
+            np.testing.assert_allclose(scores.numpy(), arr[p + 'scores'], rtol=0, atol=2e-5)
+        else:
+            np.testing.assert_allclose(scores.numpy(), arr[p + 'scores'], rtol=2e-5, atol=1e-7)
         H = g['H']
         for l, a in enumerate(inter):
             np.testing.assert_allclose(a[:4].numpy(), arr[p + 'act%d_head' % l], rtol=1e-4, atol=1e-6)
