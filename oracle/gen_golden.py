@@ -155,7 +155,9 @@ def main(variant='panoptic'):
                  ('arp_robot_only_all_streams', F(persons=2, add_id_key=True), [3])]   # the other four cameras' skeletons arrive too
     elif variant == 'ring23':
         cases = [('ring23x3', F(persons=3, noise_px=0.5), [0]),
-                 ('ring23_sparse', F(persons=2, cameras=names[3::4], joint_drop=0.1), [1])]
+                 ('ring23_sparse', F(persons=2, cameras=names[3::4], joint_drop=0.1), [1]),
+                 # round 6, as for PANOPTIC below; at most three skeletons per camera (the capacity of the tests' 23-camera engines)
+                 ('fz_random_shapes', random_shape_specs(names, 8, 808, max_persons=2, max_spurious=1), list(range(800, 808)))]
     else:
       cases = [
         ('c1_2view_1person', F(persons=1, cameras=['trackera', 'trackerb']), [0, 1]),
@@ -292,7 +294,7 @@ def main(variant='panoptic'):
         json.dump(meta, fh, indent=1)
 
 
-def random_shape_specs(names, n, seed):
+def random_shape_specs(names, n, seed, max_persons=6, max_spurious=2):
     """n FrameSpecs of random shape (the generator of tests/checkers/shape_fuzz.py, restricted to frames the reference builds a graph
     for: at least two cameras that hold skeletons, at least one person)."""
     from importlib import import_module
@@ -305,9 +307,9 @@ def random_shape_specs(names, n, seed):
         empty = tuple(c for c in cams if rng.rand() < 0.15)
         if len(cams) - len(empty) < 2:
             continue
-        specs.append(syn.FrameSpec(persons=int(rng.randint(1, 7)), cameras=cams, noise_px=float(rng.choice([0.0, 1.0, 3.0])),
+        specs.append(syn.FrameSpec(persons=int(rng.randint(1, max_persons + 1)), cameras=cams, noise_px=float(rng.choice([0.0, 1.0, 3.0])),
                                    joint_drop=float(rng.choice([0.0, 0.2, 0.5])), add_id_key=bool(rng.rand() < 0.3),
-                                   spurious=int(rng.randint(0, 3)), empty_cameras=empty, float_conf=bool(rng.rand() < 0.7)))
+                                   spurious=int(rng.randint(0, max_spurious + 1)), empty_cameras=empty, float_conf=bool(rng.rand() < 0.7)))
     return specs
 
 

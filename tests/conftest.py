@@ -35,9 +35,9 @@ VARIANT_CASES = {
 }
 CASES = VARIANT_CASES['panoptic']
 ALL_CASES = [(v, c) for v, cs in VARIANT_CASES.items() for c in cs]
-# round 6: 40 (PANOPTIC) and 30 (ARPLAB) frames of random shape through the reference (oracle/gen_golden.py: random_shape_specs) -- one case, used by the stage tests
+# round 6: 40 (PANOPTIC), 30 (ARPLAB) and 8 (23 cameras) frames of random shape through the reference (oracle/gen_golden.py: random_shape_specs) -- one case, used by the stage tests
 # that take any case; not part of CASES (tests that walk the hand-made cases keep their size)
-FUZZ_CASES = [('panoptic', 'fz_random_shapes'), ('arplab', 'fz_random_shapes')]
+FUZZ_CASES = [('panoptic', 'fz_random_shapes'), ('arplab', 'fz_random_shapes'), ('ring23', 'fz_random_shapes')]
 ALL_CASES_FZ = ALL_CASES + FUZZ_CASES
 
 
