@@ -35,7 +35,7 @@ def dropin(gat_weights, mlp_weights):
     return locals()
 
 
-@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('name', CASES + ['fz_random_shapes'])      # + 40 frames of random shape through the reference (round 6)
 def test_reference_loop_on_dropin(dropin, name, mlp_weights):
     d = dropin
     parameters = d['parameters']
