@@ -183,7 +183,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'generated_graphs.npz'), **arrays)
     report = {'printed': printed, 'seed': SEED, 'n_graphs': len(graphs), 'files': [os.path.basename(n) for n in names],
               'gat': {'kind': 'matcher', 'noise_seed': GAT_NOISE_SEED, 'noise_bound': GAT_NOISE}, 'hash_gat': HASH_GAT, 'graphs': meta,
-              'numpy': np.__version__, 'python': sys.version.split()[0]}
+              'numpy': np.__version__, 'python': sys.version.split()[0],
+              'torch_threads': int(__import__('torch').get_num_threads())}      # the fp32 scores depend on it (profiles/r06_reference_score_noise_by_threads.txt)
     with open(os.path.join(OUT, 'generated_expected.json'), 'w') as fh:
         json.dump(report, fh, indent=1)
     print(json.dumps({k: v for k, v in report.items() if k != 'graphs'}, indent=1))

@@ -175,7 +175,10 @@ def main(variant='panoptic'):
       cases.append(('fz_random_shapes', random_shape_specs(names, 40, 606), list(range(600, 640))))
     meta = {'gat_seed': GAT_SEED, 'mlp_seed': MLP_SEED, 'logit_gain': LOGIT_GAIN, 'logit_shift': shift,
             'num_feats': nf, 'mlp_in': in_dim, 'variant': variant, 'cases': {},
-            'room_mlp': {'kind': 'decoder', 'noise_seed': ROOM_NOISE_SEED, 'noise_bound': ROOM_NOISE}}
+            'room_mlp': {'kind': 'decoder', 'noise_seed': ROOM_NOISE_SEED, 'noise_bound': ROOM_NOISE},
+            # the reference's fp32 scores depend on how MKL partitions its sums, i.e. on the host's thread count (up to 1.65e-5 in a score,
+            # profiles/r06_reference_score_noise_by_threads.txt): the oracle's torch-CPU evaluation equals them to a few ulp only under the same count
+            'torch_threads': int(torch.get_num_threads())}
     for name, spec, idxs in cases:
         frames_json = []
         arrays = {}

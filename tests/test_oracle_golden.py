@@ -58,7 +58,10 @@ def test_graph_and_gat(variant, name):
         # differ by up to 1.17e-5 in a score with 8 host threads (ARPLAB frame 5, at a score of 0.369) and by up to 1.65e-5 with other thread
         # counts, on PANOPTIC too (profiles/r06_reference_score_noise_by_threads.txt): MKL's blocking of the sums, amplified by
         # the fixture weights' logit gain of 25.  That is the size of the noise the 2e-5 bound of the GPU tests is about.
-        if name.startswith('fz_'):
+        # The hand-made cases keep the tight check where the host runs torch with the thread count the fixtures were written under
+        # (meta.json: torch_threads; with 4 threads instead of 8, arp_6x3 frame 1 is 9.2e-6 away) and take the absolute bound elsewhere.
+        same_host = torch.get_num_threads() == env(variant).meta.get('torch_threads')
+        if name.startswith('fz_') or not same_host:
             np.testing.assert_allclose(scores.numpy(), arr[p + 'scores'], rtol=0, atol=2e-5)
         else:
             np.testing.assert_allclose(scores.numpy(), arr[p + 'scores'], rtol=2e-5, atol=1e-7)
@@ -314,6 +317,7 @@ def test_generated_scenes_oracle_vs_reference_script():
     sd, prm = generated_gat_weights(exp)
     hg = exp['hash_gat']
     sd2 = pkg('synthetic').gat_state_dict(hg['seed'], prm['num_feats'], logit_gain=hg['logit_gain'], logit_shift=hg['logit_shift'])
+    same_host = torch.get_num_threads() == exp.get('torch_threads')
     sm = list(e.params.used_cameras_skeleton_matching)
     blk = len(e.params.joint_list) * 10
     for i, g in enumerate(graphs):
@@ -326,10 +330,17 @@ def test_generated_scenes_oracle_vs_reference_script():
         rows = np.stack([g['feats'][h, 2 + c * blk: 2 + (c + 1) * blk].numpy() for h, c in enumerate(arr['head_cam_%d' % i])])
         assert np.array_equal(rows, arr['head_blocks_%d' % i])
         assert np.count_nonzero(g['feats'].numpy()) == np.count_nonzero(rows) + g['N']      # col 0 / col 1 + the own block only
+        # (bit-equal where torch runs with the thread count the fixture was written under; the reference's own fp32 scores move by
+        # up to 1.65e-5 with it, profiles/r06_reference_score_noise_by_threads.txt)
+        # with 1 / 2 / 4 / 6 threads the hand-built matcher network's edge-node scores sit up to 2.05e-5 from the script's, its head-node
+        # scores -- consumed by nothing -- up to 1.7e-3; the hash network's 6.6e-6)
+        H_ = g['H']
+        same = (lambda a, b: np.array_equal(a, b)) if same_host else \
+            (lambda a, b: float(np.abs(a - b)[H_:].max()) <= 3e-5 and float(np.abs(a - b)[:H_].max()) <= 5e-3)
         sc = onp.gat_forward(sd, prm, g['feats'], g['src'], g['dst']).numpy()
-        assert np.array_equal(sc, arr['scores_%d' % i])
+        assert same(sc, arr['scores_%d' % i])
         sc2 = onp.gat_forward(sd2, prm, g['feats'], g['src'], g['dst']).numpy()          # the second (hash) weight set
-        assert np.array_equal(sc2, arr['scores_hash_%d' % i])
+        assert same(sc2, arr['scores_hash_%d' % i])
         head_cam = [sm.index(c) for c in g['nodes_camera'][:g['H']]]
         assert onp.cluster(sc2[g['H']:], g['pairs'], g['H'], head_cam, len(sm), e.params.min_number_of_views) == \
             proposals_as_rows(meta['est_hash'], sm)
